@@ -1,0 +1,281 @@
+"""numpy restatement of the pfv-rs hot path -- the SECOND, independently written oracle.
+
+TEST INFRASTRUCTURE ONLY (see oracle/pfv_oracle.c header).  It exists so that the C oracle
+is cross-checked by something written separately from the same reference lines, and to
+generate the committed golden vectors under tests/golden/ (tests/golden/make_golden.py).
+
+It is written array-at-a-time (all 8x8 subblocks of a plane at once) rather than
+block-at-a-time like the C oracle, so the two share no structure.  Paths cite the
+reference (relative to the reference root).  Parity status: "unpinned by upstream golden
+vectors" -- the reference's tests assert nothing about DCT/quant/motion.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FP_BITS = 8  # src/dct.rs:1
+
+# src/dct.rs:4-13 (data)
+DCT_SCALE_FACTOR = np.array(
+    [32, 37, 34, 26, 32, 26, 34, 37, 37, 43, 39, 31, 37, 31, 39, 43,
+     34, 39, 35, 28, 34, 28, 35, 39, 26, 31, 28, 22, 26, 22, 28, 31,
+     32, 37, 34, 26, 32, 26, 34, 37, 26, 31, 28, 22, 26, 22, 28, 31,
+     34, 39, 35, 28, 34, 28, 35, 39, 37, 43, 39, 31, 37, 31, 39, 43], dtype=np.int32)
+# src/dct.rs:16-25 (data)
+Q_TABLE_INTRA = np.array(
+    [8, 16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37,
+     19, 22, 26, 27, 29, 34, 34, 38, 22, 22, 26, 27, 29, 34, 37, 40,
+     22, 26, 27, 29, 32, 35, 40, 48, 26, 27, 29, 32, 35, 40, 48, 58,
+     26, 27, 29, 34, 38, 46, 56, 69, 27, 29, 35, 38, 46, 56, 69, 83], dtype=np.int32)
+# src/dct.rs:28-37 (data)
+Q_TABLE_INTER = np.full(64, 16, dtype=np.int32)
+# src/dct.rs:39-42 (data)
+INV_ZIGZAG_TABLE = np.array(
+    [0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42,
+     3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+     10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+     21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63], dtype=np.int64)
+# src/dct.rs:44-47 (data)
+ZIGZAG_TABLE = np.array(
+    [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+     12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+     58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63], dtype=np.int64)
+
+
+def _tdiv(x: np.ndarray, d: int) -> np.ndarray:
+    """Rust `/` on i32 by a positive power of two: truncation toward zero."""
+    x = x.astype(np.int64)
+    return (np.sign(x) * (np.abs(x) // d)).astype(np.int64)
+
+
+def _wrap(x: np.ndarray) -> np.ndarray:
+    """wrap an int64 array to i32 two's complement (Rust release-mode arithmetic)."""
+    return ((x.astype(np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)).astype(np.int64)
+
+
+def fdct(v: np.ndarray) -> np.ndarray:
+    """src/dct.rs:176-239 on the LAST axis (length 8); int64 in, wrapped-i32 values out."""
+    i = [v[..., k].astype(np.int64) for k in range(8)]
+    a0, a1, a2, a3 = _wrap(i[0] + i[7]), _wrap(i[1] + i[6]), _wrap(i[2] + i[5]), _wrap(i[3] + i[4])
+    a4, a5, a6, a7 = _wrap(i[0] - i[7]), _wrap(i[1] - i[6]), _wrap(i[2] - i[5]), _wrap(i[3] - i[4])
+    b0, b1, b2, b3 = _wrap(a0 + a3), _wrap(a1 + a2), _wrap(a0 - a3), _wrap(a1 - a2)
+    c0, c1 = _wrap(b0 + b1), _wrap(b0 - b1)
+    c2 = _wrap(_wrap(b2 + _tdiv(b2, 4)) + _tdiv(b3, 2))
+    c3 = _wrap(_wrap(_tdiv(b2, 2) - b3) - _tdiv(b3, 4))
+    b4 = _wrap(_wrap(_wrap(_tdiv(a7, 4) + a4) + _tdiv(a4, 4)) - _tdiv(a4, 16))
+    b7 = _wrap(_wrap(_wrap(_tdiv(a4, 4) - a7) - _tdiv(a7, 4)) + _tdiv(a7, 16))
+    b5 = _wrap(_wrap(_wrap(a5 + a6) - _tdiv(a6, 4)) - _tdiv(a6, 16))
+    b6 = _wrap(_wrap(_wrap(a6 - a5) + _tdiv(a5, 4)) + _tdiv(a5, 16))
+    c4, c5, c6, c7 = _wrap(b4 + b5), _wrap(b4 - b5), _wrap(b6 + b7), _wrap(b6 - b7)
+    d4, d5, d6, d7 = c4, _wrap(c5 + c7), _wrap(c5 - c7), c6
+    return np.stack([c0, d4, c2, d6, c1, d5, c3, d7], axis=-1)
+
+
+def idct(v: np.ndarray) -> np.ndarray:
+    """src/dct.rs:241-293 on the LAST axis."""
+    c0, d4, c2, d6, c1, d5, c3, d7 = [v[..., k].astype(np.int64) for k in range(8)]
+    c4, c5, c7, c6 = d4, _wrap(d5 + d6), _wrap(d5 - d6), d7
+    b4, b5, b6, b7 = _wrap(c4 + c5), _wrap(c4 - c5), _wrap(c6 + c7), _wrap(c6 - c7)
+    b0, b1 = _wrap(c0 + c1), _wrap(c0 - c1)
+    b2 = _wrap(_wrap(c2 + _tdiv(c2, 4)) + _tdiv(c3, 2))
+    b3 = _wrap(_wrap(_tdiv(c2, 2) - c3) - _tdiv(c3, 4))
+    a4 = _wrap(_wrap(_wrap(_tdiv(b7, 4) + b4) + _tdiv(b4, 4)) - _tdiv(b4, 16))
+    a7 = _wrap(_wrap(_wrap(_tdiv(b4, 4) - b7) - _tdiv(b7, 4)) + _tdiv(b7, 16))
+    a5 = _wrap(_wrap(_wrap(b5 - b6) + _tdiv(b6, 4)) + _tdiv(b6, 16))
+    a6 = _wrap(_wrap(_wrap(b6 + b5) - _tdiv(b5, 4)) - _tdiv(b5, 16))
+    a0, a1, a2, a3 = _wrap(b0 + b2), _wrap(b1 + b3), _wrap(b1 - b3), _wrap(b0 - b2)
+    return np.stack([_wrap(a0 + a4), _wrap(a1 + a5), _wrap(a2 + a6), _wrap(a3 + a7),
+                     _wrap(a3 - a7), _wrap(a2 - a6), _wrap(a1 - a5), _wrap(a0 - a4)], axis=-1)
+
+
+def fdct2d(m: np.ndarray) -> np.ndarray:
+    """rows then columns (src/common.rs:294-295); m: [..., 8(row), 8(col)]."""
+    m = fdct(m)                                    # each row (last axis)
+    return np.swapaxes(fdct(np.swapaxes(m, -1, -2)), -1, -2)   # each column
+
+
+def idct2d(m: np.ndarray) -> np.ndarray:
+    """columns then rows (src/common.rs:315-316)."""
+    m = np.swapaxes(idct(np.swapaxes(m, -1, -2)), -1, -2)
+    return idct(m)
+
+
+def dct_encode(m: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """src/dct.rs:88-99; m: [..., 64] raster (wrapped i32 values) -> [..., 64] i16 zigzag."""
+    raster = m.reshape(m.shape[:-1] + (64,)).astype(np.int64)
+    n = _wrap(raster * DCT_SCALE_FACTOR.astype(np.int64)) >> (FP_BITS * 2)      # floor shift
+    d = q.astype(np.int64)
+    quo = np.sign(n) * (np.abs(n) // np.abs(d)) * np.sign(d)                     # truncating /
+    return ((quo[..., ZIGZAG_TABLE] + 32768) % 65536 - 32768).astype(np.int16)     # `as i16` wraps
+
+
+def dct_decode(src: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """src/dct.rs:75-86; src [..., 64] i16 zigzag -> [..., 64] raster wrapped i32 (as int64).
+    SCALE and q are indexed by the zigzag position (asymmetric with encode)."""
+    s = src.astype(np.int64)
+    t = _wrap(_wrap(s * DCT_SCALE_FACTOR.astype(np.int64)) * q.astype(np.int64))   # per zigzag position
+    return t[..., INV_ZIGZAG_TABLE]
+
+
+def _to_subblocks(blocks16: np.ndarray) -> np.ndarray:
+    """[n,16,16] -> [n,4,8,8] in quadrant order TL,TR,BL,BR (src/common.rs:145-149)."""
+    n = blocks16.shape[0]
+    b = blocks16.reshape(n, 2, 8, 2, 8)            # [n, qy, r, qx, c]
+    return b.transpose(0, 1, 3, 2, 4).reshape(n, 4, 8, 8)
+
+
+def _from_subblocks(sub: np.ndarray) -> np.ndarray:
+    n = sub.shape[0]
+    return sub.reshape(n, 2, 2, 8, 8).transpose(0, 1, 3, 2, 4).reshape(n, 16, 16)
+
+
+def pad16(x: int) -> int:
+    return x + (16 - (x % 16)) % 16               # src/common.rs:352-353
+
+
+def pad_plane(px: np.ndarray, clear: int) -> np.ndarray:
+    """src/common.rs:352-356."""
+    h, w = px.shape
+    out = np.full((pad16(h), pad16(w)), clear, dtype=np.uint8)
+    out[:h, :w] = px
+    return out
+
+
+def _gather(img: np.ndarray) -> np.ndarray:
+    """[H,W] -> [bh*bw,16,16] raster MB order (src/common.rs:364-369)."""
+    H, W = img.shape
+    return img.reshape(H // 16, 16, W // 16, 16).transpose(0, 2, 1, 3).reshape(-1, 16, 16)
+
+
+def _scatter(blocks: np.ndarray, bw: int, bh: int) -> np.ndarray:
+    return blocks.reshape(bh, bw, 16, 16).transpose(0, 2, 1, 3).reshape(bh * 16, bw * 16)
+
+
+def encode_blocks(blocks16: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """src/common.rs:141-152 + :287-298 over an array of macroblocks -> [n,256] i16."""
+    sub = _to_subblocks(blocks16.astype(np.int64))
+    m = (sub - 128) << FP_BITS
+    coef = dct_encode(fdct2d(m).reshape(sub.shape[0], 4, 64), q)
+    return coef.reshape(-1, 256)
+
+
+def encode_blocks_delta(delta16: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """src/common.rs:300-311 over an array of i16 residual macroblocks -> [n,256] i16."""
+    sub = _to_subblocks(delta16.astype(np.int64))
+    m = _tdiv(sub, 2) << FP_BITS
+    coef = dct_encode(fdct2d(m).reshape(sub.shape[0], 4, 64), q)
+    return coef.reshape(-1, 256)
+
+
+def decode_blocks(coef: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """src/common.rs:238-252 + :313-325; coef [n,256] i16 -> [n,16,16] u8."""
+    n = coef.shape[0]
+    m = dct_decode(coef.reshape(n, 4, 64), q).reshape(n, 4, 8, 8)
+    px = idct2d(m)
+    px = np.clip((px >> FP_BITS) + 128, 0, 255).astype(np.uint8)
+    return _from_subblocks(px)
+
+
+def encode_plane(px: np.ndarray, q: np.ndarray, clear: int):
+    """src/common.rs:351-386 -> (coef [n,256] i16, bw, bh)."""
+    img = pad_plane(px, clear)
+    return encode_blocks(_gather(img), q), img.shape[1] // 16, img.shape[0] // 16
+
+
+def decode_plane(coef: np.ndarray, bw: int, bh: int, q: np.ndarray) -> np.ndarray:
+    """src/common.rs:423-446."""
+    return _scatter(decode_blocks(coef, q), bw, bh)
+
+
+def ssd(a: np.ndarray, b: np.ndarray) -> int:
+    """full integer SSD; equals calc_error (src/common.rs:125-139) whenever the caller's
+    comparison outcome matters."""
+    d = a.astype(np.int64) - b.astype(np.int64)
+    return int((d * d).sum())
+
+
+def block_search(src: np.ndarray, ref: np.ndarray, cx: int, cy: int):
+    """src/common.rs:154-204 with exact integer SSD instead of the early-exit f32 one."""
+    H, W = ref.shape
+    tdx = tdy = 0
+    best = None
+    step = 8
+    while step >= 1:
+        best = ssd(src, ref[cy:cy + 16, cx:cx + 16])
+        bdx = bdy = 0
+        for my in (-1, 0, 1):
+            oy = cy + my * step
+            if oy < 0 or oy > H - 16:
+                continue
+            for mx in (-1, 0, 1):
+                if mx == 0 and my == 0:
+                    continue
+                ox = cx + mx * step
+                if ox < 0 or ox > W - 16:
+                    continue
+                e = ssd(src, ref[oy:oy + 16, ox:ox + 16])
+                if e < best:
+                    best, bdx, bdy = e, mx * step, my * step
+        cx += bdx
+        cy += bdy
+        tdx += bdx
+        tdy += bdy
+        step //= 2
+    return tdx, tdy, best
+
+
+def encode_plane_delta(px: np.ndarray, ref: np.ndarray, q: np.ndarray, px_err: float, clear: int):
+    """src/common.rs:388-421 + :206-236 -> (mv [n,2] i8, has_coef [n] u8, coef [n,256] i16)."""
+    img = pad_plane(px, clear)
+    bw, bh = img.shape[1] // 16, img.shape[0] // 16
+    blocks = _gather(img)
+    n = bw * bh
+    mv = np.zeros((n, 2), dtype=np.int8)
+    has = np.zeros(n, dtype=np.uint8)
+    coef = np.zeros((n, 256), dtype=np.int16)
+    min_err = np.float32(px_err) * np.float32(px_err) * np.float32(256.0)
+    for i in range(n):
+        bx, by = (i % bw) * 16, (i // bw) * 16
+        dx, dy, err = block_search(blocks[i], ref, bx, by)
+        mv[i] = (dx, dy)
+        if np.float32(err) <= min_err:
+            continue
+        has[i] = 1
+        prev = ref[by + dy:by + dy + 16, bx + dx:bx + dx + 16]
+        delta = np.clip(blocks[i].astype(np.int64) - prev.astype(np.int64), -255, 255)
+        coef[i] = encode_blocks_delta(delta[None], q)[0]
+    return mv, has, coef
+
+
+def decode_plane_delta(mv: np.ndarray, has: np.ndarray, coef: np.ndarray, bw: int, bh: int, q: np.ndarray,
+                       ref: np.ndarray) -> np.ndarray:
+    """src/common.rs:448-475 + :254-285 + :98-104."""
+    n = bw * bh
+    out = np.zeros((n, 16, 16), dtype=np.uint8)
+    dec = decode_blocks(coef, q).astype(np.int64)
+    for i in range(n):
+        bx, by = (i % bw) * 16, (i // bw) * 16
+        sx, sy = bx + int(mv[i, 0]), by + int(mv[i, 1])
+        prev = ref[sy:sy + 16, sx:sx + 16].astype(np.int64)
+        if has[i]:
+            out[i] = np.clip(prev + (dec[i] - 128) * 2, 0, 255).astype(np.uint8)
+        else:
+            out[i] = prev.astype(np.uint8)
+    return _scatter(out, bw, bh)
+
+
+def qtables(quality: int):
+    """src/enc.rs:40-51 in f32 -> (intra_l, intra_c, inter_l, inter_c, px_err)."""
+    qs = np.float32(quality) * np.float32(0.25)
+    half = np.float32(0.5)
+    one = np.float32(1.0)
+
+    def mk(base, luma):
+        t = base.astype(np.float32) * qs
+        if luma:
+            t = t * half
+        return np.maximum(t, one).astype(np.int32)
+
+    return (mk(Q_TABLE_INTRA, True), mk(Q_TABLE_INTRA, False), mk(Q_TABLE_INTER, True), mk(Q_TABLE_INTER, False),
+            float(np.float32(quality) * np.float32(1.5)))
