@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- macroblocks/s (encode+decode) on synthetic 1080p YUV 4:2:0, MI355X.
+
+One "step" = one GOP-15 (1 i-frame + 14 p-frames, README.md:34-41 pattern) of S independent
+synthetic 1080p streams per GPU, each frame ENCODED (with closed-loop reconstruction) and then
+DECODED from the coefficients just produced, all streams batched into one kernel launch per
+frame operation.  Inputs (the raw frames) are resident in HBM before the timed region starts;
+coefficients / motion vectors / reconstructed frames never leave HBM.  Entropy coding (host)
+is outside this path.
+
+    python bench.py --gpus N --steps K --warmup W [--streams S] [--width 1920 --height 1080]
+
+N > 1: one process per GPU (torchrun); the streams are independent, so they are sharded
+across ranks with NO data-path collective ("weak" scaling: S streams per GPU).  RCCL is used
+only for the stream-assignment broadcast and the final counter gather.
+
+The JSON line also carries
+  roofline     -- dominant kernel (k_enc_pframe): algorithmic bytes per launch (1284 B per
+                  macroblock) / its average HIP-event duration on the
+                  context's own stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm with its fork/join
+                  structure; the Rust reference itself cannot be built here) timed on this
+                  node's host cores on one GOP of one stream of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GOP = 15
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_MB_PENC = 1284        # src 256 + ref 256 + coef 512 + mv/flag 4 + recon 256
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=32, help="independent streams per GPU, batched per launch")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--quality", type=int, default=5)
+    ap.add_argument("--unique", type=int, default=2, help="distinct synthetic streams generated on the host per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, width, height, quality, frames_one_stream):
+    """encode+decode one GOP of one stream with the CPU oracle on all host cores"""
+    from oracle_bind import Oracle, OracleDecoder
+    ora = Oracle()
+    cores = os.cpu_count() or 1
+    enc = ora.encoder(width, height, quality, threads=cores)
+    dec = OracleDecoder(ora, width, height, np.stack(ora.qtables(quality)[:4]), threads=cores)
+    n_mb = enc.total_blocks
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        for t, f in enumerate(frames_one_stream):
+            if t == 0:
+                coef = enc.encode_iframe(f)
+                dec.decode_iframe(coef)
+            else:
+                mv, has, coef = enc.encode_pframe(f)
+                dec.decode_pframe(mv, has, coef)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 8:
+            break
+    assert np.array_equal(dec.framebuffer(), enc.prev_frame())
+    return {"value": reps * len(frames_one_stream) * n_mb / el, "unit": "macroblocks/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x GOP-{len(frames_one_stream)} encode+decode of one {width}x{height} stream "
+                      f"({reps * len(frames_one_stream) * n_mb} macroblocks, {el:.1f} s), C oracle with the reference's "
+                      f"per-plane fork/join over {cores} pthreads"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as graft
+    graft.build_hip()
+    pkg = graft.load_package()
+    from importlib import import_module
+    shard = import_module("pretty_fast_video_amd.shard")
+
+    W, H, S, Q = args.width, args.height, args.streams, args.quality
+
+    # ---- stream assignment: rank 0 decides, everyone learns it through one tiny broadcast
+    # (the only "scatter" this path has: stream ids / seeds, a few hundred bytes)
+    table = shard.assign_streams(n_streams_total=S * world, world=world, base_seed=pkg.synth.SEED)
+    if world > 1:
+        t = torch.tensor(table if rank == 0 else np.zeros_like(table), device=dev)
+        dist.broadcast(t, src=0)
+        table = t.cpu().numpy()
+    mine = shard.streams_of_rank(table, rank)
+    assert len(mine) == S
+
+    # ---- synthetic input, resident in HBM: [GOP][S][frame_bytes]
+    uniq = max(1, min(args.unique, S))
+    fb = int(pkg._lib.load().pfv_frame_bytes(W, H))
+    host = np.empty((GOP, uniq, fb), dtype=np.uint8)
+    for u in range(uniq):
+        st = pkg.SyntheticStream(W, H, seed=int(mine[u][1]))
+        for t in range(GOP):
+            host[t, u] = st.frame(t)
+    frames = torch.from_numpy(host).to(dev)                              # [GOP, uniq, fb]
+    frames = frames[:, torch.arange(S, device=dev) % uniq].contiguous()  # [GOP, S, fb]
+
+    ctx = pkg.Context(local_rank)
+    enc = pkg.EncoderSession(ctx, W, H, Q, S)
+    dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), S)
+    n_mb = enc.total_blocks
+    coef = torch.empty((S, n_mb, 256), dtype=torch.int16, device=dev)
+    mv = torch.empty((S, n_mb, 2), dtype=torch.int8, device=dev)
+    has = torch.empty((S, n_mb), dtype=torch.uint8, device=dev)
+    out_frames = torch.empty((S, fb), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.ExternalStream(ctx.stream, device=dev)           # HIP events on the kernels' own stream
+    torch.cuda.synchronize()
+
+    ev_pairs = []
+
+    def step(timed: bool):
+        for t in range(GOP):
+            f = frames[t].data_ptr()
+            if t == 0:
+                enc.encode_iframe_dev(f, coef.data_ptr())
+                dec.decode_iframe_dev(coef.data_ptr())
+            else:
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                enc.encode_pframe_dev(f, mv.data_ptr(), has.data_ptr(), coef.data_ptr())
+                if timed:
+                    e1.record(stream)
+                    ev_pairs.append((e0, e1))
+                dec.decode_pframe_dev(mv.data_ptr(), has.data_ptr(), coef.data_ptr())
+            dec.get_frame_dev(out_frames.data_ptr())                     # crop to retframe (src/dec.rs:209-211)
+
+    for _ in range(args.warmup):
+        step(False)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    dec.check()
+
+    # sanity inside the bench: decoder output == encoder reconstruction, and the p-frames did real work
+    assert np.array_equal(enc.prev_frame(), dec.framebuffer()), "decoder framebuffer != encoder reconstruction"
+    coded_frac = float(has.float().mean().item())
+
+    pe_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
+    elt = torch.tensor([el], device=dev, dtype=torch.float64)
+    cnt = torch.tensor([float(args.steps) * GOP * S * n_mb], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elt, op=dist.ReduceOp.MAX)       # max over ranks
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)       # counter gather
+    el_max, total_mb = float(elt.item()), float(cnt.item())
+
+    if rank == 0:
+        launch_mbs = S * n_mb
+        achieved = launch_mbs * BYTES_PER_MB_PENC / (pe_ms * 1e-3) / 1e9
+        res = {
+            "metric": "macroblocks/s (encode+decode) 1080p YUV420",
+            "value": total_mb / el_max,
+            "unit": "macroblocks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i32",
+            "data": f"synthetic ({uniq} distinct integer-hash texture streams per GPU tiled to {S}; quality {Q})",
+            "config": {"workload": f"{W}x{H} YUV420 GOP-{GOP} encode+decode, {S} independent streams per GPU batched per launch",
+                       "streams_per_gpu": S, "macroblocks_per_frame": n_mb, "quality": Q,
+                       "pframe_coded_fraction": round(coded_frac, 4), "parallelism": f"streams sharded over {world} GPU(s)"},
+            "roofline": {"bound": "hbm", "kernel": "k_enc_pframe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": pe_ms, "macroblocks_per_launch": launch_mbs,
+                         "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(pkg, W, H, Q, [host[t, 0] for t in range(GOP)])
+        elif not args.no_cpu_baseline:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+
+    enc.close()
+    dec.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

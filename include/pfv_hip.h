@@ -1,0 +1,181 @@
+/*
+ * pfv_hip.h -- C ABI of libpfv_hip.so: the MI355X (gfx950) implementation of the
+ * Pretty Fast Video (pfv-rs 0.2.2, codec 2.1.1) per-macroblock transform / motion path.
+ *
+ * This is the drop-in boundary: every entry point replaces one operator of the
+ * reference's plane-level API (`impl VideoPlane` in src/common.rs) or one hot-path
+ * section of its session objects (src/enc.rs, src/dec.rs).  The reference-side binding a
+ * maintainer would add (Rust `extern "C"`) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  `*_dev` entry points take DEVICE pointers and are
+ *     asynchronous on the context's HIP stream; the others take HOST pointers, stage
+ *     through the context and return when the result is in the caller's buffer
+ *     (the reference's calls are synchronous: `tp.install` blocks, src/common.rs:374).
+ *   - Every function returns PFV_OK (0) or a negative pfv_status; nothing unwinds or
+ *     aborts across this boundary (the reference panics on contract violations:
+ *     src/common.rs:217-218, src/enc.rs:38,76-80).
+ *   - Data layouts are the reference's own flattened structs:
+ *       coefficients  int16_t[n_mb][4][64]   (EncodedMacroBlock, src/common.rs:9-12:
+ *                                              subblocks TL,TR,BL,BR, zigzag order inside)
+ *       motion        int8_t [n_mb][2]       (DeltaEncodedMacroBlock.motion_x/_y, :14-19)
+ *       has_coef      uint8_t[n_mb]          (subblocks.is_some(); coefficients of a
+ *                                              skipped macroblock are written as zeros)
+ *       planes        uint8_t row-major, stride = width (VideoPlane, src/plane.rs:1-5)
+ *     Macroblocks are in raster order (src/common.rs:364-369); planes in Y,U,V order.
+ *   - Quantiser tables are int32_t[64] in raster order with every entry in [1, 65535]
+ *     (the file format stores them as u16, src/enc.rs:201-215).
+ *   - A context is not thread-safe; distinct contexts are independent (one HIP stream
+ *     each), like distinct Encoder/Decoder instances with their own rayon pools.
+ */
+#ifndef PFV_HIP_H
+#define PFV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFV_API __attribute__((visibility("default")))
+
+typedef enum pfv_status {
+    PFV_OK = 0,
+    PFV_ERR_BAD_ARG = -1,   /* null pointer, non-positive size, q entry outside [1,65535], quality outside 0..10 */
+    PFV_ERR_HIP = -2,       /* a HIP runtime call failed; see pfv_last_error() */
+    PFV_ERR_NOMEM = -3,
+    PFV_ERR_BAD_MV = -4,    /* a motion vector points outside the reference plane (src/common.rs:258-259) */
+    PFV_ERR_NO_DEVICE = -5, /* no usable gfx950 device */
+    PFV_ERR_FORMAT = -6,    /* DecodeError::FormatError (src/dec.rs:30-35) */
+    PFV_ERR_VERSION = -7,   /* DecodeError::VersionError */
+    PFV_ERR_IO = -8,        /* truncated / unreadable stream */
+    PFV_ERR_STATE = -9      /* e.g. encode after finish (src/enc.rs:80 assert) */
+} pfv_status;
+
+typedef struct pfv_ctx pfv_ctx;
+
+/* ------------------------------------------------------------------ context */
+/* Replaces the `num_threads` / rayon::ThreadPool slot of Encoder::new (src/enc.rs:37,54)
+ * and Decoder::new (src/dec.rs:38,125): the parallel resource is a device + stream. */
+PFV_API int pfv_ctx_create(int device, pfv_ctx **out);
+PFV_API void pfv_ctx_destroy(pfv_ctx *ctx);
+PFV_API int pfv_ctx_sync(pfv_ctx *ctx);
+/* hipStream_t of the context (for callers that enqueue their own work / HIP events) */
+PFV_API void *pfv_ctx_stream(pfv_ctx *ctx);
+/* last error text of this context (or of the calling thread when ctx == NULL) */
+PFV_API const char *pfv_last_error(pfv_ctx *ctx);
+PFV_API const char *pfv_version(void);
+
+/* x + (16 - x%16)%16  (src/common.rs:352-353, src/frame.rs:29-36) */
+PFV_API int pfv_pad16(int x);
+
+/* Encoder::new q-table derivation (src/enc.rs:40-51).  quality in 0..10. */
+PFV_API int pfv_qtables_from_quality(int quality, int32_t intra_l[64], int32_t intra_c[64], int32_t inter_l[64],
+                                     int32_t inter_c[64], float *px_err);
+
+/* ------------------------------------------------------------------ plane-level operators, host buffers */
+/* VideoPlane::encode_plane (src/common.rs:351-386).
+ * px: w*h source plane.  coef_out: pad16(w)/16 * pad16(h)/16 macroblocks * 256 int16. */
+PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, const int32_t q[64], uint8_t clear,
+                             int16_t *coef_out);
+
+/* VideoPlane::encode_plane_delta (src/common.rs:388-421).
+ * ref: previous reconstructed plane, pad16(w) x pad16(h). */
+PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h, const uint8_t *ref,
+                                   const int32_t q[64], float px_err, uint8_t clear, int8_t *mv_out,
+                                   uint8_t *has_coef_out, int16_t *coef_out);
+
+/* VideoPlane::decode_plane (src/common.rs:423-446) and decode_plane_into (:477-496):
+ * target is the bw*16 x bh*16 plane; every pixel is overwritten. */
+PFV_API int pfv_decode_plane_into(pfv_ctx *ctx, const int16_t *coef, int bw, int bh, const int32_t q[64],
+                                  uint8_t *target);
+
+/* VideoPlane::decode_plane_delta (src/common.rs:448-475): ref -> out (distinct buffers). */
+PFV_API int pfv_decode_plane_delta(pfv_ctx *ctx, const int8_t *mv, const uint8_t *has_coef, const int16_t *coef,
+                                   int bw, int bh, const int32_t q[64], const uint8_t *ref, uint8_t *out);
+
+/* VideoPlane::decode_plane_delta_into (src/common.rs:498-521): read-all-then-write-all
+ * into the same plane. */
+PFV_API int pfv_decode_plane_delta_into(pfv_ctx *ctx, const int8_t *mv, const uint8_t *has_coef,
+                                        const int16_t *coef, int bw, int bh, const int32_t q[64],
+                                        uint8_t *ref_and_target);
+
+/* VideoPlane::blit (src/plane.rs:20-29) on device-resident planes. */
+PFV_API int pfv_blit_dev(pfv_ctx *ctx, uint8_t *dst, int dst_w, int dst_h, const uint8_t *src, int src_w, int src_h,
+                         int dx, int dy, int sx, int sy, int sw, int sh);
+
+/* ------------------------------------------------------------------ device memory helpers */
+PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);
+PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p);
+PFV_API int pfv_dev_upload(pfv_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+PFV_API int pfv_dev_download(pfv_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ------------------------------------------------------------------ encoder session (hot-path half of enc::Encoder)
+ * Holds what Encoder holds for the hot path (src/enc.rs:12-26): width/height, the four
+ * q-tables, px_err and `prev_frame` (padded, resident in HBM, ping-ponged), for
+ * `n_streams` independent streams processed in one launch per frame step.
+ *
+ * Frame layout handed to the session ("frame" = VideoFrame, src/frame.rs:3-9):
+ *   one stream's frame = Y (w*h) | U (w/2*h/2) | V (w/2*h/2), tightly packed;
+ *   n_streams frames back to back.  pfv_frame_bytes(w,h) gives the size of one.
+ * Outputs per stream: total_blocks = blocks(Y)+blocks(U)+blocks(V) macroblocks in
+ * Y,U,V order -- exactly the order write_iframe_packet / write_pframe_packet consume
+ * (src/enc.rs:247-287, 342-400, 414-451). */
+typedef struct pfv_enc_session pfv_enc_session;
+
+PFV_API size_t pfv_frame_bytes(int width, int height);
+PFV_API size_t pfv_padded_frame_bytes(int width, int height);
+PFV_API int pfv_total_blocks(int width, int height);
+
+PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int quality, int n_streams,
+                                   pfv_enc_session **out);
+PFV_API void pfv_enc_session_destroy(pfv_enc_session *s);
+
+/* Encoder::encode_iframe, hot-path part (src/enc.rs:84-97): per plane encode_plane ->
+ * decode_plane -> prev_frame.blit, fused into one launch over all streams and planes. */
+PFV_API int pfv_enc_iframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, int16_t *coef_dev);
+/* Encoder::encode_pframe, hot-path part (src/enc.rs:134-147). */
+PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, int8_t *mv_dev, uint8_t *has_coef_dev,
+                               int16_t *coef_dev);
+/* host-buffer forms (one call = upload + launch + download + sync) */
+PFV_API int pfv_enc_iframe(pfv_enc_session *s, const uint8_t *frames, int16_t *coef_out);
+PFV_API int pfv_enc_pframe(pfv_enc_session *s, const uint8_t *frames, int8_t *mv_out, uint8_t *has_coef_out,
+                           int16_t *coef_out);
+/* device pointer of stream `stream`'s current prev_frame (padded Y|U|V), for checks */
+PFV_API const uint8_t *pfv_enc_prev_frame_dev(pfv_enc_session *s, int stream);
+/* copy prev_frame of all streams (padded) to host: n_streams * pfv_padded_frame_bytes */
+PFV_API int pfv_enc_prev_frame(pfv_enc_session *s, uint8_t *out_host);
+
+/* ------------------------------------------------------------------ decoder session (hot-path half of dec::Decoder)
+ * Holds `qtables` and the padded `framebuffer` (src/dec.rs:15-28), n_streams-wide.
+ * qtables: n_qtables tables of 64 (header order: intra_l, intra_c, inter_l, inter_c;
+ * src/enc.rs:199-215). */
+typedef struct pfv_dec_session pfv_dec_session;
+
+PFV_API int pfv_dec_session_create(pfv_ctx *ctx, int width, int height, const int32_t *qtables, int n_qtables,
+                                   int n_streams, pfv_dec_session **out);
+PFV_API void pfv_dec_session_destroy(pfv_dec_session *s);
+/* Decoder::decode_iframe after entropy decoding (src/dec.rs:298-323 -> deserialize_plane
+ * :450-479 -> decode_plane_into).  qidx: the three per-plane q-table indices of the
+ * packet (src/dec.rs:249-251). */
+PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, const uint8_t qidx[3]);
+/* Decoder::decode_pframe after entropy decoding (src/dec.rs:419-445 -> :481-517). */
+PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev,
+                               const int16_t *coef_dev, const uint8_t qidx[3]);
+PFV_API int pfv_dec_iframe(pfv_dec_session *s, const int16_t *coef, const uint8_t qidx[3]);
+PFV_API int pfv_dec_pframe(pfv_dec_session *s, const int8_t *mv, const uint8_t *has_coef, const int16_t *coef,
+                           const uint8_t qidx[3]);
+/* Decoder::advance_frame's crop of framebuffer into retframe (src/dec.rs:195-197,
+ * 209-211): frames_out = n_streams unpadded frames (Y|U|V). */
+PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev);
+PFV_API int pfv_dec_get_frame(pfv_dec_session *s, uint8_t *frames_out);
+/* padded framebuffer of all streams to host */
+PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host);
+/* asynchronous bad-motion-vector flag raised by the last *_dev p-frame decode(s); reading it syncs. */
+PFV_API int pfv_dec_check(pfv_dec_session *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFV_HIP_H */

@@ -602,3 +602,62 @@ PFVO_API void pfvo_encode_pframe(pfvo_encoder *e, const uint8_t *y, const uint8_
         off += (size_t)bw * bh;
     }
 }
+
+/* Decoder state restated from src/dec.rs:15-28 (hot-path fields only): q-tables + padded framebuffer. */
+typedef struct {
+    int width, height, threads, n_qtables;
+    int pw[3], ph[3];
+    uint8_t *fb[3];
+    int32_t *qtables; /* n_qtables x 64 */
+} pfvo_decoder;
+
+PFVO_API pfvo_decoder *pfvo_decoder_new(int width, int height, const int32_t *qtables, int n_qtables, int threads)
+{
+    pfvo_decoder *d = (pfvo_decoder *)calloc(1, sizeof *d);
+    d->width = width; d->height = height; d->threads = threads; d->n_qtables = n_qtables;
+    d->pw[0] = pad16(width); d->ph[0] = pad16(height);
+    d->pw[1] = d->pw[2] = pad16(width / 2); d->ph[1] = d->ph[2] = pad16(height / 2);
+    for (int p = 0; p < 3; p++) { /* VideoFrame::new_padded, src/dec.rs:123 + frame.rs:38-43 */
+        d->fb[p] = (uint8_t *)malloc((size_t)d->pw[p] * d->ph[p]);
+        memset(d->fb[p], p == 0 ? 0 : 128, (size_t)d->pw[p] * d->ph[p]);
+    }
+    d->qtables = (int32_t *)malloc((size_t)n_qtables * 64 * sizeof(int32_t));
+    memcpy(d->qtables, qtables, (size_t)n_qtables * 64 * sizeof(int32_t));
+    return d;
+}
+PFVO_API void pfvo_decoder_free(pfvo_decoder *d)
+{
+    if (!d) return;
+    for (int p = 0; p < 3; p++) free(d->fb[p]);
+    free(d->qtables);
+    free(d);
+}
+PFVO_API const uint8_t *pfvo_decoder_plane(const pfvo_decoder *d, int p, int *pw, int *ph)
+{
+    *pw = d->pw[p]; *ph = d->ph[p];
+    return d->fb[p];
+}
+/* src/dec.rs:298-323 (after entropy decoding): deserialize_plane x3 -> decode_plane_into */
+PFVO_API void pfvo_decode_iframe(pfvo_decoder *d, const int16_t *coef, const uint8_t qidx[3])
+{
+    size_t off = 0;
+    for (int p = 0; p < 3; p++) {
+        int bw = d->pw[p] / 16, bh = d->ph[p] / 16;
+        pfvo_decode_plane_into(coef + off * 256, bw, bh, d->qtables + (size_t)qidx[p] * 64, d->fb[p], d->threads);
+        off += (size_t)bw * bh;
+    }
+}
+/* src/dec.rs:419-445: deserialize_plane_delta x3 -> decode_plane_delta_into */
+PFVO_API int pfvo_decode_pframe(pfvo_decoder *d, const int8_t *mv, const uint8_t *has_coef, const int16_t *coef,
+                                const uint8_t qidx[3])
+{
+    size_t off = 0;
+    for (int p = 0; p < 3; p++) {
+        int bw = d->pw[p] / 16, bh = d->ph[p] / 16;
+        int rc = pfvo_decode_plane_delta(mv + off * 2, has_coef + off, coef + off * 256, bw, bh,
+                                         d->qtables + (size_t)qidx[p] * 64, d->fb[p], d->fb[p], d->threads);
+        if (rc) return rc;
+        off += (size_t)bw * bh;
+    }
+    return 0;
+}

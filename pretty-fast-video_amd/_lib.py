@@ -1,0 +1,108 @@
+"""ctypes loader for libpfv_hip.so (the C ABI declared in include/pfv_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+There is no fallback: if the shared object is missing or no GPU is visible, the calls fail
+loudly.  ``PFV_HIP_LIB`` may point at another build of the same C ABI (the test-suite uses
+this for the CPU emulator build of the *same sources*, tests/hipemu).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libpfv_hip.so")
+
+PFV_OK = 0
+PFV_ERR_BAD_ARG = -1
+PFV_ERR_HIP = -2
+PFV_ERR_NOMEM = -3
+PFV_ERR_BAD_MV = -4
+PFV_ERR_NO_DEVICE = -5
+PFV_ERR_FORMAT = -6
+PFV_ERR_VERSION = -7
+PFV_ERR_IO = -8
+PFV_ERR_STATE = -9
+
+
+class PfvError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pfv_hip error {code}: {msg}")
+        self.code = code
+
+
+# (name, restype, argtypes) -- must list every PFV_API symbol of include/pfv_hip.h
+_P = c_void_p
+SIGNATURES = [
+    ("pfv_ctx_create", c_int, [c_int, POINTER(_P)]),
+    ("pfv_ctx_destroy", None, [_P]),
+    ("pfv_ctx_sync", c_int, [_P]),
+    ("pfv_ctx_stream", _P, [_P]),
+    ("pfv_last_error", c_char_p, [_P]),
+    ("pfv_version", c_char_p, []),
+    ("pfv_pad16", c_int, [c_int]),
+    ("pfv_qtables_from_quality", c_int, [c_int, _P, _P, _P, _P, POINTER(c_float)]),
+    ("pfv_encode_plane", c_int, [_P, _P, c_int, c_int, _P, c_uint8, _P]),
+    ("pfv_encode_plane_delta", c_int, [_P, _P, c_int, c_int, _P, _P, c_float, c_uint8, _P, _P, _P]),
+    ("pfv_decode_plane_into", c_int, [_P, _P, c_int, c_int, _P, _P]),
+    ("pfv_decode_plane_delta", c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+    ("pfv_decode_plane_delta_into", c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
+    ("pfv_blit_dev", c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    ("pfv_dev_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
+    ("pfv_dev_free", c_int, [_P, _P]),
+    ("pfv_dev_upload", c_int, [_P, _P, _P, c_size_t]),
+    ("pfv_dev_download", c_int, [_P, _P, _P, c_size_t]),
+    ("pfv_frame_bytes", c_size_t, [c_int, c_int]),
+    ("pfv_padded_frame_bytes", c_size_t, [c_int, c_int]),
+    ("pfv_total_blocks", c_int, [c_int, c_int]),
+    ("pfv_enc_session_create", c_int, [_P, c_int, c_int, c_int, c_int, POINTER(_P)]),
+    ("pfv_enc_session_destroy", None, [_P]),
+    ("pfv_enc_iframe_dev", c_int, [_P, _P, _P]),
+    ("pfv_enc_pframe_dev", c_int, [_P, _P, _P, _P, _P]),
+    ("pfv_enc_iframe", c_int, [_P, _P, _P]),
+    ("pfv_enc_pframe", c_int, [_P, _P, _P, _P, _P]),
+    ("pfv_enc_prev_frame_dev", _P, [_P, c_int]),
+    ("pfv_enc_prev_frame", c_int, [_P, _P]),
+    ("pfv_dec_session_create", c_int, [_P, c_int, c_int, _P, c_int, c_int, POINTER(_P)]),
+    ("pfv_dec_session_destroy", None, [_P]),
+    ("pfv_dec_iframe_dev", c_int, [_P, _P, _P]),
+    ("pfv_dec_pframe_dev", c_int, [_P, _P, _P, _P, _P]),
+    ("pfv_dec_iframe", c_int, [_P, _P, _P]),
+    ("pfv_dec_pframe", c_int, [_P, _P, _P, _P, _P]),
+    ("pfv_dec_get_frame_dev", c_int, [_P, _P]),
+    ("pfv_dec_get_frame", c_int, [_P, _P]),
+    ("pfv_dec_framebuffer", c_int, [_P, _P]),
+    ("pfv_dec_check", c_int, [_P]),
+]
+
+_lib = None
+_lib_path = None
+
+
+def lib_path() -> str:
+    return os.environ.get("PFV_HIP_LIB", DEFAULT_LIB)
+
+
+def load():
+    """Load the shared object and bind every symbol; raises if it is missing (no fallback)."""
+    global _lib, _lib_path
+    path = lib_path()
+    if _lib is not None and _lib_path == path:
+        return _lib
+    if not os.path.exists(path):
+        raise PfvError(PFV_ERR_NO_DEVICE, f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(path)
+    for name, restype, argtypes in SIGNATURES:
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def check(ctx_handle, rc: int):
+    if rc != PFV_OK:
+        msg = load().pfv_last_error(ctx_handle)
+        raise PfvError(rc, msg.decode() if msg else "")

@@ -1,0 +1,76 @@
+"""Context = the parallel resource handed to every operator.
+
+Takes the place of the reference's ``tp: &rayon::ThreadPool`` argument (src/common.rs:351)
+and of ``num_threads`` in ``Encoder::new`` / ``Decoder::new`` (src/enc.rs:37, src/dec.rs:38):
+here the resource is one MI355X device + one HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.pfv_ctx_create(int(device), ctypes.byref(h))
+        if rc != _lib.PFV_OK:
+            msg = self._lib.pfv_last_error(None)
+            raise _lib.PfvError(rc, msg.decode() if msg else "")
+        self.handle = h
+        self.device = int(device)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.pfv_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- helpers
+    def check(self, rc: int):
+        _lib.check(self.handle, rc)
+
+    def sync(self):
+        self.check(self._lib.pfv_ctx_sync(self.handle))
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.pfv_ctx_stream(self.handle) or 0)
+
+    def alloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self.check(self._lib.pfv_dev_alloc(self.handle, int(nbytes), ctypes.byref(p)))
+        return int(p.value)
+
+    def free(self, ptr: int):
+        self.check(self._lib.pfv_dev_free(self.handle, ctypes.c_void_p(ptr)))
+
+    def upload(self, dst_dev: int, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        self.check(self._lib.pfv_dev_upload(self.handle, ctypes.c_void_p(dst_dev), src.ctypes.data_as(ctypes.c_void_p),
+                                            src.nbytes))
+
+    def download(self, dst: np.ndarray, src_dev: int):
+        assert dst.flags["C_CONTIGUOUS"]
+        self.check(self._lib.pfv_dev_download(self.handle, dst.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(src_dev),
+                                              dst.nbytes))
+
+
+def ptr(a: np.ndarray) -> ctypes.c_void_p:
+    return a.ctypes.data_as(ctypes.c_void_p)

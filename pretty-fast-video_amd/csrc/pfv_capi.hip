@@ -1,0 +1,833 @@
+// pfv_capi.hip -- the extern "C" boundary (include/pfv_hip.h) over the gfx950 kernels.
+// One translation unit with the kernels: hipcc --offload-arch=gfx950 -shared.
+//
+// There is NO CPU fallback here: every entry point either runs the HIP kernels or returns
+// a negative status.
+#include "pfv_kernels.hip"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pfv_hip.h"
+
+using namespace pfv;
+
+// ------------------------------------------------------------------ reference constants (data)
+// src/dct.rs:4-13
+static const int32_t H_SCALE[64] = {
+    32, 37, 34, 26, 32, 26, 34, 37, 37, 43, 39, 31, 37, 31, 39, 43, 34, 39, 35, 28, 34, 28, 35, 39, 26, 31, 28, 22, 26, 22,
+    28, 31, 32, 37, 34, 26, 32, 26, 34, 37, 26, 31, 28, 22, 26, 22, 28, 31, 34, 39, 35, 28, 34, 28, 35, 39, 37, 43, 39, 31,
+    37, 31, 39, 43,
+};
+// src/dct.rs:16-25
+static const int32_t H_Q_INTRA[64] = {
+    8,  16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37, 19, 22, 26, 27, 29, 34, 34, 38, 22, 22, 26, 27, 29, 34,
+    37, 40, 22, 26, 27, 29, 32, 35, 40, 48, 26, 27, 29, 32, 35, 40, 48, 58, 26, 27, 29, 34, 38, 46, 56, 69, 27, 29, 35, 38,
+    46, 56, 69, 83,
+};
+// src/dct.rs:28-37: all 16
+static const int32_t H_Q_INTER = 16;
+// src/dct.rs:39-42
+static const uint8_t H_INV_ZIGZAG[64] = {
+    0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40,
+    44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49,
+    57, 58, 62, 63,
+};
+
+// ------------------------------------------------------------------ context
+struct pfv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only device scratch for the host-pointer entry points
+    void *scratch[8] = {};
+    size_t scratch_cap[8] = {};
+    QTab *qtab_dev = nullptr;    // 4 slots
+    QTab *qtab_host = nullptr;   // pinned mirror
+    int *flag_dev = nullptr;
+};
+
+static thread_local std::string g_tls_err;
+
+static int fail(pfv_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    g_tls_err = msg;
+    return code;
+}
+static int hip_fail(pfv_ctx *ctx, hipError_t e, const char *what)
+{
+    (void)hipGetLastError();
+    return fail(ctx, e == hipErrorOutOfMemory ? PFV_ERR_NOMEM : PFV_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, expr)                                        \
+    do {                                                          \
+        hipError_t e__ = (expr);                                  \
+        if (e__ != hipSuccess) return hip_fail(ctx, e__, #expr);  \
+    } while (0)
+
+static inline int pad16(int x) { return x + (16 - (x % 16)) % 16; }
+
+extern "C" {
+
+PFV_API const char *pfv_version(void) { return "pfv-hip 0.1 (gfx950; pfv-rs 0.2.2 / codec 2.1.1 hot path)"; }
+PFV_API int pfv_pad16(int x) { return pad16(x); }
+
+PFV_API const char *pfv_last_error(pfv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+
+PFV_API int pfv_ctx_create(int device, pfv_ctx **out)
+{
+    if (!out) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_ctx_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, PFV_ERR_NO_DEVICE, "pfv_ctx_create: no HIP device visible (the HIP path has no CPU fallback)");
+    }
+    if (device < 0 || device >= n) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_ctx_create: device ordinal out of range");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    pfv_ctx *ctx = new pfv_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->qtab_dev, 4 * sizeof(QTab));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->qtab_host, 4 * sizeof(QTab), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->flag_dev, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream);
+    if (e != hipSuccess) {
+        int rc = hip_fail(nullptr, e, "pfv_ctx_create");
+        pfv_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return PFV_OK;
+}
+
+PFV_API void pfv_ctx_destroy(pfv_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 8; i++)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->qtab_dev) (void)hipFree(ctx->qtab_dev);
+    if (ctx->qtab_host) (void)hipHostFree(ctx->qtab_host);
+    if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+PFV_API int pfv_ctx_sync(pfv_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+PFV_API void *pfv_ctx_stream(pfv_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// Encoder::new, src/enc.rs:40-51
+PFV_API int pfv_qtables_from_quality(int quality, int32_t intra_l[64], int32_t intra_c[64], int32_t inter_l[64],
+                                     int32_t inter_c[64], float *px_err)
+{
+    if (quality < 0 || quality > 10) return fail(nullptr, PFV_ERR_BAD_ARG, "quality must be in 0..10 (src/enc.rs:38)");
+    float qscale = (float)quality * 0.25f;
+    if (px_err) *px_err = (float)quality * 1.5f;
+    for (int i = 0; i < 64; i++) {
+        if (inter_l) inter_l[i] = (int32_t)fmaxf((float)H_Q_INTER * qscale * 0.5f, 1.0f);
+        if (inter_c) inter_c[i] = (int32_t)fmaxf((float)H_Q_INTER * qscale, 1.0f);
+        if (intra_l) intra_l[i] = (int32_t)fmaxf((float)H_Q_INTRA[i] * qscale * 0.5f, 1.0f);
+        if (intra_c) intra_c[i] = (int32_t)fmaxf((float)H_Q_INTRA[i] * qscale, 1.0f);
+    }
+    return PFV_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ internal helpers
+static int make_qtab(pfv_ctx *ctx, const int32_t q[64], QTab *out)
+{
+    if (!q) return fail(ctx, PFV_ERR_BAD_ARG, "q-table is null");
+    for (int i = 0; i < 64; i++)
+        if (q[i] < 1 || q[i] > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "q-table entry outside [1,65535]");
+    for (int i = 0; i < 64; i++) {
+        volatile float r = 1.0f / (float)q[i];
+        r = r * 1.000000476837158203125f;   // 1 + 2^-21: see QTab::rcp
+        out->rcp[i] = r;
+        int z = H_INV_ZIGZAG[i];
+        out->deq[i] = (int32_t)((uint32_t)H_SCALE[z] * (uint32_t)q[z]);
+    }
+    return PFV_OK;
+}
+
+static int ensure_scratch(pfv_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    if (ctx->scratch_cap[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_cap[slot] = 0;
+        }
+        size_t cap = (bytes + 4095) & ~(size_t)4095;
+        HIP_TRY(ctx, hipMalloc(&ctx->scratch[slot], cap));
+        ctx->scratch_cap[slot] = cap;
+    }
+    *out = ctx->scratch[slot];
+    return PFV_OK;
+}
+
+static void fill_plane(PlaneGeom &p, int w, int h, int strip0, int mb0, long src_off, long pad_off, int qsel, int clear)
+{
+    p.w = w; p.h = h;
+    p.pw = pad16(w); p.ph = pad16(h);
+    p.bw = p.pw / 16; p.bh = p.ph / 16;
+    p.strips_x = (p.bw + kStripMB - 1) / kStripMB;
+    p.strip0 = strip0; p.mb0 = mb0;
+    p.qsel = qsel; p.clear = clear;
+    p.src_off = src_off; p.pad_off = pad_off;
+    p.fast_src = 0;
+}
+
+// geometry of a single plane handed over on its own (plane-level operators)
+static FrameGeom plane_geom(int w, int h, int clear)
+{
+    FrameGeom g;
+    memset(&g, 0, sizeof g);
+    fill_plane(g.p[0], w, h, 0, 0, 0, 0, 0, clear);
+    g.p[1] = g.p[0]; g.p[2] = g.p[0];
+    g.n_planes = 1;
+    g.strips_per_frame = g.p[0].strips_x * g.p[0].bh;
+    g.mbs_per_frame = g.p[0].bw * g.p[0].bh;
+    g.n_streams = 1;
+    g.src_frame_bytes = (long)w * h;
+    g.pad_frame_bytes = (long)g.p[0].pw * g.p[0].ph;
+    g.p[0].fast_src = (w % 16 == 0);
+    return g;
+}
+
+// geometry of a YUV 4:2:0 VideoFrame (src/frame.rs:12-49): chroma = (w/2) x (h/2),
+// padded independently (frame.rs:31-36)
+static FrameGeom frame_geom(int w, int h, int n_streams)
+{
+    FrameGeom g;
+    memset(&g, 0, sizeof g);
+    int cw = w / 2, ch = h / 2;
+    fill_plane(g.p[0], w, h, 0, 0, 0, 0, 0, 0);
+    long y_src = (long)w * h, y_pad = (long)g.p[0].pw * g.p[0].ph;
+    int s1 = g.p[0].strips_x * g.p[0].bh, m1 = g.p[0].bw * g.p[0].bh;
+    fill_plane(g.p[1], cw, ch, s1, m1, y_src, y_pad, 1, 128);
+    long c_src = (long)cw * ch, c_pad = (long)g.p[1].pw * g.p[1].ph;
+    int s2 = s1 + g.p[1].strips_x * g.p[1].bh, m2 = m1 + g.p[1].bw * g.p[1].bh;
+    fill_plane(g.p[2], cw, ch, s2, m2, y_src + c_src, y_pad + c_pad, 1, 128);
+    g.n_planes = 3;
+    g.strips_per_frame = s2 + g.p[2].strips_x * g.p[2].bh;
+    g.mbs_per_frame = m2 + g.p[2].bw * g.p[2].bh;
+    g.n_streams = n_streams;
+    g.src_frame_bytes = y_src + 2 * c_src;
+    g.pad_frame_bytes = y_pad + 2 * c_pad;
+    for (int i = 0; i < 3; i++)
+        g.p[i].fast_src = (g.p[i].w % 16 == 0) && (g.p[i].src_off % 16 == 0) && (g.src_frame_bytes % 16 == 0);
+    return g;
+}
+
+static FrameGeom with_base_alignment(FrameGeom g, const void *src_base)
+{
+    if (((uintptr_t)src_base & 15) != 0)
+        for (int i = 0; i < 3; i++) g.p[i].fast_src = 0;
+    return g;
+}
+
+static int launch_check(pfv_ctx *ctx, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(ctx, e, what);
+    return PFV_OK;
+}
+
+static int upload_qtabs(pfv_ctx *ctx, const int32_t *const *tables, int n)
+{
+    // the previous user of the pinned mirror has finished: plane-level host calls sync before returning
+    for (int i = 0; i < n; i++) {
+        int rc = make_qtab(ctx, tables[i], &ctx->qtab_host[i]);
+        if (rc) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->qtab_dev, ctx->qtab_host, n * sizeof(QTab), hipMemcpyHostToDevice, ctx->stream));
+    return PFV_OK;
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------ plane-level operators (host buffers)
+PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, const int32_t q[64], uint8_t clear,
+                             int16_t *coef_out)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!px || !coef_out || w <= 0 || h <= 0) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_encode_plane: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g = plane_geom(w, h, clear);
+    const int32_t *tabs[1] = {q};
+    int rc = upload_qtabs(ctx, tabs, 1);
+    if (rc) return rc;
+    void *d_src, *d_coef;
+    size_t coef_bytes = (size_t)g.mbs_per_frame * 512;
+    if ((rc = ensure_scratch(ctx, 0, (size_t)w * h, &d_src))) return rc;
+    if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_enc_iframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
+                                                                   ctx->qtab_dev);
+    if ((rc = launch_check(ctx, "k_enc_iframe"))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h, const uint8_t *ref,
+                                   const int32_t q[64], float px_err, uint8_t clear, int8_t *mv_out,
+                                   uint8_t *has_coef_out, int16_t *coef_out)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!px || !ref || !mv_out || !has_coef_out || !coef_out || w <= 0 || h <= 0)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_encode_plane_delta: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g = plane_geom(w, h, clear);
+    const int32_t *tabs[1] = {q};
+    int rc = upload_qtabs(ctx, tabs, 1);
+    if (rc) return rc;
+    size_t n = (size_t)g.mbs_per_frame, coef_bytes = n * 512, pad_bytes = (size_t)g.pad_frame_bytes;
+    void *d_src, *d_coef, *d_ref, *d_mv, *d_has;
+    if ((rc = ensure_scratch(ctx, 0, (size_t)w * h, &d_src))) return rc;
+    if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
+    if ((rc = ensure_scratch(ctx, 2, pad_bytes, &d_ref))) return rc;
+    if ((rc = ensure_scratch(ctx, 3, n * 2, &d_mv))) return rc;
+    if ((rc = ensure_scratch(ctx, 4, n, &d_has))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
+    float min_err = px_err * px_err * 256.0f;   // src/common.rs:209
+    hipLaunchKernelGGL(k_enc_pframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
+                                                                   (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
+                                                                   nullptr, ctx->qtab_dev, min_err);
+    if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mv_out, d_mv, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(has_coef_out, d_has, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+PFV_API int pfv_decode_plane_into(pfv_ctx *ctx, const int16_t *coef, int bw, int bh, const int32_t q[64],
+                                  uint8_t *target)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!coef || !target || bw <= 0 || bh <= 0) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_decode_plane_into: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g = plane_geom(bw * 16, bh * 16, 0);
+    const int32_t *tabs[1] = {q};
+    int rc = upload_qtabs(ctx, tabs, 1);
+    if (rc) return rc;
+    size_t n = (size_t)bw * bh, coef_bytes = n * 512, pad_bytes = (size_t)g.pad_frame_bytes;
+    void *d_coef, *d_out;
+    if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
+    if ((rc = ensure_scratch(ctx, 5, pad_bytes, &d_out))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_coef, coef, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_dec_iframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const int16_t *)d_coef, (uint8_t *)d_out,
+                                                                   ctx->qtab_dev);
+    if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(target, d_out, pad_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+PFV_API int pfv_decode_plane_delta(pfv_ctx *ctx, const int8_t *mv, const uint8_t *has_coef, const int16_t *coef,
+                                   int bw, int bh, const int32_t q[64], const uint8_t *ref, uint8_t *out)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!mv || !has_coef || !coef || !ref || !out || bw <= 0 || bh <= 0)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_decode_plane_delta: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g = plane_geom(bw * 16, bh * 16, 0);
+    const int32_t *tabs[1] = {q};
+    int rc = upload_qtabs(ctx, tabs, 1);
+    if (rc) return rc;
+    size_t n = (size_t)bw * bh, coef_bytes = n * 512, pad_bytes = (size_t)g.pad_frame_bytes;
+    void *d_coef, *d_ref, *d_mv, *d_has, *d_out;
+    if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
+    if ((rc = ensure_scratch(ctx, 2, pad_bytes, &d_ref))) return rc;
+    if ((rc = ensure_scratch(ctx, 3, n * 2, &d_mv))) return rc;
+    if ((rc = ensure_scratch(ctx, 4, n, &d_has))) return rc;
+    if ((rc = ensure_scratch(ctx, 5, pad_bytes, &d_out))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_coef, coef, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_mv, mv, n * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_has, has_coef, n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_dec_pframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const int8_t *)d_mv, (const uint8_t *)d_has,
+                                                                   (const int16_t *)d_coef, (const uint8_t *)d_ref,
+                                                                   (uint8_t *)d_out, ctx->qtab_dev, ctx->flag_dev);
+    if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
+    int flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) return fail(ctx, PFV_ERR_BAD_MV, "motion vector points outside the reference plane (src/common.rs:258-259)");
+    HIP_TRY(ctx, hipMemcpy(out, d_out, pad_bytes, hipMemcpyDeviceToHost));
+    return PFV_OK;
+}
+
+PFV_API int pfv_decode_plane_delta_into(pfv_ctx *ctx, const int8_t *mv, const uint8_t *has_coef,
+                                        const int16_t *coef, int bw, int bh, const int32_t q[64],
+                                        uint8_t *ref_and_target)
+{
+    // read-all-then-write-all (src/common.rs:498-521): the device reads plane A and writes plane B
+    return pfv_decode_plane_delta(ctx, mv, has_coef, coef, bw, bh, q, ref_and_target, ref_and_target);
+}
+
+PFV_API int pfv_blit_dev(pfv_ctx *ctx, uint8_t *dst, int dst_w, int dst_h, const uint8_t *src, int src_w, int src_h,
+                         int dx, int dy, int sx, int sy, int sw, int sh)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!dst || !src || sw < 0 || sh < 0 || dx < 0 || dy < 0 || sx < 0 || sy < 0 || dx + sw > dst_w || dy + sh > dst_h ||
+        sx + sw > src_w || sy + sh > src_h)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_blit_dev: rectangle outside a plane (the reference panics on slice bounds)");
+    if (sw == 0 || sh == 0) return PFV_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    long n = (long)sw * sh;
+    int blocks = (int)((n + kThreads - 1) / kThreads);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_blit, dim3(blocks), dim3(kThreads), 0, ctx->stream, dst, dst_w, src, src_w, dx, dy, sx, sy, sw, sh);
+    return launch_check(ctx, "k_blit");
+}
+
+// ------------------------------------------------------------------ device memory helpers
+PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dev_alloc: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(out, bytes ? bytes : 16));
+    return PFV_OK;
+}
+PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!p) return PFV_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(p));
+    return PFV_OK;
+}
+PFV_API int pfv_dev_upload(pfv_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (!ctx || !dst_dev || !src_host) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dev_upload: bad argument");
+    HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+PFV_API int pfv_dev_download(pfv_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (!ctx || !dst_host || !src_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dev_download: bad argument");
+    HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+// ------------------------------------------------------------------ frame geometry queries
+PFV_API size_t pfv_frame_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    return (size_t)width * height + 2 * (size_t)(width / 2) * (height / 2);
+}
+PFV_API size_t pfv_padded_frame_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    return (size_t)pad16(width) * pad16(height) + 2 * (size_t)pad16(width / 2) * pad16(height / 2);
+}
+PFV_API int pfv_total_blocks(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    return (pad16(width) / 16) * (pad16(height) / 16) + 2 * (pad16(width / 2) / 16) * (pad16(height / 2) / 16);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ sessions
+static int init_padded(pfv_ctx *ctx, const FrameGeom &g, uint8_t *buf)
+{
+    dim3 grid(64, 3, g.n_streams);
+    hipLaunchKernelGGL(k_init_padded, grid, dim3(kThreads), 0, ctx->stream, g, buf);
+    return launch_check(ctx, "k_init_padded");
+}
+
+struct pfv_enc_session {
+    pfv_ctx *ctx = nullptr;
+    int width = 0, height = 0, n_streams = 0;
+    FrameGeom geom;
+    QTab *qtab_dev = nullptr;       // intra_l, intra_c, inter_l, inter_c
+    float px_err = 0.0f;
+    uint8_t *prev[2] = {nullptr, nullptr};   // ping-pong prev_frame, padded, n_streams wide
+    int cur = 0;                             // prev[cur] is the current prev_frame
+    // staging for the host-buffer entry points
+    uint8_t *st_frames = nullptr;
+    int16_t *st_coef = nullptr;
+    int8_t *st_mv = nullptr;
+    uint8_t *st_has = nullptr;
+};
+
+struct pfv_dec_session {
+    pfv_ctx *ctx = nullptr;
+    int width = 0, height = 0, n_streams = 0, n_qtables = 0;
+    FrameGeom geom;
+    QTab *qtab_dev = nullptr;
+    uint8_t *fb[2] = {nullptr, nullptr};     // ping-pong framebuffer
+    int cur = 0;
+    int *flag_dev = nullptr;
+    int16_t *st_coef = nullptr;
+    int8_t *st_mv = nullptr;
+    uint8_t *st_has = nullptr;
+    uint8_t *st_frames = nullptr;
+};
+
+extern "C" {
+
+PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int quality, int n_streams,
+                                   pfv_enc_session **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_session_create: bad argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (width & 1) || (height & 1) || width > 65535 || height > 65535)
+        return fail(ctx, PFV_ERR_BAD_ARG, "width/height must be even (src/frame.rs:13) and fit u16 (src/enc.rs:195-196)");
+    if (quality < 0 || quality > 10) return fail(ctx, PFV_ERR_BAD_ARG, "quality must be in 0..10 (src/enc.rs:38)");
+    if (n_streams <= 0) return fail(ctx, PFV_ERR_BAD_ARG, "n_streams must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pfv_enc_session *s = new pfv_enc_session();
+    s->ctx = ctx; s->width = width; s->height = height; s->n_streams = n_streams;
+    s->geom = frame_geom(width, height, n_streams);
+    int32_t q[4][64];
+    pfv_qtables_from_quality(quality, q[0], q[1], q[2], q[3], &s->px_err);
+    QTab tabs[4];
+    for (int i = 0; i < 4; i++) {
+        int rc = make_qtab(ctx, q[i], &tabs[i]);
+        if (rc) { delete s; return rc; }
+    }
+    size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
+    hipError_t e = hipMalloc((void **)&s->qtab_dev, sizeof tabs);
+    if (e == hipSuccess) e = hipMemcpy(s->qtab_dev, tabs, sizeof tabs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->prev[0], pad_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->prev[1], pad_bytes);
+    if (e != hipSuccess) {
+        int rc = hip_fail(ctx, e, "pfv_enc_session_create");
+        pfv_enc_session_destroy(s);
+        return rc;
+    }
+    // prev_frame = VideoFrame::new_padded (src/enc.rs:46)
+    int rc = init_padded(ctx, s->geom, s->prev[0]);
+    if (!rc) rc = init_padded(ctx, s->geom, s->prev[1]);
+    if (rc) { pfv_enc_session_destroy(s); return rc; }
+    *out = s;
+    return PFV_OK;
+}
+
+PFV_API void pfv_enc_session_destroy(pfv_enc_session *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    void *bufs[] = {s->qtab_dev, s->prev[0], s->prev[1], s->st_frames, s->st_coef, s->st_mv, s->st_has};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete s;
+}
+
+PFV_API int pfv_enc_iframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, int16_t *coef_dev)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!frames_dev || !coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_iframe_dev: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g = with_base_alignment(s->geom, frames_dev);
+    int nxt = s->cur ^ 1;
+    hipLaunchKernelGGL(k_enc_iframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt],
+                                                                                 s->qtab_dev + 0);
+    int rc = launch_check(ctx, "k_enc_iframe");
+    if (rc) return rc;
+    s->cur = nxt;
+    return PFV_OK;
+}
+
+PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, int8_t *mv_dev, uint8_t *has_coef_dev,
+                               int16_t *coef_dev)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!frames_dev || !mv_dev || !has_coef_dev || !coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_pframe_dev: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g = with_base_alignment(s->geom, frames_dev);
+    int nxt = s->cur ^ 1;
+    float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
+    hipLaunchKernelGGL(k_enc_pframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, 
+        g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err);
+    int rc = launch_check(ctx, "k_enc_pframe");
+    if (rc) return rc;
+    s->cur = nxt;
+    return PFV_OK;
+}
+
+static int enc_staging(pfv_enc_session *s)
+{
+    pfv_ctx *ctx = s->ctx;
+    if (s->st_frames) return PFV_OK;
+    size_t n = (size_t)s->geom.mbs_per_frame * s->n_streams;
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_frames, (size_t)s->geom.src_frame_bytes * s->n_streams));
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_coef, n * 512));
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_mv, n * 2));
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_has, n));
+    return PFV_OK;
+}
+
+PFV_API int pfv_enc_iframe(pfv_enc_session *s, const uint8_t *frames, int16_t *coef_out)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!frames || !coef_out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_iframe: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = enc_staging(s);
+    if (rc) return rc;
+    size_t n = (size_t)s->geom.mbs_per_frame * s->n_streams;
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_frames, frames, (size_t)s->geom.src_frame_bytes * s->n_streams,
+                                hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pfv_enc_iframe_dev(s, s->st_frames, s->st_coef))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(coef_out, s->st_coef, n * 512, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+PFV_API int pfv_enc_pframe(pfv_enc_session *s, const uint8_t *frames, int8_t *mv_out, uint8_t *has_coef_out,
+                           int16_t *coef_out)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!frames || !mv_out || !has_coef_out || !coef_out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_pframe: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = enc_staging(s);
+    if (rc) return rc;
+    size_t n = (size_t)s->geom.mbs_per_frame * s->n_streams;
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_frames, frames, (size_t)s->geom.src_frame_bytes * s->n_streams,
+                                hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pfv_enc_pframe_dev(s, s->st_frames, s->st_mv, s->st_has, s->st_coef))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(coef_out, s->st_coef, n * 512, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mv_out, s->st_mv, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(has_coef_out, s->st_has, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+PFV_API const uint8_t *pfv_enc_prev_frame_dev(pfv_enc_session *s, int stream)
+{
+    if (!s || stream < 0 || stream >= s->n_streams) return nullptr;
+    return s->prev[s->cur] + (size_t)stream * s->geom.pad_frame_bytes;
+}
+
+PFV_API int pfv_enc_prev_frame(pfv_enc_session *s, uint8_t *out_host)
+{
+    if (!s || !out_host) return fail(s ? s->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_enc_prev_frame: bad argument");
+    pfv_ctx *ctx = s->ctx;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, s->prev[s->cur], (size_t)s->geom.pad_frame_bytes * s->n_streams,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+// ------------------------------------------------------------------ decoder session
+PFV_API int pfv_dec_session_create(pfv_ctx *ctx, int width, int height, const int32_t *qtables, int n_qtables,
+                                   int n_streams, pfv_dec_session **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_session_create: bad argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (width & 1) || (height & 1) || width > 65535 || height > 65535)
+        return fail(ctx, PFV_ERR_BAD_ARG, "width/height must be even (src/frame.rs:13) and fit u16");
+    if (!qtables || n_qtables <= 0 || n_qtables > 256 || n_streams <= 0)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_session_create: bad q-table set or stream count");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<QTab> tabs((size_t)n_qtables);
+    for (int i = 0; i < n_qtables; i++) {
+        int rc = make_qtab(ctx, qtables + (size_t)i * 64, &tabs[i]);
+        if (rc) return rc;
+    }
+    pfv_dec_session *s = new pfv_dec_session();
+    s->ctx = ctx; s->width = width; s->height = height; s->n_streams = n_streams; s->n_qtables = n_qtables;
+    s->geom = frame_geom(width, height, n_streams);
+    size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
+    hipError_t e = hipMalloc((void **)&s->qtab_dev, tabs.size() * sizeof(QTab));
+    if (e == hipSuccess) e = hipMemcpy(s->qtab_dev, tabs.data(), tabs.size() * sizeof(QTab), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->fb[0], pad_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->fb[1], pad_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->flag_dev, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(s->flag_dev, 0, sizeof(int));
+    if (e != hipSuccess) {
+        int rc = hip_fail(ctx, e, "pfv_dec_session_create");
+        pfv_dec_session_destroy(s);
+        return rc;
+    }
+    // framebuffer = VideoFrame::new_padded (src/dec.rs:123)
+    int rc = init_padded(ctx, s->geom, s->fb[0]);
+    if (!rc) rc = init_padded(ctx, s->geom, s->fb[1]);
+    if (rc) { pfv_dec_session_destroy(s); return rc; }
+    *out = s;
+    return PFV_OK;
+}
+
+PFV_API void pfv_dec_session_destroy(pfv_dec_session *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    void *bufs[] = {s->qtab_dev, s->fb[0], s->fb[1], s->flag_dev, s->st_coef, s->st_mv, s->st_has, s->st_frames};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete s;
+}
+
+static int dec_geom(pfv_dec_session *s, const uint8_t qidx[3], FrameGeom *g)
+{
+    if (!qidx) return fail(s->ctx, PFV_ERR_BAD_ARG, "qidx is null");
+    *g = s->geom;
+    for (int i = 0; i < 3; i++) {
+        if (qidx[i] >= s->n_qtables)
+            return fail(s->ctx, PFV_ERR_FORMAT, "q-table index out of range (the reference panics: src/dec.rs:249-251)");
+        g->p[i].qsel = qidx[i];
+    }
+    return PFV_OK;
+}
+
+PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_dev: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g;
+    int rc = dec_geom(s, qidx, &g);
+    if (rc) return rc;
+    int nxt = s->cur ^ 1;
+    hipLaunchKernelGGL(k_dec_iframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, g, coef_dev, s->fb[nxt], s->qtab_dev);
+    if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
+    s->cur = nxt;
+    return PFV_OK;
+}
+
+PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev,
+                               const int16_t *coef_dev, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!mv_dev || !has_coef_dev || !coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_dev: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g;
+    int rc = dec_geom(s, qidx, &g);
+    if (rc) return rc;
+    int nxt = s->cur ^ 1;
+    hipLaunchKernelGGL(k_dec_pframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, 
+        g, mv_dev, has_coef_dev, coef_dev, s->fb[s->cur], s->fb[nxt], s->qtab_dev, s->flag_dev);
+    if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
+    s->cur = nxt;
+    return PFV_OK;
+}
+
+PFV_API int pfv_dec_check(pfv_dec_session *s)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    int flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, s->flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        HIP_TRY(ctx, hipMemsetAsync(s->flag_dev, 0, sizeof(int), ctx->stream));
+        return fail(ctx, PFV_ERR_BAD_MV, "motion vector points outside the reference plane (src/common.rs:258-259)");
+    }
+    return PFV_OK;
+}
+
+static int dec_staging(pfv_dec_session *s)
+{
+    pfv_ctx *ctx = s->ctx;
+    if (s->st_coef) return PFV_OK;
+    size_t n = (size_t)s->geom.mbs_per_frame * s->n_streams;
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_coef, n * 512));
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_mv, n * 2));
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_has, n));
+    HIP_TRY(ctx, hipMalloc((void **)&s->st_frames, (size_t)s->geom.src_frame_bytes * s->n_streams));
+    return PFV_OK;
+}
+
+PFV_API int pfv_dec_iframe(pfv_dec_session *s, const int16_t *coef, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!coef) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = dec_staging(s);
+    if (rc) return rc;
+    size_t n = (size_t)s->geom.mbs_per_frame * s->n_streams;
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_coef, coef, n * 512, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pfv_dec_iframe_dev(s, s->st_coef, qidx))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+PFV_API int pfv_dec_pframe(pfv_dec_session *s, const int8_t *mv, const uint8_t *has_coef, const int16_t *coef,
+                           const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!mv || !has_coef || !coef) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = dec_staging(s);
+    if (rc) return rc;
+    size_t n = (size_t)s->geom.mbs_per_frame * s->n_streams;
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_coef, coef, n * 512, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_mv, mv, n * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_has, has_coef, n, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pfv_dec_pframe_dev(s, s->st_mv, s->st_has, s->st_coef, qidx))) return rc;
+    return pfv_dec_check(s);
+}
+
+PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!frames_out_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_get_frame_dev: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FrameGeom g = with_base_alignment(s->geom, frames_out_dev);
+    dim3 grid(128, 3, g.n_streams);
+    hipLaunchKernelGGL(k_crop_frames, grid, dim3(kThreads), 0, ctx->stream, g, s->fb[s->cur], frames_out_dev);
+    return launch_check(ctx, "k_crop_frames");
+}
+
+PFV_API int pfv_dec_get_frame(pfv_dec_session *s, uint8_t *frames_out)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!frames_out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_get_frame: null buffer");
+    int rc = dec_staging(s);
+    if (rc) return rc;
+    if ((rc = pfv_dec_get_frame_dev(s, s->st_frames))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(frames_out, s->st_frames, (size_t)s->geom.src_frame_bytes * s->n_streams,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host)
+{
+    if (!s || !out_host) return fail(s ? s->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_dec_framebuffer: bad argument");
+    pfv_ctx *ctx = s->ctx;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, s->fb[s->cur], (size_t)s->geom.pad_frame_bytes * s->n_streams,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// pfv_device.h -- shared definitions between the HIP kernels (pfv_kernels.hip) and the
+// C-ABI host layer (pfv_capi.cpp).  gfx950 only.
+#pragma once
+#include <stdint.h>
+
+namespace pfv {
+
+constexpr int kStripMB = 8;     // macroblocks per workgroup: a 128 x 16 pixel strip
+constexpr int kThreads = 256;   // 4 wavefronts; each wavefront owns 2 macroblocks (32 lanes each)
+
+// Per-plane quantiser constants, prepared on the host from one reference q-table
+// (int32_t[64], raster order, entries in [1,65535]).
+//   rcp[i]  : float reciprocal of q[i], biased up by 2^-21 so that
+//             trunc(float(n) * rcp[i]) == n / q[i] (Rust truncating `/`, src/dct.rs:95)
+//             for every |n| <= 2^15 (proved exhaustively in tests/test_quant_recip.py).
+//   deq[i]  : SCALE[z] * q[z] with z = INV_ZIGZAG[i] -- the decode side indexes its tables
+//             by zigzag POSITION (src/dct.rs:78-82), reproduced on purpose.
+struct QTab {
+    float rcp[64];
+    int32_t deq[64];
+};
+
+struct PlaneGeom {
+    int w, h;        // source (unpadded) plane dims            (VideoPlane.width/height)
+    int pw, ph;      // padded dims, multiples of 16            (src/common.rs:352-353)
+    int bw, bh;      // macroblocks                              (src/common.rs:358-359)
+    int strips_x;    // ceil(bw / kStripMB)
+    int strip0;      // first strip index of this plane inside one frame
+    int mb0;         // first macroblock index of this plane inside one frame
+    int qsel;        // which QTab of the launch this plane uses
+    int clear;       // pad colour: 0 luma, 128 chroma           (src/enc.rs:84-90)
+    int fast_src;    // 1 when 16-byte vector loads of the source plane are legal
+    long src_off;    // byte offset of the plane inside one unpadded frame
+    long pad_off;    // byte offset of the plane inside one padded frame
+};
+
+struct FrameGeom {
+    PlaneGeom p[3];
+    int n_planes;
+    int strips_per_frame;
+    int mbs_per_frame;
+    int n_streams;
+    long src_frame_bytes;   // stride between streams, unpadded frames
+    long pad_frame_bytes;   // stride between streams, padded frames
+};
+
+}  // namespace pfv

@@ -1,0 +1,151 @@
+"""Device-resident encoder / decoder sessions: the hot-path half of ``enc::Encoder`` and
+``dec::Decoder`` (src/enc.rs:12-173, src/dec.rs:15-224) for ``n_streams`` independent
+streams per launch.  prev_frame / framebuffer stay in HBM between frames.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .context import Context, ptr
+
+
+def qtables_from_quality(quality: int):
+    """Encoder::new's table derivation (src/enc.rs:40-51) -> (intra_l, intra_c, inter_l, inter_c, px_err)."""
+    lib = _lib.load()
+    t = [np.zeros(64, dtype=np.int32) for _ in range(4)]
+    pe = ctypes.c_float()
+    rc = lib.pfv_qtables_from_quality(int(quality), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), ctypes.byref(pe))
+    _lib.check(None, rc)
+    return t[0], t[1], t[2], t[3], float(pe.value)
+
+
+class _Geometry:
+    def __init__(self, width: int, height: int, n_streams: int):
+        lib = _lib.load()
+        self.width, self.height, self.n_streams = int(width), int(height), int(n_streams)
+        self.frame_bytes = int(lib.pfv_frame_bytes(width, height))
+        self.padded_frame_bytes = int(lib.pfv_padded_frame_bytes(width, height))
+        self.total_blocks = int(lib.pfv_total_blocks(width, height))
+
+
+class EncoderSession(_Geometry):
+    def __init__(self, ctx: Context, width: int, height: int, quality: int, n_streams: int = 1):
+        super().__init__(width, height, n_streams)
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.pfv_enc_session_create(ctx.handle, int(width), int(height), int(quality), int(n_streams),
+                                                  ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx._lib.pfv_enc_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # host-buffer forms ------------------------------------------------
+    def _frames(self, frames) -> np.ndarray:
+        f = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1)
+        assert f.size == self.frame_bytes * self.n_streams
+        return f
+
+    def encode_iframe(self, frames) -> np.ndarray:
+        """src/enc.rs:84-97 for every stream; returns coef int16 [n_streams, total_blocks, 256]."""
+        f = self._frames(frames)
+        coef = np.empty((self.n_streams, self.total_blocks, 256), dtype=np.int16)
+        self.ctx.check(self.ctx._lib.pfv_enc_iframe(self.handle, ptr(f), ptr(coef)))
+        return coef
+
+    def encode_pframe(self, frames):
+        """src/enc.rs:134-147 for every stream; returns (mv, has_coef, coef)."""
+        f = self._frames(frames)
+        mv = np.empty((self.n_streams, self.total_blocks, 2), dtype=np.int8)
+        has = np.empty((self.n_streams, self.total_blocks), dtype=np.uint8)
+        coef = np.empty((self.n_streams, self.total_blocks, 256), dtype=np.int16)
+        self.ctx.check(self.ctx._lib.pfv_enc_pframe(self.handle, ptr(f), ptr(mv), ptr(has), ptr(coef)))
+        return mv, has, coef
+
+    def prev_frame(self) -> np.ndarray:
+        out = np.empty((self.n_streams, self.padded_frame_bytes), dtype=np.uint8)
+        self.ctx.check(self.ctx._lib.pfv_enc_prev_frame(self.handle, ptr(out)))
+        return out
+
+    # device-pointer forms (asynchronous on the context's stream) -------
+    def encode_iframe_dev(self, frames_dev: int, coef_dev: int):
+        self.ctx.check(self.ctx._lib.pfv_enc_iframe_dev(self.handle, ctypes.c_void_p(frames_dev), ctypes.c_void_p(coef_dev)))
+
+    def encode_pframe_dev(self, frames_dev: int, mv_dev: int, has_dev: int, coef_dev: int):
+        self.ctx.check(self.ctx._lib.pfv_enc_pframe_dev(self.handle, ctypes.c_void_p(frames_dev), ctypes.c_void_p(mv_dev),
+                                                        ctypes.c_void_p(has_dev), ctypes.c_void_p(coef_dev)))
+
+
+class DecoderSession(_Geometry):
+    def __init__(self, ctx: Context, width: int, height: int, qtables, n_streams: int = 1):
+        super().__init__(width, height, n_streams)
+        self.ctx = ctx
+        q = np.ascontiguousarray(qtables, dtype=np.int32).reshape(-1, 64)
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.pfv_dec_session_create(ctx.handle, int(width), int(height), ptr(q), int(q.shape[0]),
+                                                  int(n_streams), ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx._lib.pfv_dec_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _qidx(qidx) -> np.ndarray:
+        q = np.ascontiguousarray(qidx, dtype=np.uint8)
+        assert q.shape == (3,)
+        return q
+
+    def decode_iframe(self, coef, qidx=(0, 1, 1)):
+        c = np.ascontiguousarray(coef, dtype=np.int16)
+        assert c.size == self.n_streams * self.total_blocks * 256
+        self.ctx.check(self.ctx._lib.pfv_dec_iframe(self.handle, ptr(c), ptr(self._qidx(qidx))))
+
+    def decode_pframe(self, mv, has_coef, coef, qidx=(2, 3, 3)):
+        m = np.ascontiguousarray(mv, dtype=np.int8)
+        hc = np.ascontiguousarray(has_coef, dtype=np.uint8)
+        c = np.ascontiguousarray(coef, dtype=np.int16)
+        assert c.size == self.n_streams * self.total_blocks * 256
+        self.ctx.check(self.ctx._lib.pfv_dec_pframe(self.handle, ptr(m), ptr(hc), ptr(c), ptr(self._qidx(qidx))))
+
+    def decode_iframe_dev(self, coef_dev: int, qidx=(0, 1, 1)):
+        self.ctx.check(self.ctx._lib.pfv_dec_iframe_dev(self.handle, ctypes.c_void_p(coef_dev), ptr(self._qidx(qidx))))
+
+    def decode_pframe_dev(self, mv_dev: int, has_dev: int, coef_dev: int, qidx=(2, 3, 3)):
+        self.ctx.check(self.ctx._lib.pfv_dec_pframe_dev(self.handle, ctypes.c_void_p(mv_dev), ctypes.c_void_p(has_dev),
+                                                        ctypes.c_void_p(coef_dev), ptr(self._qidx(qidx))))
+
+    def check(self):
+        self.ctx.check(self.ctx._lib.pfv_dec_check(self.handle))
+
+    def get_frame(self) -> np.ndarray:
+        """retframe of every stream (src/dec.rs:195-197): uint8 [n_streams, frame_bytes]."""
+        out = np.empty((self.n_streams, self.frame_bytes), dtype=np.uint8)
+        self.ctx.check(self.ctx._lib.pfv_dec_get_frame(self.handle, ptr(out)))
+        return out
+
+    def get_frame_dev(self, frames_dev: int):
+        self.ctx.check(self.ctx._lib.pfv_dec_get_frame_dev(self.handle, ctypes.c_void_p(frames_dev)))
+
+    def framebuffer(self) -> np.ndarray:
+        out = np.empty((self.n_streams, self.padded_frame_bytes), dtype=np.uint8)
+        self.ctx.check(self.ctx._lib.pfv_dec_framebuffer(self.handle, ptr(out)))
+        return out

@@ -1,0 +1,78 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "libpfv_emu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def build_emulator() -> str:
+    """g++ build of the UNMODIFIED csrc/ sources against tests/hipemu (CPU fiber emulator)."""
+    csrc = os.path.join(ROOT, "pretty-fast-video_amd", "csrc")
+    emu = os.path.join(ROOT, "tests", "hipemu")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(emu, "hipemu.cpp"),
+                                                                os.path.join(emu, "hip", "hip_runtime.h"),
+                                                                os.path.join(ROOT, "include", "pfv_hip.h")]
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_LIB) for s in srcs):
+        return EMU_LIB
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I", emu, "-x", "c++",
+                    os.path.join(csrc, "pfv_capi.hip"), os.path.join(emu, "hipemu.cpp"), "-o", EMU_LIB], check=True)
+    return EMU_LIB
+
+
+@pytest.fixture(scope="session")
+def graft():
+    import __graft_entry__ as g
+    return g
+
+
+@pytest.fixture(scope="session")
+def pkg(graft):
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle_bind import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(graft, pkg):
+    """context on the real GPU through the in-tree libpfv_hip.so (no emulator, no fallback)"""
+    if os.environ.get("PFV_TEST_EMU_AS_GPU") == "1":
+        # developer dry-run of the -m gpu tests in the GPU-less build container (never set by the driver)
+        os.environ["PFV_HIP_LIB"] = build_emulator()
+    else:
+        os.environ.pop("PFV_HIP_LIB", None)
+        graft.build_hip()
+    pkg._lib._lib = None
+    ctx = pkg.Context(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
+def emu_ctx(graft, pkg):
+    """context on the CPU emulator build of the same kernel sources (logic check only)"""
+    old = os.environ.get("PFV_HIP_LIB")
+    os.environ["PFV_HIP_LIB"] = build_emulator()
+    pkg._lib._lib = None
+    ctx = pkg.Context(0)
+    yield ctx
+    ctx.close()
+    pkg._lib._lib = None
+    if old is None:
+        os.environ.pop("PFV_HIP_LIB", None)
+    else:
+        os.environ["PFV_HIP_LIB"] = old

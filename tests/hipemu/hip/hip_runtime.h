@@ -1,0 +1,123 @@
+// tests/hipemu/hip/hip_runtime.h -- TEST INFRASTRUCTURE.
+//
+// A tiny single-threaded emulator of the subset of the HIP runtime + gfx950 builtins that
+// pretty-fast-video_amd/csrc uses, so that the *unmodified* kernel and C-ABI sources can be
+// compiled with g++ and exercised on a machine without a GPU (the build container).  Every
+// GPU thread of a workgroup is a ucontext fiber; __syncthreads and every wavefront-level
+// exchange (DPP, shuffles, votes, the LDS hand-off barrier) are rendezvous points of the
+// fiber scheduler.  Wavefront = 64 lanes.  This checks indexing, LDS layout, cross-lane
+// logic and integer arithmetic; it says nothing about performance or hardware memory
+// ordering -- the `-m gpu` tests on a real MI355X remain the parity gate.
+//
+// Never linked into libpfv_hip.so.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __constant__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct int4 { int x, y, z, w; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+
+namespace hipemu {
+
+struct Idx { unsigned x, y, z; };
+extern Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+void block_barrier();
+void wave_barrier();
+int wave_exchange(int value, int src_lane);   // returns `value` of lane src_lane of the caller's wavefront
+bool wave_any(bool pred);
+
+}  // namespace hipemu
+
+#define threadIdx hipemu::g_threadIdx
+#define blockIdx hipemu::g_blockIdx
+#define blockDim hipemu::g_blockDim
+#define gridDim hipemu::g_gridDim
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline int __shfl_xor(int v, int mask) { return hipemu::wave_exchange(v, (int)((threadIdx.x & 63) ^ (unsigned)mask)); }
+static inline bool __any(bool p) { return hipemu::wave_any(p); }
+static inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
+
+// ---- gfx950 builtins used by the kernels
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_barrier()
+static inline unsigned hipemu_udot4(unsigned a, unsigned b, unsigned c, bool)
+{
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+    return c;
+}
+#define __builtin_amdgcn_udot4 hipemu_udot4
+static inline unsigned hipemu_alignbyte(unsigned hi, unsigned lo, unsigned sh)
+{
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (unsigned)(v >> (8 * (sh & 3)));
+}
+#define __builtin_amdgcn_alignbyte hipemu_alignbyte
+static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool)
+{
+    (void)old;
+    int lane = (int)(threadIdx.x & 63), from;
+    if (ctrl >= 0 && ctrl <= 0xff) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);   // quad_perm
+    else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));                       // row_mirror
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));                          // row_half_mirror
+    else abort();
+    return hipemu::wave_exchange(src, from);
+}
+#define __builtin_amdgcn_update_dpp hipemu_update_dpp
+
+// ---- runtime API subset
+typedef int hipError_t;
+typedef void *hipStream_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+static inline const char *hipGetErrorString(hipError_t) { return "hipemu error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (void *)1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+
+template <class K, class... A>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args)
+{
+    hipemu::launch(grid, block, [=]() { kernel(args...); });
+}

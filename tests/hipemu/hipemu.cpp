@@ -1,0 +1,128 @@
+// tests/hipemu/hipemu.cpp -- fiber scheduler of the HIP emulator (TEST INFRASTRUCTURE).
+#include "hip/hip_runtime.h"
+
+#include <stdio.h>
+
+namespace hipemu {
+
+Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+namespace {
+constexpr size_t kStack = 128 * 1024;
+struct Fiber {
+    ucontext_t ctx;
+    void *stack = nullptr;
+    bool done = false;
+    Idx tid;
+};
+std::vector<Fiber> fibers;
+ucontext_t sched_ctx;
+int cur = -1;
+const std::function<void()> *cur_body = nullptr;
+
+int n_threads = 0;
+// block barrier
+int bar_count = 0, bar_gen = 0;
+// per-wave rendezvous
+struct Wave { int count = 0, gen = 0; int slot[64]; int votes = 0; };
+std::vector<Wave> waves;
+
+void yield()
+{
+    int me = cur;
+    swapcontext(&fibers[me].ctx, &sched_ctx);
+    g_threadIdx = fibers[me].tid;
+}
+void trampoline()
+{
+    (*cur_body)();
+    fibers[cur].done = true;
+    swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+int lane_id() { return (int)(g_threadIdx.x & 63); }
+Wave &my_wave() { return waves[g_threadIdx.x >> 6]; }
+int wave_size(int w) { int lo = w * 64; int hi = lo + 64 < n_threads ? lo + 64 : n_threads; return hi - lo; }
+}  // namespace
+
+void block_barrier()
+{
+    int gen = bar_gen;
+    if (++bar_count == n_threads) { bar_count = 0; bar_gen++; }
+    else while (bar_gen == gen) yield();
+}
+void wave_barrier()
+{
+    Wave &w = my_wave();
+    int gen = w.gen;
+    if (++w.count == wave_size((int)(g_threadIdx.x >> 6))) { w.count = 0; w.gen++; }
+    else while (w.gen == gen) yield();
+}
+int wave_exchange(int value, int src_lane)
+{
+    Wave &w = my_wave();
+    w.slot[lane_id()] = value;
+    wave_barrier();
+    int r = w.slot[src_lane & 63];
+    wave_barrier();
+    return r;
+}
+bool wave_any(bool pred)
+{
+    int r = 0;
+    for (int m = 1; m < 64; m <<= 1) { }   // (kept simple: gather through exchange of own predicate)
+    Wave &w = my_wave();
+    w.slot[lane_id()] = pred ? 1 : 0;
+    wave_barrier();
+    int n = wave_size((int)(g_threadIdx.x >> 6));
+    for (int i = 0; i < n; i++) r |= w.slot[i];
+    wave_barrier();
+    return r != 0;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body)
+{
+    if (block.y != 1 || block.z != 1) abort();
+    n_threads = (int)block.x;
+    g_blockDim = Idx{block.x, block.y, block.z};
+    g_gridDim = Idx{grid.x, grid.y, grid.z};
+    if ((int)fibers.size() < n_threads) {
+        fibers.resize(n_threads);
+        for (auto &f : fibers)
+            if (!f.stack) f.stack = malloc(kStack);
+    }
+    waves.assign((n_threads + 63) / 64, Wave());
+    cur_body = &body;
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                g_blockIdx = Idx{bx, by, bz};
+                bar_count = 0;
+                for (auto &w : waves) { w.count = 0; }
+                for (int t = 0; t < n_threads; t++) {
+                    Fiber &f = fibers[t];
+                    f.done = false;
+                    f.tid = Idx{(unsigned)t, 0, 0};
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = nullptr;
+                    makecontext(&f.ctx, trampoline, 0);
+                }
+                int remaining = n_threads;
+                long spins = 0;
+                while (remaining > 0) {
+                    for (int t = 0; t < n_threads; t++) {
+                        Fiber &f = fibers[t];
+                        if (f.done) continue;
+                        cur = t;
+                        g_threadIdx = f.tid;
+                        swapcontext(&sched_ctx, &f.ctx);
+                        if (f.done) remaining--;
+                    }
+                    if (++spins > 10000000) { fprintf(stderr, "hipemu: deadlock (divergent barrier?)\n"); abort(); }
+                }
+            }
+    cur_body = nullptr;
+}
+
+}  // namespace hipemu

@@ -1,0 +1,111 @@
+"""Parity checks shared by the GPU tests (tests/test_gpu_parity.py, real MI355X through the
+C ABI) and the emulator tests (tests/test_emulated_kernels.py, same kernel sources compiled
+for the CPU).  Every check is bit-exact: integer / byte / index work."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle_bind import pad16
+
+
+def smooth_plane(h, w, seed):
+    """deterministic smooth-ish u8 plane with fine noise (the 4-step search needs gradients)"""
+    rng = np.random.default_rng(seed)
+    gh, gw = h // 8 + 2, w // 8 + 2
+    g = rng.integers(0, 256, (gh, gw)).astype(np.int32)
+    y, x = np.arange(h), np.arange(w)
+    gy, fy = (y >> 3)[:, None], (y & 7)[:, None]
+    gx, fx = (x >> 3)[None, :], (x & 7)[None, :]
+    t = ((8 - fy) * ((8 - fx) * g[gy, gx] + fx * g[gy, gx + 1]) + fy * ((8 - fx) * g[gy + 1, gx] + fx * g[gy + 1, gx + 1])) >> 6
+    return np.clip(t + rng.integers(-3, 4, (h, w)), 0, 255).astype(np.uint8)
+
+
+def shifted_ref(px, dx, dy, seed, noise=2, clear=0):
+    """a padded 'previous frame' = px shifted by (dx,dy) with a little noise on half the blocks"""
+    h, w = px.shape
+    ph, pw = pad16(h), pad16(w)
+    rng = np.random.default_rng(seed)
+    img = np.full((ph, pw), clear, dtype=np.int32)
+    img[:h, :w] = px
+    img = np.roll(img, (dy, dx), (0, 1))
+    mask = np.repeat(np.repeat(rng.integers(0, 2, (ph // 16, pw // 16)), 16, 0), 16, 1).astype(bool)
+    img = np.where(mask, img + rng.integers(-noise, noise + 1, img.shape), img)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def check_encode_plane(pkg, ctx, oracle, px, q, clear):
+    h, w = px.shape
+    plane = pkg.VideoPlane.from_slice(w, h, px)
+    enc = plane.encode_plane(q, clear, ctx)
+    ocoef, bw, bh = oracle.encode_plane(px, q, clear)
+    assert (enc.blocks_wide, enc.blocks_high) == (bw, bh)
+    assert enc.width == pad16(w) and enc.height == pad16(h)
+    assert np.array_equal(enc.blocks, ocoef), "encode_plane coefficients differ"
+    dec = pkg.VideoPlane.decode_plane(enc, q, ctx)
+    odec = oracle.decode_plane(ocoef, bw, bh, q)
+    assert np.array_equal(dec.image(), odec), "decode_plane pixels differ"
+    return enc, dec
+
+
+def check_encode_plane_delta(pkg, ctx, oracle, px, ref, q, px_err, clear):
+    h, w = px.shape
+    plane = pkg.VideoPlane.from_slice(w, h, px)
+    refplane = pkg.VideoPlane.from_slice(ref.shape[1], ref.shape[0], ref)
+    enc = plane.encode_plane_delta(refplane, q, px_err, clear, ctx)
+    omv, ohas, ocoef = oracle.encode_plane_delta(px, ref, q, px_err, clear)
+    assert np.array_equal(enc.motion, omv), "motion vectors differ"
+    assert np.array_equal(enc.has_coeff, ohas), "skip flags differ"
+    assert np.array_equal(enc.blocks, ocoef), "residual coefficients differ"
+    dec = pkg.VideoPlane.decode_plane_delta(enc, refplane, q, ctx)
+    odec = oracle.decode_plane_delta(omv, ohas, ocoef, enc.blocks_wide, enc.blocks_high, q, ref)
+    assert np.array_equal(dec.image(), odec), "decode_plane_delta pixels differ"
+    # _into form: read-all-then-write-all into the same plane (src/common.rs:498-521)
+    target = pkg.VideoPlane.from_slice(ref.shape[1], ref.shape[0], ref)
+    pkg.VideoPlane.decode_plane_delta_into(enc, target, q, ctx)
+    assert np.array_equal(target.image(), odec), "decode_plane_delta_into pixels differ"
+    return enc, dec
+
+
+def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames, gop=15, threads=1):
+    """encode n_frames of n_streams synthetic streams (i-frame every `gop`), decode them again,
+    compare everything with the oracle stream by stream."""
+    streams = [pkg.SyntheticStream(width, height, seed=pkg.synth.SEED + 17 * s) for s in range(n_streams)]
+    enc = pkg.EncoderSession(ctx, width, height, quality, n_streams)
+    tabs = pkg.qtables_from_quality(quality)
+    dec = pkg.DecoderSession(ctx, width, height, np.stack(tabs[:4]), n_streams)
+    oencs = [oracle.encoder(width, height, quality, threads) for _ in range(n_streams)]
+    stats = {"coded": 0, "mbs": 0}
+    for t in range(n_frames):
+        frames = np.stack([s.frame(t) for s in streams])
+        if t % gop == 0:
+            coef = enc.encode_iframe(frames)
+            dec.decode_iframe(coef)
+            for s in range(n_streams):
+                ocoef = oencs[s].encode_iframe(frames[s])
+                assert np.array_equal(coef[s], ocoef), f"frame {t} stream {s}: i-frame coefficients differ"
+        else:
+            mv, has, coef = enc.encode_pframe(frames)
+            dec.decode_pframe(mv, has, coef)
+            for s in range(n_streams):
+                omv, ohas, ocoef = oencs[s].encode_pframe(frames[s])
+                assert np.array_equal(mv[s], omv), f"frame {t} stream {s}: motion vectors differ"
+                assert np.array_equal(has[s], ohas), f"frame {t} stream {s}: skip flags differ"
+                assert np.array_equal(coef[s], ocoef), f"frame {t} stream {s}: p-frame coefficients differ"
+            stats["coded"] += int(has.sum())
+            stats["mbs"] += has.size
+        recon = enc.prev_frame()
+        fb = dec.framebuffer()
+        out = dec.get_frame()
+        for s in range(n_streams):
+            oprev = oencs[s].prev_frame()
+            assert np.array_equal(recon[s], oprev), f"frame {t} stream {s}: encoder reconstruction differs"
+            assert np.array_equal(fb[s], oprev), f"frame {t} stream {s}: decoder framebuffer differs"
+            # retframe = crop of the padded framebuffer (src/dec.rs:195-197)
+            f = pkg.VideoFrame.from_packed(width, height, oprev, padded=True)
+            crop = np.concatenate([f.plane_y.image()[:height, :width].reshape(-1),
+                                   f.plane_u.image()[:height // 2, :width // 2].reshape(-1),
+                                   f.plane_v.image()[:height // 2, :width // 2].reshape(-1)])
+            assert np.array_equal(out[s], crop), f"frame {t} stream {s}: cropped retframe differs"
+    enc.close()
+    dec.close()
+    return stats

@@ -1,0 +1,34 @@
+"""CPU-only logic check of the HIP kernel SOURCES: pretty-fast-video_amd/csrc/*.hip compiled
+unmodified with g++ against tests/hipemu (every GPU thread a fiber, wavefront = 64) and driven
+through the same C ABI and the same parity checks as the real-GPU tests, at tiny sizes.
+This is not the parity gate (that is tests/test_gpu_parity.py on a real MI355X); it keeps
+indexing / cross-lane / LDS-layout regressions from reaching the GPU box."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (50, 38), (144, 16)])
+@pytest.mark.parametrize("quality", [0, 5, 10])
+def test_emu_plane_ops(pkg, emu_ctx, oracle, w, h, quality):
+    il, ic, pl, pcq, px_err = oracle.qtables(quality)
+    px = pc.smooth_plane(h, w, seed=w * 1000 + h + quality)
+    pc.check_encode_plane(pkg, emu_ctx, oracle, px, il, 0)
+    ref = pc.shifted_ref(px, 3, -2, seed=7, clear=128)
+    pc.check_encode_plane_delta(pkg, emu_ctx, oracle, px, ref, pcq, px_err, 128)
+
+
+def test_emu_session_two_streams(pkg, emu_ctx, oracle):
+    stats = pc.check_session(pkg, emu_ctx, oracle, 64, 48, 5, n_streams=2, n_frames=3)
+    assert 0 < stats["coded"] < stats["mbs"]
+
+
+def test_emu_bad_motion_vector(pkg, emu_ctx, oracle):
+    q = oracle.qtables(5)[2]
+    ref = pkg.VideoPlane(32, 32)
+    src = pkg.EncodedPPlane(32, 32, 2, 2, np.array([[-1, 0], [0, 0], [0, 0], [0, 0]], np.int8), np.zeros(4, np.uint8),
+                            np.zeros((4, 256), np.int16))
+    with pytest.raises(pkg.PfvError) as e:
+        pkg.VideoPlane.decode_plane_delta(src, ref, q, emu_ctx)
+    assert e.value.code == pkg._lib.PFV_ERR_BAD_MV

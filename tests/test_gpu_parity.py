@@ -1,0 +1,194 @@
+"""Parity tests proper: the HIP kernels on a real MI355X, called through the C ABI
+(libpfv_hip.so), against the CPU oracle on the same seeded inputs.  Bit-exact everywhere
+(integer / byte / index work)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_the_one_loaded(pkg, gpu_ctx):
+    """the in-tree gfx950 build must be what runs (no emulator, no fallback)"""
+    assert pkg._lib._lib_path == pkg._lib.DEFAULT_LIB
+    with open("/proc/self/maps") as f:
+        assert "libpfv_hip.so" in f.read()
+    assert b"gfx950" in pkg._lib.load().pfv_version()
+
+
+@pytest.mark.parametrize("quality", list(range(0, 11)))
+def test_iframe_plane_all_qualities(pkg, gpu_ctx, oracle, quality):
+    il, ic, _, _, _ = oracle.qtables(quality)
+    px = pc.smooth_plane(96, 208, seed=quality)
+    pc.check_encode_plane(pkg, gpu_ctx, oracle, px, il, 0)
+    pc.check_encode_plane(pkg, gpu_ctx, oracle, px, ic, 128)
+
+
+@pytest.mark.parametrize("w,h", [(16, 16), (50, 38), (128, 16), (130, 18), (144, 160), (1, 1), (17, 33), (960, 540)])
+def test_iframe_plane_ragged_sizes(pkg, gpu_ctx, oracle, w, h):
+    il = oracle.qtables(5)[0]
+    rng = np.random.default_rng(w * 7 + h)
+    px = rng.integers(0, 256, (h, w), dtype=np.uint8)          # uniform noise: worst case for the quantiser
+    pc.check_encode_plane(pkg, gpu_ctx, oracle, px, il, 77)
+
+
+@pytest.mark.parametrize("fill", ["zeros", "ones", "checker", "checker8", "ramp"])
+def test_iframe_extreme_blocks(pkg, gpu_ctx, oracle, fill):
+    h, w = 64, 160
+    y, x = np.mgrid[0:h, 0:w]
+    px = {"zeros": np.zeros((h, w)), "ones": np.full((h, w), 255), "checker": ((x + y) & 1) * 255,
+          "checker8": (((x >> 3) + (y >> 3)) & 1) * 255, "ramp": (x * 3 + y * 5) & 255}[fill].astype(np.uint8)
+    for quality in (0, 1, 5, 10):
+        il = oracle.qtables(quality)[0]
+        pc.check_encode_plane(pkg, gpu_ctx, oracle, px, il, 0)
+
+
+def test_iframe_arbitrary_qtable_and_coefficients(pkg, gpu_ctx, oracle):
+    """decode side with hostile input: random i16 coefficients (i32 wrap-around in the iDCT)
+    and q entries up to 65535"""
+    rng = np.random.default_rng(3)
+    q = rng.integers(1, 65536, 64).astype(np.int32)
+    bw, bh = 9, 3
+    coef = rng.integers(-32768, 32768, (bw * bh, 256)).astype(np.int16)
+    src = pkg.EncodedIPlane(bw * 16, bh * 16, bw, bh, coef)
+    dec = pkg.VideoPlane.decode_plane(src, q, gpu_ctx)
+    assert np.array_equal(dec.image(), oracle.decode_plane(coef, bw, bh, q))
+    # encode side with large q
+    px = rng.integers(0, 256, (48, 144), dtype=np.uint8)
+    q2 = rng.integers(1, 300, 64).astype(np.int32)
+    pc.check_encode_plane(pkg, gpu_ctx, oracle, px, q2, 0)
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2, 5, 8, 10])
+@pytest.mark.parametrize("w,h,dx,dy", [(208, 96, 5, -3), (50, 38, -7, 2), (272, 48, 15, 15), (144, 160, -15, -9)])
+def test_pframe_plane(pkg, gpu_ctx, oracle, quality, w, h, dx, dy):
+    _, _, pl, pcq, px_err = oracle.qtables(quality)
+    px = pc.smooth_plane(h, w, seed=quality * 31 + w)
+    ref = pc.shifted_ref(px, dx, dy, seed=quality + h, clear=128)
+    enc, _ = pc.check_encode_plane_delta(pkg, gpu_ctx, oracle, px, ref, pl, px_err, 128)
+    pc.check_encode_plane_delta(pkg, gpu_ctx, oracle, px, ref, pcq, px_err, 0)
+    if quality >= 5:
+        assert enc.has_coeff.sum() < enc.has_coeff.size      # the skip path ran too
+
+
+def test_pframe_noise_and_ties(pkg, gpu_ctx, oracle):
+    """white noise (no gradient: many near-ties), a flat plane (exact ties everywhere: the
+    centre must win) and a reference identical to the source (zero error)"""
+    _, _, pl, _, px_err = oracle.qtables(5)
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, (80, 176), dtype=np.uint8)
+    pc.check_encode_plane_delta(pkg, gpu_ctx, oracle, noise, rng.integers(0, 256, (80, 176), dtype=np.uint8), pl, px_err, 0)
+    flat = np.full((80, 176), 90, np.uint8)
+    enc, _ = pc.check_encode_plane_delta(pkg, gpu_ctx, oracle, flat, np.full((80, 176), 93, np.uint8), pl, 0.0, 0)
+    assert not enc.motion.any()
+    enc, _ = pc.check_encode_plane_delta(pkg, gpu_ctx, oracle, noise, noise.copy(), pl, px_err, 0)
+    assert not enc.motion.any() and not enc.has_coeff.any()
+    # periodic pattern: many exactly equal candidates, first-visited must win
+    y, x = np.mgrid[0:80, 0:176]
+    per = (((x >> 2) + (y >> 2)) & 1).astype(np.uint8) * 200
+    pc.check_encode_plane_delta(pkg, gpu_ctx, oracle, per, np.roll(per, (4, 4), (0, 1)), pl, 0.0, 0)
+
+
+def test_pframe_residual_extremes(pkg, gpu_ctx, oracle):
+    """+-255 residuals (clamp and halving paths)"""
+    _, _, pl, _, _ = oracle.qtables(1)
+    y, x = np.mgrid[0:48, 0:144]
+    a = ((((x >> 1) + (y >> 1)) & 1) * 255).astype(np.uint8)
+    pc.check_encode_plane_delta(pkg, gpu_ctx, oracle, a, (255 - a).astype(np.uint8), pl, 0.0, 0)
+
+
+def test_bad_motion_vector_is_an_error(pkg, gpu_ctx, oracle):
+    q = oracle.qtables(5)[2]
+    ref = pkg.VideoPlane(32, 32)
+    for mvbad in ([-1, 0], [0, -1], [17, 0], [0, 17]):
+        mv = np.zeros((4, 2), np.int8)
+        mv[0 if mvbad[0] < 0 or mvbad[1] < 0 else 3] = mvbad
+        src = pkg.EncodedPPlane(32, 32, 2, 2, mv, np.zeros(4, np.uint8), np.zeros((4, 256), np.int16))
+        with pytest.raises(pkg.PfvError) as e:
+            pkg.VideoPlane.decode_plane_delta(src, ref, q, gpu_ctx)
+        assert e.value.code == pkg._lib.PFV_ERR_BAD_MV
+
+
+def test_bad_arguments(pkg, gpu_ctx, oracle):
+    plane = pkg.VideoPlane(32, 32)
+    q = np.zeros(64, np.int32)                        # q == 0: the reference divides by zero (panic)
+    with pytest.raises(pkg.PfvError) as e:
+        plane.encode_plane(q, 0, gpu_ctx)
+    assert e.value.code == pkg._lib.PFV_ERR_BAD_ARG
+    with pytest.raises(pkg.PfvError):
+        pkg.EncoderSession(gpu_ctx, 63, 48, 5, 1)     # odd width (src/frame.rs:13)
+    with pytest.raises(pkg.PfvError):
+        pkg.EncoderSession(gpu_ctx, 64, 48, 11, 1)    # quality > 10 (src/enc.rs:38)
+
+
+def test_session_small_gop_multistream(pkg, gpu_ctx, oracle):
+    stats = pc.check_session(pkg, gpu_ctx, oracle, 176, 144, 5, n_streams=3, n_frames=6, gop=4)
+    assert 0 < stats["coded"] < stats["mbs"]
+
+
+def test_session_odd_chroma_geometry(pkg, gpu_ctx, oracle):
+    """width/2 not a multiple of 16 (chroma padded independently, src/frame.rs:31-36) and
+    sizes whose chroma rows are not 16-byte aligned (slow-path source loads)"""
+    pc.check_session(pkg, gpu_ctx, oracle, 100, 60, 2, n_streams=2, n_frames=3, gop=15)
+    pc.check_session(pkg, gpu_ctx, oracle, 18, 2, 10, n_streams=1, n_frames=2, gop=15)
+
+
+def test_session_1080p_iframe_and_pframe(pkg, gpu_ctx, oracle):
+    """BASELINE configs #2 and #3 at full size: one 1080p i-frame round trip and one p-frame
+    encode, every byte compared with the oracle (6 266 880 B of coefficients per frame)."""
+    stats = pc.check_session(pkg, gpu_ctx, oracle, 1920, 1080, 5, n_streams=1, n_frames=2, threads=os.cpu_count() or 1)
+    assert stats["mbs"] == 12240
+    assert 0 < stats["coded"] < stats["mbs"]
+
+
+def test_session_4k_roundtrip_property(pkg, gpu_ctx):
+    """BASELINE config #4 geometry (3840x2160, 48 720 MB/frame): size-independent property --
+    the decoder's framebuffer equals the encoder's closed-loop reconstruction for every frame
+    of a short GOP (no oracle involved at this size)."""
+    W, H = 3840, 2160
+    stream = pkg.SyntheticStream(W, H)
+    enc = pkg.EncoderSession(gpu_ctx, W, H, 5, 1)
+    assert enc.total_blocks == 48720
+    dec = pkg.DecoderSession(gpu_ctx, W, H, np.stack(pkg.qtables_from_quality(5)[:4]), 1)
+    for t in range(3):
+        f = stream.frame(t)
+        if t == 0:
+            coef = enc.encode_iframe(f)
+            dec.decode_iframe(coef)
+        else:
+            mv, has, coef = enc.encode_pframe(f)
+            assert np.abs(mv).max() <= 15
+            assert not coef[0][has[0] == 0].any()          # skipped macroblocks carry zero coefficients
+            dec.decode_pframe(mv, has, coef)
+        assert np.array_equal(enc.prev_frame(), dec.framebuffer())
+    # PSNR sanity of the reconstruction against the source luma (not a parity claim)
+    y = dec.get_frame()[0][:W * H].astype(np.float64)
+    mse = ((y - stream.frame(2)[:W * H]) ** 2).mean()
+    assert mse < 40.0
+    enc.close()
+    dec.close()
+
+
+def test_blit_dev(pkg, gpu_ctx):
+    """VideoPlane::blit (src/plane.rs:20-29) on device planes vs the host container op"""
+    rng = np.random.default_rng(5)
+    src = pkg.VideoPlane.from_slice(100, 40, rng.integers(0, 256, 4000, dtype=np.uint8))
+    dst = pkg.VideoPlane.from_slice(64, 64, rng.integers(0, 256, 4096, dtype=np.uint8))
+    d_src, d_dst = gpu_ctx.alloc(4000), gpu_ctx.alloc(4096)
+    gpu_ctx.upload(d_src, src.pixels)
+    gpu_ctx.upload(d_dst, dst.pixels)
+    lib = gpu_ctx._lib
+    gpu_ctx.check(lib.pfv_blit_dev(gpu_ctx.handle, ctypes.c_void_p(d_dst), 64, 64, ctypes.c_void_p(d_src), 100, 40, 3, 5, 7,
+                                   9, 33, 21))
+    out = np.empty(4096, np.uint8)
+    gpu_ctx.download(out, d_dst)
+    dst.blit(src, 3, 5, 7, 9, 33, 21)
+    assert np.array_equal(out, dst.pixels)
+    rc = lib.pfv_blit_dev(gpu_ctx.handle, ctypes.c_void_p(d_dst), 64, 64, ctypes.c_void_p(d_src), 100, 40, 60, 0, 0, 0, 8, 8)
+    assert rc == pkg._lib.PFV_ERR_BAD_ARG
+    gpu_ctx.free(d_src)
+    gpu_ctx.free(d_dst)
