@@ -7,6 +7,7 @@ here the resource is one MI355X device + one HIP stream.
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -23,10 +24,13 @@ class Context:
             raise _lib.PfvError(rc, msg.decode() if msg else "")
         self.handle = h
         self.device = int(device)
+        self._sessions = weakref.WeakSet()   # sessions die with their context (they hold device buffers of it)
 
     # -- lifetime
     def close(self):
         if getattr(self, "handle", None):
+            for s in list(self._sessions):
+                s.close()
             self._lib.pfv_ctx_destroy(self.handle)
             self.handle = None
 

@@ -39,11 +39,12 @@ class EncoderSession(_Geometry):
         ctx.check(ctx._lib.pfv_enc_session_create(ctx.handle, int(width), int(height), int(quality), int(n_streams),
                                                   ctypes.byref(h)))
         self.handle = h
+        ctx._sessions.add(self)
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and self.ctx.handle:
             self.ctx._lib.pfv_enc_session_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
@@ -96,11 +97,12 @@ class DecoderSession(_Geometry):
         ctx.check(ctx._lib.pfv_dec_session_create(ctx.handle, int(width), int(height), ptr(q), int(q.shape[0]),
                                                   int(n_streams), ctypes.byref(h)))
         self.handle = h
+        ctx._sessions.add(self)
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and self.ctx.handle:
             self.ctx._lib.pfv_dec_session_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

