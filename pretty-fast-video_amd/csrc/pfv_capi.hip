@@ -189,7 +189,9 @@ static void fill_plane(PlaneGeom &p, int w, int h, int strip0, int mb0, long src
     p.pw = pad16(w); p.ph = pad16(h);
     p.bw = p.pw / 16; p.bh = p.ph / 16;
     p.strips_x = (p.bw + kStripMB - 1) / kStripMB;
+    p.tiles_y = (p.bh + kStripsPerWG - 1) / kStripsPerWG;
     p.strip0 = strip0; p.mb0 = mb0;
+    p.tile0 = 0;
     p.qsel = qsel; p.clear = clear;
     p.src_off = src_off; p.pad_off = pad_off;
     p.fast_src = 0;
@@ -204,6 +206,7 @@ static FrameGeom plane_geom(int w, int h, int clear)
     g.p[1] = g.p[0]; g.p[2] = g.p[0];
     g.n_planes = 1;
     g.strips_per_frame = g.p[0].strips_x * g.p[0].bh;
+    g.tiles_per_frame = g.p[0].strips_x * g.p[0].tiles_y;
     g.mbs_per_frame = g.p[0].bw * g.p[0].bh;
     g.n_streams = 1;
     g.src_frame_bytes = (long)w * h;
@@ -228,6 +231,9 @@ static FrameGeom frame_geom(int w, int h, int n_streams)
     fill_plane(g.p[2], cw, ch, s2, m2, y_src + c_src, y_pad + c_pad, 1, 128);
     g.n_planes = 3;
     g.strips_per_frame = s2 + g.p[2].strips_x * g.p[2].bh;
+    g.p[1].tile0 = g.p[0].strips_x * g.p[0].tiles_y;
+    g.p[2].tile0 = g.p[1].tile0 + g.p[1].strips_x * g.p[1].tiles_y;
+    g.tiles_per_frame = g.p[2].tile0 + g.p[2].strips_x * g.p[2].tiles_y;
     g.mbs_per_frame = m2 + g.p[2].bw * g.p[2].bh;
     g.n_streams = n_streams;
     g.src_frame_bytes = y_src + 2 * c_src;
@@ -242,6 +248,13 @@ static FrameGeom with_base_alignment(FrameGeom g, const void *src_base)
     if (((uintptr_t)src_base & 15) != 0)
         for (int i = 0; i < 3; i++) g.p[i].fast_src = 0;
     return g;
+}
+
+// one strip per wavefront, kStripsPerWG strips per workgroup
+static inline unsigned strip_blocks(const FrameGeom &g)
+{
+    long strips = (long)g.strips_per_frame * g.n_streams;
+    return (unsigned)((strips + kStripsPerWG - 1) / kStripsPerWG);
 }
 
 static int launch_check(pfv_ctx *ctx, const char *what)
@@ -280,7 +293,7 @@ PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, cons
     if ((rc = ensure_scratch(ctx, 0, (size_t)w * h, &d_src))) return rc;
     if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_enc_iframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
+    hipLaunchKernelGGL(k_enc_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
                                                                    ctx->qtab_dev);
     if ((rc = launch_check(ctx, "k_enc_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -310,7 +323,7 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
     float min_err = px_err * px_err * 256.0f;   // src/common.rs:209
-    hipLaunchKernelGGL(k_enc_pframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
+    hipLaunchKernelGGL(k_enc_pframe, dim3(g.tiles_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
                                                                    (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
                                                                    nullptr, ctx->qtab_dev, min_err);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
@@ -336,7 +349,7 @@ PFV_API int pfv_decode_plane_into(pfv_ctx *ctx, const int16_t *coef, int bw, int
     if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
     if ((rc = ensure_scratch(ctx, 5, pad_bytes, &d_out))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_coef, coef, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_dec_iframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const int16_t *)d_coef, (uint8_t *)d_out,
+    hipLaunchKernelGGL(k_dec_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const int16_t *)d_coef, (uint8_t *)d_out,
                                                                    ctx->qtab_dev);
     if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(target, d_out, pad_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -367,7 +380,7 @@ PFV_API int pfv_decode_plane_delta(pfv_ctx *ctx, const int8_t *mv, const uint8_t
     HIP_TRY(ctx, hipMemcpyAsync(d_mv, mv, n * 2, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_has, has_coef, n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_dec_pframe, dim3(g.strips_per_frame), dim3(kThreads), 0, ctx->stream, g, (const int8_t *)d_mv, (const uint8_t *)d_has,
+    hipLaunchKernelGGL(k_dec_pframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const int8_t *)d_mv, (const uint8_t *)d_has,
                                                                    (const int16_t *)d_coef, (const uint8_t *)d_ref,
                                                                    (uint8_t *)d_out, ctx->qtab_dev, ctx->flag_dev);
     if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
@@ -549,7 +562,7 @@ PFV_API int pfv_enc_iframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
-    hipLaunchKernelGGL(k_enc_iframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt],
+    hipLaunchKernelGGL(k_enc_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt],
                                                                                  s->qtab_dev + 0);
     int rc = launch_check(ctx, "k_enc_iframe");
     if (rc) return rc;
@@ -567,7 +580,7 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
     float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
-    hipLaunchKernelGGL(k_enc_pframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, 
+    hipLaunchKernelGGL(k_enc_pframe, dim3(g.tiles_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, 
         g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err);
     int rc = launch_check(ctx, "k_enc_pframe");
     if (rc) return rc;
@@ -712,7 +725,7 @@ PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, cons
     int rc = dec_geom(s, qidx, &g);
     if (rc) return rc;
     int nxt = s->cur ^ 1;
-    hipLaunchKernelGGL(k_dec_iframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, g, coef_dev, s->fb[nxt], s->qtab_dev);
+    hipLaunchKernelGGL(k_dec_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef_dev, s->fb[nxt], s->qtab_dev);
     if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
     s->cur = nxt;
     return PFV_OK;
@@ -729,7 +742,7 @@ PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const u
     int rc = dec_geom(s, qidx, &g);
     if (rc) return rc;
     int nxt = s->cur ^ 1;
-    hipLaunchKernelGGL(k_dec_pframe, dim3(g.strips_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, 
+    hipLaunchKernelGGL(k_dec_pframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, 
         g, mv_dev, has_coef_dev, coef_dev, s->fb[s->cur], s->fb[nxt], s->qtab_dev, s->flag_dev);
     if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
     s->cur = nxt;

@@ -5,8 +5,9 @@
 
 namespace pfv {
 
-constexpr int kStripMB = 8;     // macroblocks per workgroup: a 128 x 16 pixel strip
-constexpr int kThreads = 256;   // 4 wavefronts; each wavefront owns 2 macroblocks (32 lanes each)
+constexpr int kStripMB = 8;     // macroblocks per wavefront: a 128 x 16 pixel strip, 8 lanes per macroblock
+constexpr int kStripsPerWG = 4; // wavefronts (= strips) per workgroup
+constexpr int kThreads = 256;
 
 // Per-plane quantiser constants, prepared on the host from one reference q-table
 // (int32_t[64], raster order, entries in [1,65535]).
@@ -26,6 +27,8 @@ struct PlaneGeom {
     int bw, bh;      // macroblocks                              (src/common.rs:358-359)
     int strips_x;    // ceil(bw / kStripMB)
     int strip0;      // first strip index of this plane inside one frame
+    int tiles_y;     // ceil(bh / kStripsPerWG): p-frame encode tiles are 4 vertically stacked strips
+    int tile0;       // first tile index of this plane inside one frame
     int mb0;         // first macroblock index of this plane inside one frame
     int qsel;        // which QTab of the launch this plane uses
     int clear;       // pad colour: 0 luma, 128 chroma           (src/enc.rs:84-90)
@@ -38,6 +41,7 @@ struct FrameGeom {
     PlaneGeom p[3];
     int n_planes;
     int strips_per_frame;
+    int tiles_per_frame;
     int mbs_per_frame;
     int n_streams;
     long src_frame_bytes;   // stride between streams, unpadded frames

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Per-kernel mean of each PMC counter from a rocprofv3 counter_collection.csv (pfv:: kernels only)."""
+import csv, collections, sys
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+with open(sys.argv[1]) as f:
+    for row in csv.DictReader(f):
+        k = row.get("Kernel_Name", "")
+        if "pfv::" not in k:
+            continue
+        k = k.split("(")[0].replace("pfv::", "")
+        acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k in sorted(acc):
+    for c in sorted(acc[k]):
+        v = acc[k][c]
+        print(f"{k:16s} {c:24s} n={len(v):4d} mean={sum(v)/len(v):.6g}")
