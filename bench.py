@@ -138,6 +138,7 @@ def main():
     mv = torch.empty((S, n_mb, 2), dtype=torch.int8, device=dev)
     has = torch.empty((S, n_mb), dtype=torch.uint8, device=dev)
     out_frames = torch.empty((S, fb), dtype=torch.uint8, device=dev)
+    dec.set_output_dev(out_frames.data_ptr())                            # retframe crop (src/dec.rs:209-211) fused into decode
     stream = torch.cuda.ExternalStream(ctx.stream, device=dev)           # HIP events on the kernels' own stream
     torch.cuda.synchronize()
 
@@ -158,7 +159,6 @@ def main():
                     e1.record(stream)
                     ev_pairs.append((e0, e1))
                 dec.decode_pframe_dev(mv.data_ptr(), has.data_ptr(), coef.data_ptr())
-            dec.get_frame_dev(out_frames.data_ptr())                     # crop to retframe (src/dec.rs:209-211)
 
     for _ in range(args.warmup):
         step(False)

@@ -169,6 +169,11 @@ PFV_API int pfv_dec_pframe(pfv_dec_session *s, const int8_t *mv, const uint8_t *
 /* Decoder::advance_frame's crop of framebuffer into retframe (src/dec.rs:195-197,
  * 209-211): frames_out = n_streams unpadded frames (Y|U|V). */
 PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev);
+/* Fused form of the same crop: once a device buffer of n_streams unpadded frames is set, every
+ * following pfv_dec_iframe_dev / pfv_dec_pframe_dev also writes the retframe into it (the decode
+ * kernels store each reconstructed row twice: padded framebuffer + cropped retframe), saving the
+ * separate blit pass.  NULL switches it off. */
+PFV_API int pfv_dec_set_output_dev(pfv_dec_session *s, uint8_t *frames_out_dev);
 PFV_API int pfv_dec_get_frame(pfv_dec_session *s, uint8_t *frames_out);
 /* padded framebuffer of all streams to host */
 PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host);

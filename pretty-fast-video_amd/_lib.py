@@ -71,6 +71,7 @@ SIGNATURES = [
     ("pfv_dec_iframe", c_int, [_P, _P, _P]),
     ("pfv_dec_pframe", c_int, [_P, _P, _P, _P, _P]),
     ("pfv_dec_get_frame_dev", c_int, [_P, _P]),
+    ("pfv_dec_set_output_dev", c_int, [_P, _P]),
     ("pfv_dec_get_frame", c_int, [_P, _P]),
     ("pfv_dec_framebuffer", c_int, [_P, _P]),
     ("pfv_dec_check", c_int, [_P]),

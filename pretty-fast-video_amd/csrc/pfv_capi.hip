@@ -350,7 +350,7 @@ PFV_API int pfv_decode_plane_into(pfv_ctx *ctx, const int16_t *coef, int bw, int
     if ((rc = ensure_scratch(ctx, 5, pad_bytes, &d_out))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_coef, coef, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_dec_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const int16_t *)d_coef, (uint8_t *)d_out,
-                                                                   ctx->qtab_dev);
+                                                                   ctx->qtab_dev, (uint8_t *)nullptr);
     if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(target, d_out, pad_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -382,7 +382,7 @@ PFV_API int pfv_decode_plane_delta(pfv_ctx *ctx, const int8_t *mv, const uint8_t
     HIP_TRY(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_dec_pframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const int8_t *)d_mv, (const uint8_t *)d_has,
                                                                    (const int16_t *)d_coef, (const uint8_t *)d_ref,
-                                                                   (uint8_t *)d_out, ctx->qtab_dev, ctx->flag_dev);
+                                                                   (uint8_t *)d_out, ctx->qtab_dev, ctx->flag_dev, (uint8_t *)nullptr);
     if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
     int flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -497,6 +497,7 @@ struct pfv_dec_session {
     uint8_t *fb[2] = {nullptr, nullptr};     // ping-pong framebuffer
     int cur = 0;
     int *flag_dev = nullptr;
+    uint8_t *frames_out = nullptr;           // optional fused retframe output (pfv_dec_set_output_dev)
     int16_t *st_coef = nullptr;
     int8_t *st_mv = nullptr;
     uint8_t *st_has = nullptr;
@@ -703,6 +704,21 @@ PFV_API void pfv_dec_session_destroy(pfv_dec_session *s)
     delete s;
 }
 
+PFV_API int pfv_dec_set_output_dev(pfv_dec_session *s, uint8_t *frames_out_dev)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    s->frames_out = frames_out_dev;
+    return PFV_OK;
+}
+
+// the decode kernels can write the retframe themselves only with 16-byte vector stores
+static bool fused_output_ok(const pfv_dec_session *s)
+{
+    if (!s->frames_out) return false;
+    FrameGeom g = with_base_alignment(s->geom, s->frames_out);
+    return g.p[0].fast_src && g.p[1].fast_src && g.p[2].fast_src;
+}
+
 static int dec_geom(pfv_dec_session *s, const uint8_t qidx[3], FrameGeom *g)
 {
     if (!qidx) return fail(s->ctx, PFV_ERR_BAD_ARG, "qidx is null");
@@ -725,9 +741,10 @@ PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, cons
     int rc = dec_geom(s, qidx, &g);
     if (rc) return rc;
     int nxt = s->cur ^ 1;
-    hipLaunchKernelGGL(k_dec_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef_dev, s->fb[nxt], s->qtab_dev);
+    hipLaunchKernelGGL(k_dec_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef_dev, s->fb[nxt], s->qtab_dev, fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
     if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
     s->cur = nxt;
+    if (s->frames_out && !fused_output_ok(s)) return pfv_dec_get_frame_dev(s, s->frames_out);
     return PFV_OK;
 }
 
@@ -743,9 +760,11 @@ PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const u
     if (rc) return rc;
     int nxt = s->cur ^ 1;
     hipLaunchKernelGGL(k_dec_pframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, 
-        g, mv_dev, has_coef_dev, coef_dev, s->fb[s->cur], s->fb[nxt], s->qtab_dev, s->flag_dev);
+        g, mv_dev, has_coef_dev, coef_dev, s->fb[s->cur], s->fb[nxt], s->qtab_dev, s->flag_dev,
+        fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
     if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
     s->cur = nxt;
+    if (s->frames_out && !fused_output_ok(s)) return pfv_dec_get_frame_dev(s, s->frames_out);
     return PFV_OK;
 }
 

@@ -56,24 +56,37 @@ __constant__ int kInvZigzag[64] = {
 constexpr int kWinRows = 16 * kStripsPerWG + 30;   // reference window of a 128 x 64 tile: +-15 rows
 constexpr int kWinStride = 176;                    // bytes per window row: 160 used (x0-16 .. x0+143)
 constexpr int kWinBytes = kWinRows * kWinStride;
-constexpr int kMBPitch = 4 * 64 + 8;               // dwords per macroblock in the exchange region (== 8 mod 32)
-constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 2112 dwords = 8448 B
+constexpr int kMBPitch = 2 * 64 + 8;               // dwords per macroblock in the exchange region (== 8 mod 32)
+constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 1088 dwords = 4352 B
 
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 __device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 
-// Rust `/` by 2, 4, 16 on i32 (truncation toward zero) as  (x + sign * (2^k - 1)) >> k ;
-// the sign bit is extracted once per operand and reused.
-struct TDiv {
-    int x;
-    unsigned sb;   // x < 0 ? 1 : 0
-    __device__ __forceinline__ explicit TDiv(int v) : x(v), sb((unsigned)v >> 31) {}
-    __device__ __forceinline__ int d2() const { return (int)((unsigned)x + sb) >> 1; }
-    __device__ __forceinline__ int d4() const { return (int)((unsigned)x + sb * 3u) >> 2; }
-    __device__ __forceinline__ int d16() const { return (int)((unsigned)x + sb * 15u) >> 4; }
+// Rust `/` by 2, 4, 16 on i32 (truncation toward zero).  trunc(x / 2^k) = (x + bias) >> k with
+// bias = (2^k - 1) for negative x; truncating divisions compose (trunc(trunc(x/a)/b) = trunc(x/(ab)))
+// and keep the sign (or give 0, where the bias is harmless), so x/4 is taken from x/2 and x/16
+// from x/4 with the SAME one- or two-bit bias: one sign extraction + one mask per operand.
+struct TDiv24 {   // operand needing x/2 and x/4
+    int x, h, q;
+    __device__ __forceinline__ explicit TDiv24(int v) : x(v)
+    {
+        unsigned b = (unsigned)v >> 31;
+        h = (int)((unsigned)v + b) >> 1;
+        q = (int)((unsigned)h + b) >> 1;
+    }
 };
+struct TDiv416 {   // operand needing x/4 and x/16
+    int x, q, s;
+    __device__ __forceinline__ explicit TDiv416(int v) : x(v)
+    {
+        unsigned b = (unsigned)(v >> 31) & 3u;
+        q = (int)((unsigned)v + b) >> 2;
+        s = (int)((unsigned)q + b) >> 2;
+    }
+};
+__device__ __forceinline__ int tdiv2(int x) { return (int)((unsigned)x + ((unsigned)x >> 31)) >> 1; }
 
 // Intra-wavefront LDS hand-off: DS operations of one wavefront execute in issue order, so
 // only the compiler has to be kept from moving accesses across this point.
@@ -100,13 +113,6 @@ __device__ __forceinline__ int mb_sum(int v)
     v += dpp<kQuadXor1>(v);
     v += dpp<kQuadXor2>(v);
     v += dpp<kRowHalfMirror>(v);
-    return v;
-}
-__device__ __forceinline__ unsigned mb_min(unsigned v)
-{
-    v = min(v, (unsigned)dpp<kQuadXor1>((int)v));
-    v = min(v, (unsigned)dpp<kQuadXor2>((int)v));
-    v = min(v, (unsigned)dpp<kRowHalfMirror>((int)v));
     return v;
 }
 
@@ -161,17 +167,16 @@ __device__ __forceinline__ StripPos locate_strip(const FrameGeom &g, int gstrip)
 __device__ __forceinline__ void fdct8(int (&v)[8])
 {
     int a0 = wadd(v[0], v[7]), a1 = wadd(v[1], v[6]), a2 = wadd(v[2], v[5]), a3 = wadd(v[3], v[4]);
-    TDiv a4(wsub(v[0], v[7])), a5(wsub(v[1], v[6])), a6(wsub(v[2], v[5])), a7(wsub(v[3], v[4]));
+    TDiv416 a4(wsub(v[0], v[7])), a5(wsub(v[1], v[6])), a6(wsub(v[2], v[5])), a7(wsub(v[3], v[4]));
     int b0 = wadd(a0, a3), b1 = wadd(a1, a2);
-    TDiv b2(wsub(a0, a3)), b3(wsub(a1, a2));
+    TDiv24 b2(wsub(a0, a3)), b3(wsub(a1, a2));
     int c0 = wadd(b0, b1), c1 = wsub(b0, b1);
-    int c2 = wadd(wadd(b2.x, b2.d4()), b3.d2());
-    int c3 = wsub(wsub(b2.d2(), b3.x), b3.d4());
-    int a4q = a4.d4(), a7q = a7.d4();
-    int b4 = wsub(wadd(wadd(a7q, a4.x), a4q), a4.d16());
-    int b7 = wadd(wsub(wsub(a4q, a7.x), a7q), a7.d16());
-    int b5 = wsub(wsub(wadd(a5.x, a6.x), a6.d4()), a6.d16());
-    int b6 = wadd(wadd(wsub(a6.x, a5.x), a5.d4()), a5.d16());
+    int c2 = wadd(wadd(b2.x, b2.q), b3.h);
+    int c3 = wsub(wsub(b2.h, b3.x), b3.q);
+    int b4 = wsub(wadd(wadd(a7.q, a4.x), a4.q), a4.s);
+    int b7 = wadd(wsub(wsub(a4.q, a7.x), a7.q), a7.s);
+    int b5 = wsub(wsub(wadd(a5.x, a6.x), a6.q), a6.s);
+    int b6 = wadd(wadd(wsub(a6.x, a5.x), a5.q), a5.s);
     int c4 = wadd(b4, b5), c5 = wsub(b4, b5), c6 = wadd(b6, b7), c7 = wsub(b6, b7);
     v[0] = c0; v[1] = c4; v[2] = c2; v[3] = wsub(c5, c7);
     v[4] = c1; v[5] = wadd(c5, c7); v[6] = c3; v[7] = c6;
@@ -181,32 +186,31 @@ __device__ __forceinline__ void fdct8(int (&v)[8])
 __device__ __forceinline__ void idct8(int (&v)[8])
 {
     int c0 = v[0], d4 = v[1], d6 = v[3], c1 = v[4], d5 = v[5], d7 = v[7];
-    TDiv c2(v[2]), c3(v[6]);
+    TDiv24 c2(v[2]), c3(v[6]);
     int c4 = d4, c5 = wadd(d5, d6), c7 = wsub(d5, d6), c6 = d7;
-    TDiv b4(wadd(c4, c5)), b5(wsub(c4, c5)), b6(wadd(c6, c7)), b7(wsub(c6, c7));
+    TDiv416 b4(wadd(c4, c5)), b5(wsub(c4, c5)), b6(wadd(c6, c7)), b7(wsub(c6, c7));
     int b0 = wadd(c0, c1), b1 = wsub(c0, c1);
-    int b2 = wadd(wadd(c2.x, c2.d4()), c3.d2());
-    int b3 = wsub(wsub(c2.d2(), c3.x), c3.d4());
-    int b4q = b4.d4(), b7q = b7.d4();
-    int a4 = wsub(wadd(wadd(b7q, b4.x), b4q), b4.d16());
-    int a7 = wadd(wsub(wsub(b4q, b7.x), b7q), b7.d16());
-    int a5 = wadd(wadd(wsub(b5.x, b6.x), b6.d4()), b6.d16());
-    int a6 = wsub(wsub(wadd(b6.x, b5.x), b5.d4()), b5.d16());
+    int b2 = wadd(wadd(c2.x, c2.q), c3.h);
+    int b3 = wsub(wsub(c2.h, c3.x), c3.q);
+    int a4 = wsub(wadd(wadd(b7.q, b4.x), b4.q), b4.s);
+    int a7 = wadd(wsub(wsub(b4.q, b7.x), b7.q), b7.s);
+    int a5 = wadd(wadd(wsub(b5.x, b6.x), b6.q), b6.s);
+    int a6 = wsub(wsub(wadd(b6.x, b5.x), b5.q), b5.s);
     int a0 = wadd(b0, b2), a1 = wadd(b1, b3), a2 = wsub(b1, b3), a3 = wsub(b0, b2);
     v[0] = wadd(a0, a4); v[1] = wadd(a1, a5); v[2] = wadd(a2, a6); v[3] = wadd(a3, a7);
     v[4] = wsub(a3, a7); v[5] = wsub(a2, a6); v[6] = wsub(a1, a5); v[7] = wsub(a0, a4);
 }
 
 // ------------------------------------------------------------------ 8x8 transposes through LDS
-// Exchange region of macroblock m: four subblocks of 64 dwords, M[s][row][col], with the two
+// Exchange region of macroblock m: two subblocks of 64 dwords, M[s][row][col], with the two
 // 16-byte halves of row `row` swapped when (row & 4): lanes i and i+4 then write different
 // banks (b128 writes are serviced in groups of 8 consecutive lanes = one macroblock).
 // row layout (lane i holds M[s][i][0..7])  ->  column layout (lane i holds M[s][0..7][i])
-__device__ __forceinline__ void rows_to_cols4(int (&v)[4][8], int *mb, int i)
+__device__ __forceinline__ void rows_to_cols2(int (&v)[2][8], int *mb, int i)
 {
     const int sw = (i >> 2) & 1;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
         int4 *w = reinterpret_cast<int4 *>(mb + s * 64 + i * 8);
         w[sw] = make_int4(v[s][0], v[s][1], v[s][2], v[s][3]);
         w[sw ^ 1] = make_int4(v[s][4], v[s][5], v[s][6], v[s][7]);
@@ -214,25 +218,25 @@ __device__ __forceinline__ void rows_to_cols4(int (&v)[4][8], int *mb, int i)
     wave_lds_sync();
     const int lo = i, hi = i ^ 4;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) v[s][r] = mb[s * 64 + r * 8 + (r < 4 ? lo : hi)];
     }
     wave_lds_sync();
 }
 // column layout  ->  row layout
-__device__ __forceinline__ void cols_to_rows4(int (&v)[4][8], int *mb, int i)
+__device__ __forceinline__ void cols_to_rows2(int (&v)[2][8], int *mb, int i)
 {
     const int lo = i, hi = i ^ 4;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) mb[s * 64 + r * 8 + (r < 4 ? lo : hi)] = v[s][r];
     }
     wave_lds_sync();
     const int sw = (i >> 2) & 1;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
         const int4 *w = reinterpret_cast<const int4 *>(mb + s * 64 + i * 8);
         int4 a = w[sw], b = w[sw ^ 1];
         v[s][0] = a.x; v[s][1] = a.y; v[s][2] = a.z; v[s][3] = a.w;
@@ -264,32 +268,25 @@ __device__ __forceinline__ void load_lane_q(LaneQ &lq, const QTab *qt, int c)
     }
 }
 
-// reference src/common.rs:313-325 decode_subblock tail: ((v >> 8) + 128).clamp(0,255)
-__device__ __forceinline__ int to_pixel(int v) { return min(max(wadd(v >> 8, 128), 0), 255); }
-
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
 {
     return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24);
 }
 __device__ __forceinline__ int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 0xffu); }
 
-// rows i (subblocks 0,1) and i+8 (subblocks 2,3) of a macroblock as two 16-pixel vectors
-__device__ __forceinline__ void unpack_rows(const uint4 &top, const uint4 &bot, int (&px)[4][8])
+// one 16-pixel macroblock row = subblock 2h (left 8 pixels) and 2h+1 (right 8 pixels)
+__device__ __forceinline__ void unpack_row(const uint4 &row, int (&px)[2][8])
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        px[0][k] = byte_of(top.x, k); px[0][k + 4] = byte_of(top.y, k);
-        px[1][k] = byte_of(top.z, k); px[1][k + 4] = byte_of(top.w, k);
-        px[2][k] = byte_of(bot.x, k); px[2][k + 4] = byte_of(bot.y, k);
-        px[3][k] = byte_of(bot.z, k); px[3][k + 4] = byte_of(bot.w, k);
+        px[0][k] = byte_of(row.x, k); px[0][k + 4] = byte_of(row.y, k);
+        px[1][k] = byte_of(row.z, k); px[1][k + 4] = byte_of(row.w, k);
     }
 }
-__device__ __forceinline__ void pack_rows(const int (&px)[4][8], uint4 &top, uint4 &bot)
+__device__ __forceinline__ uint4 pack_row(const int (&px)[2][8])
 {
-    top = make_uint4(pack4(px[0][0], px[0][1], px[0][2], px[0][3]), pack4(px[0][4], px[0][5], px[0][6], px[0][7]),
-                     pack4(px[1][0], px[1][1], px[1][2], px[1][3]), pack4(px[1][4], px[1][5], px[1][6], px[1][7]));
-    bot = make_uint4(pack4(px[2][0], px[2][1], px[2][2], px[2][3]), pack4(px[2][4], px[2][5], px[2][6], px[2][7]),
-                     pack4(px[3][0], px[3][1], px[3][2], px[3][3]), pack4(px[3][4], px[3][5], px[3][6], px[3][7]));
+    return make_uint4(pack4(px[0][0], px[0][1], px[0][2], px[0][3]), pack4(px[0][4], px[0][5], px[0][6], px[0][7]),
+                      pack4(px[1][0], px[1][1], px[1][2], px[1][3]), pack4(px[1][4], px[1][5], px[1][6], px[1][7]));
 }
 
 // ------------------------------------------------------------------ strip I/O
@@ -322,80 +319,103 @@ __device__ __forceinline__ uint4 load_src16(const uint8_t *plane, const PlaneGeo
     return val;
 }
 
-// The strip's coefficient block (n_mb * 512 contiguous bytes) <-> LDS stage, 4 x 1 KiB
-// fully coalesced vector accesses per wavefront.
-__device__ __forceinline__ void store_coef_strip(const int *stage, int16_t *coef_mb0, int n_mb, int lane)
+// Decoder::advance_frame's crop of the padded framebuffer into the unpadded retframe
+// (src/dec.rs:195-197, 209-211), fused into the decode kernels: the lane's 16 reconstructed pixels
+// of row y, columns x..x+15, also go to the tightly packed output plane if they lie inside it.
+// Only used when every plane allows 16-byte vector stores (w % 16 == 0, aligned bases); other
+// geometries run the separate k_crop_frames pass.
+__device__ __forceinline__ void store_cropped16(uint8_t *plane, const PlaneGeom &p, int x, int y, const uint4 &val)
 {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int ch = j * 64 + lane;   // 16-byte chunk; 32 chunks per macroblock
-        if ((ch >> 5) < n_mb) reinterpret_cast<uint4 *>(coef_mb0)[ch] = reinterpret_cast<const uint4 *>(stage)[ch];
-    }
-}
-__device__ __forceinline__ void load_coef_strip(int *stage, const int16_t *coef_mb0, int n_mb, int lane)
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int ch = j * 64 + lane;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if ((ch >> 5) < n_mb) v = reinterpret_cast<const uint4 *>(coef_mb0)[ch];
-        reinterpret_cast<uint4 *>(stage)[ch] = v;
-    }
+    if (y < p.h && x < p.w) *reinterpret_cast<uint4 *>(plane + (long)y * p.w + x) = val;
 }
 
-// ------------------------------------------------------------------ macroblock pipelines (per lane: 4 subblocks)
+// Coefficients of one HALF (h = 0: subblocks 0,1; h = 1: subblocks 2,3) of every macroblock of
+// the strip <-> LDS stage (8 macroblocks x 256 B).  Global side: 256-byte runs, 16 B per lane.
+__device__ __forceinline__ void store_coef_half(const int *stage, int16_t *coef_mb0, int n_mb, int lane, int h)
+{
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int ch = j * 64 + lane;   // 16-byte chunk of the stage; 16 chunks per macroblock half
+        int mb = ch >> 4;
+        if (mb < n_mb) reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)] = reinterpret_cast<const uint4 *>(stage)[ch];
+    }
+}
+__device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int h)
+{
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int ch = j * 64 + lane;
+        int mb = ch >> 4;
+        buf[j] = make_uint4(0, 0, 0, 0);
+        if (mb < n_mb) buf[j] = reinterpret_cast<const uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)];
+    }
+}
+__device__ __forceinline__ void stage_coef_half(int *stage, const uint4 (&buf)[2], int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 2; j++) reinterpret_cast<uint4 *>(stage)[j * 64 + lane] = buf[j];
+}
+
+// ------------------------------------------------------------------ half-macroblock pipelines (per lane: 2 subblocks)
 // Forward: row-layout inputs (24.8 fixed point) -> quantised coefficients in column layout
 // (left in v) and scattered in zigzag order into the strip's coefficient stage.
 // reference src/common.rs:294-297 + src/dct.rs:88-99 (encode: n = (m*SCALE)>>16; n / q).
 // The division is float(n) * rcp followed by a truncating convert; exact for |n| <= 2^15
 // (QTab::rcp); |n| <= 5160 for any u8 input (|m| <= 240 * 32768, SCALE <= 43).
+// The reference's `as i16` (src/dct.rs:95) cannot wrap for these magnitudes, so it is a no-op here.
 // `keep`: lanes of skipped / absent macroblocks store zeros instead.
-__device__ __forceinline__ void forward_mb(int (&v)[4][8], int *xw, int m, int i, const LaneQ &lq, bool keep)
+__device__ __forceinline__ void forward_half(int (&v)[2][8], int *xw, int m, int i, const LaneQ &lq, bool keep)
 {
+    const int keepmask = keep ? -1 : 0;
     int *mb = xw + m * kMBPitch;
+    fdct8(v[0]);   // dct_transform_rows
+    fdct8(v[1]);
+    rows_to_cols2(v, mb, i);
+    fdct8(v[0]);   // dct_transform_columns
+    fdct8(v[1]);
+    int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 128;
 #pragma unroll
-    for (int s = 0; s < 4; s++) fdct8(v[s]);   // dct_transform_rows
-    rows_to_cols4(v, mb, i);
-#pragma unroll
-    for (int s = 0; s < 4; s++) fdct8(v[s]);   // dct_transform_columns
-    int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 256;
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             int n = wmul(v[s][k], lq.scale[k]) >> 16;
-            int q = (int)(short)(int)((float)n * lq.rcp[k]);
-            v[s][k] = keep ? q : 0;
+            v[s][k] = (int)((float)n * lq.rcp[k]) & keepmask;
             stage[s * 64 + lq.zz[k]] = (int16_t)v[s][k];
         }
     }
     wave_lds_sync();
 }
-// Inverse: quantised coefficients in column layout (v) -> row-layout pixel values 0..255.
-// reference src/dct.rs:75-86 (decode) + src/common.rs:314-322 (columns first, then rows).
-__device__ __forceinline__ void inverse_mb(int (&v)[4][8], int *xw, int m, int i, const LaneQ &lq)
+// Inverse: quantised coefficients in column layout (v) -> row-layout term t = min(x >> 8, 127).
+// The reference's pixel is ((x >> 8) + 128).clamp(0, 255) (src/common.rs:321); callers apply the
+// +128 and the clamp.  For p-frames the reference clamps that "delta byte" d first and then forms
+// clamp(prev + (d - 128) * 2) (src/common.rs:100-102), i.e. clamp(prev + 2 * clamp(t, -128, 127)).
+// The lower clamp of t is redundant (prev <= 255, so any t <= -128 saturates to 0 either way); the
+// upper one is not (t = 127 gives prev + 254, t = 128 would give 255 for prev = 0), so it is kept.
+// |t| < 2^23, so 2t cannot overflow.
+// reference src/dct.rs:75-86 (decode) + src/common.rs:314-316 (columns first, then rows).
+__device__ __forceinline__ void inverse_half(int (&v)[2][8], int *xw, int m, int i, const LaneQ &lq)
 {
     int *mb = xw + m * kMBPitch;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
 #pragma unroll
         for (int k = 0; k < 8; k++) v[s][k] = wmul(v[s][k], lq.deq[k]);
         idct8(v[s]);   // dct_inverse_transform_columns
     }
-    cols_to_rows4(v, mb, i);
+    cols_to_rows2(v, mb, i);
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
         idct8(v[s]);   // dct_inverse_transform_rows
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[s][k] = to_pixel(v[s][k]);
+        for (int k = 0; k < 8; k++) v[s][k] = min(v[s][k] >> 8, 127);
     }
 }
 // gather the lane's column of quantised coefficients out of the zigzag-ordered stage
-__device__ __forceinline__ void gather_coefs(int (&v)[4][8], const int *xw, int m, const LaneQ &lq)
+__device__ __forceinline__ void gather_half(int (&v)[2][8], const int *xw, int m, const LaneQ &lq)
 {
-    const int16_t *stage = reinterpret_cast<const int16_t *>(xw) + m * 256;
+    const int16_t *stage = reinterpret_cast<const int16_t *>(xw) + m * 128;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 2; s++) {
 #pragma unroll
         for (int k = 0; k < 8; k++) v[s][k] = (int)stage[s * 64 + lq.zz[k]];
     }
@@ -421,30 +441,34 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
     int *xw = xchg[wave];
 
     const uint8_t *plane = src + (long)sp.stream * g.src_frame_bytes + p.src_off;
-    const uint4 top = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
-    const uint4 bot = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
+    uint4 rows[2];
+    rows[0] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
+    rows[1] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
 
     LaneQ lq;
     load_lane_q<true>(lq, qtabs + p.qsel, i);
-
-    int v[4][8];
-    unpack_rows(top, bot, v);
+    int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
+    uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16
+                         : nullptr;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int h = 0; h < 2; h++) {
+        int v[2][8];
+        unpack_row(rows[h], v);
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[s][k] = (int)((unsigned)(v[s][k] - 128) << 8);   // src/common.rs:291
-    }
-    forward_mb(v, xw, m, i, lq, true);
-    store_coef_strip(xw, coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256, sp.n_mb, lane);
-    if (recon) {
-        wave_lds_sync();   // the stage has been read back before the inverse transposes reuse the region
-        inverse_mb(v, xw, m, i, lq);
-        if (m < sp.n_mb) {
-            uint4 o0, o1;
-            pack_rows(v, o0, o1);
-            uint8_t *dst = recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16;
-            *reinterpret_cast<uint4 *>(dst) = o0;
-            *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = o1;
+        for (int s = 0; s < 2; s++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[s][k] = (int)((unsigned)(v[s][k] - 128) << 8);   // src/common.rs:291
+        }
+        forward_half(v, xw, m, i, lq, true);
+        store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+        wave_lds_sync();   // the stage has been read back before the region is reused
+        if (recon) {
+            inverse_half(v, xw, m, i, lq);
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[s][k] = min(max(v[s][k] + 128, 0), 255);   // src/common.rs:321
+            if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(v);
         }
     }
 }
@@ -456,6 +480,127 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
 // decode_block_delta :254-285, apply_residuals :98-104) that Encoder::encode_pframe runs on
 // the result (src/enc.rs:134-147).  recon == nullptr -> encode only.
 // One workgroup = a 128 x 64 tile (4 vertically stacked strips) sharing one reference window.
+//
+// Search ("row owner" form): lane i of a macroblock owns source rows i and i+8 for the whole
+// search.  For one level it reads, for each vertical candidate offset, the two reference rows
+// it needs ONCE as an aligned dword span wide enough for all three horizontal offsets, and
+// accumulates  sum b^2 - 2 sum ab  for every candidate from registers; the partial sums are
+// all-reduced over the macroblock's 8 lanes with DPP.  After levels 8 and 4 the displacement
+// is a multiple of 4 pixels, so those levels need no byte realignment at all; levels 2 and 1
+// rebase each span once by (cx & 3) and then use compile-time byte offsets.
+struct SearchState {
+    int cx, cy;     // accumulated displacement (reference src/common.rs:199-200)
+    int err;        // error of the current centre = best so far (:164, :191)
+};
+
+__device__ __forceinline__ void dot_row(const uint4 &a, unsigned b0, unsigned b1, unsigned b2, unsigned b3, unsigned &ab,
+                                        unsigned &bb)
+{
+    ab = __builtin_amdgcn_udot4(a.x, b0, ab, false);
+    ab = __builtin_amdgcn_udot4(a.y, b1, ab, false);
+    ab = __builtin_amdgcn_udot4(a.z, b2, ab, false);
+    ab = __builtin_amdgcn_udot4(a.w, b3, ab, false);
+    bb = __builtin_amdgcn_udot4(b0, b0, bb, false);
+    bb = __builtin_amdgcn_udot4(b1, b1, bb, false);
+    bb = __builtin_amdgcn_udot4(b2, b2, bb, false);
+    bb = __builtin_amdgcn_udot4(b3, b3, bb, false);
+}
+
+// One search level with step S.  wrow0 / wcol0: window coordinates of the macroblock origin
+// row (already + lane row i) and column.  Candidate (my, mx) sits at displacement
+// (st.cx + mx*S, st.cy + my*S).  FIRST: the centre's error is not known yet (first level).
+template <int S, bool FIRST>
+__device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int wcol0, const uint4 &top, const uint4 &bot,
+                                             int a2, int mbx, int mby, int pw, int ph, SearchState &st)
+{
+    constexpr bool kAligned = (S >= 4);            // displacement is a multiple of 4 pixels: no byte shifts
+    constexpr int kN = kAligned ? (16 + 2 * S) / 4 : 7;   // dwords per span
+    const int sh = st.cx & 3;                      // only used when !kAligned
+    // span origin (bytes from the window row start): dword aligned
+    const int col = kAligned ? (wcol0 + st.cx - S) : (wcol0 + (st.cx & ~3) - 4);
+    int part[3][3];
+#pragma unroll
+    for (int my = -1; my <= 1; my++) {
+        const uint8_t *rp = win + (wrow0 + st.cy + my * S) * kWinStride + col;
+        unsigned dT[8], dB[8];
+        if (S == 8) {   // col = 16m + 8 (mod 16 == 8): 8-byte, 16-byte, 8-byte pieces
+            uint2 t0 = *reinterpret_cast<const uint2 *>(rp), b0 = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride);
+            uint4 t1 = *reinterpret_cast<const uint4 *>(rp + 8), b1 = *reinterpret_cast<const uint4 *>(rp + 8 * kWinStride + 8);
+            uint2 t2 = *reinterpret_cast<const uint2 *>(rp + 24), b2 = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride + 24);
+            dT[0] = t0.x; dT[1] = t0.y; dT[2] = t1.x; dT[3] = t1.y; dT[4] = t1.z; dT[5] = t1.w; dT[6] = t2.x; dT[7] = t2.y;
+            dB[0] = b0.x; dB[1] = b0.y; dB[2] = b1.x; dB[3] = b1.y; dB[4] = b1.z; dB[5] = b1.w; dB[6] = b2.x; dB[7] = b2.y;
+        } else if (S == 4) {   // col == 12 (mod 16): dword, 16-byte, dword
+            const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);
+            uint4 t1 = *reinterpret_cast<const uint4 *>(rp + 4), b1 = *reinterpret_cast<const uint4 *>(rp + 8 * kWinStride + 4);
+            dT[0] = t[0]; dT[1] = t1.x; dT[2] = t1.y; dT[3] = t1.z; dT[4] = t1.w; dT[5] = t[5];
+            dB[0] = b[0]; dB[1] = b1.x; dB[2] = b1.y; dB[3] = b1.z; dB[4] = b1.w; dB[5] = b[5];
+        } else {
+            const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);
+            unsigned rt[7], rb[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) { rt[k] = t[k]; rb[k] = b[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) {   // rebase: e[k] = bytes starting at (cx - 4) + 4k
+                dT[k] = __builtin_amdgcn_alignbyte(rt[k + 1], rt[k], sh);
+                dB[k] = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
+            }
+        }
+#pragma unroll
+        for (int mx = -1; mx <= 1; mx++) {
+            if (!FIRST && my == 0 && mx == 0) { part[1][1] = 0; continue; }   // centre already known (:176)
+            unsigned ab = 0, bb = 0;
+            if (kAligned) {
+                constexpr int dummy = 0; (void)dummy;
+                const int o = (mx + 1) * S / 4;
+                dot_row(top, dT[o], dT[o + 1], dT[o + 2], dT[o + 3], ab, bb);
+                dot_row(bot, dB[o], dB[o + 1], dB[o + 2], dB[o + 3], ab, bb);
+            } else {
+                const int ob = 4 + mx * S, o = ob >> 2, bs = ob & 3;   // compile-time byte offset from the rebased origin
+                if (bs == 0) {
+                    dot_row(top, dT[o], dT[o + 1], dT[o + 2], dT[o + 3], ab, bb);
+                    dot_row(bot, dB[o], dB[o + 1], dB[o + 2], dB[o + 3], ab, bb);
+                } else {
+                    dot_row(top, __builtin_amdgcn_alignbyte(dT[o + 1], dT[o], bs), __builtin_amdgcn_alignbyte(dT[o + 2], dT[o + 1], bs),
+                            __builtin_amdgcn_alignbyte(dT[o + 3], dT[o + 2], bs), __builtin_amdgcn_alignbyte(dT[o + 4], dT[o + 3], bs),
+                            ab, bb);
+                    dot_row(bot, __builtin_amdgcn_alignbyte(dB[o + 1], dB[o], bs), __builtin_amdgcn_alignbyte(dB[o + 2], dB[o + 1], bs),
+                            __builtin_amdgcn_alignbyte(dB[o + 3], dB[o + 2], bs), __builtin_amdgcn_alignbyte(dB[o + 4], dB[o + 3], bs),
+                            ab, bb);
+                }
+            }
+            part[my + 1][mx + 1] = (int)bb - 2 * (int)ab;
+        }
+    }
+    // all-reduce every candidate's partial sum over the macroblock's 8 lanes, then the
+    // sequential accept rule of the reference: strict `<`, first visited wins (:189), centre first
+    unsigned best = FIRST ? 0xffffffffu : ((unsigned)st.err << 4);
+    if (FIRST) best = ((unsigned)(a2 + mb_sum(part[1][1])) << 4);
+    int ord = 0;
+#pragma unroll
+    for (int my = -1; my <= 1; my++) {
+        const int oy = mby + st.cy + my * S;
+        const bool vy = oy >= 0 && oy <= ph - 16;                       // :171
+#pragma unroll
+        for (int mx = -1; mx <= 1; mx++) {
+            if (my == 0 && mx == 0) continue;
+            ord++;
+            const int ox = mbx + st.cx + mx * S;
+            const bool valid = vy && ox >= 0 && ox <= pw - 16;          // :182
+            int err = a2 + mb_sum(part[my + 1][mx + 1]);
+            unsigned key = valid ? (((unsigned)err << 4) | (unsigned)ord) : 0xffffffffu;
+            best = min(best, key);
+        }
+    }
+    const int bo = (int)(best & 15u);
+    st.err = (int)(best >> 4);
+    if (bo) {
+        int b9 = bo - 1;
+        b9 = b9 < 4 ? b9 : b9 + 1;
+        st.cy += (b9 / 3 - 1) * S;
+        st.cx += (b9 - (b9 / 3) * 3 - 1) * S;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
@@ -494,11 +639,12 @@ __global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint
             *reinterpret_cast<uint4 *>(win + row * kWinStride + ch * 16) = val;
         }
     }
-    uint4 top = make_uint4(0, 0, 0, 0), bot = top;
+    uint4 rows[2];
+    rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
     if (wave_valid) {
         const uint8_t *plane = src + (long)sp.stream * g.src_frame_bytes + p.src_off;
-        top = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
-        bot = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
+        rows[0] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
+        rows[1] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
     }
     __syncthreads();
     if (!wave_valid) return;   // the only workgroup-wide barrier is behind us
@@ -506,136 +652,81 @@ __global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint
     int *xw = xchg[wave];
     const bool mb_valid = m < sp.n_mb;
     const int mbx = sp.x0 + m * 16, mby = sp.y0;
+    const int wcol0 = mbx - winx0;                 // = 16 + 16 m
+    const int wrow0 = mby - winy0 + i;             // window row of source row i
 
-    // ---- whole 16x16 source block into registers: rows through the exchange region
-    // (the 8 lanes of a macroblock read identical addresses: LDS broadcast)
-    {
-        uint4 *t = reinterpret_cast<uint4 *>(xw);
-        t[i * 8 + m] = top;
-        t[(i + 8) * 8 + m] = bot;
-    }
-    wave_lds_sync();
-    uint4 a[16];
+    // sum of squares of the source block (2 rows per lane)
+    unsigned s2 = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) a[r] = reinterpret_cast<const uint4 *>(xw)[r * 8 + m];
-    wave_lds_sync();
-
-    auto sq4 = [](const uint4 &q, unsigned acc) -> unsigned {
-        acc = __builtin_amdgcn_udot4(q.x, q.x, acc, false);
-        acc = __builtin_amdgcn_udot4(q.y, q.y, acc, false);
-        acc = __builtin_amdgcn_udot4(q.z, q.z, acc, false);
-        acc = __builtin_amdgcn_udot4(q.w, q.w, acc, false);
-        return acc;
-    };
-    // (sum b^2, sum ab) over one 16-pixel row of the window starting at byte `wx` of row pointer `rowp`
-    auto row_terms = [](const uint8_t *rowp, int sh, const uint4 &av, unsigned &ab, unsigned &bb, uint4 *keep) {
-        const unsigned *d = reinterpret_cast<const unsigned *>(rowp);
-        unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
-        unsigned b0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-        unsigned b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        unsigned b2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-        unsigned b3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-        ab = __builtin_amdgcn_udot4(av.x, b0, ab, false);
-        ab = __builtin_amdgcn_udot4(av.y, b1, ab, false);
-        ab = __builtin_amdgcn_udot4(av.z, b2, ab, false);
-        ab = __builtin_amdgcn_udot4(av.w, b3, ab, false);
-        bb = __builtin_amdgcn_udot4(b0, b0, bb, false);
-        bb = __builtin_amdgcn_udot4(b1, b1, bb, false);
-        bb = __builtin_amdgcn_udot4(b2, b2, bb, false);
-        bb = __builtin_amdgcn_udot4(b3, b3, bb, false);
-        if (keep) *keep = make_uint4(b0, b1, b2, b3);
-    };
-
-    // sum of squares of the source block and error of the first centre (src/common.rs:161-165):
-    // the macroblock's 8 lanes take 2 rows each
-    const int wx0 = mbx - winx0, wy0 = mby - winy0;   // window coordinates of the block origin
-    int a2, cur_err;
-    {
-        unsigned s2 = sq4(top, sq4(bot, 0u));
-        unsigned ab = 0, bb = 0;
-        const uint8_t *rp = win + (wy0 + i) * kWinStride + (wx0 & ~3);
-        row_terms(rp, wx0 & 3, top, ab, bb, nullptr);
-        row_terms(rp + 8 * kWinStride, wx0 & 3, bot, ab, bb, nullptr);
-        a2 = mb_sum((int)s2);
-        cur_err = a2 + mb_sum((int)bb - 2 * (int)ab);
+    for (int h = 0; h < 2; h++) {
+        s2 = __builtin_amdgcn_udot4(rows[h].x, rows[h].x, s2, false);
+        s2 = __builtin_amdgcn_udot4(rows[h].y, rows[h].y, s2, false);
+        s2 = __builtin_amdgcn_udot4(rows[h].z, rows[h].z, s2, false);
+        s2 = __builtin_amdgcn_udot4(rows[h].w, rows[h].w, s2, false);
     }
+    const int a2 = mb_sum((int)s2);
 
-    // ---- 4-step search: lane i evaluates candidate i of the level
-    const int k9 = i < 4 ? i : i + 1;                            // skip the centre slot of the 3x3 pattern
-    const int cmy = k9 / 3 - 1, cmx = k9 - (k9 / 3) * 3 - 1;      // visiting order: my outer, mx inner (:168-175)
-    int cx = 0, cy = 0;                                           // accumulated displacement
-#pragma unroll 1
-    for (int step = 8; step >= 1; step >>= 1) {
-        int ox = mbx + cx + cmx * step, oy = mby + cy + cmy * step;
-        bool valid = ox >= 0 && ox <= p.pw - 16 && oy >= 0 && oy <= p.ph - 16;   // :171, :182
-        int ex = valid ? ox : mbx + cx, ey = valid ? oy : mby + cy;
-        int wx = ex - winx0, wy = ey - winy0;
-        const uint8_t *rp = win + wy * kWinStride + (wx & ~3);
-        const int sh = wx & 3;
-        unsigned ab = 0, bb = 0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) row_terms(rp + r * kWinStride, sh, a[r], ab, bb, nullptr);
-        int err = a2 + (int)bb - 2 * (int)ab;
-        // strict `<` with first-visited-wins (:189)  ==  lexicographic min of (err, visiting order),
-        // the centre being order 0
-        unsigned key = valid ? (((unsigned)err << 4) | (unsigned)(i + 1)) : 0xffffffffu;
-        key = min(mb_min(key), (unsigned)cur_err << 4);
-        int ord = (int)(key & 15u);
-        cur_err = (int)(key >> 4);
-        if (ord) {
-            int b9 = ord - 1;
-            b9 = b9 < 4 ? b9 : b9 + 1;
-            cy += (b9 / 3 - 1) * step;
-            cx += (b9 - (b9 / 3) * 3 - 1) * step;
-        }
-    }
+    // ---- 4-step search (reference src/common.rs:154-204, steps 8, 4, 2, 1)
+    SearchState st;
+    st.cx = 0; st.cy = 0; st.err = 0;
+    search_level<8, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+    search_level<4, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+    search_level<2, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+    search_level<1, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
 
     // ---- skip decision (src/common.rs:209, :221): best_err <= px_err^2 * 256, compared in f32
-    const bool coded = mb_valid && !((float)cur_err <= min_err);
+    const bool coded = mb_valid && !((float)st.err <= min_err);
     if (i == 0 && mb_valid) {
         long mbi = (long)sp.stream * g.mbs_per_frame + sp.mb_first + m;
-        mv_out[mbi * 2 + 0] = (int8_t)cx;
-        mv_out[mbi * 2 + 1] = (int8_t)cy;
+        mv_out[mbi * 2 + 0] = (int8_t)st.cx;
+        mv_out[mbi * 2 + 1] = (int8_t)st.cy;
         has_out[mbi] = coded ? 1 : 0;
     }
 
     // ---- the lane's two rows of the chosen patch (get_block of the reconstruction, :261)
-    uint4 ptop, pbot;
+    uint4 patch[2];
     {
-        int wx = wx0 + cx, wy = wy0 + cy;
-        const uint8_t *rp = win + (wy + i) * kWinStride + (wx & ~3);
-        unsigned ab = 0, bb = 0;
-        row_terms(rp, wx & 3, top, ab, bb, &ptop);
-        row_terms(rp + 8 * kWinStride, wx & 3, bot, ab, bb, &pbot);
+        const int wx = wcol0 + st.cx, shp = wx & 3;
+        const uint8_t *rp = win + (wrow0 + st.cy) * kWinStride + (wx & ~3);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned *d = reinterpret_cast<const unsigned *>(rp + 8 * h * kWinStride);
+            unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+            patch[h] = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, shp), __builtin_amdgcn_alignbyte(d2, d1, shp),
+                                  __builtin_amdgcn_alignbyte(d3, d2, shp), __builtin_amdgcn_alignbyte(d4, d3, shp));
+        }
     }
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
+    uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
 
-    int v[4][8], pp[4][8];
-    unpack_rows(ptop, pbot, pp);   // skip: copy the patch (:281-283)
-    if (__any(coded)) {            // wavefront-uniform: the LDS transposes need all lanes
+    if (__any(coded)) {   // wavefront-uniform: the LDS transposes need all lanes
         LaneQ lq;
         load_lane_q<true>(lq, qtabs + p.qsel, i);
-        unpack_rows(top, bot, v);
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int h = 0; h < 2; h++) {
+            int v[2][8], pp[2][8];
+            unpack_row(rows[h], v);
+            unpack_row(patch[h], pp);
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                int d = v[s][k] - pp[s][k];                       // calc_residuals (:118-119); |d| <= 255
-                v[s][k] = (int)((unsigned)TDiv(d).d2() << 8);     // (:304)
-            }
-        }
-        forward_mb(v, xw, m, i, lq, coded);
-        store_coef_strip(xw, coef_mb0, sp.n_mb, lane);
-        if (recon) {
-            wave_lds_sync();
-            inverse_mb(v, xw, m, i, lq);
-            if (coded) {
+            for (int s = 0; s < 2; s++) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++)   // apply_residuals (:98-104)
-                        pp[s][k] = min(max(pp[s][k] + (v[s][k] - 128) * 2, 0), 255);
+                for (int k = 0; k < 8; k++) {
+                    int d = v[s][k] - pp[s][k];                       // calc_residuals (:118-119); |d| <= 255
+                    v[s][k] = (int)((unsigned)tdiv2(d) << 8);         // (:304)
                 }
+            }
+            forward_half(v, xw, m, i, lq, coded);
+            store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+            wave_lds_sync();
+            if (recon) {
+                inverse_half(v, xw, m, i, lq);
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
+                        pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
+                }
+                if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
             }
         }
     } else {
@@ -645,20 +736,19 @@ __global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint
             int ch = j * 64 + lane;
             if ((ch >> 5) < sp.n_mb) reinterpret_cast<uint4 *>(coef_mb0)[ch] = make_uint4(0, 0, 0, 0);
         }
-    }
-    if (recon && mb_valid) {
-        uint4 o0, o1;
-        pack_rows(pp, o0, o1);
-        uint8_t *dst = recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx;
-        *reinterpret_cast<uint4 *>(dst) = o0;
-        *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = o1;
+        if (recon && mb_valid) {
+            *reinterpret_cast<uint4 *>(dst) = patch[0];
+            *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = patch[1];
+        }
     }
 }
 
 // ================================================================== I-frame decode
 // reference: VideoPlane::decode_plane / decode_plane_into (src/common.rs:423-446, 477-496)
+// frames_out != nullptr: also write the cropped, tightly packed retframe (n_streams frames).
 __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int16_t *__restrict__ coef,
-                                                          uint8_t *__restrict__ out, const QTab *__restrict__ qtabs)
+                                                          uint8_t *__restrict__ out, const QTab *__restrict__ qtabs,
+                                                          uint8_t *__restrict__ frames_out)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
 
@@ -670,20 +760,30 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
     const int m = lane >> 3, i = lane & 7;
     int *xw = xchg[wave];
 
-    load_coef_strip(xw, coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256, sp.n_mb, lane);
+    const int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
+    uint4 cbuf[2][2];
+    fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
+    fetch_coef_half(cbuf[1], coef_mb0, sp.n_mb, lane, 1);
     LaneQ lq;
     load_lane_q<false>(lq, qtabs + p.qsel, i);
-    wave_lds_sync();
-
-    int v[4][8];
-    gather_coefs(v, xw, m, lq);
-    inverse_mb(v, xw, m, i, lq);
-    if (m < sp.n_mb) {
-        uint4 o0, o1;
-        pack_rows(v, o0, o1);
-        uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16;
-        *reinterpret_cast<uint4 *>(dst) = o0;
-        *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = o1;
+    uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        stage_coef_half(xw, cbuf[h], lane);
+        wave_lds_sync();
+        int v[2][8];
+        gather_half(v, xw, m, lq);
+        inverse_half(v, xw, m, i, lq);
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[s][k] = min(max(v[s][k] + 128, 0), 255);   // src/common.rs:321
+        if (m < sp.n_mb) {
+            const uint4 o = pack_row(v);
+            *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = o;
+            if (frames_out)
+                store_cropped16(frames_out + (long)sp.stream * g.src_frame_bytes + p.src_off, p, sp.x0 + m * 16, sp.y0 + i + 8 * h, o);
+        }
     }
 }
 
@@ -695,8 +795,8 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
 // vector is then treated as (0,0) so that no out-of-bounds access happens.
 __device__ __forceinline__ uint4 load_unaligned16(const uint8_t *p)
 {
-    // 16 bytes at an arbitrary address from aligned dwords (never touches bytes past p+15's dword
-    // unless p is misaligned, in which case that dword holds wanted bytes)
+    // 16 bytes at an arbitrary address from aligned dwords; the 5th dword is only touched when
+    // the address is misaligned, in which case it holds wanted bytes
     int sh = (int)((uintptr_t)p & 3);
     const unsigned *d = reinterpret_cast<const unsigned *>(p - sh);
     unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = sh ? d[4] : 0u;
@@ -707,7 +807,8 @@ __device__ __forceinline__ uint4 load_unaligned16(const uint8_t *p)
 __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8_t *__restrict__ mv,
                                                           const uint8_t *__restrict__ has, const int16_t *__restrict__ coef,
                                                           const uint8_t *__restrict__ ref, uint8_t *__restrict__ out,
-                                                          const QTab *__restrict__ qtabs, int *__restrict__ err_flag)
+                                                          const QTab *__restrict__ qtabs, int *__restrict__ err_flag,
+                                                          uint8_t *__restrict__ frames_out)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
 
@@ -721,8 +822,12 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     const bool mb_valid = m < sp.n_mb;
     const long mbi = (long)sp.stream * g.mbs_per_frame + sp.mb_first + (mb_valid ? m : 0);
 
+    // first round trip: block headers and (independent of them) the quantiser constants
     int mx = mv[mbi * 2 + 0], my = mv[mbi * 2 + 1];
     const bool coded = mb_valid && has[mbi] != 0;
+    LaneQ lq;
+    load_lane_q<false>(lq, qtabs + p.qsel, i);
+
     const int mbx = sp.x0 + m * 16, mby = sp.y0;
     if (mb_valid) {
         int sx = mbx + mx, sy = mby + my;
@@ -731,41 +836,52 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
             mx = 0; my = 0;
         }
     }
+    // second round trip: coefficients (only if some macroblock of the strip has any) and patch rows
     const bool any_coded = __any(coded);
-    if (any_coded) load_coef_strip(xw, coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256, sp.n_mb, lane);
-
-    int pp[4][8];
+    const int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
+    uint4 cbuf[2][2];
+    if (any_coded) {
+        fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
+        fetch_coef_half(cbuf[1], coef_mb0, sp.n_mb, lane, 1);
+    }
+    uint4 patch[2];
+    patch[0] = patch[1] = make_uint4(0, 0, 0, 0);
     if (mb_valid) {   // the lane's two rows of the motion-compensated patch (get_block, :327-339)
         const uint8_t *rp = ref + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(mby + my + i) * p.pw + (mbx + mx);
-        uint4 ptop = load_unaligned16(rp), pbot = load_unaligned16(rp + 8 * (long)p.pw);
-        unpack_rows(ptop, pbot, pp);
-    } else {
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int k = 0; k < 8; k++) pp[s][k] = 0;
+        patch[0] = load_unaligned16(rp);
+        patch[1] = load_unaligned16(rp + 8 * (long)p.pw);
     }
+    uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx;
+    uint8_t *crop = frames_out ? frames_out + (long)sp.stream * g.src_frame_bytes + p.src_off : nullptr;
 
     if (any_coded) {
-        LaneQ lq;
-        load_lane_q<false>(lq, qtabs + p.qsel, i);
-        wave_lds_sync();
-        int v[4][8];
-        gather_coefs(v, xw, m, lq);
-        inverse_mb(v, xw, m, i, lq);
-        if (coded) {
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+        for (int h = 0; h < 2; h++) {
+            stage_coef_half(xw, cbuf[h], lane);
+            wave_lds_sync();
+            int v[2][8], pp[2][8];
+            const int codedmask = coded ? -1 : 0;
+            gather_half(v, xw, m, lq);
+            inverse_half(v, xw, m, i, lq);
+            unpack_row(patch[h], pp);
 #pragma unroll
-                for (int k = 0; k < 8; k++) pp[s][k] = min(max(pp[s][k] + (v[s][k] - 128) * 2, 0), 255);
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); masked to 0 for skipped blocks: copy
+                    pp[s][k] = min(max(pp[s][k] + 2 * (v[s][k] & codedmask), 0), 255);
+            if (mb_valid) {
+                const uint4 o = pack_row(pp);
+                *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = o;
+                if (crop) store_cropped16(crop, p, mbx, sp.y0 + i + 8 * h, o);
+            }
         }
-    }
-    if (mb_valid) {
-        uint4 o0, o1;
-        pack_rows(pp, o0, o1);
-        uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx;
-        *reinterpret_cast<uint4 *>(dst) = o0;
-        *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = o1;
+    } else if (mb_valid) {
+        *reinterpret_cast<uint4 *>(dst) = patch[0];
+        *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = patch[1];
+        if (crop) {
+            store_cropped16(crop, p, mbx, sp.y0 + i, patch[0]);
+            store_cropped16(crop, p, mbx, sp.y0 + i + 8, patch[1]);
+        }
     }
 }
 

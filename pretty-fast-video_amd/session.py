@@ -144,6 +144,10 @@ class DecoderSession(_Geometry):
         self.ctx.check(self.ctx._lib.pfv_dec_get_frame(self.handle, ptr(out)))
         return out
 
+    def set_output_dev(self, frames_dev):
+        """fuse the retframe crop into the decode kernels (None switches it off)"""
+        self.ctx.check(self.ctx._lib.pfv_dec_set_output_dev(self.handle, ctypes.c_void_p(frames_dev or 0)))
+
     def get_frame_dev(self, frames_dev: int):
         self.ctx.check(self.ctx._lib.pfv_dec_get_frame_dev(self.handle, ctypes.c_void_p(frames_dev)))
 

@@ -75,6 +75,10 @@ def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames,
     dec = pkg.DecoderSession(ctx, width, height, np.stack(tabs[:4]), n_streams)
     oencs = [oracle.encoder(width, height, quality, threads) for _ in range(n_streams)]
     stats = {"coded": 0, "mbs": 0}
+    # fused retframe output of the decode kernels (pfv_dec_set_output_dev), checked against the same crop
+    fused_dev = ctx.alloc(n_streams * dec.frame_bytes)
+    dec.set_output_dev(fused_dev)
+    fused = np.empty((n_streams, dec.frame_bytes), dtype=np.uint8)
     for t in range(n_frames):
         frames = np.stack([s.frame(t) for s in streams])
         if t % gop == 0:
@@ -96,6 +100,7 @@ def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames,
         recon = enc.prev_frame()
         fb = dec.framebuffer()
         out = dec.get_frame()
+        ctx.download(fused, fused_dev)
         for s in range(n_streams):
             oprev = oencs[s].prev_frame()
             assert np.array_equal(recon[s], oprev), f"frame {t} stream {s}: encoder reconstruction differs"
@@ -106,6 +111,9 @@ def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames,
                                    f.plane_u.image()[:height // 2, :width // 2].reshape(-1),
                                    f.plane_v.image()[:height // 2, :width // 2].reshape(-1)])
             assert np.array_equal(out[s], crop), f"frame {t} stream {s}: cropped retframe differs"
+            assert np.array_equal(fused[s], crop), f"frame {t} stream {s}: fused retframe output differs"
+    dec.set_output_dev(None)
+    ctx.free(fused_dev)
     enc.close()
     dec.close()
     return stats
