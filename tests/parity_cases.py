@@ -117,3 +117,39 @@ def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames,
     enc.close()
     dec.close()
     return stats
+
+
+def check_golden(pkg, ctx, oracle):
+    """the HIP path against the committed known-answer vectors (tests/golden/hotpath_vectors.npz)"""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_vectors.npz"))
+    il, _, pl, _, px_err = oracle.qtables(5)
+    # the src/lib.rs:61-66 block as the top-left subblock of a 16x16 plane (rest = clear colour 128 -> zero AC)
+    plane = pkg.VideoPlane.from_slice(8, 8, gold["lib_block"])
+    enc = plane.encode_plane(gold["lib_q"], 128, ctx)
+    assert np.array_equal(enc.blocks[0, :64], gold["lib_quant"])
+    rec = pkg.VideoPlane.decode_plane(enc, gold["lib_q"], ctx)
+    assert np.array_equal(rec.image()[:8, :8].reshape(-1), gold["lib_recon"])
+    # 64 random subblocks, 4 per macroblock, all golden qualities / tables
+    px = gold["sub_px"].reshape(16, 4, 8, 8)
+    img = px.reshape(16, 2, 2, 8, 8).transpose(0, 1, 3, 2, 4).reshape(16 * 16, 16)     # 16 macroblocks stacked vertically
+    plane = pkg.VideoPlane.from_slice(16, 256, img)
+    for quality in (0, 2, 5, 10):
+        tabs = oracle.qtables(quality)
+        for name, q in (("intra_l", tabs[0]), ("intra_c", tabs[1]), ("inter_l", tabs[2])):
+            e = plane.encode_plane(q, 0, ctx)
+            assert np.array_equal(e.blocks.reshape(64, 64), gold[f"q{quality}_{name}_enc"]), (quality, name)
+            d = pkg.VideoPlane.decode_plane(e, q, ctx).image().reshape(16, 2, 8, 2, 8).transpose(0, 1, 3, 2, 4).reshape(64, 64)
+            assert np.array_equal(d, gold[f"q{quality}_{name}_dec"]), (quality, name)
+    # the 64x48 p-frame case
+    f0 = pkg.VideoPlane.from_slice(64, 48, gold["pf_f0"])
+    f1 = pkg.VideoPlane.from_slice(64, 48, gold["pf_f1"])
+    e0 = f0.encode_plane(il, 0, ctx)
+    assert np.array_equal(e0.blocks, gold["pf_c0"])
+    r0 = pkg.VideoPlane.decode_plane(e0, il, ctx)
+    assert np.array_equal(r0.image(), gold["pf_rec0"])
+    e1 = f1.encode_plane_delta(r0, pl, px_err, 0, ctx)
+    assert np.array_equal(e1.motion, gold["pf_mv"]) and np.array_equal(e1.has_coeff, gold["pf_has"])
+    assert np.array_equal(e1.blocks, gold["pf_c1"])
+    r1 = pkg.VideoPlane.decode_plane_delta(e1, r0, pl, ctx)
+    assert np.array_equal(r1.image(), gold["pf_rec1"])

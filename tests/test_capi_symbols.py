@@ -1,0 +1,67 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports every symbol that include/pfv_hip.h
+declares; without a GPU the product fails loudly instead of falling back to anything."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pfv_hip.h")).read()
+    return sorted(set(re.findall(r"PFV_API\s+[\w\s\*]+?\b(pfv_\w+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_bound_and_exported(graft, pkg):
+    graft.build_hip()
+    os.environ.pop("PFV_HIP_LIB", None)
+    pkg._lib._lib = None
+    lib = pkg._lib.load()                       # binds every entry of SIGNATURES; AttributeError if one is missing
+    assert pkg._lib._lib_path == pkg._lib.DEFAULT_LIB
+    declared = declared_symbols()
+    bound = sorted(name for name, _, _ in pkg._lib.SIGNATURES)
+    assert declared == bound, f"header vs binding mismatch: {set(declared) ^ set(bound)}"
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b"gfx950" in lib.pfv_version()
+    assert lib.pfv_pad16(1080) == 1088 and lib.pfv_pad16(1920) == 1920
+    assert lib.pfv_total_blocks(1920, 1080) == 12240 and lib.pfv_total_blocks(3840, 2160) == 48720
+    assert lib.pfv_frame_bytes(1920, 1080) == 3110400 and lib.pfv_padded_frame_bytes(1920, 1080) == 3133440
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    """nothing under the package or the C sources refers to oracle/"""
+    pkgdir = os.path.join(ROOT, "pretty-fast-video_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pfv_oracle" not in text and "oracle_bind" not in text and "pfvo_" not in text, f
+
+
+def test_no_gpu_fails_loudly(graft, pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    graft.build_hip()
+    os.environ.pop("PFV_HIP_LIB", None)
+    pkg._lib._lib = None
+    with pytest.raises(pkg.PfvError) as e:
+        pkg.Context(0)
+    assert e.value.code in (pkg._lib.PFV_ERR_NO_DEVICE, pkg._lib.PFV_ERR_HIP)
+
+
+def test_qtables_entry_point_matches_oracle(graft, pkg, oracle):
+    graft.build_hip()
+    os.environ.pop("PFV_HIP_LIB", None)
+    pkg._lib._lib = None
+    import numpy as np
+    for quality in range(11):
+        got = pkg.qtables_from_quality(quality)
+        want = oracle.qtables(quality)
+        for a, b in zip(got[:4], want[:4]):
+            assert np.array_equal(a, b)
+        assert got[4] == want[4]
+    with pytest.raises(pkg.PfvError):
+        pkg.qtables_from_quality(11)

@@ -19,6 +19,10 @@ def test_emu_plane_ops(pkg, emu_ctx, oracle, w, h, quality):
     pc.check_encode_plane_delta(pkg, emu_ctx, oracle, px, ref, pcq, px_err, 128)
 
 
+def test_emu_golden_vectors(pkg, emu_ctx, oracle):
+    pc.check_golden(pkg, emu_ctx, oracle)
+
+
 def test_emu_session_two_streams(pkg, emu_ctx, oracle):
     stats = pc.check_session(pkg, emu_ctx, oracle, 64, 48, 5, n_streams=2, n_frames=3)
     assert 0 < stats["coded"] < stats["mbs"]

@@ -20,6 +20,10 @@ def test_native_library_is_the_one_loaded(pkg, gpu_ctx):
     assert b"gfx950" in pkg._lib.load().pfv_version()
 
 
+def test_golden_vectors(pkg, gpu_ctx, oracle):
+    pc.check_golden(pkg, gpu_ctx, oracle)
+
+
 @pytest.mark.parametrize("quality", list(range(0, 11)))
 def test_iframe_plane_all_qualities(pkg, gpu_ctx, oracle, quality):
     il, ic, _, _, _ = oracle.qtables(quality)
