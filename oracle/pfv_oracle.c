@@ -342,32 +342,71 @@ static void decode_block_delta(const int8_t mv[2], int has_coef, const int16_t c
 
 /* ---------------------------------------------------------------- fork/join helper
  * Stand-in for `tp.install(|| par_iter().map().collect())` (src/common.rs:374-378 and the
- * five sibling call sites): a static partition of the macroblock index range over
- * `threads` pthreads.  Results are index-ordered, like rayon's collect(). */
+ * five sibling call sites): a persistent pool of `threads` workers (like the rayon pool the
+ * reference builds once per Encoder/Decoder, src/enc.rs:54) that pull chunks of macroblock
+ * indices from a shared counter; the caller blocks until the map is complete.  Results are
+ * index-ordered, like rayon's collect(). */
 typedef void (*mb_fn)(void *ctx, int mb_index);
-typedef struct { mb_fn fn; void *ctx; int lo, hi; } par_job;
-static void *par_worker(void *p)
+#define PFVO_MAX_THREADS 512
+#define PFVO_CHUNK 8
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_done;
+    pthread_t th[PFVO_MAX_THREADS];
+    int n_threads;          /* workers alive */
+    mb_fn fn; void *ctx; int total;
+    int next;               /* next unclaimed index (atomic) */
+    int generation;         /* bumped per job */
+    int busy;               /* workers still inside the current job */
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0};
+
+static void pool_run_chunks(void)
 {
-    par_job *j = (par_job *)p;
-    for (int i = j->lo; i < j->hi; i++) j->fn(j->ctx, i);
+    /* lock-free chunk claiming: fn/ctx/total were published under the mutex before the workers woke */
+    mb_fn fn = g_pool.fn; void *ctx = g_pool.ctx; const int total = g_pool.total;
+    for (;;) {
+        int lo = __atomic_fetch_add(&g_pool.next, PFVO_CHUNK, __ATOMIC_RELAXED);
+        if (lo >= total) return;
+        int hi = lo + PFVO_CHUNK > total ? total : lo + PFVO_CHUNK;
+        for (int i = lo; i < hi; i++) fn(ctx, i);
+    }
+}
+static void *pool_worker(void *arg)
+{
+    (void)arg;
+    int seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+        seen = g_pool.generation;
+        pthread_mutex_unlock(&g_pool.mu);
+        pool_run_chunks();
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.busy == 0) pthread_cond_signal(&g_pool.cv_done);
+    }
     return NULL;
 }
 static void par_for(int n, int threads, mb_fn fn, void *ctx)
 {
-    if (threads <= 1 || n < 2 * threads) {
+    if (threads <= 1 || n < 2 * PFVO_CHUNK) {
         for (int i = 0; i < n; i++) fn(ctx, i);
         return;
     }
-    if (threads > 256) threads = 256;
-    pthread_t tid[256];
-    par_job jobs[256];
-    for (int t = 0; t < threads; t++) {
-        jobs[t].fn = fn; jobs[t].ctx = ctx;
-        jobs[t].lo = (int)((int64_t)n * t / threads);
-        jobs[t].hi = (int)((int64_t)n * (t + 1) / threads);
-        pthread_create(&tid[t], NULL, par_worker, &jobs[t]);
+    if (threads > PFVO_MAX_THREADS) threads = PFVO_MAX_THREADS;
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.n_threads < threads - 1) {   /* the caller is the last "thread" */
+        pthread_create(&g_pool.th[g_pool.n_threads], NULL, pool_worker, NULL);
+        g_pool.n_threads++;
     }
-    for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+    g_pool.fn = fn; g_pool.ctx = ctx; g_pool.total = n; g_pool.next = 0;
+    g_pool.busy = g_pool.n_threads;
+    g_pool.generation++;
+    pthread_cond_broadcast(&g_pool.cv_work);
+    pthread_mutex_unlock(&g_pool.mu);
+    pool_run_chunks();
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.busy > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
 }
 
 static inline int pad16(int x) { return x + (16 - (x % 16)) % 16; } /* common.rs:352-353 */
