@@ -201,6 +201,16 @@ def main():
     if rank == 0:
         launch_mbs = S * n_mb
         achieved = launch_mbs * BYTES_PER_MB_PENC / (pe_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+        # tools/gpu_pmc.sh); only quoted when it was collected on this exact configuration
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            c = pm["config"]
+            if (int(c["streams"]), int(c["width"]), int(c["height"]), int(c["quality"])) == (S, W, H, Q):
+                traffic = pm["kernels"]["k_enc_pframe"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "macroblocks/s (encode+decode) 1080p YUV420",
             "value": total_mb / el_max,
@@ -218,7 +228,8 @@ def main():
                        "streams_per_gpu": S, "macroblocks_per_frame": n_mb, "quality": Q,
                        "pframe_coded_fraction": round(coded_frac, 4), "parallelism": f"streams sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "k_enc_pframe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": launch_mbs * BYTES_PER_MB_PENC,
                          "avg_launch_ms": pe_ms, "macroblocks_per_launch": launch_mbs,
                          "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC},
         }

@@ -180,6 +180,41 @@ PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host);
 /* asynchronous bad-motion-vector flag raised by the last *_dev p-frame decode(s); reading it syncs. */
 PFV_API int pfv_dec_check(pfv_dec_session *s);
 
+/* ------------------------------------------------------------------ stream-level session objects
+ * enc::Encoder<W: Write> (src/enc.rs:12-188) with the writer being an in-memory byte vector, and
+ * dec::Decoder<R: Read + Seek> (src/dec.rs:15-224) over a caller-owned byte slice.  The per-macroblock work runs
+ * on the device sessions above; RLE / Huffman / bit packing and the container run on the host.
+ * Planes: y = width*height, u and v = (width/2)*(height/2) (VideoFrame, src/frame.rs:3-9). */
+typedef struct pfv_encoder pfv_encoder;
+typedef struct pfv_decoder pfv_decoder;
+typedef void (*pfv_video_cb)(void *user, const uint8_t *y, const uint8_t *u, const uint8_t *v, int width, int height);
+
+PFV_API int pfv_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, pfv_encoder **out);
+PFV_API int pfv_encoder_encode_iframe(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+PFV_API int pfv_encoder_encode_pframe(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+PFV_API int pfv_encoder_encode_dropframe(pfv_encoder *e);
+PFV_API int pfv_encoder_finish(pfv_encoder *e);
+/* the bytes written so far (header + packets); valid until the next call on this encoder */
+PFV_API int pfv_encoder_bytes(pfv_encoder *e, const uint8_t **data, size_t *len);
+PFV_API void pfv_encoder_destroy(pfv_encoder *e);
+/* packet payload serialisers alone (write_iframe_packet / write_pframe_packet bodies, src/enc.rs:237-320, 332-470);
+ * return the payload size (0 on error); the payload is copied to `out` when it fits `cap` */
+PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap);
+PFV_API size_t pfv_serialize_pframe_payload(const int8_t *mv, const uint8_t *has_coef, const int16_t *coef, int total_blocks,
+                                            uint8_t *out, size_t cap);
+
+/* `data` must stay valid while the decoder lives.  Errors: PFV_ERR_FORMAT / PFV_ERR_VERSION / PFV_ERR_IO
+ * = DecodeError::{FormatError, VersionError, IOError} (src/dec.rs:30-35). */
+PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pfv_decoder **out);
+PFV_API void pfv_decoder_destroy(pfv_decoder *d);
+PFV_API int pfv_decoder_width(const pfv_decoder *d);
+PFV_API int pfv_decoder_height(const pfv_decoder *d);
+PFV_API int pfv_decoder_framerate(const pfv_decoder *d);
+PFV_API int pfv_decoder_reset(pfv_decoder *d);
+/* 1 = Ok(true) (more data), 0 = Ok(false) (EOF), negative = error */
+PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void *user);
+PFV_API int pfv_decoder_advance_delta(pfv_decoder *d, double delta, pfv_video_cb onvideo, void *user);
+
 #ifdef __cplusplus
 }
 #endif

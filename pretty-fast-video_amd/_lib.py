@@ -75,6 +75,23 @@ SIGNATURES = [
     ("pfv_dec_get_frame", c_int, [_P, _P]),
     ("pfv_dec_framebuffer", c_int, [_P, _P]),
     ("pfv_dec_check", c_int, [_P]),
+    ("pfv_encoder_create", c_int, [_P, c_int, c_int, c_int, c_int, POINTER(_P)]),
+    ("pfv_encoder_encode_iframe", c_int, [_P, _P, _P, _P]),
+    ("pfv_encoder_encode_pframe", c_int, [_P, _P, _P, _P]),
+    ("pfv_encoder_encode_dropframe", c_int, [_P]),
+    ("pfv_encoder_finish", c_int, [_P]),
+    ("pfv_encoder_bytes", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
+    ("pfv_encoder_destroy", None, [_P]),
+    ("pfv_serialize_iframe_payload", c_size_t, [_P, c_int, _P, c_size_t]),
+    ("pfv_serialize_pframe_payload", c_size_t, [_P, _P, _P, c_int, _P, c_size_t]),
+    ("pfv_decoder_create", c_int, [_P, _P, c_size_t, POINTER(_P)]),
+    ("pfv_decoder_destroy", None, [_P]),
+    ("pfv_decoder_width", c_int, [_P]),
+    ("pfv_decoder_height", c_int, [_P]),
+    ("pfv_decoder_framerate", c_int, [_P]),
+    ("pfv_decoder_reset", c_int, [_P]),
+    ("pfv_decoder_advance_frame", c_int, [_P, _P, _P]),
+    ("pfv_decoder_advance_delta", c_int, [_P, ctypes.c_double, _P, _P]),
 ]
 
 _lib = None

@@ -4,6 +4,7 @@
 // There is NO CPU fallback here: every entry point either runs the HIP kernels or returns
 // a negative status.
 #include "pfv_kernels.hip"
+#include "pfv_host.hip"
 
 #include <math.h>
 #include <stdio.h>
@@ -860,6 +861,265 @@ PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host)
                                 hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PFV_OK;
+}
+
+}  // extern "C"
+
+// ================================================================== stream-level session objects
+// enc::Encoder<W> (src/enc.rs:12-188) with W = an in-memory byte vector (the reference's tests use
+// Cursor<Vec<u8>>, src/lib.rs:319-321), dec::Decoder<R> (src/dec.rs:15-224) with R = a caller-owned byte slice.
+struct pfv_encoder {
+    pfv_ctx *ctx = nullptr;
+    pfv_enc_session *hot = nullptr;
+    int width = 0, height = 0, framerate = 0, total_blocks = 0;
+    bool finished = false;
+    std::vector<uint8_t> out;              // the writer
+    std::vector<uint8_t> frame;            // packed Y|U|V staging
+    std::vector<int16_t> coef;
+    std::vector<int8_t> mv;
+    std::vector<uint8_t> has;
+};
+
+struct pfv_decoder {
+    pfv_ctx *ctx = nullptr;
+    pfv_dec_session *hot = nullptr;
+    const uint8_t *data = nullptr;
+    size_t len = 0, pos = 0, reset_pos = 0;
+    int width = 0, height = 0, framerate = 0, n_qtables = 0, total_blocks = 0;
+    bool eof = false;
+    double delta_accum = 0.0;
+    std::vector<int16_t> coef;
+    std::vector<int8_t> mv;
+    std::vector<uint8_t> has;
+    std::vector<uint8_t> retframe;         // Y|U|V, unpadded (src/dec.rs:22)
+};
+
+static void put_u16(std::vector<uint8_t> &o, unsigned v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); }
+static void put_u32(std::vector<uint8_t> &o, uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+static void put_packet(std::vector<uint8_t> &o, uint8_t type, const std::vector<uint8_t> *payload)
+{
+    o.push_back(type);
+    put_u32(o, payload ? (uint32_t)payload->size() : 0u);
+    if (payload) o.insert(o.end(), payload->begin(), payload->end());
+}
+
+extern "C" {
+
+// Encoder::new (src/enc.rs:37-73): q-tables from quality, prev_frame = new_padded, write_header (:190-219)
+PFV_API int pfv_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, pfv_encoder **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_encoder_create: bad argument");
+    *out = nullptr;
+    if (framerate < 0 || framerate > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "framerate must fit u16 (src/enc.rs:197)");
+    pfv_enc_session *hot = nullptr;
+    int rc = pfv_enc_session_create(ctx, width, height, quality, 1, &hot);
+    if (rc) return rc;
+    pfv_encoder *e = new pfv_encoder();
+    e->ctx = ctx; e->hot = hot; e->width = width; e->height = height; e->framerate = framerate;
+    e->total_blocks = pfv_total_blocks(width, height);
+    e->frame.resize(pfv_frame_bytes(width, height));
+    e->coef.resize((size_t)e->total_blocks * 256);
+    e->mv.resize((size_t)e->total_blocks * 2);
+    e->has.resize((size_t)e->total_blocks);
+    int32_t q[4][64];
+    pfv_qtables_from_quality(quality, q[0], q[1], q[2], q[3], nullptr);
+    static const char magic[8] = {'P', 'F', 'V', 'I', 'D', 'E', 'O', 0};      // common.rs:1
+    e->out.insert(e->out.end(), magic, magic + 8);
+    put_u32(e->out, 211);                                                      // common.rs:2
+    put_u16(e->out, (unsigned)width); put_u16(e->out, (unsigned)height); put_u16(e->out, (unsigned)framerate);
+    put_u16(e->out, 4);
+    for (int t = 0; t < 4; t++)                                                // intra_l, intra_c, inter_l, inter_c
+        for (int i = 0; i < 64; i++) put_u16(e->out, (unsigned)q[t][i]);
+    *out = e;
+    return PFV_OK;
+}
+
+static int pack_frame(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+{
+    if (!y || !u || !v) return fail(e->ctx, PFV_ERR_BAD_ARG, "null plane");
+    if (e->finished) return fail(e->ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:80)");
+    size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
+    memcpy(e->frame.data(), y, ny);
+    memcpy(e->frame.data() + ny, u, nc);
+    memcpy(e->frame.data() + ny + nc, v, nc);
+    return PFV_OK;
+}
+
+// Encoder::encode_iframe (src/enc.rs:75-123)
+PFV_API int pfv_encoder_encode_iframe(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    int rc = pack_frame(e, y, u, v);
+    if (rc) return rc;
+    if ((rc = pfv_enc_iframe(e->hot, e->frame.data(), e->coef.data()))) return rc;
+    std::vector<uint8_t> payload;
+    if (!serialize_iframe(payload, e->coef.data(), e->total_blocks))
+        return fail(e->ctx, PFV_ERR_FORMAT, "coefficient needs more than 15 size bits (src/rle.rs:44)");
+    put_packet(e->out, 1, &payload);
+    return PFV_OK;
+}
+// Encoder::encode_pframe (src/enc.rs:125-173)
+PFV_API int pfv_encoder_encode_pframe(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    int rc = pack_frame(e, y, u, v);
+    if (rc) return rc;
+    if ((rc = pfv_enc_pframe(e->hot, e->frame.data(), e->mv.data(), e->has.data(), e->coef.data()))) return rc;
+    std::vector<uint8_t> payload;
+    if (!serialize_pframe(payload, e->mv.data(), e->has.data(), e->coef.data(), e->total_blocks))
+        return fail(e->ctx, PFV_ERR_FORMAT, "coefficient needs more than 15 size bits (src/rle.rs:44)");
+    put_packet(e->out, 2, &payload);
+    return PFV_OK;
+}
+// Encoder::encode_dropframe (src/enc.rs:175-180): an i-frame packet with an empty payload
+PFV_API int pfv_encoder_encode_dropframe(pfv_encoder *e)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    if (e->finished) return fail(e->ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:176)");
+    put_packet(e->out, 1, nullptr);
+    return PFV_OK;
+}
+// Encoder::finish (src/enc.rs:182-188): EOF packet
+PFV_API int pfv_encoder_finish(pfv_encoder *e)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    if (e->finished) return fail(e->ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:183)");
+    e->finished = true;
+    put_packet(e->out, 0, nullptr);
+    return PFV_OK;
+}
+PFV_API int pfv_encoder_bytes(pfv_encoder *e, const uint8_t **data, size_t *len)
+{
+    if (!e || !data || !len) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_encoder_bytes: bad argument");
+    *data = e->out.data();
+    *len = e->out.size();
+    return PFV_OK;
+}
+// Drop for Encoder (src/enc.rs:28-34): finishes the stream if the caller did not
+PFV_API void pfv_encoder_destroy(pfv_encoder *e)
+{
+    if (!e) return;
+    pfv_enc_session_destroy(e->hot);
+    delete e;
+}
+// payload serialisers alone (for tests: product vs oracle on identical coefficient input)
+PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap)
+{
+    std::vector<uint8_t> p;
+    if (!coef || total_blocks <= 0 || !serialize_iframe(p, coef, total_blocks)) return 0;
+    if (out && p.size() <= cap) memcpy(out, p.data(), p.size());
+    return p.size();
+}
+PFV_API size_t pfv_serialize_pframe_payload(const int8_t *mv, const uint8_t *has_coef, const int16_t *coef, int total_blocks,
+                                            uint8_t *out, size_t cap)
+{
+    std::vector<uint8_t> p;
+    if (!mv || !has_coef || !coef || total_blocks <= 0 || !serialize_pframe(p, mv, has_coef, coef, total_blocks)) return 0;
+    if (out && p.size() <= cap) memcpy(out, p.data(), p.size());
+    return p.size();
+}
+
+// Decoder::new (src/dec.rs:38-134).  `data` must stay valid for the decoder's lifetime (R: Read + Seek).
+PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pfv_decoder **out)
+{
+    if (!ctx || !data || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_decoder_create: bad argument");
+    *out = nullptr;
+    static const char magic[8] = {'P', 'F', 'V', 'I', 'D', 'E', 'O', 0};
+    if (len < 8) return fail(ctx, PFV_ERR_IO, "stream shorter than the magic (DecodeError::IOError)");
+    if (memcmp(data, magic, 8) != 0) return fail(ctx, PFV_ERR_FORMAT, "bad magic (DecodeError::FormatError, src/dec.rs:50-52)");
+    if (len < 12) return fail(ctx, PFV_ERR_IO, "truncated header");
+    uint32_t ver = (uint32_t)data[8] | ((uint32_t)data[9] << 8) | ((uint32_t)data[10] << 16) | ((uint32_t)data[11] << 24);
+    if (ver != 211) return fail(ctx, PFV_ERR_VERSION, "codec version is not 2.1.1 (DecodeError::VersionError, src/dec.rs:57-59)");
+    if (len < 20) return fail(ctx, PFV_ERR_IO, "truncated header");
+    auto u16 = [&](size_t o) { return (int)data[o] | ((int)data[o + 1] << 8); };
+    int w = u16(12), h = u16(14), fps = u16(16), nq = u16(18);
+    if (len < 20 + (size_t)nq * 128) return fail(ctx, PFV_ERR_IO, "truncated q-tables");
+    std::vector<int32_t> q((size_t)std::max(nq, 1) * 64, 1);
+    for (int i = 0; i < nq * 64; i++) q[i] = u16(20 + 2 * (size_t)i);
+    pfv_dec_session *hot = nullptr;
+    int rc = pfv_dec_session_create(ctx, w, h, q.data(), nq, 1, &hot);
+    if (rc) return rc;
+    pfv_decoder *d = new pfv_decoder();
+    d->ctx = ctx; d->hot = hot; d->data = data; d->len = len;
+    d->pos = d->reset_pos = 20 + (size_t)nq * 128;
+    d->width = w; d->height = h; d->framerate = fps; d->n_qtables = nq;
+    d->total_blocks = pfv_total_blocks(w, h);
+    d->coef.resize((size_t)d->total_blocks * 256);
+    d->mv.resize((size_t)d->total_blocks * 2);
+    d->has.resize((size_t)d->total_blocks);
+    d->retframe.assign(pfv_frame_bytes(w, h), 0);                              // VideoFrame::new (frame.rs:12-26): Y 0, U/V 128
+    std::fill(d->retframe.begin() + (size_t)w * h, d->retframe.end(), (uint8_t)128);
+    *out = d;
+    return PFV_OK;
+}
+PFV_API void pfv_decoder_destroy(pfv_decoder *d)
+{
+    if (!d) return;
+    pfv_dec_session_destroy(d->hot);
+    delete d;
+}
+PFV_API int pfv_decoder_width(const pfv_decoder *d) { return d ? d->width : 0; }          // dec.rs:136-138
+PFV_API int pfv_decoder_height(const pfv_decoder *d) { return d ? d->height : 0; }        // dec.rs:140-142
+PFV_API int pfv_decoder_framerate(const pfv_decoder *d) { return d ? d->framerate : 0; }  // dec.rs:144-146
+// Decoder::reset (src/dec.rs:148-152)
+PFV_API int pfv_decoder_reset(pfv_decoder *d)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    d->eof = false;
+    d->pos = d->reset_pos;
+    return PFV_OK;
+}
+
+// Decoder::advance_frame (src/dec.rs:169-224).  Returns 1 = Ok(true), 0 = Ok(false) (EOF), negative = error.
+// onvideo(user, y, u, v, width, height) is called for every decoded frame (not for drop frames).
+PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void *user)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    if (d->eof) return 0;
+    for (;;) {
+        if (d->pos + 5 > d->len) return fail(d->ctx, PFV_ERR_IO, "unexpected end of stream in a packet header");
+        uint8_t type = d->data[d->pos];
+        uint32_t plen = (uint32_t)d->data[d->pos + 1] | ((uint32_t)d->data[d->pos + 2] << 8) | ((uint32_t)d->data[d->pos + 3] << 16) |
+                        ((uint32_t)d->data[d->pos + 4] << 24);
+        d->pos += 5;
+        if (type == 0) {   // EOF marker (:183-187)
+            d->eof = true;
+            return 0;
+        }
+        if (d->pos + plen > d->len) return fail(d->ctx, PFV_ERR_IO, "packet payload runs past the end of the stream");
+        const uint8_t *payload = d->data + d->pos;
+        d->pos += plen;
+        if (type != 1 && type != 2) continue;   // unknown packet: skipped (:216-219)
+        if (type == 1 && plen == 0) break;      // drop frame: nothing decoded, no callback (:190)
+        uint8_t qidx[3];
+        int rc = type == 1 ? parse_iframe(payload, plen, d->total_blocks, d->coef.data(), qidx)
+                           : parse_pframe(payload, plen, d->total_blocks, d->mv.data(), d->has.data(), d->coef.data(), qidx);
+        if (rc) return fail(d->ctx, rc, "malformed packet payload");
+        rc = type == 1 ? pfv_dec_iframe(d->hot, d->coef.data(), qidx)
+                       : pfv_dec_pframe(d->hot, d->mv.data(), d->has.data(), d->coef.data(), qidx);
+        if (rc) return rc;
+        if ((rc = pfv_dec_get_frame(d->hot, d->retframe.data()))) return rc;   // crop blits (:195-197, 209-211)
+        if (onvideo) {
+            size_t ny = (size_t)d->width * d->height, nc = (size_t)(d->width / 2) * (d->height / 2);
+            onvideo(user, d->retframe.data(), d->retframe.data() + ny, d->retframe.data() + ny + nc, d->width, d->height);
+        }
+        break;
+    }
+    return 1;
+}
+
+// Decoder::advance_delta (src/dec.rs:154-167)
+PFV_API int pfv_decoder_advance_delta(pfv_decoder *d, double delta, pfv_video_cb onvideo, void *user)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    d->delta_accum += delta;
+    double delta_per_frame = 1.0 / (double)d->framerate;
+    while (d->delta_accum >= delta_per_frame) {
+        int rc = pfv_decoder_advance_frame(d, onvideo, user);
+        if (rc <= 0) return rc;
+        d->delta_accum -= delta_per_frame;
+    }
+    return 1;
 }
 
 }  // extern "C"

@@ -218,3 +218,89 @@ class OracleDecoder:
             ptr = self.L.pfvo_decoder_plane(self.h, p, ctypes.byref(pw), ctypes.byref(ph))
             parts.append(np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(c_uint8)), shape=(pw.value * ph.value,)).copy())
         return np.concatenate(parts)
+
+
+class OracleStreamEncoder:
+    """enc::Encoder on the CPU oracle, whole .pfv byte stream (oracle/pfv_oracle_entropy.c)"""
+
+    def __init__(self, ora: Oracle, width, height, framerate, quality, threads=1):
+        L = self.L = ora.L
+        L.pfvo_stream_encoder_new.argtypes = [c_int] * 5
+        L.pfvo_stream_encoder_new.restype = c_void_p
+        for name in ("pfvo_stream_encode_iframe", "pfvo_stream_encode_pframe"):
+            getattr(L, name).argtypes = [c_void_p] * 4
+        L.pfvo_stream_encode_dropframe.argtypes = [c_void_p]
+        L.pfvo_stream_finish.argtypes = [c_void_p]
+        L.pfvo_stream_bytes.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        L.pfvo_stream_bytes.restype = c_void_p
+        L.pfvo_stream_encoder_free.argtypes = [c_void_p]
+        self.h = L.pfvo_stream_encoder_new(width, height, framerate, quality, threads)
+        assert self.h
+        self.width, self.height = width, height
+
+    def _split(self, frame):
+        f = np.ascontiguousarray(frame, dtype=np.uint8).reshape(-1)
+        w, h = self.width, self.height
+        o1, o2 = w * h, w * h + (w // 2) * (h // 2)
+        return np.ascontiguousarray(f[:o1]), np.ascontiguousarray(f[o1:o2]), np.ascontiguousarray(f[o2:])
+
+    def encode_iframe(self, frame):
+        y, u, v = self._split(frame)
+        self.L.pfvo_stream_encode_iframe(self.h, _p(y), _p(u), _p(v))
+
+    def encode_pframe(self, frame):
+        y, u, v = self._split(frame)
+        self.L.pfvo_stream_encode_pframe(self.h, _p(y), _p(u), _p(v))
+
+    def encode_dropframe(self):
+        self.L.pfvo_stream_encode_dropframe(self.h)
+
+    def finish(self):
+        self.L.pfvo_stream_finish(self.h)
+
+    def bytes(self) -> bytes:
+        n = ctypes.c_size_t()
+        p = self.L.pfvo_stream_bytes(self.h, ctypes.byref(n))
+        return ctypes.string_at(p, n.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.pfvo_stream_encoder_free(self.h)
+            self.h = None
+
+
+class OracleStreamDecoder:
+    """dec::Decoder on the CPU oracle"""
+
+    def __init__(self, ora: Oracle, data: bytes, threads=1):
+        L = self.L = ora.L
+        L.pfvo_stream_decoder_new.argtypes = [c_void_p, ctypes.c_size_t, c_int, ctypes.POINTER(c_int)]
+        L.pfvo_stream_decoder_new.restype = c_void_p
+        L.pfvo_stream_decoder_free.argtypes = [c_void_p]
+        L.pfvo_stream_decoder_info.argtypes = [c_void_p] + [ctypes.POINTER(c_int)] * 3
+        L.pfvo_stream_decoder_reset.argtypes = [c_void_p]
+        L.pfvo_stream_advance_frame.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_int)]
+        L.pfvo_stream_advance_frame.restype = c_int
+        self._data = np.frombuffer(data, dtype=np.uint8).copy()
+        err = c_int()
+        self.h = L.pfvo_stream_decoder_new(_p(self._data), self._data.size, threads, ctypes.byref(err))
+        self.err = err.value
+        if self.h:
+            w, h, f = c_int(), c_int(), c_int()
+            L.pfvo_stream_decoder_info(self.h, ctypes.byref(w), ctypes.byref(h), ctypes.byref(f))
+            self.width, self.height, self.framerate = w.value, h.value, f.value
+            self._frame = np.zeros(self.width * self.height + 2 * (self.width // 2) * (self.height // 2), dtype=np.uint8)
+
+    def advance_frame(self):
+        """-> (rc, frame or None): rc 1 more data / 0 EOF / negative error"""
+        got = c_int()
+        rc = self.L.pfvo_stream_advance_frame(self.h, _p(self._frame), ctypes.byref(got))
+        return rc, (self._frame.copy() if got.value else None)
+
+    def reset(self):
+        self.L.pfvo_stream_decoder_reset(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.pfvo_stream_decoder_free(self.h)
+            self.h = None

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import parity_cases as pc
+import stream_cases as sc
 
 
 @pytest.mark.parametrize("w,h", [(64, 48), (50, 38), (144, 16)])
@@ -36,3 +37,10 @@ def test_emu_bad_motion_vector(pkg, emu_ctx, oracle):
     with pytest.raises(pkg.PfvError) as e:
         pkg.VideoPlane.decode_plane_delta(src, ref, q, emu_ctx)
     assert e.value.code == pkg._lib.PFV_ERR_BAD_MV
+
+
+def test_emu_stream_encoder_decoder(pkg, emu_ctx, oracle):
+    """product Encoder/Decoder vs the oracle's, whole .pfv byte stream"""
+    data = sc.check_stream_roundtrip(pkg, emu_ctx, oracle, 48, 32, 5, n_frames=5, gop=3, drop_at=(2,))
+    sc.check_advance_delta(pkg, emu_ctx, oracle, data, kinds=[True, True, False, True, True])
+    sc.check_header_errors(pkg, emu_ctx, data)

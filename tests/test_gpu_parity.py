@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import parity_cases as pc
+import stream_cases as sc
 
 pytestmark = pytest.mark.gpu
 
@@ -196,3 +197,12 @@ def test_blit_dev(pkg, gpu_ctx):
     assert rc == pkg._lib.PFV_ERR_BAD_ARG
     gpu_ctx.free(d_src)
     gpu_ctx.free(d_dst)
+
+
+def test_stream_encoder_decoder_vs_oracle(pkg, gpu_ctx, oracle):
+    """Encoder -> .pfv bytes -> Decoder; stream bytes and decoded frames equal the oracle's"""
+    data = sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 176, 144, 5, n_frames=7, gop=3, drop_at=(4,))
+    sc.check_advance_delta(pkg, gpu_ctx, oracle, data, kinds=[True, True, True, True, False, True, True])
+    sc.check_header_errors(pkg, gpu_ctx, data)
+    sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 100, 60, 2, n_frames=3, gop=15)
+    sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 64, 48, 10, n_frames=3, gop=15)

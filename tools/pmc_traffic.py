@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE counter passes (rocprofv3 --pmc, separate runs) into per-kernel HBM bytes per launch.
+
+usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json key=value...
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced
+read stream (MI355X_MICROARCH.md, section HBM): it is doubled here; WRITE_SIZE is taken as is."""
+import collections, csv, json, sys
+
+def means(path, counter):
+    acc = collections.defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = row.get("Kernel_Name", "")
+            if "pfv::" in k and row["Counter_Name"] == counter:
+                acc[k.split("(")[0].replace("pfv::", "")].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
+out = {"note": "HBM bytes per launch = FETCH_SIZE[KiB]*1024*2 (gfx950 half-count correction) + WRITE_SIZE[KiB]*1024",
+       "config": dict(kv.split("=", 1) for kv in sys.argv[4:]), "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    rd, wr = fetch.get(k, 0.0) * 1024 * 2, write.get(k, 0.0) * 1024
+    out["kernels"][k] = {"read_bytes": rd, "write_bytes": wr, "traffic_bytes": rd + wr}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))
