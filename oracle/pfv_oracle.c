@@ -357,8 +357,9 @@ static struct {
     mb_fn fn; void *ctx; int total;
     int next;               /* next unclaimed index (atomic) */
     int generation;         /* bumped per job */
+    int active;             /* workers taking part in the current job (indices < active) */
     int busy;               /* workers still inside the current job */
-} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0};
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static void pool_run_chunks(void)
 {
@@ -373,12 +374,13 @@ static void pool_run_chunks(void)
 }
 static void *pool_worker(void *arg)
 {
-    (void)arg;
+    const int my_index = (int)(intptr_t)arg;
     int seen = 0;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
         while (g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
         seen = g_pool.generation;
+        if (my_index >= g_pool.active) continue;   /* this job uses a smaller pool */
         pthread_mutex_unlock(&g_pool.mu);
         pool_run_chunks();
         pthread_mutex_lock(&g_pool.mu);
@@ -395,11 +397,12 @@ static void par_for(int n, int threads, mb_fn fn, void *ctx)
     if (threads > PFVO_MAX_THREADS) threads = PFVO_MAX_THREADS;
     pthread_mutex_lock(&g_pool.mu);
     while (g_pool.n_threads < threads - 1) {   /* the caller is the last "thread" */
-        pthread_create(&g_pool.th[g_pool.n_threads], NULL, pool_worker, NULL);
+        pthread_create(&g_pool.th[g_pool.n_threads], NULL, pool_worker, (void *)(intptr_t)g_pool.n_threads);
         g_pool.n_threads++;
     }
     g_pool.fn = fn; g_pool.ctx = ctx; g_pool.total = n; g_pool.next = 0;
-    g_pool.busy = g_pool.n_threads;
+    g_pool.active = threads - 1;
+    g_pool.busy = g_pool.active;
     g_pool.generation++;
     pthread_cond_broadcast(&g_pool.cv_work);
     pthread_mutex_unlock(&g_pool.mu);
