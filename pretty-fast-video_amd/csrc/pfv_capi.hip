@@ -51,6 +51,7 @@ struct pfv_ctx {
     QTab *qtab_dev = nullptr;    // 4 slots
     QTab *qtab_host = nullptr;   // pinned mirror
     int *flag_dev = nullptr;
+    int n_cus = 256;             // compute units of the device (persistent-kernel grid sizing)
 };
 
 static thread_local std::string g_tls_err;
@@ -96,6 +97,10 @@ PFV_API int pfv_ctx_create(int device, pfv_ctx **out)
     HIP_TRY(nullptr, hipSetDevice(device));
     pfv_ctx *ctx = new pfv_ctx();
     ctx->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
+    }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->qtab_dev, 4 * sizeof(QTab));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->qtab_host, 4 * sizeof(QTab), hipHostMallocDefault);
@@ -251,6 +256,9 @@ static FrameGeom with_base_alignment(FrameGeom g, const void *src_base)
     return g;
 }
 
+// p-frame encoder: one workgroup per 128 x 64 tile
+static inline unsigned penc_blocks(const pfv_ctx *, const FrameGeom &g) { return (unsigned)((long)g.tiles_per_frame * g.n_streams); }
+
 // one strip per wavefront, kStripsPerWG strips per workgroup
 static inline unsigned strip_blocks(const FrameGeom &g)
 {
@@ -324,7 +332,7 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
     float min_err = px_err * px_err * 256.0f;   // src/common.rs:209
-    hipLaunchKernelGGL(k_enc_pframe, dim3(g.tiles_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
+    hipLaunchKernelGGL(k_enc_pframe, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
                                                                    (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
                                                                    nullptr, ctx->qtab_dev, min_err);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
@@ -582,7 +590,7 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
     float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
-    hipLaunchKernelGGL(k_enc_pframe, dim3(g.tiles_per_frame * g.n_streams), dim3(kThreads), 0, ctx->stream, 
+    hipLaunchKernelGGL(k_enc_pframe, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, 
         g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err);
     int rc = launch_check(ctx, "k_enc_pframe");
     if (rc) return rc;

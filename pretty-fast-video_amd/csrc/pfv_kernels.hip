@@ -56,8 +56,13 @@ __constant__ int kInvZigzag[64] = {
 constexpr int kWinRows = 16 * kStripsPerWG + 30;   // reference window of a 128 x 64 tile: +-15 rows
 constexpr int kWinStride = 176;                    // bytes per window row: 160 used (x0-16 .. x0+143)
 constexpr int kWinBytes = kWinRows * kWinStride;
+constexpr int kWinChunksPerRow = kWinStride / 16;                                    // 11 (10 of pixels + 1 pad)
+constexpr int kWinIssuesPerWave = 5;                                                 // 1 KiB LDS-DMA loads per wavefront and window
+constexpr int kWinAlloc = kStripsPerWG * kWinIssuesPerWave * 1024;                   // 20 KiB per window buffer (1034 chunks used)
+static_assert(kStripsPerWG * kWinIssuesPerWave * 64 >= kWinRows * kWinChunksPerRow, "window does not fit its LDS-DMA issues");
 constexpr int kMBPitch = 2 * 64 + 8;               // dwords per macroblock in the exchange region (== 8 mod 32)
 constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 1088 dwords = 4352 B
+static_assert(kXchgDwords * 4 <= 5 * 1024, "exchange region must fit a wavefront's window slice");
 
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -163,20 +168,27 @@ __device__ __forceinline__ StripPos locate_strip(const FrameGeom &g, int gstrip)
 }
 
 // ------------------------------------------------------------------ 1-D transforms
-// reference src/dct.rs:176-239  DctMatrix8x8::fdct
+// reference src/dct.rs:176-239  DctMatrix8x8::fdct -- EXACT form.
+// Every forward transform in this codec starts from samples with 8 zero fraction bits
+// ((px - 128) << 8, src/common.rs:291, or (delta / 2) << 8, :304).  In the row pass all operands of the
+// truncating divisions (/2, /4, /16, dct.rs:206-214) are then multiples of 256, so the divisions are exact
+// and every row output is a multiple of 16; in the column pass the operands are multiples of 16, so the
+// divisions are exact again.  Truncation toward zero therefore never happens in an fdct, and `x / 2^k` is a
+// plain arithmetic shift -- no sign bias needed (tests/test_oracle.py::test_forward_dct_is_exact checks the
+// claim against the truncating form; the GPU parity tests check the kernels bit for bit).
 __device__ __forceinline__ void fdct8(int (&v)[8])
 {
     int a0 = wadd(v[0], v[7]), a1 = wadd(v[1], v[6]), a2 = wadd(v[2], v[5]), a3 = wadd(v[3], v[4]);
-    TDiv416 a4(wsub(v[0], v[7])), a5(wsub(v[1], v[6])), a6(wsub(v[2], v[5])), a7(wsub(v[3], v[4]));
-    int b0 = wadd(a0, a3), b1 = wadd(a1, a2);
-    TDiv24 b2(wsub(a0, a3)), b3(wsub(a1, a2));
+    int a4 = wsub(v[0], v[7]), a5 = wsub(v[1], v[6]), a6 = wsub(v[2], v[5]), a7 = wsub(v[3], v[4]);
+    int b0 = wadd(a0, a3), b1 = wadd(a1, a2), b2 = wsub(a0, a3), b3 = wsub(a1, a2);
     int c0 = wadd(b0, b1), c1 = wsub(b0, b1);
-    int c2 = wadd(wadd(b2.x, b2.q), b3.h);
-    int c3 = wsub(wsub(b2.h, b3.x), b3.q);
-    int b4 = wsub(wadd(wadd(a7.q, a4.x), a4.q), a4.s);
-    int b7 = wadd(wsub(wsub(a4.q, a7.x), a7.q), a7.s);
-    int b5 = wsub(wsub(wadd(a5.x, a6.x), a6.q), a6.s);
-    int b6 = wadd(wadd(wsub(a6.x, a5.x), a5.q), a5.s);
+    int c2 = wadd(wadd(b2, b2 >> 2), b3 >> 1);
+    int c3 = wsub(wsub(b2 >> 1, b3), b3 >> 2);
+    int a4q = a4 >> 2, a7q = a7 >> 2;
+    int b4 = wsub(wadd(wadd(a7q, a4), a4q), a4 >> 4);
+    int b7 = wadd(wsub(wsub(a4q, a7), a7q), a7 >> 4);
+    int b5 = wsub(wsub(wadd(a5, a6), a6 >> 2), a6 >> 4);
+    int b6 = wadd(wadd(wsub(a6, a5), a5 >> 2), a5 >> 4);
     int c4 = wadd(b4, b5), c5 = wsub(b4, b5), c6 = wadd(b6, b7), c7 = wsub(b6, b7);
     v[0] = c0; v[1] = c4; v[2] = c2; v[3] = wsub(c5, c7);
     v[4] = c1; v[5] = wadd(c5, c7); v[6] = c3; v[7] = c6;
@@ -290,6 +302,19 @@ __device__ __forceinline__ uint4 pack_row(const int (&px)[2][8])
 }
 
 // ------------------------------------------------------------------ strip I/O
+// streaming (read-once / write-once) global accesses: non-temporal, so that coefficient and retframe traffic does
+// not evict the reference planes that neighbouring strips re-read from L2 (measured +1.3 % on the GOP bench)
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p)
+{
+    return make_uint4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y), __builtin_nontemporal_load(&p->z),
+                      __builtin_nontemporal_load(&p->w));
+}
+__device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
+{
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+}
+
 // 16 source pixels (x .. x+15, row y) of an unpadded plane with the reference's pad rule
 // (src/common.rs:352-356: img_copy.fill(clear); blit(source)).
 __device__ __forceinline__ uint4 load_src16(const uint8_t *plane, const PlaneGeom &p, int x, int y)
@@ -326,7 +351,7 @@ __device__ __forceinline__ uint4 load_src16(const uint8_t *plane, const PlaneGeo
 // geometries run the separate k_crop_frames pass.
 __device__ __forceinline__ void store_cropped16(uint8_t *plane, const PlaneGeom &p, int x, int y, const uint4 &val)
 {
-    if (y < p.h && x < p.w) *reinterpret_cast<uint4 *>(plane + (long)y * p.w + x) = val;
+    if (y < p.h && x < p.w) st_stream(reinterpret_cast<uint4 *>(plane + (long)y * p.w + x), val);
 }
 
 // Coefficients of one HALF (h = 0: subblocks 0,1; h = 1: subblocks 2,3) of every macroblock of
@@ -337,7 +362,7 @@ __device__ __forceinline__ void store_coef_half(const int *stage, int16_t *coef_
     for (int j = 0; j < 2; j++) {
         int ch = j * 64 + lane;   // 16-byte chunk of the stage; 16 chunks per macroblock half
         int mb = ch >> 4;
-        if (mb < n_mb) reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)] = reinterpret_cast<const uint4 *>(stage)[ch];
+        if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(stage)[ch]);
     }
 }
 __device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int h)
@@ -347,7 +372,7 @@ __device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *
         int ch = j * 64 + lane;
         int mb = ch >> 4;
         buf[j] = make_uint4(0, 0, 0, 0);
-        if (mb < n_mb) buf[j] = reinterpret_cast<const uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)];
+        if (mb < n_mb) buf[j] = ld_stream(&reinterpret_cast<const uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)]);
     }
 }
 __device__ __forceinline__ void stage_coef_half(int *stage, const uint4 (&buf)[2], int lane)
@@ -432,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
     if (gstrip >= g.strips_per_frame * g.n_streams) return;   // no cross-wavefront sync in this kernel
     const StripPos sp = locate_strip(g, gstrip);
@@ -601,59 +626,74 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
-                                                          const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
-                                                          uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
-                                                          uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs,
-                                                          float min_err)
+// Geometry of one p-frame tile (128 x 64 px = 4 vertically stacked strips) as seen by one wavefront.
+#ifndef PFV_PENC_WAVES
+#define PFV_PENC_WAVES 5   // wavefronts per SIMD the p-frame encoder is compiled for (VGPR budget 96; measured best of 4/5/6)
+#endif
+struct TilePos {
+    StripPos sp;        // this wavefront's strip
+    int plane_ty;       // tile row inside the plane
+    int winx0, winy0;   // plane coordinates of the window origin
+    bool wave_valid;    // the strip exists (the last tile row of a plane may be partial)
+};
+__device__ __forceinline__ TilePos locate_tile(const FrameGeom &g, int vt, int wave)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t win[kWinBytes];
-    __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = lane >> 3, i = lane & 7;
-
-    // ---- tile -> (stream, plane, strip column, tile row)
-    const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    StripPos sp;
-    sp.stream = vb / g.tiles_per_frame;
-    int tl = vb - sp.stream * g.tiles_per_frame;
-    sp.plane = plane_of(g, tl, true);
-    const PlaneGeom &p = g.p[sp.plane];
+    TilePos t;
+    t.sp.stream = vt / g.tiles_per_frame;
+    int tl = vt - t.sp.stream * g.tiles_per_frame;
+    t.sp.plane = plane_of(g, tl, true);
+    const PlaneGeom &p = g.p[t.sp.plane];
     tl -= p.tile0;
-    const int ty = tl / p.strips_x;
-    sp.sx = tl - ty * p.strips_x;
-    sp.by = ty * kStripsPerWG + wave;
-    finish_strip(g, sp);
-    const bool wave_valid = sp.by < p.bh;
+    t.plane_ty = tl / p.strips_x;
+    t.sp.sx = tl - t.plane_ty * p.strips_x;
+    t.sp.by = t.plane_ty * kStripsPerWG + wave;
+    finish_strip(g, t.sp);
+    t.wave_valid = t.sp.by < p.bh;
+    t.winx0 = t.sp.x0 - 16;
+    t.winy0 = t.plane_ty * (16 * kStripsPerWG) - 15;
+    return t;
+}
 
-    const uint8_t *refp = ref + (long)sp.stream * g.pad_frame_bytes + p.pad_off;
-    const int winx0 = sp.x0 - 16, winy0 = ty * (16 * kStripsPerWG) - 15;
-
-    // ---- stage the reference window (whole workgroup), fetch this lane's two source rows
-    for (int c = threadIdx.x; c < kWinRows * 10; c += kThreads) {
-        int row = c / 10, ch = c - row * 10;
-        int y = winy0 + row, x = winx0 + ch * 16;
-        if (y >= 0 && y < p.ph && x >= 0 && x < p.pw) {
-            uint4 val = *reinterpret_cast<const uint4 *>(refp + (long)y * p.pw + x);
-            *reinterpret_cast<uint4 *>(win + row * kWinStride + ch * 16) = val;
-        }
+// Stage the tile's reference window with direct global->LDS loads (global_load_lds_dwordx4: no VGPR
+// round trip, completion tracked by vmcnt and drained at the next workgroup barrier).  The LDS image of one
+// wave-instruction is lane-linear (base + lane * 16), so a window row is 11 chunks of 16 B (160 B of pixels +
+// 16 B pad = kWinStride); wavefront w owns the contiguous chunks [w*320, (w+1)*320) of the buffer = 5 KiB, 5
+// instructions.  Chunks outside the plane (or past the last window row) are redirected to a clamped in-plane
+// address so that every lane stays active (the LDS address is derived from the first active lane); their
+// content is never used (candidates outside the plane are invalid).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+__device__ __forceinline__ void issue_window(const PlaneGeom &p, const uint8_t *refp, const TilePos &t, uint8_t *winbuf, int wave,
+                                             int lane)
+{
+#pragma unroll
+    for (int k = 0; k < kWinIssuesPerWave; k++) {
+        const int c = (wave * kWinIssuesPerWave + k) * 64 + lane;
+        const int row = c / kWinChunksPerRow, col = c - row * kWinChunksPerRow;
+        const int y = min(max(t.winy0 + row, 0), p.ph - 1), x = min(max(t.winx0 + col * 16, 0), p.pw - 16);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(refp + (long)y * p.pw + x), (lds_void_t *)(winbuf + c * 16), 16, 0, 0);
     }
-    uint4 rows[2];
-    rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
-    if (wave_valid) {
-        const uint8_t *plane = src + (long)sp.stream * g.src_frame_bytes + p.src_off;
-        rows[0] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
-        rows[1] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
-    }
-    __syncthreads();
-    if (!wave_valid) return;   // the only workgroup-wide barrier is behind us
+}
 
-    int *xw = xchg[wave];
+// Result of the search phase of one macroblock (identical in its 8 lanes) plus the lane's patch rows.
+struct SearchOut {
+    int cx, cy;
+    bool coded;
+    uint4 patch[2];
+};
+
+// Phase 1 of a tile for one wavefront: motion search, skip decision, fetch of the chosen patch rows.
+// Reads the window; issues no global memory operation.
+__device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &tp, const uint8_t *win, const uint4 (&rows)[2], int lane,
+                                            float min_err, SearchOut &so)
+{
+    const StripPos &sp = tp.sp;
+    const PlaneGeom &p = g.p[sp.plane];
+    const int m = lane >> 3, i = lane & 7;
     const bool mb_valid = m < sp.n_mb;
     const int mbx = sp.x0 + m * 16, mby = sp.y0;
-    const int wcol0 = mbx - winx0;                 // = 16 + 16 m
-    const int wrow0 = mby - winy0 + i;             // window row of source row i
+    const int wcol0 = mbx - tp.winx0;              // = 16 + 16 m
+    const int wrow0 = mby - tp.winy0 + i;          // window row of source row i
 
     // sum of squares of the source block (2 rows per lane)
     unsigned s2 = 0;
@@ -666,35 +706,52 @@ __global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint
     }
     const int a2 = mb_sum((int)s2);
 
-    // ---- 4-step search (reference src/common.rs:154-204, steps 8, 4, 2, 1)
+    // 4-step search (reference src/common.rs:154-204, steps 8, 4, 2, 1)
     SearchState st;
     st.cx = 0; st.cy = 0; st.err = 0;
     search_level<8, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+#ifndef PFV_ABL_SEARCH1   // ablation experiment only (results invalid): first search level alone
     search_level<4, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
     search_level<2, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
     search_level<1, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+#endif
 
-    // ---- skip decision (src/common.rs:209, :221): best_err <= px_err^2 * 256, compared in f32
-    const bool coded = mb_valid && !((float)st.err <= min_err);
+    // skip decision (src/common.rs:209, :221): best_err <= px_err^2 * 256, compared in f32
+#ifdef PFV_ABL_NOXFORM   // ablation experiment only (results invalid): never code
+    so.coded = mb_valid && !((float)st.err <= 1e30f);
+#else
+    so.coded = mb_valid && !((float)st.err <= min_err);
+#endif
+    so.cx = st.cx; so.cy = st.cy;
+
+    // the lane's two rows of the chosen patch (get_block of the reconstruction, :261)
+    const int wx = wcol0 + st.cx, shp = wx & 3;
+    const uint8_t *rp = win + (wrow0 + st.cy) * kWinStride + (wx & ~3);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const unsigned *d = reinterpret_cast<const unsigned *>(rp + 8 * h * kWinStride);
+        unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+        so.patch[h] = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, shp), __builtin_amdgcn_alignbyte(d2, d1, shp),
+                                 __builtin_amdgcn_alignbyte(d3, d2, shp), __builtin_amdgcn_alignbyte(d4, d3, shp));
+    }
+}
+
+// Phase 2: block headers, residual transform, coefficient + reconstruction stores.  xw: this wavefront's
+// exchange region (lives in the wavefront's own part of the window buffer that has just been released).
+__device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos &tp, const SearchOut &so, const uint4 (&rows)[2], int *xw,
+                                               int lane, int8_t *__restrict__ mv_out, uint8_t *__restrict__ has_out,
+                                               int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs)
+{
+    const StripPos &sp = tp.sp;
+    const PlaneGeom &p = g.p[sp.plane];
+    const int m = lane >> 3, i = lane & 7;
+    const bool mb_valid = m < sp.n_mb, coded = so.coded;
+    const int mbx = sp.x0 + m * 16;
     if (i == 0 && mb_valid) {
         long mbi = (long)sp.stream * g.mbs_per_frame + sp.mb_first + m;
-        mv_out[mbi * 2 + 0] = (int8_t)st.cx;
-        mv_out[mbi * 2 + 1] = (int8_t)st.cy;
+        mv_out[mbi * 2 + 0] = (int8_t)so.cx;
+        mv_out[mbi * 2 + 1] = (int8_t)so.cy;
         has_out[mbi] = coded ? 1 : 0;
-    }
-
-    // ---- the lane's two rows of the chosen patch (get_block of the reconstruction, :261)
-    uint4 patch[2];
-    {
-        const int wx = wcol0 + st.cx, shp = wx & 3;
-        const uint8_t *rp = win + (wrow0 + st.cy) * kWinStride + (wx & ~3);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const unsigned *d = reinterpret_cast<const unsigned *>(rp + 8 * h * kWinStride);
-            unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
-            patch[h] = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, shp), __builtin_amdgcn_alignbyte(d2, d1, shp),
-                                  __builtin_amdgcn_alignbyte(d3, d2, shp), __builtin_amdgcn_alignbyte(d4, d3, shp));
-        }
     }
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
@@ -706,7 +763,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint
         for (int h = 0; h < 2; h++) {
             int v[2][8], pp[2][8];
             unpack_row(rows[h], v);
-            unpack_row(patch[h], pp);
+            unpack_row(so.patch[h], pp);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
 #pragma unroll
@@ -734,13 +791,52 @@ __global__ __launch_bounds__(kThreads) void k_enc_pframe(FrameGeom g, const uint
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             int ch = j * 64 + lane;
-            if ((ch >> 5) < sp.n_mb) reinterpret_cast<uint4 *>(coef_mb0)[ch] = make_uint4(0, 0, 0, 0);
+            if ((ch >> 5) < sp.n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[ch], make_uint4(0, 0, 0, 0));
         }
         if (recon && mb_valid) {
-            *reinterpret_cast<uint4 *>(dst) = patch[0];
-            *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = patch[1];
+            *reinterpret_cast<uint4 *>(dst) = so.patch[0];
+            *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = so.patch[1];
         }
     }
+}
+
+// One workgroup per tile (128 x 64 px = 4 vertically stacked strips).  Per wavefront:
+//     LDS-DMA of the tile's window (each wavefront its own 5 KiB slice), source rows -> registers
+//     ---- workgroup barrier: window complete ----
+//     search, fetch the chosen patch rows
+//     ---- workgroup barrier: window released ----
+//     transform + reconstruct + store; the exchange region lives in the wavefront's own window slice
+// so the kernel needs one 20 KiB LDS buffer per workgroup.
+__global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
+                                                          const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
+                                                          uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
+                                                          uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs,
+                                                          float min_err)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWinAlloc];
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
+    const int m = lane >> 3, i = lane & 7;
+    const TilePos cur = locate_tile(g, xcd_remap((int)blockIdx.x, (int)gridDim.x), wave);
+    const PlaneGeom &p = g.p[cur.sp.plane];
+
+    issue_window(p, ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off, cur, win, wave, lane);
+    uint4 rows[2];
+    rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
+    if (cur.wave_valid) {
+        const uint8_t *plane = src + (long)cur.sp.stream * g.src_frame_bytes + p.src_off;
+        rows[0] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i);
+        rows[1] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i + 8);
+    }
+    __syncthreads();   // window complete (vmcnt drained at the barrier)
+    SearchOut so;
+    so.cx = so.cy = 0; so.coded = false;
+    so.patch[0] = so.patch[1] = make_uint4(0, 0, 0, 0);
+    if (cur.wave_valid) penc_search(g, cur, win, rows, lane, min_err, so);
+    __syncthreads();   // window released by every wavefront
+    if (cur.wave_valid)
+        penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + wave * (kWinIssuesPerWave * 1024)), lane, mv_out, has_out, coef,
+                       recon, qtabs);
 }
 
 // ================================================================== I-frame decode
@@ -752,7 +848,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
     if (gstrip >= g.strips_per_frame * g.n_streams) return;
     const StripPos sp = locate_strip(g, gstrip);
@@ -812,7 +908,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
     if (gstrip >= g.strips_per_frame * g.n_streams) return;
     const StripPos sp = locate_strip(g, gstrip);

@@ -20,6 +20,7 @@
 #include <functional>
 #include <vector>
 
+#define address_space(n)
 #define __global__
 #define __device__
 #define __host__
@@ -93,6 +94,12 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool)
     return hipemu::wave_exchange(src, from);
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
+// global_load_lds: per-lane copy global -> LDS (the emulator has no lane-linear restriction; the kernels keep to it)
+static inline void hipemu_global_load_lds(const void *g, void *l, unsigned size, int offset, int) { memcpy((char *)l + offset, (const char *)g + offset, size); }
+#define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 
 // ---- runtime API subset
 typedef int hipError_t;
@@ -104,6 +111,8 @@ static inline const char *hipGetErrorString(hipError_t) { return "hipemu error";
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }   // tiny "GPU": forces persistent loops to iterate
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (void *)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

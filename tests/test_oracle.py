@@ -136,3 +136,36 @@ def test_session_oracle_encoder_decoder_agree(oracle):
         else:
             dec.decode_pframe(*enc.encode_pframe(st.frame(t)))
         assert np.array_equal(enc.prev_frame(), dec.framebuffer())
+
+
+def test_forward_dct_is_exact(oracle):
+    """The kernels compute the forward DCT with plain arithmetic shifts instead of truncating divisions
+    (csrc/pfv_kernels.hip::fdct8): with 8 zero fraction bits on the input, every division in the row pass acts on
+    a multiple of 256 and every division in the column pass on a multiple of 16, so nothing is ever truncated.
+    Checked here by evaluating the reference form (truncating, numpy oracle) and a floor-shift form on u8 blocks
+    and on +-255 residual blocks, incl. all-extreme inputs."""
+    def fdct_floor(v):
+        i = [v[..., k].astype(np.int64) for k in range(8)]
+        a0, a1, a2, a3 = i[0] + i[7], i[1] + i[6], i[2] + i[5], i[3] + i[4]
+        a4, a5, a6, a7 = i[0] - i[7], i[1] - i[6], i[2] - i[5], i[3] - i[4]
+        b0, b1, b2, b3 = a0 + a3, a1 + a2, a0 - a3, a1 - a2
+        c0, c1 = b0 + b1, b0 - b1
+        c2 = b2 + (b2 >> 2) + (b3 >> 1)
+        c3 = (b2 >> 1) - b3 - (b3 >> 2)
+        b4 = (a7 >> 2) + a4 + (a4 >> 2) - (a4 >> 4)
+        b7 = (a4 >> 2) - a7 - (a7 >> 2) + (a7 >> 4)
+        b5 = a5 + a6 - (a6 >> 2) - (a6 >> 4)
+        b6 = a6 - a5 + (a5 >> 2) + (a5 >> 4)
+        c4, c5, c6, c7 = b4 + b5, b4 - b5, b6 + b7, b6 - b7
+        return np.stack([c0, c4, c2, c5 - c7, c1, c5 + c7, c3, c6], axis=-1)
+
+    rng = np.random.default_rng(12)
+    px = [rng.integers(0, 256, (400, 8, 8)), rng.choice([0, 255], (400, 8, 8)), np.zeros((1, 8, 8), int), np.full((1, 8, 8), 255)]
+    blocks = [((b.astype(np.int64) - 128) << 8) for b in px]
+    d = np.concatenate([rng.integers(-255, 256, (400, 8, 8)), rng.choice([-255, 255], (200, 8, 8))])
+    blocks.append((np.sign(d) * (np.abs(d) // 2)).astype(np.int64) << 8)          # (delta / 2) << 8, common.rs:304
+    for m in blocks:
+        rows_ref, rows_fl = onp.fdct(m), fdct_floor(m)
+        assert np.array_equal(rows_ref, rows_fl) and not (rows_ref & 15).any()     # row outputs: multiples of 16
+        cols_ref = onp.fdct(np.swapaxes(rows_ref, -1, -2))
+        assert np.array_equal(cols_ref, fdct_floor(np.swapaxes(rows_fl, -1, -2)))
