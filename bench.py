@@ -65,6 +65,7 @@ def cpu_baseline(pkg, width, height, quality, frames_one_stream):
     tabs = np.stack(ora.qtables(quality)[:4])
 
     def run(threads, max_reps, budget_s):
+        ora.L.pfvo_pool_shutdown()          # fresh pool of exactly `threads` workers
         enc = ora.encoder(width, height, quality, threads=threads)
         dec = OracleDecoder(ora, width, height, tabs, threads=threads)
         t0 = time.perf_counter()

@@ -359,7 +359,8 @@ static struct {
     int generation;         /* bumped per job */
     int active;             /* workers taking part in the current job (indices < active) */
     int busy;               /* workers still inside the current job */
-} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, 0};
+    int quit;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 static void pool_run_chunks(void)
 {
@@ -380,13 +381,30 @@ static void *pool_worker(void *arg)
     for (;;) {
         while (g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
         seen = g_pool.generation;
+        if (g_pool.quit) break;
         if (my_index >= g_pool.active) continue;   /* this job uses a smaller pool */
         pthread_mutex_unlock(&g_pool.mu);
         pool_run_chunks();
         pthread_mutex_lock(&g_pool.mu);
         if (--g_pool.busy == 0) pthread_cond_signal(&g_pool.cv_done);
     }
+    pthread_mutex_unlock(&g_pool.mu);
     return NULL;
+}
+/* joins every worker (so that a later, smaller pool is not slowed down by idle wake-ups) */
+PFVO_API void pfvo_pool_shutdown(void)
+{
+    pthread_mutex_lock(&g_pool.mu);
+    int n = g_pool.n_threads;
+    g_pool.quit = 1;
+    g_pool.generation++;
+    pthread_cond_broadcast(&g_pool.cv_work);
+    pthread_mutex_unlock(&g_pool.mu);
+    for (int i = 0; i < n; i++) pthread_join(g_pool.th[i], NULL);
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.n_threads = 0;
+    g_pool.quit = 0;
+    pthread_mutex_unlock(&g_pool.mu);
 }
 static void par_for(int n, int threads, mb_fn fn, void *ctx)
 {
