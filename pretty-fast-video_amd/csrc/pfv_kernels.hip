@@ -265,17 +265,32 @@ struct LaneQ {
     int deq[8];     // SCALE[z]*q[z], z = INV_ZIGZAG[k*8+c]        (decode, zigzag-position-indexed)
     int zz[8];      // INV_ZIGZAG[k*8+c]: where coefficient (k,c) sits in the 64-entry zigzag run
 };
+// The 64-entry tables live in LDS (kQTabDwords per copy), written once per wavefront / workgroup with four
+// coalesced 256-byte loads, so that the per-lane constants cost LDS reads instead of 32 scattered vector
+// memory loads per lane (which would put more bytes through the CU's texture-addresser path than the pixels
+// and coefficients themselves).  Layout: [0] zigzag position, [1] deq, [2] scale, [3] rcp (float bits).
+constexpr int kQTabDwords = 4 * 64;
 template <bool ENC>
-__device__ __forceinline__ void load_lane_q(LaneQ &lq, const QTab *qt, int c)
+__device__ __forceinline__ void fill_qtable(int *tab, const QTab *qt, int lane)
+{
+    tab[lane] = kInvZigzag[lane];
+    tab[64 + lane] = qt->deq[lane];
+    if (ENC) {
+        tab[128 + lane] = kScale[lane];
+        tab[192 + lane] = __float_as_int(qt->rcp[lane]);
+    }
+}
+template <bool ENC>
+__device__ __forceinline__ void load_lane_q(LaneQ &lq, const int *tab, int c)
 {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         int idx = k * 8 + c;
-        lq.zz[k] = kInvZigzag[idx];
-        lq.deq[k] = qt->deq[idx];
+        lq.zz[k] = tab[idx];
+        lq.deq[k] = tab[64 + idx];
         if (ENC) {
-            lq.scale[k] = kScale[idx];
-            lq.rcp[k] = qt->rcp[idx];
+            lq.scale[k] = tab[128 + idx];
+            lq.rcp[k] = __int_as_float(tab[192 + idx]);
         }
     }
 }
@@ -311,8 +326,12 @@ __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 }
 __device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
 {
+#ifdef PFV_V_PLAINST   // A/B switch
+    *p = v;
+#else
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+#endif
 }
 
 // 16 source pixels (x .. x+15, row y) of an unpadded plane with the reference's pad rule
@@ -456,6 +475,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
                                                           const QTab *__restrict__ qtabs)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
+    __shared__ int qtab_lds[kStripsPerWG][kQTabDwords];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
@@ -465,13 +485,15 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
     const int m = lane >> 3, i = lane & 7;
     int *xw = xchg[wave];
 
+    fill_qtable<true>(qtab_lds[wave], qtabs + p.qsel, lane);
     const uint8_t *plane = src + (long)sp.stream * g.src_frame_bytes + p.src_off;
     uint4 rows[2];
     rows[0] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
     rows[1] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
 
+    wave_lds_sync();
     LaneQ lq;
-    load_lane_q<true>(lq, qtabs + p.qsel, i);
+    load_lane_q<true>(lq, qtab_lds[wave], i);
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16
                          : nullptr;
@@ -534,7 +556,9 @@ __device__ __forceinline__ void dot_row(const uint4 &a, unsigned b0, unsigned b1
 // One search level with step S.  wrow0 / wcol0: window coordinates of the macroblock origin
 // row (already + lane row i) and column.  Candidate (my, mx) sits at displacement
 // (st.cx + mx*S, st.cy + my*S).  FIRST: the centre's error is not known yet (first level).
-template <int S, bool FIRST>
+// BOUNDS: check every candidate against the plane (src/common.rs:171, :182); false for wavefronts whose whole
+// strip lies at least 15 pixels inside the plane, where no candidate can leave it.
+template <int S, bool FIRST, bool BOUNDS>
 __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int wcol0, const uint4 &top, const uint4 &bot,
                                              int a2, int mbx, int mby, int pw, int ph, SearchState &st)
 {
@@ -610,7 +634,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
             if (my == 0 && mx == 0) continue;
             ord++;
             const int ox = mbx + st.cx + mx * S;
-            const bool valid = vy && ox >= 0 && ox <= pw - 16;          // :182
+            const bool valid = !BOUNDS || (vy && ox >= 0 && ox <= pw - 16);          // :182
             int err = a2 + mb_sum(part[my + 1][mx + 1]);
             unsigned key = valid ? (((unsigned)err << 4) | (unsigned)ord) : 0xffffffffu;
             best = min(best, key);
@@ -709,12 +733,27 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
     // 4-step search (reference src/common.rs:154-204, steps 8, 4, 2, 1)
     SearchState st;
     st.cx = 0; st.cy = 0; st.err = 0;
-    search_level<8, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
-#ifndef PFV_ABL_SEARCH1   // ablation experiment only (results invalid): first search level alone
-    search_level<4, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
-    search_level<2, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
-    search_level<1, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+    // strips at least 15 px inside the plane on every side (84 % of a 1080p luma plane) skip the bounds tests
+#ifdef PFV_NO_INTERIOR   // A/B switch
+    const bool interior = false;
+#else
+    const bool interior = sp.x0 >= 16 && sp.x0 + kStripMB * 16 + 16 <= p.pw && sp.y0 >= 16 && sp.y0 + 32 <= p.ph;   // wave-uniform
 #endif
+    if (interior) {
+        search_level<8, true, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+#ifndef PFV_ABL_SEARCH1   // ablation experiment only (results invalid): first search level alone
+        search_level<4, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<2, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<1, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+#endif
+    } else {
+        search_level<8, true, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+#ifndef PFV_ABL_SEARCH1
+        search_level<4, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<2, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<1, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+#endif
+    }
 
     // skip decision (src/common.rs:209, :221): best_err <= px_err^2 * 256, compared in f32
 #ifdef PFV_ABL_NOXFORM   // ablation experiment only (results invalid): never code
@@ -740,7 +779,7 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
 // exchange region (lives in the wavefront's own part of the window buffer that has just been released).
 __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos &tp, const SearchOut &so, const uint4 (&rows)[2], int *xw,
                                                int lane, int8_t *__restrict__ mv_out, uint8_t *__restrict__ has_out,
-                                               int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs)
+                                               int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const int *qtab_lds)
 {
     const StripPos &sp = tp.sp;
     const PlaneGeom &p = g.p[sp.plane];
@@ -758,7 +797,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
 
     if (__any(coded)) {   // wavefront-uniform: the LDS transposes need all lanes
         LaneQ lq;
-        load_lane_q<true>(lq, qtabs + p.qsel, i);
+        load_lane_q<true>(lq, qtab_lds, i);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             int v[2][8], pp[2][8];
@@ -773,7 +812,9 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                 }
             }
             forward_half(v, xw, m, i, lq, coded);
+#ifndef PFV_ABL_NOSTORE
             store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+#endif
             wave_lds_sync();
             if (recon) {
                 inverse_half(v, xw, m, i, lq);
@@ -783,7 +824,11 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                     for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
                         pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
                 }
+#ifdef PFV_ABL_NOSTORE   // ablation experiment only (results invalid): one dword per lane instead of the row
+                if (mb_valid && pp[0][0] == 999) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
+#else
                 if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
+#endif
             }
         }
     } else {
@@ -814,13 +859,17 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
                                                           float min_err)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[kWinAlloc];
+    __shared__ int qtab_lds[kQTabDwords];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int m = lane >> 3, i = lane & 7;
     const TilePos cur = locate_tile(g, xcd_remap((int)blockIdx.x, (int)gridDim.x), wave);
     const PlaneGeom &p = g.p[cur.sp.plane];
+    if (wave == 0) fill_qtable<true>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
 
+#ifndef PFV_ABL_NOWIN   // ablation experiment only (results invalid): search in whatever the LDS holds
     issue_window(p, ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off, cur, win, wave, lane);
+#endif
     uint4 rows[2];
     rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) {
@@ -836,7 +885,7 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     __syncthreads();   // window released by every wavefront
     if (cur.wave_valid)
         penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + wave * (kWinIssuesPerWave * 1024)), lane, mv_out, has_out, coef,
-                       recon, qtabs);
+                       recon, qtab_lds);
 }
 
 // ================================================================== I-frame decode
@@ -847,6 +896,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
                                                           uint8_t *__restrict__ frames_out)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
+    __shared__ int qtab_lds[kStripsPerWG][kQTabDwords];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
@@ -860,8 +910,10 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
     uint4 cbuf[2][2];
     fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
     fetch_coef_half(cbuf[1], coef_mb0, sp.n_mb, lane, 1);
+    fill_qtable<false>(qtab_lds[wave], qtabs + p.qsel, lane);
+    wave_lds_sync();
     LaneQ lq;
-    load_lane_q<false>(lq, qtabs + p.qsel, i);
+    load_lane_q<false>(lq, qtab_lds[wave], i);
     uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -907,6 +959,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
                                                           uint8_t *__restrict__ frames_out)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
+    __shared__ int qtab_lds[kStripsPerWG][kQTabDwords];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
@@ -921,8 +974,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     // first round trip: block headers and (independent of them) the quantiser constants
     int mx = mv[mbi * 2 + 0], my = mv[mbi * 2 + 1];
     const bool coded = mb_valid && has[mbi] != 0;
-    LaneQ lq;
-    load_lane_q<false>(lq, qtabs + p.qsel, i);
+    fill_qtable<false>(qtab_lds[wave], qtabs + p.qsel, lane);
 
     const int mbx = sp.x0 + m * 16, mby = sp.y0;
     if (mb_valid) {
@@ -951,6 +1003,9 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     uint8_t *crop = frames_out ? frames_out + (long)sp.stream * g.src_frame_bytes + p.src_off : nullptr;
 
     if (any_coded) {
+        wave_lds_sync();
+        LaneQ lq;
+        load_lane_q<false>(lq, qtab_lds[wave], i);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             stage_coef_half(xw, cbuf[h], lane);

@@ -66,6 +66,8 @@ bool wave_any(bool pred);
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline int __shfl_xor(int v, int mask) { return hipemu::wave_exchange(v, (int)((threadIdx.x & 63) ^ (unsigned)mask)); }
 static inline bool __any(bool p) { return hipemu::wave_any(p); }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
 
 // ---- gfx950 builtins used by the kernels

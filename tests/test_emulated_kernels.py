@@ -10,7 +10,7 @@ import parity_cases as pc
 import stream_cases as sc
 
 
-@pytest.mark.parametrize("w,h", [(64, 48), (50, 38), (144, 16)])
+@pytest.mark.parametrize("w,h", [(64, 48), (50, 38), (144, 16), (400, 80)])   # 400x80 has interior strips (bounds-check-free search path)
 @pytest.mark.parametrize("quality", [0, 5, 10])
 def test_emu_plane_ops(pkg, emu_ctx, oracle, w, h, quality):
     il, ic, pl, pcq, px_err = oracle.qtables(quality)

@@ -69,7 +69,7 @@ def test_iframe_arbitrary_qtable_and_coefficients(pkg, gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("quality", [0, 1, 2, 5, 8, 10])
-@pytest.mark.parametrize("w,h,dx,dy", [(208, 96, 5, -3), (50, 38, -7, 2), (272, 48, 15, 15), (144, 160, -15, -9)])
+@pytest.mark.parametrize("w,h,dx,dy", [(208, 96, 5, -3), (50, 38, -7, 2), (272, 48, 15, 15), (144, 160, -15, -9), (528, 112, 9, -14)])
 def test_pframe_plane(pkg, gpu_ctx, oracle, quality, w, h, dx, dy):
     _, _, pl, pcq, px_err = oracle.qtables(quality)
     px = pc.smooth_plane(h, w, seed=quality * 31 + w)
