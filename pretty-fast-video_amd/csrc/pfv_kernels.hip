@@ -257,13 +257,16 @@ __device__ __forceinline__ void cols_to_rows2(int (&v)[2][8], int *mb, int i)
     wave_lds_sync();
 }
 
-// Per-lane quantiser constants for column c of a subblock (raster indices k*8 + c); shared by
-// the lane's four subblocks.
+// Per-lane quantiser constants for column c of a subblock (raster indices k*8 + c), shared by the lane's
+// four subblocks.  They are read from the LDS copy of the tables at the point of use (8 distinct addresses per
+// wave-instruction: conflict-free broadcast), which keeps them out of the long-lived register set.
 struct LaneQ {
-    int scale[8];   // DCT_SCALE_FACTOR[k*8+c]                    (encode, raster-indexed)
-    float rcp[8];   // biased 1/q[k*8+c]                          (encode, raster-indexed)
-    int deq[8];     // SCALE[z]*q[z], z = INV_ZIGZAG[k*8+c]        (decode, zigzag-position-indexed)
-    int zz[8];      // INV_ZIGZAG[k*8+c]: where coefficient (k,c) sits in the 64-entry zigzag run
+    const int *tab;   // LDS table, see fill_qtable
+    int c;            // the lane's column
+    __device__ __forceinline__ int zz(int k) const { return tab[k * 8 + c]; }             // INV_ZIGZAG[k*8+c]
+    __device__ __forceinline__ int deq(int k) const { return tab[64 + k * 8 + c]; }       // SCALE[z]*q[z], z = zz (decode)
+    __device__ __forceinline__ int scale(int k) const { return tab[128 + k * 8 + c]; }    // DCT_SCALE_FACTOR[k*8+c] (encode)
+    __device__ __forceinline__ float rcp(int k) const { return __int_as_float(tab[192 + k * 8 + c]); }   // biased 1/q (encode)
 };
 // The 64-entry tables live in LDS (kQTabDwords per copy), written once per wavefront / workgroup with four
 // coalesced 256-byte loads, so that the per-lane constants cost LDS reads instead of 32 scattered vector
@@ -280,21 +283,6 @@ __device__ __forceinline__ void fill_qtable(int *tab, const QTab *qt, int lane)
         tab[192 + lane] = __float_as_int(qt->rcp[lane]);
     }
 }
-template <bool ENC>
-__device__ __forceinline__ void load_lane_q(LaneQ &lq, const int *tab, int c)
-{
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        int idx = k * 8 + c;
-        lq.zz[k] = tab[idx];
-        lq.deq[k] = tab[64 + idx];
-        if (ENC) {
-            lq.scale[k] = tab[128 + idx];
-            lq.rcp[k] = __int_as_float(tab[192 + idx]);
-        }
-    }
-}
-
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
 {
     return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24);
@@ -419,12 +407,14 @@ __device__ __forceinline__ void forward_half(int (&v)[2][8], int *xw, int m, int
     fdct8(v[1]);
     int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 128;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int k = 0; k < 8; k++) {
+        const int scale = lq.scale(k), zz = lq.zz(k);
+        const float rcp = lq.rcp(k);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            int n = wmul(v[s][k], lq.scale[k]) >> 16;
-            v[s][k] = (int)((float)n * lq.rcp[k]) & keepmask;
-            stage[s * 64 + lq.zz[k]] = (int16_t)v[s][k];
+        for (int s = 0; s < 2; s++) {
+            int n = wmul(v[s][k], scale) >> 16;
+            v[s][k] = (int)((float)n * rcp) & keepmask;
+            stage[s * 64 + zz] = (int16_t)v[s][k];
         }
     }
     wave_lds_sync();
@@ -441,11 +431,13 @@ __device__ __forceinline__ void inverse_half(int (&v)[2][8], int *xw, int m, int
 {
     int *mb = xw + m * kMBPitch;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[s][k] = wmul(v[s][k], lq.deq[k]);
-        idct8(v[s]);   // dct_inverse_transform_columns
+    for (int k = 0; k < 8; k++) {
+        const int deq = lq.deq(k);
+        v[0][k] = wmul(v[0][k], deq);
+        v[1][k] = wmul(v[1][k], deq);
     }
+    idct8(v[0]);   // dct_inverse_transform_columns
+    idct8(v[1]);
     cols_to_rows2(v, mb, i);
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -459,9 +451,10 @@ __device__ __forceinline__ void gather_half(int (&v)[2][8], const int *xw, int m
 {
     const int16_t *stage = reinterpret_cast<const int16_t *>(xw) + m * 128;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[s][k] = (int)stage[s * 64 + lq.zz[k]];
+    for (int k = 0; k < 8; k++) {
+        const int zz = lq.zz(k);
+        v[0][k] = (int)stage[zz];
+        v[1][k] = (int)stage[64 + zz];
     }
     wave_lds_sync();
 }
@@ -492,8 +485,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
     rows[1] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
 
     wave_lds_sync();
-    LaneQ lq;
-    load_lane_q<true>(lq, qtab_lds[wave], i);
+    const LaneQ lq{qtab_lds[wave], i};
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16
                          : nullptr;
@@ -796,8 +788,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
 
     if (__any(coded)) {   // wavefront-uniform: the LDS transposes need all lanes
-        LaneQ lq;
-        load_lane_q<true>(lq, qtab_lds, i);
+        const LaneQ lq{qtab_lds, i};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             int v[2][8], pp[2][8];
@@ -912,8 +903,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
     fetch_coef_half(cbuf[1], coef_mb0, sp.n_mb, lane, 1);
     fill_qtable<false>(qtab_lds[wave], qtabs + p.qsel, lane);
     wave_lds_sync();
-    LaneQ lq;
-    load_lane_q<false>(lq, qtab_lds[wave], i);
+    const LaneQ lq{qtab_lds[wave], i};
     uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -1004,8 +994,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
 
     if (any_coded) {
         wave_lds_sync();
-        LaneQ lq;
-        load_lane_q<false>(lq, qtab_lds[wave], i);
+        const LaneQ lq{qtab_lds[wave], i};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             stage_coef_half(xw, cbuf[h], lane);
