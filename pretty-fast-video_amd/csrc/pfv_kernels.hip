@@ -57,12 +57,14 @@ constexpr int kWinRows = 16 * kStripsPerWG + 30;   // reference window of a 128 
 constexpr int kWinStride = 176;                    // bytes per window row: 160 used (x0-16 .. x0+143)
 constexpr int kWinBytes = kWinRows * kWinStride;
 constexpr int kWinChunksPerRow = kWinStride / 16;                                    // 11 (10 of pixels + 1 pad)
-constexpr int kWinIssuesPerWave = 5;                                                 // 1 KiB LDS-DMA loads per wavefront and window
-constexpr int kWinAlloc = kStripsPerWG * kWinIssuesPerWave * 1024;                   // 20 KiB per window buffer (1034 chunks used)
-static_assert(kStripsPerWG * kWinIssuesPerWave * 64 >= kWinRows * kWinChunksPerRow, "window does not fit its LDS-DMA issues");
-constexpr int kMBPitch = 2 * 64 + 8;               // dwords per macroblock in the exchange region (== 8 mod 32)
-constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 1088 dwords = 4352 B
-static_assert(kXchgDwords * 4 <= 5 * 1024, "exchange region must fit a wavefront's window slice");
+constexpr int kWinIssues = (kWinRows * kWinChunksPerRow + 63) / 64;                  // 17 wave-wide 1 KiB LDS-DMA loads per window
+constexpr int kWinAlloc = kWinIssues * 1024;                                         // 17 KiB per window buffer
+// wavefront w issues (and later owns as its exchange region) the contiguous loads [first(w), first(w+1)): 5,4,4,4
+__device__ __forceinline__ constexpr int win_first_issue(int w) { return w == 0 ? 0 : 1 + 4 * w; }
+static_assert(win_first_issue(kStripsPerWG) == kWinIssues, "window issue split");
+constexpr int kMBPitch = 2 * 64;                   // dwords per macroblock in the exchange region (bank spread by XOR swizzle)
+constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 1024 dwords = 4 KiB
+static_assert(kXchgDwords * 4 <= 4 * 1024, "exchange region must fit a wavefront's smallest window slice");
 
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -214,16 +216,20 @@ __device__ __forceinline__ void idct8(int (&v)[8])
 }
 
 // ------------------------------------------------------------------ 8x8 transposes through LDS
-// Exchange region of macroblock m: two subblocks of 64 dwords, M[s][row][col], with the two
-// 16-byte halves of row `row` swapped when (row & 4): lanes i and i+4 then write different
-// banks (b128 writes are serviced in groups of 8 consecutive lanes = one macroblock).
+// Exchange region of macroblock m: two subblocks of 64 dwords, M[s][row][col], XOR-swizzled so that neither
+// direction has bank conflicts without any padding:
+//   * the two 16-byte halves of a row are swapped when (row & 4): lanes i and i+4 of a b128 write (serviced in
+//     groups of 8 consecutive lanes = one macroblock) then hit different banks;
+//   * row `row` of macroblock m is stored at row position row ^ (m & 3): in a column read (b32, serviced in groups
+//     of 32 lanes = 4 macroblocks whose regions are 128 dwords = 0 banks apart) the 4 macroblocks then read 4
+//     different rows, i.e. banks 8 apart.
 // row layout (lane i holds M[s][i][0..7])  ->  column layout (lane i holds M[s][0..7][i])
-__device__ __forceinline__ void rows_to_cols2(int (&v)[2][8], int *mb, int i)
+__device__ __forceinline__ void rows_to_cols2(int (&v)[2][8], int *mb, int i, int mx)
 {
     const int sw = (i >> 2) & 1;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        int4 *w = reinterpret_cast<int4 *>(mb + s * 64 + i * 8);
+        int4 *w = reinterpret_cast<int4 *>(mb + s * 64 + (i ^ mx) * 8);
         w[sw] = make_int4(v[s][0], v[s][1], v[s][2], v[s][3]);
         w[sw ^ 1] = make_int4(v[s][4], v[s][5], v[s][6], v[s][7]);
     }
@@ -232,24 +238,24 @@ __device__ __forceinline__ void rows_to_cols2(int (&v)[2][8], int *mb, int i)
 #pragma unroll
     for (int s = 0; s < 2; s++) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) v[s][r] = mb[s * 64 + r * 8 + (r < 4 ? lo : hi)];
+        for (int r = 0; r < 8; r++) v[s][r] = mb[s * 64 + (r ^ mx) * 8 + (r < 4 ? lo : hi)];
     }
     wave_lds_sync();
 }
 // column layout  ->  row layout
-__device__ __forceinline__ void cols_to_rows2(int (&v)[2][8], int *mb, int i)
+__device__ __forceinline__ void cols_to_rows2(int (&v)[2][8], int *mb, int i, int mx)
 {
     const int lo = i, hi = i ^ 4;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) mb[s * 64 + r * 8 + (r < 4 ? lo : hi)] = v[s][r];
+        for (int r = 0; r < 8; r++) mb[s * 64 + (r ^ mx) * 8 + (r < 4 ? lo : hi)] = v[s][r];
     }
     wave_lds_sync();
     const int sw = (i >> 2) & 1;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const int4 *w = reinterpret_cast<const int4 *>(mb + s * 64 + i * 8);
+        const int4 *w = reinterpret_cast<const int4 *>(mb + s * 64 + (i ^ mx) * 8);
         int4 a = w[sw], b = w[sw ^ 1];
         v[s][0] = a.x; v[s][1] = a.y; v[s][2] = a.z; v[s][3] = a.w;
         v[s][4] = b.x; v[s][5] = b.y; v[s][6] = b.z; v[s][7] = b.w;
@@ -361,6 +367,9 @@ __device__ __forceinline__ void store_cropped16(uint8_t *plane, const PlaneGeom 
     if (y < p.h && x < p.w) st_stream(reinterpret_cast<uint4 *>(plane + (long)y * p.w + x), val);
 }
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
 // Coefficients of one HALF (h = 0: subblocks 0,1; h = 1: subblocks 2,3) of every macroblock of
 // the strip <-> LDS stage (8 macroblocks x 256 B).  Global side: 256-byte runs, 16 B per lane.
 __device__ __forceinline__ void store_coef_half(const int *stage, int16_t *coef_mb0, int n_mb, int lane, int h)
@@ -402,7 +411,7 @@ __device__ __forceinline__ void forward_half(int (&v)[2][8], int *xw, int m, int
     int *mb = xw + m * kMBPitch;
     fdct8(v[0]);   // dct_transform_rows
     fdct8(v[1]);
-    rows_to_cols2(v, mb, i);
+    rows_to_cols2(v, mb, i, m & 3);
     fdct8(v[0]);   // dct_transform_columns
     fdct8(v[1]);
     int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 128;
@@ -438,7 +447,7 @@ __device__ __forceinline__ void inverse_half(int (&v)[2][8], int *xw, int m, int
     }
     idct8(v[0]);   // dct_inverse_transform_columns
     idct8(v[1]);
-    cols_to_rows2(v, mb, i);
+    cols_to_rows2(v, mb, i, m & 3);
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         idct8(v[s]);   // dct_inverse_transform_rows
@@ -673,18 +682,17 @@ __device__ __forceinline__ TilePos locate_tile(const FrameGeom &g, int vt, int w
 // Stage the tile's reference window with direct global->LDS loads (global_load_lds_dwordx4: no VGPR
 // round trip, completion tracked by vmcnt and drained at the next workgroup barrier).  The LDS image of one
 // wave-instruction is lane-linear (base + lane * 16), so a window row is 11 chunks of 16 B (160 B of pixels +
-// 16 B pad = kWinStride); wavefront w owns the contiguous chunks [w*320, (w+1)*320) of the buffer = 5 KiB, 5
-// instructions.  Chunks outside the plane (or past the last window row) are redirected to a clamped in-plane
+// 16 B pad = kWinStride); wavefront w issues a contiguous run of 5 (w = 0) or 4 of the 17 1-KiB loads and later owns
+// that slice as its exchange region.  Chunks outside the plane (or past the last window row) are redirected to a clamped in-plane
 // address so that every lane stays active (the LDS address is derived from the first active lane); their
 // content is never used (candidates outside the plane are invalid).
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 __device__ __forceinline__ void issue_window(const PlaneGeom &p, const uint8_t *refp, const TilePos &t, uint8_t *winbuf, int wave,
                                              int lane)
 {
-#pragma unroll
-    for (int k = 0; k < kWinIssuesPerWave; k++) {
-        const int c = (wave * kWinIssuesPerWave + k) * 64 + lane;
+    const int q0 = win_first_issue(wave), q1 = win_first_issue(wave + 1);
+#pragma unroll 5
+    for (int q = q0; q < q1; q++) {
+        const int c = q * 64 + lane;
         const int row = c / kWinChunksPerRow, col = c - row * kWinChunksPerRow;
         const int y = min(max(t.winy0 + row, 0), p.ph - 1), x = min(max(t.winx0 + col * 16, 0), p.pw - 16);
         __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(refp + (long)y * p.pw + x), (lds_void_t *)(winbuf + c * 16), 16, 0, 0);
@@ -784,8 +792,13 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
         mv_out[mbi * 2 + 1] = (int8_t)so.cy;
         has_out[mbi] = coded ? 1 : 0;
     }
+#ifdef PFV_ABL_STORE_SMALL   // ablation experiment only (results invalid): all stores land in one L2-resident megabyte
+    int16_t *coef_mb0 = coef + (((long)sp.stream * g.mbs_per_frame + sp.mb_first) & 1023) * 256;
+    uint8_t *dst = recon ? recon + (((long)(sp.y0 + i) * p.pw + mbx) & 0xfffff) : nullptr;
+#else
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
+#endif
 
     if (__any(coded)) {   // wavefront-uniform: the LDS transposes need all lanes
         const LaneQ lq{qtab_lds, i};
@@ -875,7 +888,7 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     if (cur.wave_valid) penc_search(g, cur, win, rows, lane, min_err, so);
     __syncthreads();   // window released by every wavefront
     if (cur.wave_valid)
-        penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + wave * (kWinIssuesPerWave * 1024)), lane, mv_out, has_out, coef,
+        penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
                        recon, qtab_lds);
 }
 

@@ -23,11 +23,13 @@ def build_emulator() -> str:
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(emu, "hipemu.cpp"),
                                                                 os.path.join(emu, "hip", "hip_runtime.h"),
                                                                 os.path.join(ROOT, "include", "pfv_hip.h")]
-    if os.path.exists(EMU_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_LIB) for s in srcs):
-        return EMU_LIB
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I", emu, "-x", "c++",
-                    os.path.join(csrc, "pfv_capi.hip"), os.path.join(emu, "hipemu.cpp"), "-o", EMU_LIB], check=True)
-    return EMU_LIB
+    defs = os.environ.get("PFV_EMU_DEFS", "").split()      # developer switch: e.g. -DPFV_PENC_PERSISTENT
+    lib = EMU_LIB if not defs else EMU_LIB.replace(".so", "_" + "".join(c for c in "".join(defs) if c.isalnum()) + ".so")
+    if os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
+        return lib
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", *defs, "-I", emu, "-x", "c++",
+                    os.path.join(csrc, "pfv_capi.hip"), os.path.join(emu, "hipemu.cpp"), "-o", lib], check=True)
+    return lib
 
 
 @pytest.fixture(scope="session")

@@ -100,6 +100,7 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool)
 static inline void hipemu_global_load_lds(const void *g, void *l, unsigned size, int offset, int) { memcpy((char *)l + offset, (const char *)g + offset, size); }
 #define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 
