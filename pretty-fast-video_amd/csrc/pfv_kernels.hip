@@ -4,28 +4,28 @@
 // motion search is a data-dependent 4-step descent (src/common.rs:154-204).
 //
 // Work decomposition (all kernels):
-//   wavefront  = one STRIP of 8 horizontally adjacent macroblocks (128 x 16 pixels) of one
-//                plane of one stream; 8 lanes per macroblock: lane (m, i) = (lane >> 3, lane & 7);
-//   workgroup  = 4 wavefronts = 4 strips.  The transform-only kernels never synchronise
-//                across wavefronts; the p-frame encoder stacks its 4 strips vertically
-//                (a 128 x 64 tile) so that they share one staged reference window.
-//   transform  : lane (m, i) owns rows i and i+8 of macroblock m, i.e. row i of all four
-//                8x8 subblocks (TL,TR | BL,BR) = 32 values in registers; the 1-D butterflies
-//                run entirely in registers on four independent subblocks (ILP), the 8x8
-//                transposes between the row and column passes go through a wavefront-private,
-//                XOR-swizzled LDS exchange region (conflict-free b128 writes / b32 reads);
-//                in "column layout" the same lane owns column i of the four subblocks, so the
-//                per-column quantiser constants are shared by all four.
-//   search     : one lane = one candidate of the current search level (8 candidates x 8
-//                macroblocks per wavefront), the whole 16x16 source block in registers, the
-//                +-15 pixel reference window in LDS; squared error from v_dot4_u32_u8 as
-//                sum a^2 - 2 sum ab + sum b^2 (exact in u32); unaligned patch rows are cut
-//                out of aligned LDS dwords with v_alignbyte_b32; the per-level arg-min over 8
-//                candidates is three DPP steps.
-//   memory     : plane rows are read/written straight from/to HBM as 16-byte-per-lane vectors
-//                that tile 128-byte row segments; the strip's contiguous 4 KiB coefficient
-//                block is transposed to/from zigzag order through LDS and moved with fully
-//                coalesced 1 KiB-per-instruction vector accesses.
+//   wavefront  = one STRIP of 8 horizontally adjacent macroblocks (128 x 16 pixels) of one plane of one
+//                stream; 8 lanes per macroblock: lane (m, i) = (lane >> 3, lane & 7); the wavefront index is
+//                made scalar (readfirstlane) so that all strip geometry lives in SGPRs;
+//   workgroup  = 4 wavefronts = 4 strips.  The transform-only kernels never synchronise across wavefronts;
+//                the p-frame encoder stacks its 4 strips vertically (a 128 x 64 tile) so that they share one
+//                reference window in LDS (two workgroup barriers per tile).
+//   transform  : lane (m, i) owns rows i and i+8 of macroblock m and processes them as two passes of two 8x8
+//                subblocks (16 values in registers).  The 1-D butterflies run entirely in registers; the 8x8
+//                transposes between the row and column passes go through a wavefront-private, XOR-swizzled,
+//                pad-free 4 KiB LDS exchange region (conflict-free b128 writes / b32 reads); the same region
+//                then serves as the zigzag stage of the coefficient block.  In "column layout" the lane owns
+//                column i of its subblocks, so the per-column quantiser constants are shared; they are read
+//                from an LDS copy of the 64-entry tables at the point of use.
+//   search     : "row owner" form -- lane i keeps source rows i and i+8 in registers and accumulates, for every
+//                candidate of a level, sum b^2 - 2 sum ab over its two rows with v_dot4_u32_u8 from one aligned
+//                dword span per reference row (SSD = sum a^2 - 2 sum ab + sum b^2, exact in u32); partial sums
+//                are all-reduced over the macroblock's 8 lanes with three DPP steps; levels 8 and 4 need no
+//                byte realignment, levels 2 and 1 rebase each span once with v_alignbyte_b32.
+//   memory     : plane rows go straight between HBM and registers as 16-byte-per-lane vectors that tile
+//                128-byte row segments; the reference window is staged with direct global->LDS loads
+//                (global_load_lds_dwordx4); the strip's contiguous 4 KiB coefficient block moves as 256-byte
+//                runs, 16 B per lane, non-temporal.
 //
 // Bit-exactness notes (reference line numbers in the function comments):
 //   - i32 arithmetic wraps (Rust release) -> done in unsigned here;
