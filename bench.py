@@ -64,7 +64,9 @@ def cpu_baseline(pkg, width, height, quality, frames_one_stream):
     ncpu = os.cpu_count() or 1
     tabs = np.stack(ora.qtables(quality)[:4])
 
-    def run(threads, max_reps, budget_s):
+    penc = {"s": 0.0, "n": 0}
+
+    def run(threads, max_reps, budget_s, record=False):
         ora.L.pfvo_pool_shutdown()          # fresh pool of exactly `threads` workers
         enc = ora.encoder(width, height, quality, threads=threads)
         dec = OracleDecoder(ora, width, height, tabs, threads=threads)
@@ -75,7 +77,12 @@ def cpu_baseline(pkg, width, height, quality, frames_one_stream):
                 if t == 0:
                     dec.decode_iframe(enc.encode_iframe(f))
                 else:
-                    dec.decode_pframe(*enc.encode_pframe(f))
+                    t1 = time.perf_counter()
+                    r = enc.encode_pframe(f)
+                    if record:
+                        penc["s"] += time.perf_counter() - t1
+                        penc["n"] += enc.total_blocks
+                    dec.decode_pframe(*r)
             reps += 1
             el = time.perf_counter() - t0
             if el > budget_s or reps >= max_reps:
@@ -87,9 +94,10 @@ def cpu_baseline(pkg, width, height, quality, frames_one_stream):
     for th in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
         trials[th] = run(th, 1, 5.0)[0]
     best = max(trials, key=trials.get)
-    rate, reps, el = run(best, 6, 10.0)
+    rate, reps, el = run(best, 6, 10.0, record=True)
     n_mb = reps * len(frames_one_stream) * pkg._lib.load().pfv_total_blocks(width, height)
     return {"value": rate, "unit": "macroblocks/s", "cores": best, "kind": "port",
+            "pframe_encode_value": penc["n"] / penc["s"] if penc["s"] > 0 else None,
             "sample": f"{reps} x GOP-{len(frames_one_stream)} encode+decode of one {width}x{height} stream ({n_mb} macroblocks, "
                       f"{el:.1f} s); C oracle = port of the reference's algorithm with its per-plane fork/join, persistent "
                       f"pool of {best} threads (best of {dict((k, round(v)) for k, v in trials.items())} on {ncpu} host CPUs)"}
@@ -234,8 +242,12 @@ def main():
                          "avg_launch_ms": pe_ms, "macroblocks_per_launch": launch_mbs,
                          "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC},
         }
+        res["pframe_encode"] = {"value": launch_mbs / (pe_ms * 1e-3), "unit": "macroblocks/s",
+                                "note": "k_enc_pframe alone (motion search + residual DCT + closed-loop reconstruction), HIP-event time"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(pkg, W, H, Q, [host[t, 0] for t in range(GOP)])
+            if res["cpu_baseline"].get("pframe_encode_value"):
+                res["pframe_encode"]["vs_cpu_baseline"] = res["pframe_encode"]["value"] / res["cpu_baseline"]["pframe_encode_value"]
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
