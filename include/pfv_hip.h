@@ -105,6 +105,11 @@ PFV_API int pfv_decode_plane_delta_into(pfv_ctx *ctx, const int8_t *mv, const ui
 PFV_API int pfv_blit_dev(pfv_ctx *ctx, uint8_t *dst, int dst_w, int dst_h, const uint8_t *src, int src_w, int src_h,
                          int dx, int dy, int sx, int sy, int sw, int sh);
 
+/* VideoPlane::reduce (src/common.rs:523-536, point-sampled 2x decimation, dst = src_w/2 x src_h/2) and
+ * VideoPlane::double (:538-556, nearest 2x upsampling, dst = 2 src_w x 2 src_h) on device-resident planes. */
+PFV_API int pfv_reduce_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int src_w, int src_h);
+PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int src_w, int src_h);
+
 /* ------------------------------------------------------------------ device memory helpers */
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);
 PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p);

@@ -49,6 +49,8 @@ SIGNATURES = [
     ("pfv_decode_plane_delta", c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
     ("pfv_decode_plane_delta_into", c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P]),
     ("pfv_blit_dev", c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    ("pfv_reduce_dev", c_int, [_P, _P, _P, c_int, c_int]),
+    ("pfv_double_dev", c_int, [_P, _P, _P, c_int, c_int]),
     ("pfv_dev_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
     ("pfv_dev_free", c_int, [_P, _P]),
     ("pfv_dev_upload", c_int, [_P, _P, _P, c_size_t]),

@@ -425,6 +425,32 @@ PFV_API int pfv_blit_dev(pfv_ctx *ctx, uint8_t *dst, int dst_w, int dst_h, const
     return launch_check(ctx, "k_blit");
 }
 
+// VideoPlane::reduce / VideoPlane::double (src/common.rs:523-556) on device-resident planes
+PFV_API int pfv_reduce_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int src_w, int src_h)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!dst || !src || src_w < 0 || src_h < 0) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_reduce_dev: bad argument");
+    long n = (long)(src_w / 2) * (src_h / 2);
+    if (n == 0) return PFV_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int blocks = (int)((n + kThreads - 1) / kThreads);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_reduce2x, dim3(blocks), dim3(kThreads), 0, ctx->stream, dst, src, src_w, src_h);
+    return launch_check(ctx, "k_reduce2x");
+}
+PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int src_w, int src_h)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!dst || !src || src_w < 0 || src_h < 0) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_double_dev: bad argument");
+    long n = (long)src_w * src_h * 4;
+    if (n == 0) return PFV_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int blocks = (int)((n + kThreads - 1) / kThreads);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_double2x, dim3(blocks), dim3(kThreads), 0, ctx->stream, dst, src, src_w, src_h);
+    return launch_check(ctx, "k_double2x");
+}
+
 // ------------------------------------------------------------------ device memory helpers
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out)
 {

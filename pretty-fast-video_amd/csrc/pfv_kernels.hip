@@ -1077,6 +1077,30 @@ __global__ __launch_bounds__(kThreads) void k_crop_frames(FrameGeom g, const uin
     }
 }
 
+// VideoPlane::reduce (src/common.rs:523-536): point-sampled 2x decimation (every second pixel of every second row),
+// used by VideoFrame::from_planes (src/frame.rs:51-59) to make 4:2:0 chroma.  dst is (src_w/2) x (src_h/2).
+__global__ __launch_bounds__(kThreads) void k_reduce2x(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int src_w,
+                                                        int src_h)
+{
+    const int dw = src_w >> 1, dh = src_h >> 1;
+    const long n = (long)dw * dh;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        int y = (int)(idx / dw), x = (int)(idx - (long)y * dw);
+        dst[idx] = src[(long)(2 * y) * src_w + 2 * x];
+    }
+}
+// VideoPlane::double (src/common.rs:538-556): nearest-neighbour 2x upsampling.  dst is (2 src_w) x (2 src_h).
+__global__ __launch_bounds__(kThreads) void k_double2x(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int src_w,
+                                                        int src_h)
+{
+    const int dw = src_w * 2;
+    const long n = (long)dw * src_h * 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        int y = (int)(idx / dw), x = (int)(idx - (long)y * dw);
+        dst[idx] = src[(long)(y >> 1) * src_w + (x >> 1)];
+    }
+}
+
 // VideoFrame::new_padded initial state (src/frame.rs:38-43): Y = 0, U = V = 128.
 __global__ __launch_bounds__(kThreads) void k_init_padded(FrameGeom g, uint8_t *__restrict__ padded)
 {

@@ -153,3 +153,29 @@ def check_golden(pkg, ctx, oracle):
     assert np.array_equal(e1.blocks, gold["pf_c1"])
     r1 = pkg.VideoPlane.decode_plane_delta(e1, r0, pl, ctx)
     assert np.array_equal(r1.image(), gold["pf_rec1"])
+
+
+def check_colour_utils(pkg, ctx):
+    """VideoPlane::reduce / double on the device vs the host container ops (src/common.rs:523-556)"""
+    import ctypes
+    rng = np.random.default_rng(8)
+    for (w, h) in [(37, 21), (64, 48), (2, 2), (1, 1)]:
+        src = pkg.VideoPlane.from_slice(w, h, rng.integers(0, 256, w * h, dtype=np.uint8))
+        d_src = ctx.alloc(max(w * h, 1))
+        ctx.upload(d_src, src.pixels)
+        red = src.reduce()
+        if red.pixels.size:
+            d_red = ctx.alloc(red.pixels.size)
+            ctx.check(ctx._lib.pfv_reduce_dev(ctx.handle, ctypes.c_void_p(d_red), ctypes.c_void_p(d_src), w, h))
+            out = np.empty(red.pixels.size, np.uint8)
+            ctx.download(out, d_red)
+            assert np.array_equal(out, red.pixels), ("reduce", w, h)
+            ctx.free(d_red)
+        dbl = src.double()
+        d_dbl = ctx.alloc(dbl.pixels.size)
+        ctx.check(ctx._lib.pfv_double_dev(ctx.handle, ctypes.c_void_p(d_dbl), ctypes.c_void_p(d_src), w, h))
+        out = np.empty(dbl.pixels.size, np.uint8)
+        ctx.download(out, d_dbl)
+        assert np.array_equal(out, dbl.pixels), ("double", w, h)
+        ctx.free(d_dbl)
+        ctx.free(d_src)

@@ -44,3 +44,7 @@ def test_emu_stream_encoder_decoder(pkg, emu_ctx, oracle):
     data = sc.check_stream_roundtrip(pkg, emu_ctx, oracle, 48, 32, 5, n_frames=5, gop=3, drop_at=(2,))
     sc.check_advance_delta(pkg, emu_ctx, oracle, data, kinds=[True, True, False, True, True])
     sc.check_header_errors(pkg, emu_ctx, data)
+
+
+def test_emu_colour_utils(pkg, emu_ctx):
+    pc.check_colour_utils(pkg, emu_ctx)

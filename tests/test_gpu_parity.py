@@ -206,3 +206,7 @@ def test_stream_encoder_decoder_vs_oracle(pkg, gpu_ctx, oracle):
     sc.check_header_errors(pkg, gpu_ctx, data)
     sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 100, 60, 2, n_frames=3, gop=15)
     sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 64, 48, 10, n_frames=3, gop=15)
+
+
+def test_colour_utils(pkg, gpu_ctx):
+    pc.check_colour_utils(pkg, gpu_ctx)
