@@ -156,13 +156,15 @@ PFV_API int pfv_qtables_from_quality(int quality, int32_t intra_l[64], int32_t i
 }  // extern "C"
 
 // ------------------------------------------------------------------ internal helpers
-static int make_qtab(pfv_ctx *ctx, const int32_t q[64], QTab *out)
+// decode_only: tables read from a stream header may hold 0 (the reference's decode only multiplies, src/dct.rs:75-86);
+// an encoder table must be >= 1 (it divides, src/dct.rs:95).
+static int make_qtab(pfv_ctx *ctx, const int32_t q[64], QTab *out, bool decode_only = false)
 {
     if (!q) return fail(ctx, PFV_ERR_BAD_ARG, "q-table is null");
     for (int i = 0; i < 64; i++)
-        if (q[i] < 1 || q[i] > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "q-table entry outside [1,65535]");
+        if (q[i] < (decode_only ? 0 : 1) || q[i] > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "q-table entry outside [1,65535]");
     for (int i = 0; i < 64; i++) {
-        volatile float r = 1.0f / (float)q[i];
+        volatile float r = q[i] ? 1.0f / (float)q[i] : 0.0f;
         r = r * 1.000000476837158203125f;   // 1 + 2^-21: see QTab::rcp
         out->rcp[i] = r;
         int z = H_INV_ZIGZAG[i];
@@ -702,7 +704,7 @@ PFV_API int pfv_dec_session_create(pfv_ctx *ctx, int width, int height, const in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<QTab> tabs((size_t)n_qtables);
     for (int i = 0; i < n_qtables; i++) {
-        int rc = make_qtab(ctx, qtables + (size_t)i * 64, &tabs[i]);
+        int rc = make_qtab(ctx, qtables + (size_t)i * 64, &tabs[i], true);
         if (rc) return rc;
     }
     pfv_dec_session *s = new pfv_dec_session();

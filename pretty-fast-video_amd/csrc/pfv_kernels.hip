@@ -786,12 +786,14 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
     const int m = lane >> 3, i = lane & 7;
     const bool mb_valid = m < sp.n_mb, coded = so.coded;
     const int mbx = sp.x0 + m * 16;
+#ifndef PFV_ABL_NOHDR   // ablation experiment only (results invalid)
     if (i == 0 && mb_valid) {
         long mbi = (long)sp.stream * g.mbs_per_frame + sp.mb_first + m;
         mv_out[mbi * 2 + 0] = (int8_t)so.cx;
         mv_out[mbi * 2 + 1] = (int8_t)so.cy;
         has_out[mbi] = coded ? 1 : 0;
     }
+#endif
 #ifdef PFV_ABL_STORE_SMALL   // ablation experiment only (results invalid): all stores land in one L2-resident megabyte
     int16_t *coef_mb0 = coef + (((long)sp.stream * g.mbs_per_frame + sp.mb_first) & 1023) * 256;
     uint8_t *dst = recon ? recon + (((long)(sp.y0 + i) * p.pw + mbx) & 0xfffff) : nullptr;

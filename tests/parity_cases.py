@@ -179,3 +179,44 @@ def check_colour_utils(pkg, ctx):
         assert np.array_equal(out, dbl.pixels), ("double", w, h)
         ctx.free(d_dbl)
         ctx.free(d_src)
+
+
+def check_misaligned_device_frames(pkg, ctx, oracle):
+    """device-pointer session entry points with a frame buffer that is NOT 16-byte aligned (byte-load fallback of
+    load_src16 / separate crop pass instead of the fused one)"""
+    w, h, q = 64, 48, 5
+    st = pkg.SyntheticStream(w, h)
+    f0, f1 = st.frame(0), st.frame(1)
+    enc = pkg.EncoderSession(ctx, w, h, q, 1)
+    dec = pkg.DecoderSession(ctx, w, h, np.stack(pkg.qtables_from_quality(q)[:4]), 1)
+    nb, fb = enc.total_blocks, enc.frame_bytes
+    d_frames = ctx.alloc(fb + 64)
+    d_out = ctx.alloc(fb + 64)
+    d_coef, d_mv, d_has = ctx.alloc(nb * 512), ctx.alloc(nb * 2), ctx.alloc(nb)
+    oenc = oracle.encoder(w, h, q)
+    dec.set_output_dev(d_out + 3)                      # misaligned retframe target
+    for t, f in enumerate((f0, f1)):
+        ctx.upload(d_frames + 1, f)                    # misaligned source frames
+        if t == 0:
+            enc.encode_iframe_dev(d_frames + 1, d_coef)
+            dec.decode_iframe_dev(d_coef)
+            ocoef = oenc.encode_iframe(f)
+        else:
+            enc.encode_pframe_dev(d_frames + 1, d_mv, d_has, d_coef)
+            dec.decode_pframe_dev(d_mv, d_has, d_coef)
+            omv, ohas, ocoef = oenc.encode_pframe(f)
+            mv, has = np.empty((nb, 2), np.int8), np.empty(nb, np.uint8)
+            ctx.download(mv, d_mv); ctx.download(has, d_has)
+            assert np.array_equal(mv, omv) and np.array_equal(has, ohas)
+        coef = np.empty((nb, 256), np.int16)
+        ctx.download(coef, d_coef)
+        assert np.array_equal(coef, ocoef)
+        dec.check()
+        assert np.array_equal(enc.prev_frame()[0], oenc.prev_frame())
+        out = np.empty(fb, np.uint8)
+        ctx.download(out, d_out + 3)
+        assert np.array_equal(out, dec.get_frame()[0])
+    dec.set_output_dev(None)
+    for p in (d_frames, d_out, d_coef, d_mv, d_has):
+        ctx.free(p)
+    enc.close(); dec.close()

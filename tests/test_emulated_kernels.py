@@ -48,3 +48,7 @@ def test_emu_stream_encoder_decoder(pkg, emu_ctx, oracle):
 
 def test_emu_colour_utils(pkg, emu_ctx):
     pc.check_colour_utils(pkg, emu_ctx)
+
+
+def test_emu_misaligned_device_frames(pkg, emu_ctx, oracle):
+    pc.check_misaligned_device_frames(pkg, emu_ctx, oracle)

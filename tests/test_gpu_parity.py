@@ -210,3 +210,7 @@ def test_stream_encoder_decoder_vs_oracle(pkg, gpu_ctx, oracle):
 
 def test_colour_utils(pkg, gpu_ctx):
     pc.check_colour_utils(pkg, gpu_ctx)
+
+
+def test_misaligned_device_frames(pkg, gpu_ctx, oracle):
+    pc.check_misaligned_device_frames(pkg, gpu_ctx, oracle)
