@@ -1128,8 +1128,9 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
         if (type != 1 && type != 2) continue;   // unknown packet: skipped (:216-219)
         if (type == 1 && plen == 0) break;      // drop frame: nothing decoded, no callback (:190)
         uint8_t qidx[3];
-        int rc = type == 1 ? parse_iframe(payload, plen, d->total_blocks, d->coef.data(), qidx)
-                           : parse_pframe(payload, plen, d->total_blocks, d->mv.data(), d->has.data(), d->coef.data(), qidx);
+        int rc = type == 1 ? parse_iframe(payload, plen, d->total_blocks, d->n_qtables, d->coef.data(), qidx)
+                           : parse_pframe(payload, plen, d->total_blocks, d->n_qtables, d->mv.data(), d->has.data(),
+                                          d->coef.data(), qidx);
         if (rc) return fail(d->ctx, rc, "malformed packet payload");
         rc = type == 1 ? pfv_dec_iframe(d->hot, d->coef.data(), qidx)
                        : pfv_dec_pframe(d->hot, d->mv.data(), d->has.data(), d->coef.data(), qidx);

@@ -15,6 +15,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <emmintrin.h>
 #include <memory>
 #include <vector>
 
@@ -23,30 +24,51 @@ namespace pfv {
 // ------------------------------------------------------------------ little-endian bit packing
 class BitSink {
   public:
-    explicit BitSink(std::vector<uint8_t> &out) : out_(out) {}
+    explicit BitSink(std::vector<uint8_t> &out) : out_(out), len_(out.size()) {}
     void put(unsigned nbits, uint32_t value)   // BitWrite::write
     {
         if (nbits == 0) return;
         acc_ |= (uint64_t)(value & (nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u))) << fill_;
         fill_ += nbits;
-        while (fill_ >= 8) {
-            out_.push_back((uint8_t)acc_);
-            acc_ >>= 8;
-            fill_ -= 8;
+        if (fill_ >= 32) {                     // flush four bytes at a time (little-endian host)
+            room(4);
+            const uint32_t lo = (uint32_t)acc_;
+            std::memcpy(out_.data() + len_, &lo, 4);
+            len_ += 4;
+            acc_ >>= 32;
+            fill_ -= 32;
         }
     }
     void put_signed(unsigned nbits, int32_t value) { put(nbits, (uint32_t)value); }   // BitWrite::write_signed (LE)
+    void reserve(size_t more_bytes) { room(more_bytes + 8); }
+    // put() without the capacity check: the caller reserved the bytes; value must already fit nbits (1..32)
+    void put_reserved(unsigned nbits, uint32_t value)
+    {
+        acc_ |= (uint64_t)value << fill_;
+        fill_ += nbits;
+        if (fill_ >= 32) {
+            const uint32_t lo = (uint32_t)acc_;
+            std::memcpy(out_.data() + len_, &lo, 4);
+            len_ += 4;
+            acc_ >>= 32;
+            fill_ -= 32;
+        }
+    }
     void align()                                                                        // BitWrite::byte_align
     {
-        if (fill_) {
-            out_.push_back((uint8_t)acc_);
-            acc_ = 0;
-            fill_ = 0;
-        }
+        room(4);
+        for (; fill_ > 0; fill_ = fill_ > 8 ? fill_ - 8 : 0, acc_ >>= 8) out_[len_++] = (uint8_t)acc_;
+        acc_ = 0;
+        out_.resize(len_);
     }
 
   private:
+    void room(size_t n)
+    {
+        if (out_.size() < len_ + n) out_.resize(std::max(out_.size() * 2, len_ + n + 4096));
+    }
     std::vector<uint8_t> &out_;
+    size_t len_;
     uint64_t acc_ = 0;
     unsigned fill_ = 0;
 };
@@ -58,22 +80,34 @@ class BitSource {
     uint64_t position() const { return pos_; }
     void seek(int64_t delta) { pos_ = (uint64_t)((int64_t)pos_ + delta); }
     bool ok() const { return ok_; }
-    uint32_t get(unsigned nbits)   // BitRead::read
+    uint32_t get(unsigned nbits)   // BitRead::read (nbits <= 32)
     {
-        uint32_t v = 0;
         if (pos_ + nbits > total_) {
             ok_ = false;
             pos_ = total_;
             return 0;
         }
-        for (unsigned got = 0; got < nbits;) {
-            unsigned off = (unsigned)(pos_ & 7), take = std::min(8u - off, nbits - got);
-            v |= (uint32_t)((p_[pos_ >> 3] >> off) & ((1u << take) - 1u)) << got;
-            got += take;
-            pos_ += take;
+        if (nbits == 0) return 0;
+        const size_t byte = (size_t)(pos_ >> 3), nbytes = (size_t)(total_ >> 3);
+        uint64_t w = 0;
+        if (byte + 8 <= nbytes) {
+            std::memcpy(&w, p_ + byte, 8);                 // little-endian host: bit k of the stream = bit k of w
+        } else {
+            for (size_t k = 0; byte + k < nbytes && k < 8; k++) w |= (uint64_t)p_[byte + k] << (8 * k);
         }
-        return v;
+        w >>= (pos_ & 7);
+        pos_ += nbits;
+        return (uint32_t)(w & (nbits >= 32 ? 0xffffffffull : ((1ull << nbits) - 1ull)));
     }
+    // >= 57 valid stream bits starting at the read position, without consuming them; only when can_peek()
+    bool can_peek() const { return pos_ + 72 <= total_; }
+    uint64_t peek() const
+    {
+        uint64_t w;
+        std::memcpy(&w, p_ + (size_t)(pos_ >> 3), 8);
+        return w >> (pos_ & 7);
+    }
+    void skip(unsigned nbits) { pos_ += nbits; }
     int32_t get_signed(unsigned nbits)   // BitRead::read_signed (LE): n-bit two's complement
     {
         uint32_t v = get(nbits);
@@ -86,38 +120,6 @@ class BitSource {
     uint64_t total_, pos_ = 0;
     bool ok_ = true;
 };
-
-// ------------------------------------------------------------------ src/rle.rs
-struct RunSymbol {   // RLESequence (rle.rs:3-7)
-    uint8_t num_zeroes, coeff_size;
-    int16_t coeff;
-};
-
-// rle_encode (rle.rs:9-39).  Returns false if a coefficient needs more than 15 size bits (the reference's
-// update_table would index its 16-entry histogram out of range, rle.rs:44).
-inline bool rle_encode(std::vector<RunSymbol> &into, const int16_t *data, size_t n)
-{
-    unsigned run = 0;
-    auto flush_long_run = [&]() {
-        for (; run > 15; run -= 15) into.push_back({15, 0, 0});
-    };
-    for (size_t i = 0; i < n; i++) {
-        const int v = data[i];
-        if (v == 0) {
-            run++;
-            continue;
-        }
-        flush_long_run();
-        unsigned mag = (unsigned)(v < 0 ? -v : v), bits = 0;
-        while (mag >> bits) bits++;
-        if (bits + 1 > 15) return false;
-        into.push_back({(uint8_t)run, (uint8_t)(bits + 1), (int16_t)v});
-        run = 0;
-    }
-    flush_long_run();
-    if (run) into.push_back({(uint8_t)run, 0, 0});
-    return true;
-}
 
 // ------------------------------------------------------------------ src/huffman.rs
 struct HuffCode {
@@ -158,6 +160,7 @@ class HuffmanTree {
     }
     const std::array<uint8_t, 16> &table() const { return table_; }
     const HuffCode &code(uint8_t sym) const { return codes_[sym & 15]; }
+    const HuffCode &fast(uint32_t low8) const { return fast_[low8 & 255]; }   // len == 0: no code of <= 8 bits matches
 
     // HuffmanTree::read (huffman.rs:156-197); -1 = DecodeError, -2 = I/O error
     int read(BitSource &r, uint64_t max_bits) const
@@ -222,31 +225,78 @@ inline std::array<uint8_t, 16> normalise_histogram(const std::array<int32_t, 16>
 }
 
 // ------------------------------------------------------------------ packet payloads
+// Run symbols of all coded macroblocks back to back, one 32-bit word each: num_zeroes | coeff_size << 4 | coeff << 16
+// (rle_encode + update_table, src/rle.rs:9-47, fused into one scan; one run stream per macroblock, enc.rs:246-255).
 struct BlockRuns {
-    std::vector<RunSymbol> symbols;   // all coded macroblocks back to back
+    const uint32_t *symbols = nullptr;   // into a per-thread scratch that only ever grows (no per-frame allocation)
+    size_t count = 0;
     std::array<int32_t, 16> hist{};
 };
 
 inline bool collect_runs(BlockRuns &br, const int16_t *coef, const uint8_t *has /*nullable: all coded*/, int total_blocks)
 {
+    size_t coded = 0;
+    for (int b = 0; b < total_blocks; b++) coded += (!has || has[b]) ? 1 : 0;
+    static thread_local std::vector<uint32_t> scratch;
+    const size_t need = coded * (256 + 18);   // worst case per macroblock: 256 values (or 17 fillers + 1 tail run)
+    if (scratch.size() < need) scratch.resize(need);
+    uint32_t *out = scratch.data();
+    int32_t *hist = br.hist.data();
+    const __m128i zero = _mm_setzero_si128();
     for (int b = 0; b < total_blocks; b++) {
         if (has && !has[b]) continue;
-        size_t first = br.symbols.size();
-        if (!rle_encode(br.symbols, coef + (size_t)b * 256, 256)) return false;   // one run stream per macroblock (enc.rs:246-255)
-        for (size_t i = first; i < br.symbols.size(); i++) {                     // update_table (rle.rs:41-47)
-            br.hist[br.symbols[i].num_zeroes]++;
-            br.hist[br.symbols[i].coeff_size]++;
+        const int16_t *d = coef + (size_t)b * 256;
+        int last = -1;   // index of the previous non-zero coefficient
+        for (int base = 0; base < 256; base += 32) {
+            // one bit per coefficient: 1 = non-zero (SSE2 is baseline x86-64)
+            uint32_t nz = 0;
+            for (int k = 0; k < 4; k++) {
+                const __m128i v = _mm_loadu_si128((const __m128i *)(d + base + 8 * k));
+                const uint32_t eq = (uint32_t)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(v, zero), zero)) & 0xffu;
+                nz |= (eq ^ 0xffu) << (8 * k);
+            }
+            while (nz) {
+                const int i = base + __builtin_ctz(nz);
+                nz &= nz - 1;
+                unsigned run = (unsigned)(i - last - 1);
+                last = i;
+                for (; run > 15; run -= 15) { *out++ = 15u; hist[15]++; hist[0]++; }       // (15, size 0) fillers (rle.rs:18-21)
+                const int v = d[i];
+                const unsigned mag = (unsigned)(v < 0 ? -v : v);
+                const unsigned size = 33u - (unsigned)__builtin_clz(mag);                   // bit length + 1 (rle.rs:23-24)
+                if (size > 15) return false;                                                // the reference would index hist[16+]
+                *out++ = run | (size << 4) | ((uint32_t)(uint16_t)v << 16);
+                hist[run]++;
+                hist[size]++;
+            }
         }
+        unsigned run = (unsigned)(255 - last);
+        for (; run > 15; run -= 15) { *out++ = 15u; hist[15]++; hist[0]++; }               // rle.rs:31-34
+        if (run) { *out++ = run; hist[run]++; hist[0]++; }                                  // trailing run (rle.rs:36-38)
     }
+    br.symbols = scratch.data();
+    br.count = (size_t)(out - scratch.data());
     return true;
 }
-inline void emit_runs(BitSink &w, const HuffmanTree &tree, const BlockRuns &br)
+inline void emit_runs(std::vector<uint8_t> &payload, BitSink &w, const HuffmanTree &tree, const BlockRuns &br)
 {
-    for (const RunSymbol &s : br.symbols) {
-        const HuffCode &z = tree.code(s.num_zeroes), &n = tree.code(s.coeff_size);
-        w.put(z.len, z.val);
-        w.put(n.len, n.val);
-        if (s.coeff_size) w.put_signed(s.coeff_size, s.coeff);
+    (void)payload;
+    // (num_zeroes, coeff_size) code pairs pre-joined: two tree codes of <= 15 bits each fit one 30-bit put
+    struct Pair { uint32_t bits; uint32_t len; };
+    Pair pair[256];
+    for (unsigned z = 0; z < 16; z++)
+        for (unsigned n = 0; n < 16; n++) {
+            const HuffCode &cz = tree.code((uint8_t)z), &cn = tree.code((uint8_t)n);
+            pair[z | (n << 4)] = {cz.val | (cn.val << cz.len), cz.len + cn.len};
+        }
+    w.reserve(br.count * 6);   // <= 30 + 15 bits per symbol
+    for (size_t k = 0; k < br.count; k++) {
+        const uint32_t s = br.symbols[k];
+        const Pair &p = pair[s & 255u];
+        if (p.len) w.put_reserved(p.len, p.bits);
+        const unsigned size = (s >> 4) & 15u;
+        // write_signed: the low `size` bits of the two's complement (enc.rs:313-315)
+        if (size) w.put_reserved(size, (s >> 16) & ((1u << size) - 1u));
     }
 }
 
@@ -259,7 +309,7 @@ inline bool serialize_iframe(std::vector<uint8_t> &payload, const int16_t *coef,
     BitSink w(payload);
     for (uint8_t t : tree.table()) w.put(8, t);
     w.put(8, 0); w.put(8, 1); w.put(8, 1);   // q-table index per plane: intra_l, intra_c, intra_c (enc.rs:296-298)
-    emit_runs(w, tree, br);
+    emit_runs(payload, w, tree, br);
     w.align();
     return true;
 }
@@ -282,7 +332,7 @@ inline bool serialize_pframe(std::vector<uint8_t> &payload, const int8_t *mv, co
             w.put_signed(7, mv[2 * b + 1]);
         }
     }
-    emit_runs(w, tree, br);
+    emit_runs(payload, w, tree, br);
     w.align();
     return true;
 }
@@ -292,17 +342,41 @@ struct PacketHead {
     std::array<uint8_t, 16> table;
     uint8_t qidx[3];
 };
-inline int parse_head(BitSource &r, PacketHead &h)
+inline int parse_head(BitSource &r, PacketHead &h, int n_qtables)
 {
     for (auto &t : h.table) t = (uint8_t)r.get(8);
     for (auto &q : h.qidx) q = (uint8_t)r.get(8);
-    return r.ok() ? 0 : -8;
+    if (!r.ok()) return -8;
+    // the reference indexes self.qtables the moment it reads each index (dec.rs:244-246, 346-348): an index past the
+    // header's table count fails here, before any run is parsed
+    for (uint8_t q : h.qidx)
+        if (q >= n_qtables) return -6;
+    return 0;
 }
 // reads run symbols until `count` coefficients are covered, writing into out[0..count)
 inline int read_runs(BitSource &r, const HuffmanTree &tree, int16_t *out, size_t count)
 {
     size_t idx = 0;
     while (idx < count) {
+        if (r.can_peek()) {
+            // whole symbol from one 64-bit window when both codes hit the 8-bit table (the same lookups
+            // HuffmanTree::read makes, huffman.rs:156-197, minus the per-field refills)
+            const uint64_t win = r.peek();
+            const HuffCode &cz = tree.fast((uint32_t)win);
+            const HuffCode &cn = tree.fast((uint32_t)(win >> cz.len));
+            if (cz.len && cn.len) {
+                unsigned used = cz.len + cn.len;
+                idx += cz.symbol;
+                if (const unsigned nb = cn.symbol) {
+                    if (idx >= count) return -6;
+                    const uint32_t raw = (uint32_t)(win >> used) & ((1u << nb) - 1u);
+                    out[idx++] = (int16_t)(int32_t)((raw ^ (1u << (nb - 1))) - (1u << (nb - 1)));   // sign-extend nb bits
+                    used += nb;
+                }
+                r.skip(used);
+                continue;
+            }
+        }
         int z = tree.read(r, r.total_bits());
         if (z < 0) return z == -2 ? -8 : -6;
         idx += (size_t)z;
@@ -317,22 +391,22 @@ inline int read_runs(BitSource &r, const HuffmanTree &tree, int16_t *out, size_t
     }
     return 0;
 }
-inline int parse_iframe(const uint8_t *payload, size_t n, int total_blocks, int16_t *coef, uint8_t qidx[3])
+inline int parse_iframe(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int16_t *coef, uint8_t qidx[3])
 {
     BitSource r(payload, n);
     PacketHead h;
-    if (int rc = parse_head(r, h)) return rc;
+    if (int rc = parse_head(r, h, n_qtables)) return rc;
     HuffmanTree tree(h.table);
     std::memcpy(qidx, h.qidx, 3);
     std::memset(coef, 0, (size_t)total_blocks * 512);
     return read_runs(r, tree, coef, (size_t)total_blocks * 256);   // ONE run stream for the whole frame (dec.rs:261)
 }
-inline int parse_pframe(const uint8_t *payload, size_t n, int total_blocks, int8_t *mv, uint8_t *has, int16_t *coef,
-                        uint8_t qidx[3])
+inline int parse_pframe(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int8_t *mv, uint8_t *has,
+                        int16_t *coef, uint8_t qidx[3])
 {
     BitSource r(payload, n);
     PacketHead h;
-    if (int rc = parse_head(r, h)) return rc;
+    if (int rc = parse_head(r, h, n_qtables)) return rc;
     HuffmanTree tree(h.table);
     std::memcpy(qidx, h.qidx, 3);
     for (int b = 0; b < total_blocks; b++) {   // dec.rs:361-372

@@ -220,3 +220,28 @@ def check_misaligned_device_frames(pkg, ctx, oracle):
     for p in (d_frames, d_out, d_coef, d_mv, d_has):
         ctx.free(p)
     enc.close(); dec.close()
+
+
+def fuzz_plane_ops(pkg, ctx, oracle, n_cases, seed, max_w=420, max_h=200):
+    """randomised geometry / content / quantiser / skip-threshold sweep of the four plane operators"""
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        w, h = int(rng.integers(1, max_w + 1)), int(rng.integers(1, max_h + 1))
+        kind = case % 4
+        if kind == 0:
+            px = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1:
+            px = smooth_plane(h, w, seed * 1000 + case)
+        elif kind == 2:
+            px = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+        else:
+            px = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+        q = rng.integers(1, int(rng.choice([4, 40, 400])), 64).astype(np.int32)
+        clear = int(rng.integers(0, 256))
+        enc, dec = check_encode_plane(pkg, ctx, oracle, px, q, clear)
+        ref = dec.image().copy()
+        ref = np.ascontiguousarray(np.roll(ref, (int(rng.integers(-15, 16)), int(rng.integers(-15, 16))), (0, 1)))
+        if case % 3 == 0:
+            ref = np.clip(ref.astype(int) + rng.integers(-20, 21, ref.shape), 0, 255).astype(np.uint8)
+        px_err = float(rng.choice([0.0, 1.5, 7.5, 15.0]))
+        check_encode_plane_delta(pkg, ctx, oracle, px, ref, q, px_err, clear)

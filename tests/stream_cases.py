@@ -112,3 +112,72 @@ def check_header_errors(pkg, ctx, data):
         n += 1
     assert n >= 1
     dec.close()
+
+
+def _outcomes_product(pkg, ctx, data):
+    """one entry per advance_frame call: ('frame', bytes) / ('none',) / ('eof',) / ('err', code)"""
+    out = []
+    try:
+        dec = pkg.Decoder(data, ctx)
+    except pkg.PfvError as e:
+        return [("open-err", e.code)]
+    try:
+        for _ in range(64):
+            got = []
+            try:
+                more = dec.advance_frame(lambda fr: got.append(fr.packed()))
+            except pkg.PfvError as e:
+                out.append(("err", e.code))
+                break
+            out.append(("frame", got[0].tobytes()) if got else ("none",))
+            if not more:
+                out.append(("eof",))
+                break
+    finally:
+        dec.close()
+    return out
+
+
+def _outcomes_oracle(oracle, data):
+    odec = OracleStreamDecoder(oracle, data)
+    if not odec.h:
+        return [("open-err", odec.err)]
+    out = []
+    for _ in range(64):
+        rc, fr = odec.advance_frame()
+        if rc < 0:
+            out.append(("err", rc))
+            break
+        out.append(("frame", fr.tobytes()) if fr is not None else ("none",))
+        if rc == 0:
+            out.append(("eof",))
+            break
+    return out
+
+
+def check_corrupted_streams(pkg, ctx, oracle, data, n_trials, seed):
+    """Byte-flip fuzz of a valid .pfv stream: the product decoder and the oracle's must agree call by call -- the
+    same frames (hostile coefficients and all), the same error code on the same packet, never a crash."""
+    rng = np.random.default_rng(seed)
+    hdr = 20 + 4 * 128
+    stats = {"trials": 0, "errors": 0, "frames": 0}
+    for _ in range(n_trials):
+        bad = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(hdr, len(bad)))
+            bad[pos] = int(rng.integers(0, 256))
+        if rng.random() < 0.25:
+            bad = bad[: int(rng.integers(hdr, len(bad)))]
+        a = _outcomes_product(pkg, ctx, bytes(bad))
+        b = _outcomes_oracle(oracle, bytes(bad))
+        assert len(a) == len(b), (a[-1][:1], b[-1][:1], [x[0] for x in a], [x[0] for x in b])
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert x[0] == y[0], (k, x[0], y[0], x[1:] if x[0] == "err" else None, y[1:] if y[0] == "err" else None)
+            if x[0] == "err":
+                assert x[1] == y[1], (k, x, y)
+            elif x[0] == "frame":
+                assert x[1] == y[1], f"call {k}: decoded frames differ on a corrupted stream"
+                stats["frames"] += 1
+        stats["trials"] += 1
+        stats["errors"] += a[-1][0] == "err"
+    return stats

@@ -52,3 +52,14 @@ def test_emu_colour_utils(pkg, emu_ctx):
 
 def test_emu_misaligned_device_frames(pkg, emu_ctx, oracle):
     pc.check_misaligned_device_frames(pkg, emu_ctx, oracle)
+
+
+def test_emu_fuzz_plane_operators(pkg, emu_ctx, oracle):
+    pc.fuzz_plane_ops(pkg, emu_ctx, oracle, n_cases=12, seed=5, max_w=200, max_h=90)
+
+
+def test_emu_corrupted_streams(pkg, emu_ctx, oracle):
+    """hostile .pfv bytes: product parser + kernels vs the oracle's, outcome by outcome"""
+    data, _ = sc.encode_clip(pkg, emu_ctx, oracle, 48, 32, 30, 5, n_frames=4, gop=2)
+    stats = sc.check_corrupted_streams(pkg, emu_ctx, oracle, data, n_trials=40, seed=5)
+    assert stats["trials"] == 40

@@ -208,9 +208,23 @@ def test_stream_encoder_decoder_vs_oracle(pkg, gpu_ctx, oracle):
     sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 64, 48, 10, n_frames=3, gop=15)
 
 
+@pytest.mark.parametrize("geom", [(176, 144, 5, 5, 3), (34, 18, 2, 3, 3), (100, 60, 8, 4, 4)])
+def test_corrupted_streams_match_oracle(pkg, gpu_ctx, oracle, geom):
+    """byte-flipped / truncated .pfv streams: same frames and same error codes as the oracle's decoder, call by call"""
+    w, h, q, n, gop = geom
+    data, _ = sc.encode_clip(pkg, gpu_ctx, oracle, w, h, 30, q, n_frames=n, gop=gop)
+    stats = sc.check_corrupted_streams(pkg, gpu_ctx, oracle, data, n_trials=120, seed=w + h)
+    assert stats["trials"] == 120 and stats["frames"] > 0
+
+
 def test_colour_utils(pkg, gpu_ctx):
     pc.check_colour_utils(pkg, gpu_ctx)
 
 
 def test_misaligned_device_frames(pkg, gpu_ctx, oracle):
     pc.check_misaligned_device_frames(pkg, gpu_ctx, oracle)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_plane_operators(pkg, gpu_ctx, oracle, seed):
+    pc.fuzz_plane_ops(pkg, gpu_ctx, oracle, n_cases=40, seed=seed)
