@@ -152,6 +152,29 @@ PFV_API const uint8_t *pfv_enc_prev_frame_dev(pfv_enc_session *s, int stream);
 /* copy prev_frame of all streams (padded) to host: n_streams * pfv_padded_frame_bytes */
 PFV_API int pfv_enc_prev_frame(pfv_enc_session *s, uint8_t *out_host);
 
+/* ------------------------------------------------------------------ device entropy stage (encoder session)
+ * The reference serialises each frame on one host thread: rle_encode per macroblock (src/rle.rs:9-47), one histogram
+ * and Huffman tree per frame (rle.rs:40-66, src/huffman.rs:71-119), LSB-first bit packing into the packet payload
+ * (write_iframe_packet src/enc.rs:237-320, write_pframe_packet :332-470).  These entry points build the same payload
+ * bytes on the device from the buffers pfv_enc_iframe_dev / pfv_enc_pframe_dev produced, so only the compressed
+ * payload crosses PCIe.  Payloads are byte-identical to pfv_serialize_iframe_payload / pfv_serialize_pframe_payload. */
+/* upper bound of a payload for this geometry, in bytes (multiple of 4) */
+PFV_API size_t pfv_payload_worst_case(int width, int height);
+/* allocates the stage's buffers; payload_cap = bytes per stream (0: pfv_payload_worst_case).  Idempotent. */
+PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap);
+/* coef_dev / mv_dev / has_coef_dev: device buffers in the layout the encode entry points write (n_streams wide) */
+PFV_API int pfv_enc_pack_iframe_dev(pfv_enc_session *s, const int16_t *coef_dev);
+PFV_API int pfv_enc_pack_pframe_dev(pfv_enc_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev,
+                                    const int16_t *coef_dev);
+/* byte count of each stream's payload from the last pack call (synchronises).  PFV_ERR_FORMAT: a coefficient needs more
+ * than 15 size bits (the reference panics, rle.rs:44); PFV_ERR_NOMEM: a payload exceeds the capacity.  sizes_out is
+ * filled either way (0 for failed streams). */
+PFV_API int pfv_enc_payload_sizes(pfv_enc_session *s, uint32_t *sizes_out);
+PFV_API const uint8_t *pfv_enc_payload_dev(pfv_enc_session *s, int stream);
+PFV_API size_t pfv_enc_payload_capacity(pfv_enc_session *s);
+/* first nbytes of one stream's payload to the host (synchronises) */
+PFV_API int pfv_enc_payload_fetch(pfv_enc_session *s, int stream, uint8_t *out_host, size_t nbytes);
+
 /* ------------------------------------------------------------------ decoder session (hot-path half of dec::Decoder)
  * Holds `qtables` and the padded `framebuffer` (src/dec.rs:15-28), n_streams-wide.
  * qtables: n_qtables tables of 64 (header order: intra_l, intra_c, inter_l, inter_c;
@@ -202,6 +225,8 @@ PFV_API int pfv_encoder_finish(pfv_encoder *e);
 /* the bytes written so far (header + packets); valid until the next call on this encoder */
 PFV_API int pfv_encoder_bytes(pfv_encoder *e, const uint8_t **data, size_t *len);
 PFV_API void pfv_encoder_destroy(pfv_encoder *e);
+/* 1 (default): packet payloads come from the device entropy stage; 0: from the host serialisers.  Same bytes. */
+PFV_API int pfv_encoder_set_device_entropy(pfv_encoder *e, int on);
 /* packet payload serialisers alone (write_iframe_packet / write_pframe_packet bodies, src/enc.rs:237-320, 332-470);
  * return the payload size (0 on error); the payload is copied to `out` when it fits `cap` */
 PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap);

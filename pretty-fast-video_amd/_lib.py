@@ -66,6 +66,14 @@ SIGNATURES = [
     ("pfv_enc_pframe", c_int, [_P, _P, _P, _P, _P]),
     ("pfv_enc_prev_frame_dev", _P, [_P, c_int]),
     ("pfv_enc_prev_frame", c_int, [_P, _P]),
+    ("pfv_payload_worst_case", c_size_t, [c_int, c_int]),
+    ("pfv_enc_entropy_enable", c_int, [_P, c_size_t]),
+    ("pfv_enc_pack_iframe_dev", c_int, [_P, _P]),
+    ("pfv_enc_pack_pframe_dev", c_int, [_P, _P, _P, _P]),
+    ("pfv_enc_payload_sizes", c_int, [_P, _P]),
+    ("pfv_enc_payload_dev", _P, [_P, c_int]),
+    ("pfv_enc_payload_capacity", c_size_t, [_P]),
+    ("pfv_enc_payload_fetch", c_int, [_P, c_int, _P, c_size_t]),
     ("pfv_dec_session_create", c_int, [_P, c_int, c_int, _P, c_int, c_int, POINTER(_P)]),
     ("pfv_dec_session_destroy", None, [_P]),
     ("pfv_dec_iframe_dev", c_int, [_P, _P, _P]),
@@ -84,6 +92,7 @@ SIGNATURES = [
     ("pfv_encoder_finish", c_int, [_P]),
     ("pfv_encoder_bytes", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_encoder_destroy", None, [_P]),
+    ("pfv_encoder_set_device_entropy", c_int, [_P, c_int]),
     ("pfv_serialize_iframe_payload", c_size_t, [_P, c_int, _P, c_size_t]),
     ("pfv_serialize_pframe_payload", c_size_t, [_P, _P, _P, c_int, _P, c_size_t]),
     ("pfv_decoder_create", c_int, [_P, _P, c_size_t, POINTER(_P)]),

@@ -4,6 +4,7 @@
 // There is NO CPU fallback here: every entry point either runs the HIP kernels or returns
 // a negative status.
 #include "pfv_kernels.hip"
+#include "pfv_entropy_kernels.hip"
 #include "pfv_host.hip"
 
 #include <math.h>
@@ -524,6 +525,12 @@ struct pfv_enc_session {
     int16_t *st_coef = nullptr;
     int8_t *st_mv = nullptr;
     uint8_t *st_has = nullptr;
+    // device entropy stage (pfv_enc_entropy_enable)
+    bool ent_on = false;
+    uint32_t ent_cap = 0;
+    EntBufs ent{};
+    std::vector<void *> ent_allocs;
+    std::vector<uint32_t> ent_sizes;         // last pfv_enc_payload_sizes result
 };
 
 struct pfv_dec_session {
@@ -588,6 +595,8 @@ PFV_API void pfv_enc_session_destroy(pfv_enc_session *s)
     (void)hipStreamSynchronize(s->ctx->stream);
     void *bufs[] = {s->qtab_dev, s->prev[0], s->prev[1], s->st_frames, s->st_coef, s->st_mv, s->st_has};
     for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (void *b : s->ent_allocs)
         if (b) (void)hipFree(b);
     delete s;
 }
@@ -687,6 +696,128 @@ PFV_API int pfv_enc_prev_frame(pfv_enc_session *s, uint8_t *out_host)
     pfv_ctx *ctx = s->ctx;
     HIP_TRY(ctx, hipMemcpyAsync(out_host, s->prev[s->cur], (size_t)s->geom.pad_frame_bytes * s->n_streams,
                                 hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+
+// ------------------------------------------------------------------ device entropy stage of the encoder session
+// Packet payloads (enc.rs:237-320, :332-470) built on the device from the buffers the encode entry points produced:
+// byte-identical to serialize_iframe / serialize_pframe (pfv_host.hip) on the same coefficients.
+PFV_API size_t pfv_payload_worst_case(int width, int height)
+{
+    // 19 header bytes + per macroblock a 16-bit block header and 256 x (two 15-bit codes + 15 value bits)
+    size_t tb = (size_t)pfv_total_blocks(width, height);
+    size_t bits = 19 * 8 + tb * 16 + tb * 256 * 45;
+    return ((bits + 7) / 8 + 3) & ~(size_t)3;
+}
+
+PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (s->ent_on) return PFV_OK;
+    size_t cap = payload_cap ? ((payload_cap + 3) & ~(size_t)3) : pfv_payload_worst_case(s->width, s->height);
+    if (cap < 24 || cap > 0xfffffff0u) return fail(ctx, PFV_ERR_BAD_ARG, "payload capacity must be in [24, 2^32)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t S = (size_t)s->n_streams, tb = (size_t)s->geom.mbs_per_frame, n_sb = tb * 4;
+    auto grab = [&](void **p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) s->ent_allocs.push_back(*p);
+        return e;
+    };
+    hipError_t e = grab((void **)&s->ent.mask, S * n_sb * 8);
+    if (e == hipSuccess) e = grab((void **)&s->ent.counts, S * n_sb * 16);
+    if (e == hipSuccess) e = grab((void **)&s->ent.sumsize, S * n_sb * 4);
+    if (e == hipSuccess) e = grab((void **)&s->ent.sb_off, S * n_sb * 4);
+    if (e == hipSuccess) e = grab((void **)&s->ent.hdr_off, S * tb * 4);
+    if (e == hipSuccess) e = grab((void **)&s->ent.hist, S * 16 * 4);
+    if (e == hipSuccess) e = grab((void **)&s->ent.codes, S * sizeof(EntCodes));
+    if (e == hipSuccess) e = grab((void **)&s->ent.sizes, S * 4);
+    if (e == hipSuccess) e = grab((void **)&s->ent.payload, S * cap);
+    if (e == hipSuccess) e = hipMemsetAsync(s->ent.hist, 0, S * 16 * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->ent.codes, 0, S * sizeof(EntCodes), ctx->stream);
+    if (e != hipSuccess) {
+        for (void *b : s->ent_allocs) (void)hipFree(b);
+        s->ent_allocs.clear();
+        s->ent = EntBufs{};
+        return hip_fail(ctx, e, "pfv_enc_entropy_enable");
+    }
+    s->ent_cap = (uint32_t)cap;
+    s->ent_sizes.assign(S, 0);
+    s->ent_on = true;
+    return PFV_OK;
+}
+
+static int ent_pack(pfv_enc_session *s, bool pframe, const int8_t *mv_dev, const uint8_t *has_dev, const int16_t *coef_dev)
+{
+    pfv_ctx *ctx = s->ctx;
+    if (!s->ent_on) return fail(ctx, PFV_ERR_STATE, "call pfv_enc_entropy_enable first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    EntFrame f{};
+    f.total_blocks = s->geom.mbs_per_frame;
+    f.n_streams = s->n_streams;
+    f.pframe = pframe ? 1 : 0;
+    f.cap_bytes = s->ent_cap;
+    f.qidx[0] = pframe ? 2 : 0;                    // intra_l, intra_c, intra_c / inter_l, inter_c, inter_c
+    f.qidx[1] = f.qidx[2] = pframe ? 3 : 1;        // (enc.rs:296-298, :409-411)
+    EntBufs b = s->ent;
+    b.coef = coef_dev; b.mv = mv_dev; b.has = has_dev;
+    const unsigned sb_blocks = (unsigned)((f.total_blocks * 4 + kEntThreads - 1) / kEntThreads);
+    const dim3 per_sb(sb_blocks, (unsigned)f.n_streams);
+    hipLaunchKernelGGL(k_ent_scan, per_sb, dim3(kEntThreads), 0, ctx->stream, f, b);
+    hipLaunchKernelGGL(k_ent_codes, dim3((unsigned)f.n_streams), dim3(kEntThreads), 0, ctx->stream, f, b);
+    hipLaunchKernelGGL(k_ent_offsets, dim3((unsigned)f.n_streams), dim3(kEntScanThreads), 0, ctx->stream, f, b);
+    hipLaunchKernelGGL(k_ent_init, dim3(64, (unsigned)f.n_streams), dim3(kEntThreads), 0, ctx->stream, f, b);
+    hipLaunchKernelGGL(k_ent_pack, per_sb, dim3(kEntThreads), 0, ctx->stream, f, b);
+    return launch_check(ctx, "k_ent_*");
+}
+PFV_API int pfv_enc_pack_iframe_dev(pfv_enc_session *s, const int16_t *coef_dev)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (!coef_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_enc_pack_iframe_dev: null buffer");
+    return ent_pack(s, false, nullptr, nullptr, coef_dev);
+}
+PFV_API int pfv_enc_pack_pframe_dev(pfv_enc_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev, const int16_t *coef_dev)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (!mv_dev || !has_coef_dev || !coef_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_enc_pack_pframe_dev: null buffer");
+    return ent_pack(s, true, mv_dev, has_coef_dev, coef_dev);
+}
+// Payload byte counts of the last pack call, one per stream (synchronises the context's stream).  PFV_ERR_FORMAT when a
+// coefficient needs more than 15 size bits (the reference panics in rle.rs:44), PFV_ERR_NOMEM when a payload exceeds
+// the capacity; `sizes_out` is filled either way (failed streams read 0).
+PFV_API int pfv_enc_payload_sizes(pfv_enc_session *s, uint32_t *sizes_out)
+{
+    if (!s || !sizes_out) return fail(s ? s->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_enc_payload_sizes: bad argument");
+    pfv_ctx *ctx = s->ctx;
+    if (!s->ent_on) return fail(ctx, PFV_ERR_STATE, "call pfv_enc_entropy_enable first");
+    HIP_TRY(ctx, hipMemcpyAsync(s->ent_sizes.data(), s->ent.sizes, (size_t)s->n_streams * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = PFV_OK;
+    for (int i = 0; i < s->n_streams; i++) {
+        uint32_t v = s->ent_sizes[i];
+        if (v == kEntErrOversize) { rc = PFV_ERR_FORMAT; v = 0; }
+        else if (v == kEntErrCapacity) { if (rc == PFV_OK) rc = PFV_ERR_NOMEM; v = 0; }
+        s->ent_sizes[i] = sizes_out[i] = v;
+    }
+    if (rc == PFV_ERR_FORMAT) return fail(ctx, rc, "coefficient needs more than 15 size bits (src/rle.rs:44)");
+    if (rc == PFV_ERR_NOMEM) return fail(ctx, rc, "payload exceeds the capacity given to pfv_enc_entropy_enable");
+    return PFV_OK;
+}
+PFV_API const uint8_t *pfv_enc_payload_dev(pfv_enc_session *s, int stream)
+{
+    if (!s || !s->ent_on || stream < 0 || stream >= s->n_streams) return nullptr;
+    return s->ent.payload + (size_t)stream * s->ent_cap;
+}
+PFV_API size_t pfv_enc_payload_capacity(pfv_enc_session *s) { return s && s->ent_on ? s->ent_cap : 0; }
+// Copies the first `nbytes` of one stream's payload to the host (synchronises).
+PFV_API int pfv_enc_payload_fetch(pfv_enc_session *s, int stream, uint8_t *out, size_t nbytes)
+{
+    if (!s || !out) return fail(s ? s->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_enc_payload_fetch: bad argument");
+    pfv_ctx *ctx = s->ctx;
+    if (!s->ent_on) return fail(ctx, PFV_ERR_STATE, "call pfv_enc_entropy_enable first");
+    if (stream < 0 || stream >= s->n_streams || nbytes > s->ent_cap) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_payload_fetch: out of range");
+    if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(out, s->ent.payload + (size_t)stream * s->ent_cap, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PFV_OK;
 }
@@ -909,6 +1040,7 @@ struct pfv_encoder {
     pfv_enc_session *hot = nullptr;
     int width = 0, height = 0, framerate = 0, total_blocks = 0;
     bool finished = false;
+    bool device_entropy = true;            // payloads built by the k_ent_* kernels instead of serialize_*frame on the host
     std::vector<uint8_t> out;              // the writer
     std::vector<uint8_t> frame;            // packed Y|U|V staging
     std::vector<int16_t> coef;
@@ -981,12 +1113,44 @@ static int pack_frame(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const 
     return PFV_OK;
 }
 
+// One frame through the device entropy stage: planes up, kernels, payload size then payload bytes down.
+static int encode_on_device(pfv_encoder *e, bool pframe)
+{
+    pfv_enc_session *s = e->hot;
+    pfv_ctx *ctx = e->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = enc_staging(s);
+    if (!rc) rc = pfv_enc_entropy_enable(s, 0);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_frames, e->frame.data(), (size_t)s->geom.src_frame_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = pframe ? pfv_enc_pframe_dev(s, s->st_frames, s->st_mv, s->st_has, s->st_coef) : pfv_enc_iframe_dev(s, s->st_frames, s->st_coef);
+    if (!rc) rc = pframe ? pfv_enc_pack_pframe_dev(s, s->st_mv, s->st_has, s->st_coef) : pfv_enc_pack_iframe_dev(s, s->st_coef);
+    uint32_t nbytes = 0;
+    if (!rc) rc = pfv_enc_payload_sizes(s, &nbytes);
+    if (rc) return rc;
+    e->out.push_back(pframe ? 2 : 1);
+    put_u32(e->out, nbytes);
+    size_t at = e->out.size();
+    e->out.resize(at + nbytes);
+    return pfv_enc_payload_fetch(s, 0, e->out.data() + at, nbytes);
+}
+
+// 1 (default): RLE + Huffman + bit packing on the device; 0: on the host (serialize_iframe / serialize_pframe).  The
+// bytes written are the same either way.
+PFV_API int pfv_encoder_set_device_entropy(pfv_encoder *e, int on)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    e->device_entropy = on != 0;
+    return PFV_OK;
+}
+
 // Encoder::encode_iframe (src/enc.rs:75-123)
 PFV_API int pfv_encoder_encode_iframe(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v)
 {
     if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
     int rc = pack_frame(e, y, u, v);
     if (rc) return rc;
+    if (e->device_entropy) return encode_on_device(e, false);
     if ((rc = pfv_enc_iframe(e->hot, e->frame.data(), e->coef.data()))) return rc;
     std::vector<uint8_t> payload;
     if (!serialize_iframe(payload, e->coef.data(), e->total_blocks))
@@ -1000,6 +1164,7 @@ PFV_API int pfv_encoder_encode_pframe(pfv_encoder *e, const uint8_t *y, const ui
     if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
     int rc = pack_frame(e, y, u, v);
     if (rc) return rc;
+    if (e->device_entropy) return encode_on_device(e, true);
     if ((rc = pfv_enc_pframe(e->hot, e->frame.data(), e->mv.data(), e->has.data(), e->coef.data()))) return rc;
     std::vector<uint8_t> payload;
     if (!serialize_pframe(payload, e->mv.data(), e->has.data(), e->coef.data(), e->total_blocks))

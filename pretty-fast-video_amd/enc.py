@@ -14,13 +14,15 @@ from .frame import VideoFrame
 
 
 class Encoder:
-    def __init__(self, writer, width: int, height: int, framerate: int, quality: int, ctx: Context):
+    def __init__(self, writer, width: int, height: int, framerate: int, quality: int, ctx: Context, device_entropy: bool = True):
         assert 0 <= quality <= 10                                   # src/enc.rs:38
         self.ctx, self.writer = ctx, writer
         self.width, self.height = int(width), int(height)
         h = ctypes.c_void_p()
         ctx.check(ctx._lib.pfv_encoder_create(ctx.handle, self.width, self.height, int(framerate), int(quality), ctypes.byref(h)))
         self.handle = h
+        # packet payloads from the device entropy stage (default) or the host serialisers: same bytes
+        ctx.check(ctx._lib.pfv_encoder_set_device_entropy(h, 1 if device_entropy else 0))
         self._flushed = 0
         self.finished = False
         ctx._sessions.add(self)

@@ -87,6 +87,32 @@ class EncoderSession(_Geometry):
         self.ctx.check(self.ctx._lib.pfv_enc_pframe_dev(self.handle, ctypes.c_void_p(frames_dev), ctypes.c_void_p(mv_dev),
                                                         ctypes.c_void_p(has_dev), ctypes.c_void_p(coef_dev)))
 
+    # device entropy stage (RLE + Huffman + bit packing of enc.rs:237-470 on the device) ---------------
+    def enable_entropy(self, payload_cap: int = 0):
+        """allocate the stage; payload_cap = bytes per stream (0: worst case for the geometry)"""
+        self.ctx.check(self.ctx._lib.pfv_enc_entropy_enable(self.handle, int(payload_cap)))
+
+    def pack_iframe_dev(self, coef_dev: int):
+        self.ctx.check(self.ctx._lib.pfv_enc_pack_iframe_dev(self.handle, ctypes.c_void_p(coef_dev)))
+
+    def pack_pframe_dev(self, mv_dev: int, has_dev: int, coef_dev: int):
+        self.ctx.check(self.ctx._lib.pfv_enc_pack_pframe_dev(self.handle, ctypes.c_void_p(mv_dev), ctypes.c_void_p(has_dev),
+                                                             ctypes.c_void_p(coef_dev)))
+
+    def payload_sizes(self) -> np.ndarray:
+        """bytes per stream of the last pack call (synchronises); raises PfvError on oversize coefficients / capacity"""
+        sizes = np.zeros(self.n_streams, dtype=np.uint32)
+        self.ctx.check(self.ctx._lib.pfv_enc_payload_sizes(self.handle, ptr(sizes)))
+        return sizes
+
+    def payload(self, stream: int, nbytes: int) -> bytes:
+        out = np.empty(max(int(nbytes), 1), dtype=np.uint8)
+        self.ctx.check(self.ctx._lib.pfv_enc_payload_fetch(self.handle, int(stream), ptr(out), int(nbytes)))
+        return out[:nbytes].tobytes()
+
+    def payload_dev(self, stream: int) -> int:
+        return int(self.ctx._lib.pfv_enc_payload_dev(self.handle, int(stream)) or 0)
+
 
 class DecoderSession(_Geometry):
     def __init__(self, ctx: Context, width: int, height: int, qtables, n_streams: int = 1):

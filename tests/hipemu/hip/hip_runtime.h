@@ -68,7 +68,11 @@ static inline int __shfl_xor(int v, int mask) { return hipemu::wave_exchange(v, 
 static inline bool __any(bool p) { return hipemu::wave_any(p); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int __shfl(int v, int src_lane) { return hipemu::wave_exchange(v, src_lane); }
 static inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 
 // ---- gfx950 builtins used by the kernels
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

@@ -245,3 +245,101 @@ def fuzz_plane_ops(pkg, ctx, oracle, n_cases, seed, max_w=420, max_h=200):
             ref = np.clip(ref.astype(int) + rng.integers(-20, 21, ref.shape), 0, 255).astype(np.uint8)
         px_err = float(rng.choice([0.0, 1.5, 7.5, 15.0]))
         check_encode_plane_delta(pkg, ctx, oracle, px, ref, q, px_err, clear)
+
+
+def _oracle_serializers(oracle):
+    import ctypes
+    L = oracle.L
+    L.pfvo_serialize_iframe.restype = ctypes.c_size_t
+    L.pfvo_serialize_iframe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    L.pfvo_serialize_pframe.restype = ctypes.c_size_t
+    L.pfvo_serialize_pframe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    return L
+
+
+def _hostile_coefficients(rng, nb, kind):
+    """coefficient buffers that stress the run coder: dense, sparse, long runs, lone last value, every size class"""
+    if kind == "zero":
+        return np.zeros((nb, 256), np.int16)
+    if kind == "dense":
+        c = rng.integers(-16383, 16384, (nb, 256))
+        c[c == 0] = 1
+        return c.astype(np.int16)
+    if kind == "sparse":
+        return (rng.integers(-300, 301, (nb, 256)) * (rng.random((nb, 256)) < 0.03)).astype(np.int16)
+    if kind == "typical":       # low-frequency-heavy, like quantised DCT output in zigzag order
+        keep = rng.random((nb, 256)) < (0.6 * np.exp(-(np.arange(256) % 64) / 6.0))[None, :]
+        return (rng.integers(-40, 41, (nb, 256)) * keep).astype(np.int16)
+    if kind == "edges":
+        c = np.zeros((nb, 256), np.int16)
+        for b in range(nb):
+            pick = int(rng.integers(0, 8))
+            if pick == 0: c[b, 255] = -1                                   # 255 zeros, then one value
+            elif pick == 1: c[b, 0] = 16383                                # size 15, then 255 zeros
+            elif pick == 2: c[b, ::16] = rng.integers(1, 9, 16)            # runs of exactly 15
+            elif pick == 3: c[b, 16::17] = -2                              # runs of 16 (one filler each)
+            elif pick == 4: c[b, [63, 64, 127, 128, 191, 192]] = 7         # values on subblock boundaries
+            elif pick == 5: c[b, 31] = -16383; c[b, 62] = 1                # runs of 31 and 30
+            elif pick == 6: c[b, 64 * int(rng.integers(0, 4)) + int(rng.integers(0, 64))] = int(rng.integers(-9, 10))
+            # pick == 7: all zero
+        return c
+    raise ValueError(kind)
+
+
+def check_device_entropy(pkg, ctx, oracle, w, h, n_streams, seed, kinds=("typical", "zero", "dense", "sparse", "edges")):
+    """the device entropy stage (k_ent_*) on arbitrary coefficient / header buffers: payload bytes identical to the
+    oracle's write_iframe_packet / write_pframe_packet restatement, stream by stream"""
+    import ctypes
+    L = _oracle_serializers(oracle)
+    rng = np.random.default_rng(seed)
+    enc = pkg.EncoderSession(ctx, w, h, 5, n_streams)
+    enc.enable_entropy()
+    nb, S = enc.total_blocks, n_streams
+    d_coef, d_mv, d_has = ctx.alloc(S * nb * 512), ctx.alloc(S * nb * 2), ctx.alloc(S * nb)
+    cap = int(ctx._lib.pfv_payload_worst_case(w, h))
+    ref = np.zeros(cap + 64, np.uint8)
+    checked = 0
+    for kind in kinds:
+        coef = np.stack([_hostile_coefficients(rng, nb, kind if s % 2 == 0 else "typical") for s in range(S)])
+        mv = rng.integers(-15, 16, (S, nb, 2)).astype(np.int8)
+        mv[:, ::3] = 0
+        has = (rng.random((S, nb)) < 0.6).astype(np.uint8)
+        if kind == "zero":
+            has[0] = 0                                                     # a p-frame with no coded macroblock at all
+        ctx.upload(d_coef, coef); ctx.upload(d_mv, mv); ctx.upload(d_has, has)
+        for pframe in (False, True):
+            if pframe:
+                enc.pack_pframe_dev(d_mv, d_has, d_coef)
+            else:
+                enc.pack_iframe_dev(d_coef)
+            sizes = enc.payload_sizes()
+            for s in range(S):
+                if pframe:
+                    n = L.pfvo_serialize_pframe(mv[s].ctypes.data_as(ctypes.c_void_p), has[s].ctypes.data_as(ctypes.c_void_p),
+                                                coef[s].ctypes.data_as(ctypes.c_void_p), nb, ref.ctypes.data_as(ctypes.c_void_p), ref.size)
+                else:
+                    n = L.pfvo_serialize_iframe(coef[s].ctypes.data_as(ctypes.c_void_p), nb, ref.ctypes.data_as(ctypes.c_void_p), ref.size)
+                assert n > 0 and int(sizes[s]) == n, (kind, pframe, s, int(sizes[s]), n)
+                got = np.frombuffer(enc.payload(s, n), np.uint8)
+                if not np.array_equal(got, ref[:n]):
+                    bad = int(np.flatnonzero(got != ref[:n])[0])
+                    raise AssertionError(f"{kind} pframe={pframe} stream {s}: payload differs at byte {bad} of {n}")
+                checked += 1
+    # a coefficient that needs 16 size bits: the reference panics (rle.rs:44); the stage reports it
+    coef = np.zeros((S, nb, 256), np.int16)
+    coef[S - 1, nb - 1, 200] = -16384
+    ctx.upload(d_coef, coef)
+    enc.pack_iframe_dev(d_coef)
+    try:
+        enc.payload_sizes()
+        raise AssertionError("oversized coefficient not reported")
+    except pkg.PfvError as e:
+        assert e.code == pkg._lib.PFV_ERR_FORMAT
+    coef[S - 1, nb - 1, 200] = 16383                                        # and the stage recovers on the next frame
+    ctx.upload(d_coef, coef)
+    enc.pack_iframe_dev(d_coef)
+    assert int(enc.payload_sizes()[S - 1]) > 19
+    for p in (d_coef, d_mv, d_has):
+        ctx.free(p)
+    enc.close()
+    return checked

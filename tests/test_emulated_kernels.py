@@ -63,3 +63,9 @@ def test_emu_corrupted_streams(pkg, emu_ctx, oracle):
     data, _ = sc.encode_clip(pkg, emu_ctx, oracle, 48, 32, 30, 5, n_frames=4, gop=2)
     stats = sc.check_corrupted_streams(pkg, emu_ctx, oracle, data, n_trials=40, seed=5)
     assert stats["trials"] == 40
+
+
+def test_emu_device_entropy(pkg, emu_ctx, oracle):
+    """k_ent_* (RLE + Huffman + bit packing on the device) vs the oracle's packet serialisers, byte for byte"""
+    assert pc.check_device_entropy(pkg, emu_ctx, oracle, 48, 32, n_streams=2, seed=3) == 20
+    assert pc.check_device_entropy(pkg, emu_ctx, oracle, 34, 18, n_streams=1, seed=4, kinds=("typical", "edges")) == 4

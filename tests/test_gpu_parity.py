@@ -217,6 +217,35 @@ def test_corrupted_streams_match_oracle(pkg, gpu_ctx, oracle, geom):
     assert stats["trials"] == 120 and stats["frames"] > 0
 
 
+@pytest.mark.parametrize("geom", [(48, 32, 2), (176, 144, 3), (34, 18, 1), (640, 360, 2)])
+def test_device_entropy_payloads(pkg, gpu_ctx, oracle, geom):
+    """k_ent_* payload bytes == the oracle's write_iframe_packet / write_pframe_packet restatement"""
+    w, h, S = geom
+    assert pc.check_device_entropy(pkg, gpu_ctx, oracle, w, h, n_streams=S, seed=w) == 10 * S
+
+
+def test_device_entropy_1080p(pkg, gpu_ctx, oracle):
+    assert pc.check_device_entropy(pkg, gpu_ctx, oracle, 1920, 1080, n_streams=2, seed=9, kinds=("typical", "edges")) == 8
+
+
+def test_stream_encoder_host_and_device_entropy_agree(pkg, gpu_ctx):
+    """Encoder(device_entropy=False) and Encoder(device_entropy=True) write the same .pfv bytes"""
+    import io
+    w, h = 320, 240
+    st = pkg.SyntheticStream(w, h)
+    outs = []
+    for dev in (False, True):
+        buf = io.BytesIO()
+        enc = pkg.Encoder(buf, w, h, 30, 6, gpu_ctx, device_entropy=dev)
+        for t in range(5):
+            fr = pkg.VideoFrame.from_packed(w, h, st.frame(t)) if hasattr(pkg.VideoFrame, "from_packed") else sc.frame_of(pkg, w, h, st.frame(t))
+            (enc.encode_iframe if t % 3 == 0 else enc.encode_pframe)(fr)
+        enc.finish()
+        enc.close()
+        outs.append(buf.getvalue())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
 def test_colour_utils(pkg, gpu_ctx):
     pc.check_colour_utils(pkg, gpu_ctx)
 
