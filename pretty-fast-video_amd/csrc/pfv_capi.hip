@@ -728,8 +728,7 @@ PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap)
     hipError_t e = grab((void **)&s->ent.mask, S * n_sb * 8);
     if (e == hipSuccess) e = grab((void **)&s->ent.counts, S * n_sb * 16);
     if (e == hipSuccess) e = grab((void **)&s->ent.sumsize, S * n_sb * 4);
-    if (e == hipSuccess) e = grab((void **)&s->ent.sb_off, S * n_sb * 4);
-    if (e == hipSuccess) e = grab((void **)&s->ent.hdr_off, S * tb * 4);
+    if (e == hipSuccess) e = grab((void **)&s->ent.groups, S * ((n_sb + kEntThreads - 1) / kEntThreads) * sizeof(EntGroup));
     if (e == hipSuccess) e = grab((void **)&s->ent.hist, S * 16 * 4);
     if (e == hipSuccess) e = grab((void **)&s->ent.codes, S * sizeof(EntCodes));
     if (e == hipSuccess) e = grab((void **)&s->ent.sizes, S * 4);
@@ -756,17 +755,16 @@ static int ent_pack(pfv_enc_session *s, bool pframe, const int8_t *mv_dev, const
     EntFrame f{};
     f.total_blocks = s->geom.mbs_per_frame;
     f.n_streams = s->n_streams;
+    f.n_groups = (f.total_blocks * 4 + kEntThreads - 1) / kEntThreads;
     f.pframe = pframe ? 1 : 0;
     f.cap_bytes = s->ent_cap;
     f.qidx[0] = pframe ? 2 : 0;                    // intra_l, intra_c, intra_c / inter_l, inter_c, inter_c
     f.qidx[1] = f.qidx[2] = pframe ? 3 : 1;        // (enc.rs:296-298, :409-411)
     EntBufs b = s->ent;
     b.coef = coef_dev; b.mv = mv_dev; b.has = has_dev;
-    const unsigned sb_blocks = (unsigned)((f.total_blocks * 4 + kEntThreads - 1) / kEntThreads);
-    const dim3 per_sb(sb_blocks, (unsigned)f.n_streams);
+    const dim3 per_sb((unsigned)f.n_groups, (unsigned)f.n_streams);
     hipLaunchKernelGGL(k_ent_scan, per_sb, dim3(kEntThreads), 0, ctx->stream, f, b);
     hipLaunchKernelGGL(k_ent_codes, dim3((unsigned)f.n_streams), dim3(kEntThreads), 0, ctx->stream, f, b);
-    hipLaunchKernelGGL(k_ent_offsets, dim3((unsigned)f.n_streams), dim3(kEntScanThreads), 0, ctx->stream, f, b);
     hipLaunchKernelGGL(k_ent_init, dim3(64, (unsigned)f.n_streams), dim3(kEntThreads), 0, ctx->stream, f, b);
     hipLaunchKernelGGL(k_ent_pack, per_sb, dim3(kEntThreads), 0, ctx->stream, f, b);
     return launch_check(ctx, "k_ent_*");

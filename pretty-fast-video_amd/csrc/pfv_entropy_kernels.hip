@@ -6,19 +6,23 @@
 // whole cost of the encoder (a 1080p frame: ~30 us of kernels vs milliseconds of host entropy + 6 MB of PCIe), so
 // the same byte stream is produced here, from the coefficient / header buffers the encode kernels left in HBM:
 //
-//   k_ent_scan     one lane per 8x8 subblock: non-zero bitmap, per-subblock symbol counts (16 x 8-bit) and the sum of
-//                  coefficient sizes; block-reduced into the frame histogram of each stream
-//   k_ent_codes    one workgroup per stream: histogram -> table bytes -> Huffman codes (the reference's construction,
-//                  tie-breaks included) -> 256 pre-joined (num_zeroes, coeff_size) code pairs
-//   k_ent_offsets  one workgroup per stream: bits per subblock = counts . code lengths + sizes, exclusive prefix
-//                  sums for the block-header section (p-frames) and the symbol section; payload size
-//   k_ent_init     zeroes exactly the words the payload will occupy and writes the 19 header bytes
-//   k_ent_pack     one lane per subblock: walks the non-zero bitmap again and writes its bits at its offset (first and
-//                  last word with atomicOr, interior words with plain stores); p-frame block headers likewise
+//   k_ent_scan   workgroup = 256 consecutive subblocks of one stream (64 macroblocks), lane = one 8x8 subblock.  The
+//                group's 32 KiB of coefficients come in with coalesced 16-byte loads and are staged in LDS (rows padded
+//                to 136 B); each lane builds its non-zero bitmap and walks the set bits: symbol counts (16 x 8-bit),
+//                sum of coefficient sizes.  Per lane -> HBM (bitmap, counts, size sum); per workgroup -> HBM (counts,
+//                size sum, block-header bits); per stream -> the frame histogram (atomics).
+//   k_ent_codes  one workgroup per stream.  Wavefront 0 builds the reference's Huffman tree lane-parallel (stable
+//                rank sort, ballot-positioned merges, codes by walking the parent chain), all lanes fill the 256
+//                pre-joined (num_zeroes, coeff_size) code pairs; then bits per workgroup-of-scan = counts . code lengths
+//                + sizes, exclusive prefix over the workgroups -> base bit offsets and the payload size.
+//   k_ent_init   zeroes exactly the words the payload will occupy and writes the 19 header bytes.
+//   k_ent_pack   same tiling as k_ent_scan: bits per lane from its counts, workgroup exclusive scan + the workgroup's
+//                base = the lane's bit offset; the lane walks its bitmap again (values from LDS) and writes its bits:
+//                first and last word with atomicOr onto the zeroed payload, words in between with plain stores.
 //
 // Run order inside a macroblock is the coefficient buffer's own (zigzag within a subblock, subblocks 0..3), runs cross
 // subblock boundaries and end at the macroblock (enc.rs:246-255), so lane (mb, sb) needs only the bitmaps of the
-// earlier subblocks of its macroblock.  Included by pfv_capi.hip.
+// earlier subblocks of its macroblock (its quad).  Included by pfv_capi.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,8 +30,8 @@
 
 namespace pfv {
 
-constexpr int kEntThreads = 256;
-constexpr int kEntScanThreads = 1024;
+constexpr int kEntThreads = 256;                    // subblocks per workgroup of k_ent_scan / k_ent_pack
+constexpr int kEntRow64 = 17;                       // LDS row of one subblock: 128 B of coefficients + 8 B pad, in 8-byte units
 constexpr uint32_t kEntErrOversize = 0xffffffffu;   // a coefficient needs more than 15 size bits (rle.rs:44 would panic)
 constexpr uint32_t kEntErrCapacity = 0xfffffffeu;   // payload larger than the per-stream capacity
 
@@ -40,9 +44,19 @@ struct EntCodes {
     uint32_t pad[3];
 };
 
+// what one workgroup of k_ent_scan found in its 256 subblocks
+struct EntGroup {
+    uint32_t counts[8];        // symbol counts, two 16-bit fields per word (symbol 2j low, 2j+1 high)
+    uint32_t sumsize;          // sum of coeff_size over all values
+    uint32_t hdr_bits;         // block-header bits of its macroblocks (p-frames)
+    uint32_t sym_base;         // written by k_ent_codes: bit offset of the group's first symbol ...
+    uint32_t hdr_base;         // ... and of its first block header
+};
+
 struct EntFrame {
     int total_blocks;          // macroblocks per stream (Y then U then V)
     int n_streams;
+    int n_groups;              // workgroups of k_ent_scan per stream = ceil(total_blocks * 4 / 256)
     int pframe;                // block headers present, has_coef honoured
     uint32_t cap_bytes;        // payload capacity per stream (multiple of 4)
     uint8_t qidx[3];
@@ -56,14 +70,19 @@ struct EntBufs {
     uint64_t *mask;            // [S][total_blocks*4] non-zero bitmap per subblock (0 for uncoded macroblocks)
     uint4 *counts;             // [S][total_blocks*4] 16 x 8-bit symbol counts
     uint32_t *sumsize;         // [S][total_blocks*4] sum of coeff_size over the subblock's values
-    uint32_t *sb_off;          // [S][total_blocks*4] bit offset of the subblock's symbols in the payload
-    uint32_t *hdr_off;         // [S][total_blocks]   bit offset of the block header (p-frames)
+    EntGroup *groups;          // [S][n_groups]
     int32_t *hist;             // [S][16]
     EntCodes *codes;           // [S]
     uint32_t *sizes;           // [S] payload bytes or kEntErr*
     uint8_t *payload;          // [S][cap_bytes]
 };
 
+__device__ __forceinline__ void ent_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ uint32_t ent_shfl(uint32_t v, int src_lane)
 {
     return (uint32_t)__shfl((int)v, src_lane);
@@ -71,6 +90,16 @@ __device__ __forceinline__ uint32_t ent_shfl(uint32_t v, int src_lane)
 __device__ __forceinline__ uint32_t ent_wave_sum(uint32_t v)
 {
     for (int m = 1; m < 64; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    return v;
+}
+// inclusive prefix sum over the wavefront
+__device__ __forceinline__ uint32_t ent_wave_scan(uint32_t v)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = ent_shfl(v, lane >= d ? lane - d : lane);
+        if (lane >= d) v += up;
+    }
     return v;
 }
 
@@ -106,36 +135,53 @@ __device__ __forceinline__ void ent_split_run(unsigned run, unsigned &fillers, u
     rest = run - 15u * fillers;
 }
 
+// The workgroup's 256 subblocks (32 KiB, contiguous in the coefficient buffer) -> LDS rows, coalesced: thread t moves
+// the 16-byte pieces t, t + 256, ...; piece p belongs to subblock p / 8.
+__device__ __forceinline__ void ent_stage_rows(uint64_t *rows, const int16_t *group_base, int n_live_sb)
+{
+    const uint4 *src = (const uint4 *)group_base;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int piece = k * kEntThreads + (int)threadIdx.x, sbl = piece >> 3, part = piece & 7;
+        if (sbl < n_live_sb) {
+            const uint4 v = src[piece];
+            rows[sbl * kEntRow64 + 2 * part] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            rows[sbl * kEntRow64 + 2 * part + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- k_ent_scan
 __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
 {
-    __shared__ uint32_t blk[8];
+    __shared__ uint64_t rows[kEntThreads * kEntRow64];
+    __shared__ uint32_t blk[10];
     const int stream = (int)blockIdx.y, n_sb = f.total_blocks * 4;
-    const int sbi = (int)(blockIdx.x * kEntThreads + threadIdx.x);
+    const int sb0 = (int)blockIdx.x * kEntThreads;
+    const int sbi = sb0 + (int)threadIdx.x;
     const bool live = sbi < n_sb;
     const int mb = sbi >> 2, sb = sbi & 3;
-    if (threadIdx.x < 8) blk[threadIdx.x] = 0;
+    if (threadIdx.x < 10) blk[threadIdx.x] = 0;
+    ent_stage_rows(rows, b.coef + ((size_t)stream * f.total_blocks * 4 + sb0) * 64, min(kEntThreads, n_sb - sb0));
     __syncthreads();
 
     const size_t sbase = (size_t)stream * n_sb;
-    const int16_t *c = b.coef + ((size_t)stream * f.total_blocks + (live ? mb : 0)) * 256 + sb * 64;
-    const bool coded = live && (!f.pframe || b.has[(size_t)stream * f.total_blocks + mb] != 0);
+    const size_t bi = (size_t)stream * f.total_blocks + (live ? mb : 0);
+    const bool coded = live && (!f.pframe || b.has[bi] != 0);
+    const uint64_t *row = rows + threadIdx.x * kEntRow64;
     uint64_t mask = 0;
     if (coded) {
-        const uint4 *c4 = (const uint4 *)c;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint4 v = c4[k];
-            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t two = ((d[j] & 0xffffu) ? 1u : 0u) | ((d[j] >> 16) ? 2u : 0u);
-                mask |= (uint64_t)two << (8 * k + 2 * j);
-            }
+        for (int k = 0; k < 16; k++) {
+            const uint64_t x = row[k];
+            const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+            const uint32_t four = ((lo & 0xffffu) ? 1u : 0u) | ((lo >> 16) ? 2u : 0u) | ((hi & 0xffffu) ? 4u : 0u) | ((hi >> 16) ? 8u : 0u);
+            mask |= (uint64_t)four << (4 * k);
         }
     }
     int last = ent_prev_last(mask, sb);   // every lane of the wavefront takes part in the exchange
 
+    const int16_t *c = (const int16_t *)row;
     SymCount cnt;
     uint32_t sumsize = 0, oversize = 0;
     for (uint64_t mm = mask; mm;) {
@@ -162,101 +208,119 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
         cnt.add(0u, fillers + 1u);
         cnt.add(rest, 1u);
     }
+    uint32_t hdr_bits = 0;
+    if (f.pframe && live && sb == 0)      // has_mvec, has_coeff, then two 7-bit components (enc.rs:414-451)
+        hdr_bits = (b.mv[2 * bi] != 0 || b.mv[2 * bi + 1] != 0) ? 16u : 2u;
     if (live) {
         b.mask[sbase + sbi] = mask;
         b.counts[sbase + sbi] = make_uint4((uint32_t)cnt.lo, (uint32_t)(cnt.lo >> 32), (uint32_t)cnt.hi, (uint32_t)(cnt.hi >> 32));
         b.sumsize[sbase + sbi] = sumsize;
     }
 
-    // frame histogram: widen to 16-bit fields (two symbols per word; a workgroup adds at most 256 * 164 per field)
+    // workgroup totals: counts widened to 16-bit fields (two symbols per word; at most 256 * 164 per field)
     const uint32_t w8[4] = {(uint32_t)cnt.lo, (uint32_t)(cnt.lo >> 32), (uint32_t)cnt.hi, (uint32_t)(cnt.hi >> 32)};
+    const bool lead = (threadIdx.x & 63u) == 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t a = (w8[j] & 0xffu) | ((w8[j] & 0xff00u) << 8);
         const uint32_t c2 = ((w8[j] >> 16) & 0xffu) | ((w8[j] >> 24) << 16);
         const uint32_t sa = ent_wave_sum(a), sc = ent_wave_sum(c2);
-        if ((threadIdx.x & 63u) == 0) {
+        if (lead) {
             atomicAdd(&blk[2 * j], sa);
             atomicAdd(&blk[2 * j + 1], sc);
         }
     }
-    const uint32_t any_over = ent_wave_sum(oversize);
-    if ((threadIdx.x & 63u) == 0 && any_over) atomicOr(&b.codes[stream].oversize, 1u);
+    const uint32_t ws = ent_wave_sum(sumsize), wh = ent_wave_sum(hdr_bits), any_over = ent_wave_sum(oversize);
+    if (lead) {
+        atomicAdd(&blk[8], ws);
+        atomicAdd(&blk[9], wh);
+        if (any_over) atomicOr(&b.codes[stream].oversize, 1u);
+    }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const uint32_t w = blk[threadIdx.x >> 1];
-        const uint32_t n = (threadIdx.x & 1u) ? (w >> 16) : (w & 0xffffu);
-        if (n) atomicAdd(&b.hist[stream * 16 + (int)threadIdx.x], (int32_t)n);
+    EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
+    if (threadIdx.x < 8) g->counts[threadIdx.x] = blk[threadIdx.x];
+    if (threadIdx.x == 8) g->sumsize = blk[8];
+    if (threadIdx.x == 9) g->hdr_bits = blk[9];
+    if (threadIdx.x >= 16 && threadIdx.x < 32) {
+        const unsigned sym = threadIdx.x - 16u;
+        const uint32_t w = blk[sym >> 1];
+        const uint32_t n = (sym & 1u) ? (w >> 16) : (w & 0xffffu);
+        if (n) atomicAdd(&b.hist[stream * 16 + (int)sym], (int32_t)n);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- k_ent_codes
-// HuffmanTree::from_table (huffman.rs:71-119) + assign_codes (:204-217) on one lane; the sort is stable and the merged
-// node goes in front of the first strictly smaller entry (:61-69), exactly as on the host (pfv_host.hip HuffmanTree).
-__device__ inline void ent_build_codes(const int32_t *hist, uint8_t *table, uint32_t *val, uint8_t *len)
+// HuffmanTree::from_table (huffman.rs:71-119) + assign_codes (:204-217), lane ch = symbol ch, one wavefront:
+//  * leaves in symbol order for the non-zero table entries, list = stable sort by descending frequency (:81)
+//  * while more than one entry: pop the last two (a = last, b = the one before), new node {left a, right b} with the
+//    summed frequency goes in front of the first strictly smaller entry (:61-69, :84-93)
+//  * code of a leaf: branches from the root down, first branch in bit 0, left = 0, right = 1 (:204-217)
+// Same construction, tie-breaks included, as HuffmanTree in pfv_host.hip.
+__device__ inline void ent_build_codes_wave(const int32_t *hist_in, uint8_t *table_out, uint32_t *val_out, uint8_t *len_out,
+                                            int *parent /*[32] LDS*/, int *branch /*[32] LDS*/)
 {
-    int32_t mx = 0;
-    for (int i = 0; i < 16; i++) mx = hist[i] > mx ? hist[i] : mx;
-    for (int i = 0; i < 16; i++) {   // rle_create_huffman (rle.rs:49-66)
-        uint32_t t = 0;
-        if (hist[i] > 0) {
-            t = (uint32_t)(((uint64_t)(uint32_t)hist[i] * 255u) / (uint32_t)mx);
-            t = t < 1u ? 1u : t;
-        }
-        table[i] = (uint8_t)t;
-        val[i] = 0;
-        len[i] = 0;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int32_t h = lane < 16 ? hist_in[lane] : 0;
+    int32_t mx = h;
+    for (int m = 1; m < 16; m <<= 1) {
+        const int32_t o = __shfl_xor(mx, m);
+        mx = o > mx ? o : mx;
     }
-    uint32_t freq[16];
-    int node[16], n = 0, n_nodes = 0;
-    int left[31], right[31], sym[31];
-    for (int ch = 0; ch < 16; ch++)
-        if (table[ch]) {
-            sym[n_nodes] = ch;
-            left[n_nodes] = right[n_nodes] = -1;
-            freq[n] = table[ch];
-            node[n++] = n_nodes++;
-        }
-    for (int i = 1; i < n; i++) {   // stable, descending
-        const uint32_t fq = freq[i];
-        const int nd = node[i];
-        int j = i - 1;
-        for (; j >= 0 && freq[j] < fq; j--) { freq[j + 1] = freq[j]; node[j + 1] = node[j]; }
-        freq[j + 1] = fq;
-        node[j + 1] = nd;
+    uint32_t t = 0;   // rle_create_huffman (rle.rs:49-66)
+    if (h > 0) {
+        t = (uint32_t)(((uint64_t)(uint32_t)h * 255u) / (uint32_t)mx);
+        t = t < 1u ? 1u : t;
     }
+    const bool present = lane < 16 && t != 0;
+    const uint64_t pm = __ballot(present);
+    int n = __popcll(pm), n_nodes = n;
+    const int leaf = __popcll(pm & ((1ull << lane) - 1ull));
+    // position in the stably sorted list
+    int pos = 0;
+    for (int j = 0; j < 16; j++) {
+        const uint32_t tj = ent_shfl(t, j);
+        if (((pm >> j) & 1ull) && (tj > t || (tj == t && j < lane))) pos++;
+    }
+    if (lane < 32) { parent[lane] = -1; branch[lane] = 0; }
+    // list entry p lives on lane p: scatter through LDS (parent[] doubles as scratch before the merges start)
+    int *scratch_f = parent, *scratch_n = branch;
+    ent_wave_lds_sync();
+    if (present) { scratch_f[pos] = (int)t; scratch_n[pos] = leaf; }
+    ent_wave_lds_sync();
+    uint32_t lf = lane < n ? (uint32_t)scratch_f[lane] : 0u;
+    int ln = lane < n ? scratch_n[lane] : -1;
+    ent_wave_lds_sync();
+    if (lane < 32) { parent[lane] = -1; branch[lane] = 0; }
+    ent_wave_lds_sync();
     while (n > 1) {
-        const int a = node[n - 1], bnode = node[n - 2];
-        const uint32_t fq = freq[n - 1] + freq[n - 2];
+        const int a = (int)ent_shfl((uint32_t)ln, n - 1), bn = (int)ent_shfl((uint32_t)ln, n - 2);
+        const uint32_t fq = ent_shfl(lf, n - 1) + ent_shfl(lf, n - 2);
         n -= 2;
-        sym[n_nodes] = -1;
-        left[n_nodes] = a;
-        right[n_nodes] = bnode;
-        int pos = 0;
-        while (pos < n && !(fq > freq[pos])) pos++;
-        for (int j = n; j > pos; j--) { freq[j] = freq[j - 1]; node[j] = node[j - 1]; }
-        freq[pos] = fq;
-        node[pos] = n_nodes++;
-        n++;
-    }
-    if (n == 0) return;
-    int st_node[32];
-    uint32_t st_val[32];
-    uint8_t st_len[32];
-    int sp = 0;
-    st_node[0] = node[0]; st_val[0] = 0; st_len[0] = 0; sp = 1;
-    while (sp) {
-        sp--;
-        const int nd = st_node[sp];
-        const uint32_t v = st_val[sp];
-        const uint8_t l = st_len[sp];
-        if (sym[nd] >= 0) {
-            val[sym[nd]] = v;
-            len[sym[nd]] = l;
-            continue;
+        if (lane == 0) {
+            parent[a] = n_nodes; branch[a] = 0;    // left
+            parent[bn] = n_nodes; branch[bn] = 1;  // right
         }
-        st_node[sp] = left[nd]; st_val[sp] = v; st_len[sp] = (uint8_t)(l + 1); sp++;                    // left = 0
-        st_node[sp] = right[nd]; st_val[sp] = v | (1u << l); st_len[sp] = (uint8_t)(l + 1); sp++;       // right = 1
+        const int ins = __popcll(__ballot(lane < n && !(fq > lf)));   // entries that stay in front of the new node
+        const uint32_t up_f = ent_shfl(lf, lane > 0 ? lane - 1 : 0);
+        const int up_n = (int)ent_shfl((uint32_t)ln, lane > 0 ? lane - 1 : 0);
+        if (lane == ins) { lf = fq; ln = n_nodes; }
+        else if (lane > ins && lane <= n) { lf = up_f; ln = up_n; }
+        n++;
+        n_nodes++;
+    }
+    ent_wave_lds_sync();
+    uint32_t code = 0;
+    uint32_t len = 0;
+    if (present) {
+        for (int nd = leaf; parent[nd] >= 0; nd = parent[nd]) {
+            code = (code << 1) | (uint32_t)branch[nd];
+            len++;
+        }
+    }
+    if (lane < 16) {
+        table_out[lane] = (uint8_t)t;
+        val_out[lane] = code;
+        len_out[lane] = (uint8_t)len;
     }
 }
 
@@ -264,18 +328,13 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_codes(EntFrame f, EntBufs b
 {
     __shared__ uint32_t val[16];
     __shared__ uint8_t len[16], table[16];
+    __shared__ int parent[32], branch[32];
+    __shared__ uint32_t wave_tot[2][kEntThreads / 64];
     const int stream = (int)blockIdx.x;
     EntCodes *out = b.codes + stream;
-    if (threadIdx.x == 0) {
-        int32_t hist[16];
-        for (int i = 0; i < 16; i++) {
-            hist[i] = b.hist[stream * 16 + i];
-            b.hist[stream * 16 + i] = 0;   // ready for the next frame
-        }
-        uint32_t v[16];
-        uint8_t l[16], t[16];
-        ent_build_codes(hist, t, v, l);
-        for (int i = 0; i < 16; i++) { val[i] = v[i]; len[i] = l[i]; table[i] = t[i]; }
+    if (threadIdx.x < 64) {
+        ent_build_codes_wave(b.hist + stream * 16, table, val, len, parent, branch);
+        if (threadIdx.x < 16) b.hist[stream * 16 + threadIdx.x] = 0;   // ready for the next frame
     }
     __syncthreads();
     const unsigned z = threadIdx.x & 15u, nb = threadIdx.x >> 4;
@@ -285,72 +344,50 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_codes(EntFrame f, EntBufs b
         out->len[threadIdx.x] = len[threadIdx.x];
         out->table[threadIdx.x] = table[threadIdx.x];
     }
-    (void)f;
-}
-
-// ---------------------------------------------------------------------------------------------------- k_ent_offsets
-// Exclusive prefix sum of `n` per-item bit counts, items dealt to the workgroup's threads in contiguous chunks.
-// bits(i) is evaluated twice (count pass, write pass).  Returns the total.
-template <class Bits>
-__device__ inline uint32_t ent_block_scan(int n, uint32_t base, uint32_t *out, uint32_t *lds /*[kEntScanThreads/64 + 1]*/, Bits bits)
-{
-    const int per = (n + kEntScanThreads - 1) / kEntScanThreads;
-    const int lo = (int)threadIdx.x * per, hi = min(lo + per, n);
-    uint32_t mine = 0;
-    for (int i = lo; i < hi; i++) mine += bits(i);
-    // wavefront inclusive scan, then the wavefront totals
+    // base bit offsets of the scan workgroups: all block headers first (p-frames), then the symbols (enc.rs:414-466)
+    EntGroup *groups = b.groups + (size_t)stream * f.n_groups;
+    uint32_t hdr_run = 19u * 8u;   // 16 table bytes + 3 q-table indices (enc.rs:290-298, :403-411)
+    uint32_t sym_run = 0;          // relative to the end of the header section until the second pass
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    uint32_t incl = mine;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = ent_shfl(incl, lane >= d ? lane - d : lane);
-        if (lane >= d) incl += up;
-    }
-    __syncthreads();   // lds reuse across calls
-    if (lane == 63) lds[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0, total = 0;
-    for (int w = 0; w < kEntScanThreads / 64; w++) {
-        const uint32_t t = lds[w];
-        if (w < wave) wave_base += t;
-        total += t;
-    }
-    uint32_t run = base + wave_base + incl - mine;
-    for (int i = lo; i < hi; i++) {
-        out[i] = run;
-        run += bits(i);
-    }
-    return total;
-}
-
-__global__ void __launch_bounds__(kEntScanThreads) k_ent_offsets(EntFrame f, EntBufs b)
-{
-    __shared__ uint32_t lds[kEntScanThreads / 64 + 1];
-    __shared__ uint8_t len[16];
-    const int stream = (int)blockIdx.x, n_sb = f.total_blocks * 4;
-    const EntCodes *codes = b.codes + stream;
-    if (threadIdx.x < 16) len[threadIdx.x] = codes->len[threadIdx.x];
-    __syncthreads();
-    uint32_t bit = 19u * 8u;   // 16 table bytes + 3 q-table indices (enc.rs:290-298, :403-411)
-    if (f.pframe) {            // block headers: has_mvec, has_coeff, then two 7-bit components (enc.rs:414-451)
-        const int8_t *mv = b.mv + (size_t)stream * f.total_blocks * 2;
-        bit += ent_block_scan(f.total_blocks, bit, b.hdr_off + (size_t)stream * f.total_blocks, lds,
-                              [&](int i) { return (mv[2 * i] != 0 || mv[2 * i + 1] != 0) ? 16u : 2u; });
-    }
-    const uint4 *counts = b.counts + (size_t)stream * n_sb;
-    const uint32_t *sumsize = b.sumsize + (size_t)stream * n_sb;
-    bit += ent_block_scan(n_sb, bit, b.sb_off + (size_t)stream * n_sb, lds, [&](int i) {
-        const uint4 c = counts[i];
-        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-        uint32_t bits = sumsize[i];
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: totals of the header section (and the symbol offsets relative to its end); pass 1 writes the bases
+        uint32_t h_run = hdr_run, s_run = pass == 0 ? 0u : sym_run;
+        for (int g0 = 0; g0 < f.n_groups; g0 += kEntThreads) {
+            const int gi = g0 + (int)threadIdx.x;
+            uint32_t hb = 0, sbits = 0;
+            if (gi < f.n_groups) {
+                const EntGroup &g = groups[gi];
+                hb = g.hdr_bits;
+                sbits = g.sumsize;
 #pragma unroll
-        for (int k = 0; k < 16; k++) bits += ((w[k >> 2] >> (8 * (k & 3))) & 0xffu) * len[k];
-        return bits;
-    });
-    if (threadIdx.x == 0) {
-        uint32_t bytes = (bit + 7u) >> 3;
-        if (codes->oversize) bytes = kEntErrOversize;
-        else if (bytes > f.cap_bytes) bytes = kEntErrCapacity;
-        b.sizes[stream] = bytes;
+                for (int k = 0; k < 16; k++) sbits += ((g.counts[k >> 1] >> (16 * (k & 1))) & 0xffffu) * len[k];
+            }
+            const uint32_t hi = ent_wave_scan(hb), si = ent_wave_scan(sbits);
+            __syncthreads();
+            if (lane == 63) { wave_tot[0][wave] = hi; wave_tot[1][wave] = si; }
+            __syncthreads();
+            uint32_t h_before = 0, s_before = 0, h_all = 0, s_all = 0;
+            for (int w = 0; w < kEntThreads / 64; w++) {
+                if (w < wave) { h_before += wave_tot[0][w]; s_before += wave_tot[1][w]; }
+                h_all += wave_tot[0][w];
+                s_all += wave_tot[1][w];
+            }
+            if (pass == 1 && gi < f.n_groups) {
+                groups[gi].hdr_base = h_run + h_before + hi - hb;
+                groups[gi].sym_base = s_run + s_before + si - sbits;
+            }
+            h_run += h_all;
+            s_run += s_all;
+        }
+        if (pass == 0) {
+            sym_run = h_run;                                  // symbols start where the headers end
+            if (threadIdx.x == 0) {
+                uint32_t bytes = (h_run + s_run + 7u) >> 3;   // byte_align (enc.rs:318, :468)
+                if (out->oversize) bytes = kEntErrOversize;
+                else if (bytes > f.cap_bytes) bytes = kEntErrCapacity;
+                b.sizes[stream] = bytes;
+            }
+        }
     }
 }
 
@@ -359,7 +396,7 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_init(EntFrame f, EntBufs b)
 {
     const int stream = (int)blockIdx.y;
     const uint32_t bytes = b.sizes[stream];
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.codes[stream].oversize = 0;   // consumed by k_ent_offsets; next frame starts clean
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.codes[stream].oversize = 0;   // consumed by k_ent_codes; next frame starts clean
     if (bytes >= kEntErrCapacity) return;
     uint32_t *w = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
     const uint32_t n_words = (bytes + 3u) >> 2;
@@ -402,41 +439,64 @@ struct LaneBits {
 
 __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
 {
+    __shared__ uint64_t rows[kEntThreads * kEntRow64];
     __shared__ uint32_t pair_bits[256];
     __shared__ uint8_t pair_len[256];
+    __shared__ uint8_t len[16];
+    __shared__ uint32_t wave_tot[2][kEntThreads / 64];
     const int stream = (int)blockIdx.y, n_sb = f.total_blocks * 4;
+    if (b.sizes[stream] >= kEntErrCapacity) return;   // uniform over the workgroup
     const EntCodes *codes = b.codes + stream;
     pair_bits[threadIdx.x] = codes->pair_bits[threadIdx.x];
     pair_len[threadIdx.x] = codes->pair_len[threadIdx.x];
-    __syncthreads();
-    const int sbi = (int)(blockIdx.x * kEntThreads + threadIdx.x);
-    const bool ok = b.sizes[stream] < kEntErrCapacity;
-    const bool live = sbi < n_sb && ok;
+    if (threadIdx.x < 16) len[threadIdx.x] = codes->len[threadIdx.x];
+    const int sb0 = (int)blockIdx.x * kEntThreads;
+    const int sbi = sb0 + (int)threadIdx.x;
+    const bool live = sbi < n_sb;
     const int mb = sbi >> 2, sb = sbi & 3;
+    ent_stage_rows(rows, b.coef + ((size_t)stream * f.total_blocks * 4 + sb0) * 64, min(kEntThreads, n_sb - sb0));
+    __syncthreads();
+
     const size_t sbase = (size_t)stream * n_sb;
-    uint32_t *words = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
+    const size_t bi = (size_t)stream * f.total_blocks + (live ? mb : 0);
     const uint64_t mask = live ? b.mask[sbase + sbi] : 0;
+    // this lane's symbol bits (counts . code lengths + sizes) and block-header bits, then their place in the workgroup
+    uint32_t my_bits = 0, my_hdr = 0;
+    int mvx = 0, mvy = 0;
+    if (live) {
+        const uint4 c4 = b.counts[sbase + sbi];
+        const uint32_t w[4] = {c4.x, c4.y, c4.z, c4.w};
+        my_bits = b.sumsize[sbase + sbi];
+#pragma unroll
+        for (int k = 0; k < 16; k++) my_bits += ((w[k >> 2] >> (8 * (k & 3))) & 0xffu) * len[k];
+        if (f.pframe && sb == 0) {
+            mvx = b.mv[2 * bi];
+            mvy = b.mv[2 * bi + 1];
+            my_hdr = (mvx != 0 || mvy != 0) ? 16u : 2u;
+        }
+    }
+    const uint32_t si = ent_wave_scan(my_bits), hi = ent_wave_scan(my_hdr);
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    if (lane == 63) { wave_tot[0][wave] = si; wave_tot[1][wave] = hi; }
     int last = ent_prev_last(mask, sb);
+    __syncthreads();
+    const EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
+    uint32_t sym_off = g->sym_base + si - my_bits, hdr_off = g->hdr_base + hi - my_hdr;
+    for (int w = 0; w < wave; w++) { sym_off += wave_tot[0][w]; hdr_off += wave_tot[1][w]; }
     if (!live) return;
 
-    if (f.pframe && sb == 0) {   // block header (enc.rs:414-451)
-        const size_t bi = (size_t)stream * f.total_blocks + mb;
-        const int mx = b.mv[2 * bi], my = b.mv[2 * bi + 1];
-        const bool has_mvec = mx != 0 || my != 0;
-        uint32_t bits = (has_mvec ? 1u : 0u) | (b.has[bi] ? 2u : 0u);
-        unsigned len = 2;
-        if (has_mvec) {
-            bits |= ((uint32_t)mx & 0x7fu) << 2 | ((uint32_t)my & 0x7fu) << 9;
-            len = 16;
-        }
-        LaneBits hw(words, b.hdr_off[bi]);
-        hw.put(bits, len);
+    uint32_t *words = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
+    const bool has_coef = !f.pframe || b.has[bi] != 0;
+    if (my_hdr) {   // block header (enc.rs:414-451)
+        uint32_t bits = (my_hdr == 16u ? 1u : 0u) | (has_coef ? 2u : 0u);
+        if (my_hdr == 16u) bits |= ((uint32_t)mvx & 0x7fu) << 2 | ((uint32_t)mvy & 0x7fu) << 9;
+        LaneBits hw(words, hdr_off);
+        hw.put(bits, my_hdr);
         hw.finish();
     }
-    const bool coded = !f.pframe || b.has[(size_t)stream * f.total_blocks + mb] != 0;
-    if (!coded) return;
-    const int16_t *c = b.coef + ((size_t)stream * f.total_blocks + mb) * 256 + sb * 64;
-    LaneBits bw(words, b.sb_off[sbase + sbi]);
+    if (!has_coef) return;
+    const int16_t *c = (const int16_t *)(rows + threadIdx.x * kEntRow64);
+    LaneBits bw(words, sym_off);
     const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
     for (uint64_t mm = mask; mm;) {
         const int bit = __builtin_ctzll(mm);

@@ -66,6 +66,13 @@ bool wave_any(bool pred);
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline int __shfl_xor(int v, int mask) { return hipemu::wave_exchange(v, (int)((threadIdx.x & 63) ^ (unsigned)mask)); }
 static inline bool __any(bool p) { return hipemu::wave_any(p); }
+static inline unsigned long long __ballot(bool p)
+{
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; l++) m |= (unsigned long long)(hipemu::wave_exchange(p ? 1 : 0, l) & 1) << l;
+    return m;
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int __shfl(int v, int src_lane) { return hipemu::wave_exchange(v, src_lane); }

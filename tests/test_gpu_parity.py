@@ -228,6 +228,11 @@ def test_device_entropy_1080p(pkg, gpu_ctx, oracle):
     assert pc.check_device_entropy(pkg, gpu_ctx, oracle, 1920, 1080, n_streams=2, seed=9, kinds=("typical", "edges")) == 8
 
 
+def test_device_entropy_4k(pkg, gpu_ctx, oracle):
+    """48 960 macroblocks = 765 scan workgroups: the group prefix of k_ent_codes takes more than one 256-wide chunk"""
+    assert pc.check_device_entropy(pkg, gpu_ctx, oracle, 3840, 2160, n_streams=1, seed=10, kinds=("typical",)) == 2
+
+
 def test_stream_encoder_host_and_device_entropy_agree(pkg, gpu_ctx):
     """Encoder(device_entropy=False) and Encoder(device_entropy=True) write the same .pfv bytes"""
     import io
