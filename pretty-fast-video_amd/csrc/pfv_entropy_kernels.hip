@@ -103,17 +103,6 @@ __device__ __forceinline__ uint32_t ent_wave_scan(uint32_t v)
     return v;
 }
 
-// 8-bit counters for the 16 symbols in two 64-bit words
-struct SymCount {
-    uint64_t lo = 0, hi = 0;
-    __device__ __forceinline__ void add(unsigned bin, unsigned n)
-    {
-        const uint64_t inc = (uint64_t)n << (8u * (bin & 7u));
-        if (bin < 8u) lo += inc;
-        else hi += inc;
-    }
-};
-
 // Position of the last non-zero coefficient before subblock `sb` in macroblock order (-1: none), from the quad's bitmaps.
 __device__ __forceinline__ int ent_prev_last(uint64_t mine, int sb)
 {
@@ -140,6 +129,18 @@ __device__ __forceinline__ void ent_split_run(unsigned run, unsigned &fillers, u
 __device__ __forceinline__ void ent_stage_rows(uint64_t *rows, const int16_t *group_base, int n_live_sb)
 {
     const uint4 *src = (const uint4 *)group_base;
+    if (n_live_sb == kEntThreads) {   // every group but a stream's last: all eight loads in flight before the first LDS write
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[k * kEntThreads + (int)threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int piece = k * kEntThreads + (int)threadIdx.x, sbl = piece >> 3, part = piece & 7;
+            rows[sbl * kEntRow64 + 2 * part] = (uint64_t)v[k].x | ((uint64_t)v[k].y << 32);
+            rows[sbl * kEntRow64 + 2 * part + 1] = (uint64_t)v[k].z | ((uint64_t)v[k].w << 32);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int piece = k * kEntThreads + (int)threadIdx.x, sbl = piece >> 3, part = piece & 7;
@@ -151,10 +152,33 @@ __device__ __forceinline__ void ent_stage_rows(uint64_t *rows, const int16_t *gr
     }
 }
 
+// 1 / 2 in the low / high half where the 16-bit half of d is non-zero (v_pk_min_u16), folded to a 2-bit field
+#ifndef PFV_HIPEMU
+typedef unsigned short ent_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ent_nz2(uint32_t d)
+{
+    const ent_us2 m = __builtin_elementwise_min(__builtin_bit_cast(ent_us2, d), (ent_us2){1, 2});
+    return (uint32_t)m.x + (uint32_t)m.y;
+}
+#else
+static inline uint32_t ent_nz2(uint32_t d) { return ((d & 0xffffu) ? 1u : 0u) + ((d >> 16) ? 2u : 0u); }
+#endif
+
+// sum over each 16-lane row, valid in every lane of the row (DPP butterflies)
+__device__ __forceinline__ uint32_t ent_row_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);   // row_mirror
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------- k_ent_scan
 __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
 {
     __shared__ uint64_t rows[kEntThreads * kEntRow64];
+    __shared__ uint4 cnt4[kEntThreads];
     __shared__ uint32_t blk[10];
     const int stream = (int)blockIdx.y, n_sb = f.total_blocks * 4;
     const int sb0 = (int)blockIdx.x * kEntThreads;
@@ -171,71 +195,87 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     const uint64_t *row = rows + threadIdx.x * kEntRow64;
     uint64_t mask = 0;
     if (coded) {
+        uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint64_t x = row[k];
-            const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-            const uint32_t four = ((lo & 0xffffu) ? 1u : 0u) | ((lo >> 16) ? 2u : 0u) | ((hi & 0xffffu) ? 4u : 0u) | ((hi >> 16) ? 8u : 0u);
-            mask |= (uint64_t)four << (4 * k);
+        for (int k = 0; k < 8; k++) {
+            const uint64_t x = row[k], y = row[8 + k];
+            lo |= (ent_nz2((uint32_t)x) | (ent_nz2((uint32_t)(x >> 32)) << 2)) << (4 * k);
+            hi |= (ent_nz2((uint32_t)y) | (ent_nz2((uint32_t)(y >> 32)) << 2)) << (4 * k);
         }
+        mask = (uint64_t)lo | ((uint64_t)hi << 32);
     }
     int last = ent_prev_last(mask, sb);   // every lane of the wavefront takes part in the exchange
 
+    // symbol counts: 16 byte-wide counters per lane in LDS (ds_add without return: nothing to wait for in the loop)
+    cnt4[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    uint32_t *my_cnt = (uint32_t *)&cnt4[threadIdx.x];
+    auto count = [&](unsigned bin, unsigned n) { atomicAdd(&my_cnt[bin >> 2], n << (8u * (bin & 3u))); };
     const int16_t *c = (const int16_t *)row;
-    SymCount cnt;
     uint32_t sumsize = 0, oversize = 0;
-    for (uint64_t mm = mask; mm;) {
-        const int bit = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        const int i = 64 * sb + bit;
-        unsigned fillers, rest;
-        ent_split_run((unsigned)(i - last - 1), fillers, rest);
-        last = i;
-        const int v = c[bit];
-        const unsigned mag = (unsigned)(v < 0 ? -v : v);
-        const unsigned size = 33u - (unsigned)__builtin_clz(mag);   // bit length + 1 (rle.rs:23-24)
-        oversize |= size > 15u;
-        cnt.add(15u, fillers);
-        cnt.add(0u, fillers);
-        cnt.add(rest, 1u);
-        cnt.add(size & 15u, 1u);
-        sumsize += size;
+    if (mask) {
+        uint64_t mm = mask;
+        int bit = __builtin_ctzll(mm);
+        int v = c[bit];
+        for (;;) {
+            mm &= mm - 1;
+            const int nbit = mm ? __builtin_ctzll(mm) : 0;
+            const int nv = c[nbit];   // next value on its way while this one is processed
+            const int i = 64 * sb + bit;
+            unsigned run = (unsigned)(i - last - 1);
+            last = i;
+            if (run > 15u) {
+                unsigned fillers;
+                ent_split_run(run, fillers, run);
+                count(15u, fillers);
+                count(0u, fillers);
+            }
+            const unsigned mag = (unsigned)(v < 0 ? -v : v);
+            const unsigned size = 33u - (unsigned)__builtin_clz(mag);   // bit length + 1 (rle.rs:23-24)
+            oversize |= size > 15u;
+            count(run, 1u);
+            count(size & 15u, 1u);
+            sumsize += size;
+            if (!mm) break;
+            bit = nbit;
+            v = nv;
+        }
     }
     if (coded && sb == 3 && last < 255) {   // the trailing run closes the macroblock (rle.rs:31-38)
         unsigned fillers, rest;
         ent_split_run((unsigned)(255 - last), fillers, rest);
-        cnt.add(15u, fillers);
-        cnt.add(0u, fillers + 1u);
-        cnt.add(rest, 1u);
+        count(15u, fillers);
+        count(0u, fillers + 1u);
+        count(rest, 1u);
     }
     uint32_t hdr_bits = 0;
     if (f.pframe && live && sb == 0)      // has_mvec, has_coeff, then two 7-bit components (enc.rs:414-451)
         hdr_bits = (b.mv[2 * bi] != 0 || b.mv[2 * bi + 1] != 0) ? 16u : 2u;
+    ent_wave_lds_sync();
+    const uint4 c4 = cnt4[threadIdx.x];
     if (live) {
         b.mask[sbase + sbi] = mask;
-        b.counts[sbase + sbi] = make_uint4((uint32_t)cnt.lo, (uint32_t)(cnt.lo >> 32), (uint32_t)cnt.hi, (uint32_t)(cnt.hi >> 32));
+        b.counts[sbase + sbi] = c4;
         b.sumsize[sbase + sbi] = sumsize;
     }
 
     // workgroup totals: counts widened to 16-bit fields (two symbols per word; at most 256 * 164 per field)
-    const uint32_t w8[4] = {(uint32_t)cnt.lo, (uint32_t)(cnt.lo >> 32), (uint32_t)cnt.hi, (uint32_t)(cnt.hi >> 32)};
-    const bool lead = (threadIdx.x & 63u) == 0;
+    const uint32_t w8[4] = {c4.x, c4.y, c4.z, c4.w};
+    const bool lead = (threadIdx.x & 15u) == 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t a = (w8[j] & 0xffu) | ((w8[j] & 0xff00u) << 8);
-        const uint32_t c2 = ((w8[j] >> 16) & 0xffu) | ((w8[j] >> 24) << 16);
-        const uint32_t sa = ent_wave_sum(a), sc = ent_wave_sum(c2);
+        const uint32_t a = ent_row_sum((w8[j] & 0xffu) | ((w8[j] & 0xff00u) << 8));
+        const uint32_t c2 = ent_row_sum(((w8[j] >> 16) & 0xffu) | ((w8[j] >> 24) << 16));
         if (lead) {
-            atomicAdd(&blk[2 * j], sa);
-            atomicAdd(&blk[2 * j + 1], sc);
+            if (a) atomicAdd(&blk[2 * j], a);
+            if (c2) atomicAdd(&blk[2 * j + 1], c2);
         }
     }
-    const uint32_t ws = ent_wave_sum(sumsize), wh = ent_wave_sum(hdr_bits), any_over = ent_wave_sum(oversize);
+    const uint32_t ws = ent_row_sum(sumsize), wh = ent_row_sum(hdr_bits);
     if (lead) {
         atomicAdd(&blk[8], ws);
-        atomicAdd(&blk[9], wh);
-        if (any_over) atomicOr(&b.codes[stream].oversize, 1u);
+        if (wh) atomicAdd(&blk[9], wh);
     }
+    if (__any(oversize != 0) && (threadIdx.x & 63u) == 0) atomicOr(&b.codes[stream].oversize, 1u);
     __syncthreads();
     EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
     if (threadIdx.x < 8) g->counts[threadIdx.x] = blk[threadIdx.x];
@@ -418,7 +458,7 @@ struct LaneBits {
     unsigned fill;
     bool first = true;
     __device__ __forceinline__ LaneBits(uint32_t *words, uint32_t bit_off) : w(words + (bit_off >> 5)), fill(bit_off & 31u) {}
-    __device__ __forceinline__ void put(uint32_t bits, unsigned len)   // len <= 30, bits < 2^len
+    __device__ __forceinline__ void put(uint32_t bits, unsigned len)   // len <= 32, bits < 2^len
     {
         acc |= (uint64_t)bits << fill;
         fill += len;
@@ -498,20 +538,33 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     const int16_t *c = (const int16_t *)(rows + threadIdx.x * kEntRow64);
     LaneBits bw(words, sym_off);
     const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
-    for (uint64_t mm = mask; mm;) {
-        const int bit = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        const int i = 64 * sb + bit;
-        unsigned fillers, rest;
-        ent_split_run((unsigned)(i - last - 1), fillers, rest);
-        last = i;
-        const int v = c[bit];
-        const unsigned mag = (unsigned)(v < 0 ? -v : v);
-        const unsigned size = (33u - (unsigned)__builtin_clz(mag)) & 15u;
-        for (; fillers; fillers--) bw.put(filler_bits, filler_len);
-        const unsigned p = rest | (size << 4);
-        bw.put(pair_bits[p], pair_len[p]);
-        bw.put((uint32_t)v & ((1u << size) - 1u), size);   // write_signed: low `size` bits (enc.rs:313-315)
+    if (mask) {
+        uint64_t mm = mask;
+        int bit = __builtin_ctzll(mm);
+        int v = c[bit];
+        for (;;) {
+            mm &= mm - 1;
+            const int nbit = mm ? __builtin_ctzll(mm) : 0;
+            const int nv = c[nbit];   // next value on its way while this one is written
+            const int i = 64 * sb + bit;
+            unsigned run = (unsigned)(i - last - 1);
+            last = i;
+            if (run > 15u) {
+                unsigned fillers;
+                ent_split_run(run, fillers, run);
+                for (; fillers; fillers--) bw.put(filler_bits, filler_len);
+            }
+            const unsigned mag = (unsigned)(v < 0 ? -v : v);
+            const unsigned size = (33u - (unsigned)__builtin_clz(mag)) & 15u;
+            const unsigned p = run | (size << 4);
+            const uint32_t pb = pair_bits[p], pl = pair_len[p];
+            const uint32_t vb = (uint32_t)v & ((1u << size) - 1u);   // write_signed: low `size` bits (enc.rs:313-315)
+            if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
+            else { bw.put(pb, pl); bw.put(vb, size); }
+            if (!mm) break;
+            bit = nbit;
+            v = nv;
+        }
     }
     if (sb == 3 && last < 255) {
         unsigned fillers, rest;

@@ -20,6 +20,7 @@
 #include <functional>
 #include <vector>
 
+#define PFV_HIPEMU 1
 #define address_space(n)
 #define __global__
 #define __device__
