@@ -152,17 +152,26 @@ __device__ __forceinline__ void ent_stage_rows(uint64_t *rows, const int16_t *gr
     }
 }
 
-// 1 / 2 in the low / high half where the 16-bit half of d is non-zero (v_pk_min_u16), folded to a 2-bit field
+// v_pk_min_u16: unsigned minimum of the two 16-bit halves (the CPU emulator supplies its own primitive, same semantics)
 #ifndef PFV_HIPEMU
 typedef unsigned short ent_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t ent_nz2(uint32_t d)
+__device__ __forceinline__ uint32_t ent_pk_min_u16(uint32_t a, uint32_t b)
 {
-    const ent_us2 m = __builtin_elementwise_min(__builtin_bit_cast(ent_us2, d), (ent_us2){1, 2});
-    return (uint32_t)m.x + (uint32_t)m.y;
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ent_us2, a), __builtin_bit_cast(ent_us2, b)));
 }
 #else
-static inline uint32_t ent_nz2(uint32_t d) { return ((d & 0xffffu) ? 1u : 0u) + ((d >> 16) ? 2u : 0u); }
+static inline uint32_t ent_pk_min_u16(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+    return lo | (hi << 16);
+}
 #endif
+// bit 0 / bit 1: the low / high 16-bit half of d is non-zero
+__device__ __forceinline__ uint32_t ent_nz2(uint32_t d)
+{
+    const uint32_t m = ent_pk_min_u16(d, 0x00010001u);   // 0 or 1 in each half
+    return (m | (m >> 15)) & 3u;
+}
 
 // sum over each 16-lane row, valid in every lane of the row (DPP butterflies)
 __device__ __forceinline__ uint32_t ent_row_sum(uint32_t v)
@@ -450,53 +459,82 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_init(EntFrame f, EntBufs b)
 }
 
 // ---------------------------------------------------------------------------------------------------- k_ent_pack
-// LSB-first bit writer of one lane: the first and the last word it touches may be shared with its neighbours in the
-// stream (atomicOr onto the zeroed payload), every word in between is its own.
+// The 256 lanes of a workgroup own one contiguous bit range of the symbol section (and, for p-frames, one of the
+// header section).  Lanes OR their words into an LDS window anchored at the workgroup's first word; after a barrier
+// the window goes out with coalesced dword stores, only its first and last word -- shared with the neighbouring
+// workgroups -- as atomicOr onto the zeroed payload.  A workgroup whose symbols outgrow the window (kEntWinWords * 32
+// bits, ~6x the typical load at quality 5) sends the lanes past it straight to memory, one atomicOr for each lane's
+// first and last word; `cutoff` marks where the window's part ends.
+constexpr int kEntWinWords = 2048;
+constexpr int kEntHdrWords = 64 * 16 / 32 + 2;   // 64 macroblocks x 16 header bits, plus unaligned ends
+
 struct LaneBits {
-    uint32_t *w;
+    uint32_t *lds;        // window word, or nullptr: straight to memory
+    uint32_t *mem;
     uint64_t acc = 0;
     unsigned fill;
     bool first = true;
-    __device__ __forceinline__ LaneBits(uint32_t *words, uint32_t bit_off) : w(words + (bit_off >> 5)), fill(bit_off & 31u) {}
+    __device__ __forceinline__ LaneBits(uint32_t *window, uint32_t *words, uint32_t word0, uint32_t bit_off, bool in_window)
+        : lds(in_window ? window + ((bit_off >> 5) - word0) : nullptr), mem(words + (bit_off >> 5)), fill(bit_off & 31u) {}
+    __device__ __forceinline__ void word_out(uint32_t x, bool last)
+    {
+        if (lds) atomicOr(lds++, x);                     // ds_or_b32, nothing returned
+        else if (first || last) atomicOr(mem++, x);      // may share the word with a neighbour
+        else *mem++ = x;
+        first = false;
+    }
     __device__ __forceinline__ void put(uint32_t bits, unsigned len)   // len <= 32, bits < 2^len
     {
         acc |= (uint64_t)bits << fill;
         fill += len;
         if (fill >= 32u) {
-            if (first) atomicOr(w, (uint32_t)acc);
-            else *w = (uint32_t)acc;
-            first = false;
-            w++;
+            word_out((uint32_t)acc, false);
             acc >>= 32;
             fill -= 32u;
         }
     }
     __device__ __forceinline__ void finish()
     {
-        if (fill && (uint32_t)acc) atomicOr(w, (uint32_t)acc);
+        if (fill && (uint32_t)acc) word_out((uint32_t)acc, true);
     }
 };
 
+__device__ __forceinline__ void ent_flush_window(const uint32_t *win, uint32_t *words, uint32_t word0, uint32_t end_bit)
+{
+    if (end_bit <= (word0 << 5)) return;
+    const uint32_t n = (end_bit - (word0 << 5) + 31u) >> 5;
+    for (uint32_t i = threadIdx.x; i < n; i += kEntThreads) {
+        const uint32_t x = win[i];
+        if (i == 0 || i == n - 1) {
+            if (x) atomicOr(&words[word0 + i], x);
+        } else {
+            words[word0 + i] = x;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
 {
-    __shared__ uint64_t rows[kEntThreads * kEntRow64];
+    __shared__ uint32_t win[kEntWinWords];
+    __shared__ uint32_t hwin[kEntHdrWords];
     __shared__ uint32_t pair_bits[256];
     __shared__ uint8_t pair_len[256];
-    __shared__ uint8_t len[16];
     __shared__ uint32_t wave_tot[2][kEntThreads / 64];
+    __shared__ uint32_t cutoff;
     const int stream = (int)blockIdx.y, n_sb = f.total_blocks * 4;
     if (b.sizes[stream] >= kEntErrCapacity) return;   // uniform over the workgroup
     const EntCodes *codes = b.codes + stream;
     pair_bits[threadIdx.x] = codes->pair_bits[threadIdx.x];
     pair_len[threadIdx.x] = codes->pair_len[threadIdx.x];
-    if (threadIdx.x < 16) len[threadIdx.x] = codes->len[threadIdx.x];
-    const int sb0 = (int)blockIdx.x * kEntThreads;
-    const int sbi = sb0 + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kEntWinWords / kEntThreads; k++) win[k * kEntThreads + (int)threadIdx.x] = 0;
+    if (threadIdx.x < kEntHdrWords) hwin[threadIdx.x] = 0;
+    if (threadIdx.x == 0) cutoff = 0xffffffffu;
+    const uint32_t *len4 = (const uint32_t *)codes->len;   // 16 code lengths, four to a word
+    const uint32_t l0 = len4[0], l1 = len4[1], l2 = len4[2], l3 = len4[3];
+    const int sbi = (int)blockIdx.x * kEntThreads + (int)threadIdx.x;
     const bool live = sbi < n_sb;
     const int mb = sbi >> 2, sb = sbi & 3;
-    ent_stage_rows(rows, b.coef + ((size_t)stream * f.total_blocks * 4 + sb0) * 64, min(kEntThreads, n_sb - sb0));
-    __syncthreads();
-
     const size_t sbase = (size_t)stream * n_sb;
     const size_t bi = (size_t)stream * f.total_blocks + (live ? mb : 0);
     const uint64_t mask = live ? b.mask[sbase + sbi] : 0;
@@ -505,10 +543,11 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     int mvx = 0, mvy = 0;
     if (live) {
         const uint4 c4 = b.counts[sbase + sbi];
-        const uint32_t w[4] = {c4.x, c4.y, c4.z, c4.w};
         my_bits = b.sumsize[sbase + sbi];
-#pragma unroll
-        for (int k = 0; k < 16; k++) my_bits += ((w[k >> 2] >> (8 * (k & 3))) & 0xffu) * len[k];
+        my_bits = __builtin_amdgcn_udot4(c4.x, l0, my_bits, false);
+        my_bits = __builtin_amdgcn_udot4(c4.y, l1, my_bits, false);
+        my_bits = __builtin_amdgcn_udot4(c4.z, l2, my_bits, false);
+        my_bits = __builtin_amdgcn_udot4(c4.w, l3, my_bits, false);
         if (f.pframe && sb == 0) {
             mvx = b.mv[2 * bi];
             mvy = b.mv[2 * bi + 1];
@@ -521,58 +560,69 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     int last = ent_prev_last(mask, sb);
     __syncthreads();
     const EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
-    uint32_t sym_off = g->sym_base + si - my_bits, hdr_off = g->hdr_base + hi - my_hdr;
-    for (int w = 0; w < wave; w++) { sym_off += wave_tot[0][w]; hdr_off += wave_tot[1][w]; }
-    if (!live) return;
+    const uint32_t sym_base = g->sym_base, hdr_base = g->hdr_base;
+    uint32_t sym_off = sym_base + si - my_bits, hdr_off = hdr_base + hi - my_hdr, sym_all = 0, hdr_all = 0;
+    for (int w = 0; w < kEntThreads / 64; w++) {
+        if (w < wave) { sym_off += wave_tot[0][w]; hdr_off += wave_tot[1][w]; }
+        sym_all += wave_tot[0][w];
+        hdr_all += wave_tot[1][w];
+    }
+    const uint32_t word0 = sym_base >> 5, hword0 = hdr_base >> 5;
+    const bool in_window = sym_off + my_bits - (word0 << 5) <= (uint32_t)kEntWinWords * 32u;
+    if (!in_window && my_bits) atomicMin(&cutoff, sym_off);
 
     uint32_t *words = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
-    const bool has_coef = !f.pframe || b.has[bi] != 0;
+    const bool has_coef = live && (!f.pframe || b.has[bi] != 0);
     if (my_hdr) {   // block header (enc.rs:414-451)
         uint32_t bits = (my_hdr == 16u ? 1u : 0u) | (has_coef ? 2u : 0u);
         if (my_hdr == 16u) bits |= ((uint32_t)mvx & 0x7fu) << 2 | ((uint32_t)mvy & 0x7fu) << 9;
-        LaneBits hw(words, hdr_off);
+        LaneBits hw(hwin, words, hword0, hdr_off, true);
         hw.put(bits, my_hdr);
         hw.finish();
     }
-    if (!has_coef) return;
-    const int16_t *c = (const int16_t *)(rows + threadIdx.x * kEntRow64);
-    LaneBits bw(words, sym_off);
-    const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
-    if (mask) {
-        uint64_t mm = mask;
-        int bit = __builtin_ctzll(mm);
-        int v = c[bit];
-        for (;;) {
-            mm &= mm - 1;
-            const int nbit = mm ? __builtin_ctzll(mm) : 0;
-            const int nv = c[nbit];   // next value on its way while this one is written
-            const int i = 64 * sb + bit;
-            unsigned run = (unsigned)(i - last - 1);
-            last = i;
-            if (run > 15u) {
-                unsigned fillers;
-                ent_split_run(run, fillers, run);
-                for (; fillers; fillers--) bw.put(filler_bits, filler_len);
+    if (has_coef) {
+        const int16_t *c = b.coef + ((size_t)stream * f.total_blocks + mb) * 256 + sb * 64;
+        LaneBits bw(win, words, word0, sym_off, in_window);
+        const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
+        if (mask) {
+            uint64_t mm = mask;
+            int bit = __builtin_ctzll(mm);
+            int v = c[bit];
+            for (;;) {
+                mm &= mm - 1;
+                const int nbit = mm ? __builtin_ctzll(mm) : bit;
+                const int nv = c[nbit];   // next value on its way while this one is written
+                const int i = 64 * sb + bit;
+                unsigned run = (unsigned)(i - last - 1);
+                last = i;
+                if (run > 15u) {
+                    unsigned fillers;
+                    ent_split_run(run, fillers, run);
+                    for (; fillers; fillers--) bw.put(filler_bits, filler_len);
+                }
+                const unsigned mag = (unsigned)(v < 0 ? -v : v);
+                const unsigned size = (33u - (unsigned)__builtin_clz(mag)) & 15u;
+                const unsigned p = run | (size << 4);
+                const uint32_t pb = pair_bits[p], pl = pair_len[p];
+                const uint32_t vb = (uint32_t)v & ((1u << size) - 1u);   // write_signed: low `size` bits (enc.rs:313-315)
+                if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
+                else { bw.put(pb, pl); bw.put(vb, size); }
+                if (!mm) break;
+                bit = nbit;
+                v = nv;
             }
-            const unsigned mag = (unsigned)(v < 0 ? -v : v);
-            const unsigned size = (33u - (unsigned)__builtin_clz(mag)) & 15u;
-            const unsigned p = run | (size << 4);
-            const uint32_t pb = pair_bits[p], pl = pair_len[p];
-            const uint32_t vb = (uint32_t)v & ((1u << size) - 1u);   // write_signed: low `size` bits (enc.rs:313-315)
-            if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
-            else { bw.put(pb, pl); bw.put(vb, size); }
-            if (!mm) break;
-            bit = nbit;
-            v = nv;
         }
+        if (sb == 3 && last < 255) {
+            unsigned fillers, rest;
+            ent_split_run((unsigned)(255 - last), fillers, rest);
+            for (; fillers; fillers--) bw.put(filler_bits, filler_len);
+            bw.put(pair_bits[rest], pair_len[rest]);   // (rest, size 0)
+        }
+        bw.finish();
     }
-    if (sb == 3 && last < 255) {
-        unsigned fillers, rest;
-        ent_split_run((unsigned)(255 - last), fillers, rest);
-        for (; fillers; fillers--) bw.put(filler_bits, filler_len);
-        bw.put(pair_bits[rest], pair_len[rest]);   // (rest, size 0)
-    }
-    bw.finish();
+    __syncthreads();
+    ent_flush_window(win, words, word0, min(cutoff, sym_base + sym_all));
+    ent_flush_window(hwin, words, hword0, hdr_base + hdr_all);
 }
 
 }  // namespace pfv

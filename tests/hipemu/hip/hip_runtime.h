@@ -79,6 +79,7 @@ static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f
 static inline int __shfl(int v, int src_lane) { return hipemu::wave_exchange(v, src_lane); }
 static inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
 static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline unsigned atomicMin(unsigned *p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 
