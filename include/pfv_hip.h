@@ -237,6 +237,10 @@ PFV_API size_t pfv_serialize_pframe_payload(const int8_t *mv, const uint8_t *has
  * = DecodeError::{FormatError, VersionError, IOError} (src/dec.rs:30-35). */
 PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pfv_decoder **out);
 PFV_API void pfv_decoder_destroy(pfv_decoder *d);
+/* Packets are independent bit streams: up to n_threads of them are parsed (src/dec.rs:226-296, 328-417) ahead of the
+ * one being decoded, on worker threads; 0 = parse inline.  Default min(4, hardware threads - 1).  Frames, their order
+ * and the error returned by each advance call are those of the sequential loop (src/dec.rs:169-224). */
+PFV_API int pfv_decoder_set_lookahead(pfv_decoder *d, int n_threads);
 PFV_API int pfv_decoder_width(const pfv_decoder *d);
 PFV_API int pfv_decoder_height(const pfv_decoder *d);
 PFV_API int pfv_decoder_framerate(const pfv_decoder *d);

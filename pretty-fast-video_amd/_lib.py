@@ -97,6 +97,7 @@ SIGNATURES = [
     ("pfv_serialize_pframe_payload", c_size_t, [_P, _P, _P, c_int, _P, c_size_t]),
     ("pfv_decoder_create", c_int, [_P, _P, c_size_t, POINTER(_P)]),
     ("pfv_decoder_destroy", None, [_P]),
+    ("pfv_decoder_set_lookahead", c_int, [_P, c_int]),
     ("pfv_decoder_width", c_int, [_P]),
     ("pfv_decoder_height", c_int, [_P]),
     ("pfv_decoder_framerate", c_int, [_P]),

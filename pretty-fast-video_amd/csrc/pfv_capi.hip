@@ -12,7 +12,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pfv_hip.h"
@@ -1033,6 +1037,29 @@ PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host)
 // ================================================================== stream-level session objects
 // enc::Encoder<W> (src/enc.rs:12-188) with W = an in-memory byte vector (the reference's tests use
 // Cursor<Vec<u8>>, src/lib.rs:319-321), dec::Decoder<R> (src/dec.rs:15-224) with R = a caller-owned byte slice.
+// Page-locked host staging (hipHostMalloc): PCIe copies from / to these run at link rate without the runtime's
+// bounce through its own pinned chunks; falls back to nothing -- an allocation failure is reported by the caller.
+template <class T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    bool resize(size_t count)
+    {
+        if (count <= n) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        if (hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        n = count;
+        return true;
+    }
+    T *data() { return p; }
+    size_t size() const { return n; }
+};
+
 struct pfv_encoder {
     pfv_ctx *ctx = nullptr;
     pfv_enc_session *hot = nullptr;
@@ -1040,10 +1067,29 @@ struct pfv_encoder {
     bool finished = false;
     bool device_entropy = true;            // payloads built by the k_ent_* kernels instead of serialize_*frame on the host
     std::vector<uint8_t> out;              // the writer
-    std::vector<uint8_t> frame;            // packed Y|U|V staging
-    std::vector<int16_t> coef;
-    std::vector<int8_t> mv;
-    std::vector<uint8_t> has;
+    PinnedBuf<uint8_t> frame;              // packed Y|U|V staging
+    PinnedBuf<int16_t> coef;               // host entropy path only
+    PinnedBuf<int8_t> mv;
+    PinnedBuf<uint8_t> has;
+    PinnedBuf<uint8_t> payload;            // device entropy path: packet payload landing zone
+};
+
+// One step of Decoder::advance_frame's packet loop (src/dec.rs:169-224), found by the header scanner.  FRAME events are
+// parsed (bits -> coefficients / block headers, dec.rs:226-296, 328-417) ahead of their turn by worker threads: packets
+// are independent bit streams, only the device decode behind them is sequential.
+struct DecEvent {
+    enum Kind { FRAME, DROP, END, ERROR } kind = END;
+    enum State { FREE, QUEUED, RUNNING, DONE } state = FREE;
+    int rc = 0;                          // ERROR: the status to return; FRAME: parse result
+    const char *msg = "";
+    uint8_t type = 0;                    // FRAME: 1 = i-frame, 2 = p-frame
+    size_t pos_after = 0;                // stream position once this event has been consumed
+    const uint8_t *payload = nullptr;
+    uint32_t plen = 0;
+    uint8_t qidx[3] = {0, 0, 0};
+    PinnedBuf<int16_t> coef;
+    PinnedBuf<int8_t> mv;
+    PinnedBuf<uint8_t> has;
 };
 
 struct pfv_decoder {
@@ -1054,10 +1100,16 @@ struct pfv_decoder {
     int width = 0, height = 0, framerate = 0, n_qtables = 0, total_blocks = 0;
     bool eof = false;
     double delta_accum = 0.0;
-    std::vector<int16_t> coef;
-    std::vector<int8_t> mv;
-    std::vector<uint8_t> has;
-    std::vector<uint8_t> retframe;         // Y|U|V, unpadded (src/dec.rs:22)
+    PinnedBuf<uint8_t> retframe;           // Y|U|V, unpadded (src/dec.rs:22)
+    // look-ahead: ring of events in stream order, [head, head + count)
+    std::vector<std::unique_ptr<DecEvent>> ring;
+    size_t head = 0, count = 0;
+    size_t scan_pos = 0;
+    bool scan_stop = false;                // an END / ERROR event is pending: nothing is scanned past it
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    bool quit = false;
 };
 
 static void put_u16(std::vector<uint8_t> &o, unsigned v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); }
@@ -1083,10 +1135,10 @@ PFV_API int pfv_encoder_create(pfv_ctx *ctx, int width, int height, int framerat
     pfv_encoder *e = new pfv_encoder();
     e->ctx = ctx; e->hot = hot; e->width = width; e->height = height; e->framerate = framerate;
     e->total_blocks = pfv_total_blocks(width, height);
-    e->frame.resize(pfv_frame_bytes(width, height));
-    e->coef.resize((size_t)e->total_blocks * 256);
-    e->mv.resize((size_t)e->total_blocks * 2);
-    e->has.resize((size_t)e->total_blocks);
+    if (!e->frame.resize(pfv_frame_bytes(width, height))) {
+        pfv_encoder_destroy(e);
+        return fail(ctx, PFV_ERR_NOMEM, "pfv_encoder_create: pinned staging");
+    }
     int32_t q[4][64];
     pfv_qtables_from_quality(quality, q[0], q[1], q[2], q[3], nullptr);
     static const char magic[8] = {'P', 'F', 'V', 'I', 'D', 'E', 'O', 0};      // common.rs:1
@@ -1111,6 +1163,13 @@ static int pack_frame(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const 
     return PFV_OK;
 }
 
+static int host_entropy_staging(pfv_encoder *e)
+{
+    if (e->coef.resize((size_t)e->total_blocks * 256) && e->mv.resize((size_t)e->total_blocks * 2) && e->has.resize((size_t)e->total_blocks))
+        return PFV_OK;
+    return fail(e->ctx, PFV_ERR_NOMEM, "pinned staging for the host entropy path");
+}
+
 // One frame through the device entropy stage: planes up, kernels, payload size then payload bytes down.
 static int encode_on_device(pfv_encoder *e, bool pframe)
 {
@@ -1126,11 +1185,12 @@ static int encode_on_device(pfv_encoder *e, bool pframe)
     uint32_t nbytes = 0;
     if (!rc) rc = pfv_enc_payload_sizes(s, &nbytes);
     if (rc) return rc;
+    if (!e->payload.resize(std::max<size_t>(nbytes, 1 << 20))) return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
+    if ((rc = pfv_enc_payload_fetch(s, 0, e->payload.data(), nbytes))) return rc;
     e->out.push_back(pframe ? 2 : 1);
     put_u32(e->out, nbytes);
-    size_t at = e->out.size();
-    e->out.resize(at + nbytes);
-    return pfv_enc_payload_fetch(s, 0, e->out.data() + at, nbytes);
+    e->out.insert(e->out.end(), e->payload.data(), e->payload.data() + nbytes);
+    return PFV_OK;
 }
 
 // 1 (default): RLE + Huffman + bit packing on the device; 0: on the host (serialize_iframe / serialize_pframe).  The
@@ -1149,6 +1209,7 @@ PFV_API int pfv_encoder_encode_iframe(pfv_encoder *e, const uint8_t *y, const ui
     int rc = pack_frame(e, y, u, v);
     if (rc) return rc;
     if (e->device_entropy) return encode_on_device(e, false);
+    if ((rc = host_entropy_staging(e))) return rc;
     if ((rc = pfv_enc_iframe(e->hot, e->frame.data(), e->coef.data()))) return rc;
     std::vector<uint8_t> payload;
     if (!serialize_iframe(payload, e->coef.data(), e->total_blocks))
@@ -1163,6 +1224,7 @@ PFV_API int pfv_encoder_encode_pframe(pfv_encoder *e, const uint8_t *y, const ui
     int rc = pack_frame(e, y, u, v);
     if (rc) return rc;
     if (e->device_entropy) return encode_on_device(e, true);
+    if ((rc = host_entropy_staging(e))) return rc;
     if ((rc = pfv_enc_pframe(e->hot, e->frame.data(), e->mv.data(), e->has.data(), e->coef.data()))) return rc;
     std::vector<uint8_t> payload;
     if (!serialize_pframe(payload, e->mv.data(), e->has.data(), e->coef.data(), e->total_blocks))
@@ -1240,20 +1302,151 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
     if (rc) return rc;
     pfv_decoder *d = new pfv_decoder();
     d->ctx = ctx; d->hot = hot; d->data = data; d->len = len;
-    d->pos = d->reset_pos = 20 + (size_t)nq * 128;
+    d->pos = d->reset_pos = d->scan_pos = 20 + (size_t)nq * 128;
     d->width = w; d->height = h; d->framerate = fps; d->n_qtables = nq;
     d->total_blocks = pfv_total_blocks(w, h);
-    d->coef.resize((size_t)d->total_blocks * 256);
-    d->mv.resize((size_t)d->total_blocks * 2);
-    d->has.resize((size_t)d->total_blocks);
-    d->retframe.assign(pfv_frame_bytes(w, h), 0);                              // VideoFrame::new (frame.rs:12-26): Y 0, U/V 128
-    std::fill(d->retframe.begin() + (size_t)w * h, d->retframe.end(), (uint8_t)128);
+    if (!d->retframe.resize(pfv_frame_bytes(w, h))) {
+        pfv_decoder_destroy(d);
+        return fail(ctx, PFV_ERR_NOMEM, "pfv_decoder_create: pinned staging");
+    }
+    memset(d->retframe.data(), 0, (size_t)w * h);                              // VideoFrame::new (frame.rs:12-26): Y 0, U/V 128
+    memset(d->retframe.data() + (size_t)w * h, 128, d->retframe.size() - (size_t)w * h);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if ((rc = pfv_decoder_set_lookahead(d, hw > 1 ? (int)std::min(4u, hw - 1) : 0))) {
+        pfv_decoder_destroy(d);
+        return rc;
+    }
     *out = d;
     return PFV_OK;
 }
+}  // extern "C"
+
+// ---- look-ahead machinery of pfv_decoder
+static void dec_parse(pfv_decoder *d, DecEvent *e)   // any thread; touches only the event and the immutable stream
+{
+    const size_t tb = (size_t)d->total_blocks;
+    if (!e->coef.resize(tb * 256) || (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb)))) {
+        e->rc = PFV_ERR_NOMEM;
+        return;
+    }
+    e->rc = e->type == 1 ? parse_iframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->coef.data(), e->qidx)
+                         : parse_pframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->mv.data(), e->has.data(),
+                                        e->coef.data(), e->qidx);
+}
+static void dec_worker(pfv_decoder *d)
+{
+    (void)hipSetDevice(d->ctx->device);   // the pinned landing zones are allocated from this thread
+    std::unique_lock<std::mutex> lk(d->m);
+    for (;;) {
+        DecEvent *job = nullptr;
+        for (size_t k = 0; k < d->count && !job; k++) {
+            DecEvent *e = d->ring[(d->head + k) % d->ring.size()].get();
+            if (e->state == DecEvent::QUEUED) job = e;
+        }
+        if (d->quit) return;
+        if (!job) { d->cv_work.wait(lk); continue; }
+        job->state = DecEvent::RUNNING;
+        lk.unlock();
+        dec_parse(d, job);
+        lk.lock();
+        job->state = DecEvent::DONE;
+        d->cv_done.notify_all();
+    }
+}
+// Walks packet headers from scan_pos exactly as the reference's loop would (dec.rs:174-222) and queues what it finds
+// until the ring is full or an END / ERROR event is pending.  Caller holds the lock.
+static void dec_scan(pfv_decoder *d)
+{
+    bool queued = false;
+    while (d->count < d->ring.size() && !d->scan_stop) {
+        DecEvent *e = d->ring[(d->head + d->count) % d->ring.size()].get();
+        size_t pos = d->scan_pos;
+        auto emit = [&](DecEvent::Kind kind, DecEvent::State st, size_t pos_after) {
+            e->kind = kind; e->state = st; e->pos_after = pos_after;
+            d->count++;
+        };
+        if (pos + 5 > d->len) {
+            e->rc = PFV_ERR_IO; e->msg = "unexpected end of stream in a packet header";
+            emit(DecEvent::ERROR, DecEvent::DONE, pos);
+            d->scan_stop = true;
+            break;
+        }
+        const uint8_t type = d->data[pos];
+        const uint32_t plen = (uint32_t)d->data[pos + 1] | ((uint32_t)d->data[pos + 2] << 8) | ((uint32_t)d->data[pos + 3] << 16) |
+                              ((uint32_t)d->data[pos + 4] << 24);
+        pos += 5;
+        if (type == 0) {   // EOF marker (:183-187)
+            emit(DecEvent::END, DecEvent::DONE, pos);
+            d->scan_stop = true;
+            break;
+        }
+        if (pos + plen > d->len) {
+            e->rc = PFV_ERR_IO; e->msg = "packet payload runs past the end of the stream";
+            emit(DecEvent::ERROR, DecEvent::DONE, pos);
+            d->scan_stop = true;
+            break;
+        }
+        const uint8_t *payload = d->data + pos;
+        pos += plen;
+        d->scan_pos = pos;
+        if (type != 1 && type != 2) continue;   // unknown packet: skipped (:216-219)
+        if (type == 1 && plen == 0) {           // drop frame: nothing decoded, no callback (:190)
+            emit(DecEvent::DROP, DecEvent::DONE, pos);
+            continue;
+        }
+        e->type = type; e->payload = payload; e->plen = plen; e->rc = 0;
+        emit(DecEvent::FRAME, DecEvent::QUEUED, pos);
+        queued = true;
+    }
+    if (queued) d->cv_work.notify_all();
+}
+// Forget everything scanned ahead and continue from `pos`.  Caller holds the lock.
+static void dec_rewind(pfv_decoder *d, std::unique_lock<std::mutex> &lk, size_t pos)
+{
+    for (;;) {   // a parse in flight keeps pointers into its event: let it finish
+        bool running = false;
+        for (auto &e : d->ring) running |= e->state == DecEvent::RUNNING;
+        if (!running) break;
+        d->cv_done.wait(lk);
+    }
+    for (auto &e : d->ring) e->state = DecEvent::FREE;
+    d->head = d->count = 0;
+    d->scan_pos = d->pos = pos;
+    d->scan_stop = false;
+}
+static void dec_stop_workers(pfv_decoder *d)
+{
+    {
+        std::lock_guard<std::mutex> lk(d->m);
+        d->quit = true;
+    }
+    d->cv_work.notify_all();
+    for (auto &t : d->workers) t.join();
+    d->workers.clear();
+    d->quit = false;
+}
+
+extern "C" {
+
+// Packets parsed ahead of the one being decoded, on `n_threads` worker threads (0: parse inline, no threads).  The
+// default is min(4, hardware threads - 1).  Frames, order and error codes are those of the sequential loop.
+PFV_API int pfv_decoder_set_lookahead(pfv_decoder *d, int n_threads)
+{
+    if (!d || n_threads < 0 || n_threads > 64) return fail(d ? d->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_decoder_set_lookahead: bad argument");
+    dec_stop_workers(d);
+    std::unique_lock<std::mutex> lk(d->m);
+    dec_rewind(d, lk, d->pos);
+    d->ring.clear();
+    for (int i = 0; i < n_threads + 1; i++) d->ring.emplace_back(new DecEvent());
+    lk.unlock();
+    for (int i = 0; i < n_threads; i++) d->workers.emplace_back(dec_worker, d);
+    return PFV_OK;
+}
+
 PFV_API void pfv_decoder_destroy(pfv_decoder *d)
 {
     if (!d) return;
+    dec_stop_workers(d);
     pfv_dec_session_destroy(d->hot);
     delete d;
 }
@@ -1264,8 +1457,9 @@ PFV_API int pfv_decoder_framerate(const pfv_decoder *d) { return d ? d->framerat
 PFV_API int pfv_decoder_reset(pfv_decoder *d)
 {
     if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    std::unique_lock<std::mutex> lk(d->m);
     d->eof = false;
-    d->pos = d->reset_pos;
+    dec_rewind(d, lk, d->reset_pos);
     return PFV_OK;
 }
 
@@ -1275,35 +1469,52 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
 {
     if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
     if (d->eof) return 0;
-    for (;;) {
-        if (d->pos + 5 > d->len) return fail(d->ctx, PFV_ERR_IO, "unexpected end of stream in a packet header");
-        uint8_t type = d->data[d->pos];
-        uint32_t plen = (uint32_t)d->data[d->pos + 1] | ((uint32_t)d->data[d->pos + 2] << 8) | ((uint32_t)d->data[d->pos + 3] << 16) |
-                        ((uint32_t)d->data[d->pos + 4] << 24);
-        d->pos += 5;
-        if (type == 0) {   // EOF marker (:183-187)
+    std::unique_lock<std::mutex> lk(d->m);
+    dec_scan(d);
+    DecEvent *e = d->ring[d->head].get();
+    while (e->state != DecEvent::DONE) {
+        if (e->state == DecEvent::QUEUED) {   // nobody picked it up yet: parse it here
+            e->state = DecEvent::RUNNING;
+            lk.unlock();
+            dec_parse(d, e);
+            lk.lock();
+            e->state = DecEvent::DONE;
+        } else {
+            d->cv_done.wait(lk);
+        }
+    }
+    // consume the event; the slot stays reserved (FREE but not rescanned) until the device has read its buffers
+    d->pos = e->pos_after;
+    const DecEvent::Kind kind = e->kind;
+    if (kind == DecEvent::END || kind == DecEvent::ERROR) {
+        const int rc = e->rc;
+        const char *msg = e->msg;
+        dec_rewind(d, lk, d->pos);   // nothing was scanned past it; the next call rescans from pos like the reference
+        if (kind == DecEvent::END) {
             d->eof = true;
             return 0;
         }
-        if (d->pos + plen > d->len) return fail(d->ctx, PFV_ERR_IO, "packet payload runs past the end of the stream");
-        const uint8_t *payload = d->data + d->pos;
-        d->pos += plen;
-        if (type != 1 && type != 2) continue;   // unknown packet: skipped (:216-219)
-        if (type == 1 && plen == 0) break;      // drop frame: nothing decoded, no callback (:190)
-        uint8_t qidx[3];
-        int rc = type == 1 ? parse_iframe(payload, plen, d->total_blocks, d->n_qtables, d->coef.data(), qidx)
-                           : parse_pframe(payload, plen, d->total_blocks, d->n_qtables, d->mv.data(), d->has.data(),
-                                          d->coef.data(), qidx);
-        if (rc) return fail(d->ctx, rc, "malformed packet payload");
-        rc = type == 1 ? pfv_dec_iframe(d->hot, d->coef.data(), qidx)
-                       : pfv_dec_pframe(d->hot, d->mv.data(), d->has.data(), d->coef.data(), qidx);
-        if (rc) return rc;
-        if ((rc = pfv_dec_get_frame(d->hot, d->retframe.data()))) return rc;   // crop blits (:195-197, 209-211)
-        if (onvideo) {
-            size_t ny = (size_t)d->width * d->height, nc = (size_t)(d->width / 2) * (d->height / 2);
-            onvideo(user, d->retframe.data(), d->retframe.data() + ny, d->retframe.data() + ny + nc, d->width, d->height);
-        }
-        break;
+        return fail(d->ctx, rc, msg);
+    }
+    int rc = PFV_OK;
+    if (kind == DecEvent::FRAME) {
+        lk.unlock();   // workers keep parsing the packets behind this one while the device decodes it
+        rc = e->rc;
+        if (rc) rc = fail(d->ctx, rc, rc == PFV_ERR_NOMEM ? "pinned staging for a parsed packet" : "malformed packet payload");
+        if (!rc) rc = e->type == 1 ? pfv_dec_iframe(d->hot, e->coef.data(), e->qidx)
+                                   : pfv_dec_pframe(d->hot, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
+        if (!rc) rc = pfv_dec_get_frame(d->hot, d->retframe.data());   // crop blits (:195-197, 209-211)
+        lk.lock();
+    }
+    e->state = DecEvent::FREE;
+    d->head = (d->head + 1) % d->ring.size();
+    d->count--;
+    dec_scan(d);       // refill the freed slot right away
+    lk.unlock();
+    if (rc) return rc;
+    if (kind == DecEvent::FRAME && onvideo) {
+        size_t ny = (size_t)d->width * d->height, nc = (size_t)(d->width / 2) * (d->height / 2);
+        onvideo(user, d->retframe.data(), d->retframe.data() + ny, d->retframe.data() + ny + nc, d->width, d->height);
     }
     return 1;
 }

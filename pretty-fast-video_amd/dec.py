@@ -22,7 +22,7 @@ class DecodeError(_lib.PfvError):
 
 
 class Decoder:
-    def __init__(self, reader, ctx: Context):
+    def __init__(self, reader, ctx: Context, lookahead: int | None = None):
         data = reader.read() if hasattr(reader, "read") else bytes(reader)
         self._data = np.frombuffer(data, dtype=np.uint8).copy()     # must outlive the native decoder
         self.ctx = ctx
@@ -33,6 +33,8 @@ class Decoder:
             raise DecodeError(rc, msg.decode() if msg else "")
         self.handle = h
         ctx._sessions.add(self)
+        if lookahead is not None:                                   # packets parsed ahead on this many worker threads
+            ctx.check(ctx._lib.pfv_decoder_set_lookahead(h, int(lookahead)))
 
     def width(self) -> int:
         return self.ctx._lib.pfv_decoder_width(self.handle)

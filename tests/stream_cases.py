@@ -114,11 +114,11 @@ def check_header_errors(pkg, ctx, data):
     dec.close()
 
 
-def _outcomes_product(pkg, ctx, data):
+def _outcomes_product(pkg, ctx, data, lookahead=None):
     """one entry per advance_frame call: ('frame', bytes) / ('none',) / ('eof',) / ('err', code)"""
     out = []
     try:
-        dec = pkg.Decoder(data, ctx)
+        dec = pkg.Decoder(data, ctx, lookahead=lookahead)
     except pkg.PfvError as e:
         return [("open-err", e.code)]
     try:
@@ -168,7 +168,7 @@ def check_corrupted_streams(pkg, ctx, oracle, data, n_trials, seed):
             bad[pos] = int(rng.integers(0, 256))
         if rng.random() < 0.25:
             bad = bad[: int(rng.integers(hdr, len(bad)))]
-        a = _outcomes_product(pkg, ctx, bytes(bad))
+        a = _outcomes_product(pkg, ctx, bytes(bad), lookahead=(None, 0, 3)[stats["trials"] % 3])   # default / inline / 3 workers
         b = _outcomes_oracle(oracle, bytes(bad))
         assert len(a) == len(b), (a[-1][:1], b[-1][:1], [x[0] for x in a], [x[0] for x in b])
         for k, (x, y) in enumerate(zip(a, b)):
@@ -181,3 +181,21 @@ def check_corrupted_streams(pkg, ctx, oracle, data, n_trials, seed):
         stats["trials"] += 1
         stats["errors"] += a[-1][0] == "err"
     return stats
+
+
+def check_lookahead_reset(pkg, ctx, data, n_frames):
+    """reset() and set_lookahead in mid-stream drop whatever was parsed ahead; decoding restarts cleanly"""
+    ref = [x[1] for x in _outcomes_product(pkg, ctx, data, lookahead=0) if x[0] == "frame"]
+    assert len(ref) == n_frames
+    dec = pkg.Decoder(data, ctx, lookahead=3)
+    got = []
+    for _ in range(2):
+        assert dec.advance_frame(lambda fr: got.append(fr.packed().tobytes()))
+    dec.reset()
+    ctx.check(ctx._lib.pfv_decoder_set_lookahead(dec.handle, 1))
+    assert dec.advance_frame(lambda fr: got.append(fr.packed().tobytes()))
+    ctx.check(ctx._lib.pfv_decoder_set_lookahead(dec.handle, 2))      # mid-stream: position is kept
+    while dec.advance_frame(lambda fr: got.append(fr.packed().tobytes())):
+        pass
+    assert got == ref[:2] + ref
+    dec.close()

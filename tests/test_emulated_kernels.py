@@ -63,6 +63,7 @@ def test_emu_corrupted_streams(pkg, emu_ctx, oracle):
     data, _ = sc.encode_clip(pkg, emu_ctx, oracle, 48, 32, 30, 5, n_frames=4, gop=2)
     stats = sc.check_corrupted_streams(pkg, emu_ctx, oracle, data, n_trials=40, seed=5)
     assert stats["trials"] == 40
+    sc.check_lookahead_reset(pkg, emu_ctx, data, n_frames=4)
 
 
 def test_emu_device_entropy(pkg, emu_ctx, oracle):

@@ -215,6 +215,7 @@ def test_corrupted_streams_match_oracle(pkg, gpu_ctx, oracle, geom):
     data, _ = sc.encode_clip(pkg, gpu_ctx, oracle, w, h, 30, q, n_frames=n, gop=gop)
     stats = sc.check_corrupted_streams(pkg, gpu_ctx, oracle, data, n_trials=120, seed=w + h)
     assert stats["trials"] == 120 and stats["frames"] > 0
+    sc.check_lookahead_reset(pkg, gpu_ctx, data, n_frames=n)
 
 
 @pytest.mark.parametrize("geom", [(48, 32, 2), (176, 144, 3), (34, 18, 1), (640, 360, 2)])

@@ -36,27 +36,43 @@ with pkg.Context(0) as ctx:
     res["pcie_inclusive_mb_per_s"] = GOP * S * enc.total_blocks / el
     res["pcie_inclusive_note"] = f"{S} streams, pageable host buffers, synchronous host-pointer entry points, encode+decode+retframe download"
     enc.close(); dec.close()
-    # (iii) end to end with host entropy + container: one stream through Encoder / Decoder
-    buf = io.BytesIO()
-    e = pkg.Encoder(buf, W, H, 30, Q, ctx)
+    # (iii) end to end through the stream objects: one 1080p stream, 4 GOPs, Encoder -> .pfv bytes -> Decoder
+    import ctypes
+    lib = ctx._lib
+    NG = 4
     vf = [pkg.VideoFrame.from_packed(W, H, f) for f in frames1]
-    t0 = time.perf_counter()
-    for t, f in enumerate(vf):
-        (e.encode_iframe if t == 0 else e.encode_pframe)(f)
-    e.finish()
-    t_enc = time.perf_counter() - t0
-    e.close()
-    data = buf.getvalue()
-    d = pkg.Decoder(data, ctx)
-    n = [0]
-    t0 = time.perf_counter()
-    while d.advance_frame(lambda fr: n.__setitem__(0, n[0] + 1)):
-        pass
-    t_dec = time.perf_counter() - t0
-    d.close()
-    assert n[0] == GOP
-    nmb = GOP * 12240
-    res.update({"end_to_end_encode_mb_per_s": nmb / t_enc, "end_to_end_decode_mb_per_s": nmb / t_dec,
-                "end_to_end_encdec_mb_per_s": nmb / (t_enc + t_dec), "stream_bytes": len(data),
-                "end_to_end_note": "one 1080p stream, GOP-15, host RLE/Huffman/bit-packing (single host thread) + PCIe + kernels"})
+    nmb = NG * GOP * 12240
+    data = None
+    for mode, dev in (("host_entropy", False), ("device_entropy", True)):
+        best = 0.0
+        for rep in range(2):
+            buf = io.BytesIO()
+            e = pkg.Encoder(buf, W, H, 30, Q, ctx, device_entropy=dev)
+            t0 = time.perf_counter()
+            for g_ in range(NG):
+                for t, f in enumerate(vf):
+                    (e.encode_iframe if t == 0 else e.encode_pframe)(f)
+            e.finish()
+            best = max(best, nmb / (time.perf_counter() - t0))
+            e.close()
+            assert data is None or data == buf.getvalue()      # both entropy paths write the same bytes
+            data = buf.getvalue()
+        res[f"end_to_end_encode_{mode}_mb_per_s"] = best
+    arr = np.frombuffer(data, np.uint8)
+    for name, la in (("inline_parse", 0), ("lookahead_4", 4), ("lookahead_8", 8)):
+        best = 0.0
+        for rep in range(2):
+            d = pkg.Decoder(data, ctx, lookahead=la)
+            n = 0
+            t0 = time.perf_counter()
+            while lib.pfv_decoder_advance_frame(d.handle, None, None) == 1:      # C entry point, no Python callback
+                n += 1
+            best = max(best, nmb / (time.perf_counter() - t0))
+            d.close()
+            assert n == NG * GOP
+        res[f"end_to_end_decode_{name}_mb_per_s"] = best
+    res.update({"stream_bytes": len(data),
+                "end_to_end_note": "one 1080p stream, 4 x GOP-15, pinned staging; encode = upload + kernels (+ device entropy | + "
+                                   "coefficient download + host entropy) + packet assembly; decode = host bit parser (inline or on "
+                                   "look-ahead threads) + upload + kernels + retframe download"})
 print(json.dumps(res, indent=1))
