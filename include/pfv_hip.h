@@ -113,6 +113,11 @@ PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int s
 /* ------------------------------------------------------------------ device memory helpers */
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);
 PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p);
+/* page-locked host memory (hipHostMalloc) for the buffers handed to the host-pointer entry points: uploads / downloads
+ * from it run at PCIe rate instead of bouncing through the runtime's staging (the reference's Vec<u8> planes,
+ * src/plane.rs:1-5, would be allocated here by a binding that cares) */
+PFV_API int pfv_host_alloc(pfv_ctx *ctx, size_t bytes, void **out);
+PFV_API int pfv_host_free(pfv_ctx *ctx, void *p);
 PFV_API int pfv_dev_upload(pfv_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 PFV_API int pfv_dev_download(pfv_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 

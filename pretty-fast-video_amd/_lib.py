@@ -53,6 +53,8 @@ SIGNATURES = [
     ("pfv_double_dev", c_int, [_P, _P, _P, c_int, c_int]),
     ("pfv_dev_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
     ("pfv_dev_free", c_int, [_P, _P]),
+    ("pfv_host_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
+    ("pfv_host_free", c_int, [_P, _P]),
     ("pfv_dev_upload", c_int, [_P, _P, _P, c_size_t]),
     ("pfv_dev_download", c_int, [_P, _P, _P, c_size_t]),
     ("pfv_frame_bytes", c_size_t, [c_int, c_int]),

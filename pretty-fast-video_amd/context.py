@@ -25,12 +25,16 @@ class Context:
         self.handle = h
         self.device = int(device)
         self._sessions = weakref.WeakSet()   # sessions die with their context (they hold device buffers of it)
+        self._pinned = []                    # page-locked host blocks handed out by host_array()
 
     # -- lifetime
     def close(self):
         if getattr(self, "handle", None):
             for s in list(self._sessions):
                 s.close()
+            for p in self._pinned:
+                self._lib.pfv_host_free(self.handle, ctypes.c_void_p(p))
+            self._pinned = []
             self._lib.pfv_ctx_destroy(self.handle)
             self.handle = None
 
@@ -64,6 +68,13 @@ class Context:
 
     def free(self, ptr: int):
         self.check(self._lib.pfv_dev_free(self.handle, ctypes.c_void_p(ptr)))
+
+    def host_array(self, nbytes: int) -> np.ndarray:
+        """uint8 array over page-locked host memory (freed when the context closes)"""
+        p = ctypes.c_void_p()
+        self.check(self._lib.pfv_host_alloc(self.handle, int(nbytes), ctypes.byref(p)))
+        self._pinned.append(p.value)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(nbytes),))
 
     def upload(self, dst_dev: int, src: np.ndarray):
         src = np.ascontiguousarray(src)

@@ -474,6 +474,22 @@ PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p)
     HIP_TRY(ctx, hipFree(p));
     return PFV_OK;
 }
+// Page-locked host memory for the host-buffer entry points: copies from / to it run at PCIe rate.
+PFV_API int pfv_host_alloc(pfv_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out || !bytes) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_host_alloc: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return PFV_OK;
+}
+PFV_API int pfv_host_free(pfv_ctx *ctx, void *p)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!p) return PFV_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipHostFree(p));
+    return PFV_OK;
+}
 PFV_API int pfv_dev_upload(pfv_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (!ctx || !dst_dev || !src_host) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dev_upload: bad argument");

@@ -169,3 +169,47 @@ def test_forward_dct_is_exact(oracle):
         assert np.array_equal(rows_ref, rows_fl) and not (rows_ref & 15).any()     # row outputs: multiples of 16
         cols_ref = onp.fdct(np.swapaxes(rows_ref, -1, -2))
         assert np.array_equal(cols_ref, fdct_floor(np.swapaxes(rows_fl, -1, -2)))
+
+
+def test_config1_plumbing_161_frames_1080p(oracle, pkg):
+    """BASELINE config #1 (the reference's own CPU-runnable case; its test_frames/ fixtures are Git-LFS stubs, so the
+    161 frames are synthetic 1080p): encode_iframe every 15th frame, encode_pframe otherwise, q=5, on the
+    CPU oracle -> .pfv bytes -> decode; every decoded frame equals the encoder's closed-loop reconstruction."""
+    from oracle_bind import OracleEncoder, OracleStreamDecoder, OracleStreamEncoder
+    W, H, Q, N = 1920, 1080, 5, 161
+    th = min(8, os.cpu_count() or 1)
+    st = pkg.SyntheticStream(W, H)
+    senc = OracleStreamEncoder(oracle, W, H, 30, Q, threads=th)
+    henc = OracleEncoder(oracle, W, H, Q, threads=th)          # same hot path; exposes prev_frame
+    pw = henc.prev_frame().size
+    recon_sums = []
+    ny, nc = W * H, (W // 2) * (H // 2)
+    pwy, phy = 1920, 1088
+    for t in range(N):
+        f = st.frame(t % 30)                                    # 30 distinct frames, replayed (generation is the slow part)
+        if t % 15 == 0:
+            senc.encode_iframe(f); henc.encode_iframe(f)
+        else:
+            senc.encode_pframe(f); henc.encode_pframe(f)
+        p = henc.prev_frame()
+        y = p[:pwy * phy].reshape(phy, pwy)[:H, :W]
+        u = p[pwy * phy:pwy * phy + 960 * 544].reshape(544, 960)[:H // 2, :W // 2]
+        v = p[pwy * phy + 960 * 544:].reshape(544, 960)[:H // 2, :W // 2]
+        recon_sums.append((int(y.sum()), int(u.sum()), int(v.sum()), bytes(y[H // 2, :64])))
+    senc.finish()
+    data = senc.bytes()
+    assert 161 * 20 < len(data) < 161 * W * H                  # a real stream, smaller than raw
+    dec = OracleStreamDecoder(oracle, data, threads=th)
+    assert (dec.width, dec.height, dec.framerate) == (W, H, 30)
+    n = 0
+    while True:
+        rc, fr = dec.advance_frame()
+        assert rc >= 0
+        if fr is not None:
+            y, u, v = fr[:ny].reshape(H, W), fr[ny:ny + nc], fr[ny + nc:]
+            assert (int(y.sum()), int(u.sum()), int(v.sum()), bytes(y[H // 2, :64])) == recon_sums[n], f"frame {n}"
+            n += 1
+        if rc == 0:
+            break
+    assert n == N
+    assert pw == pwy * phy + 2 * 960 * 544
