@@ -39,6 +39,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOP = 15
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_MB_PENC = 1284        # src 256 + ref 256 + coef 512 + mv/flag 4 + recon 256
+# algorithmic bytes per macroblock of the other three codec kernels + 256 for the retframe crop the
+# decode kernels fuse (src/dec.rs:195-197, 209-211)
+BYTES_PER_MB = {"k_enc_iframe": 1024, "k_enc_pframe": BYTES_PER_MB_PENC, "k_dec_iframe": 768 + 256, "k_dec_pframe": 1028 + 256}
 
 
 def parse():
@@ -163,22 +166,33 @@ def main():
     torch.cuda.synchronize()
 
     ev_pairs = []
+    ev_other = {"k_enc_iframe": [], "k_dec_iframe": [], "k_dec_pframe": []}
 
     def step(timed: bool):
+        # HIP events on the kernels' own stream bracket every launch of the timed steps: k_enc_pframe for the roofline
+        # object, the other three for the per-kernel table (one event = ~1 us of host time, inside the timed region)
+        def ev():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            return e
         for t in range(GOP):
             f = frames[t].data_ptr()
             if t == 0:
+                a = ev() if timed else None
                 enc.encode_iframe_dev(f, coef.data_ptr())
+                b = ev() if timed else None
                 dec.decode_iframe_dev(coef.data_ptr())
+                if timed:
+                    ev_other["k_enc_iframe"].append((a, b))
+                    ev_other["k_dec_iframe"].append((b, ev()))
             else:
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
+                a = ev() if timed else None
                 enc.encode_pframe_dev(f, mv.data_ptr(), has.data_ptr(), coef.data_ptr())
-                if timed:
-                    e1.record(stream)
-                    ev_pairs.append((e0, e1))
+                b = ev() if timed else None
                 dec.decode_pframe_dev(mv.data_ptr(), has.data_ptr(), coef.data_ptr())
+                if timed:
+                    ev_pairs.append((a, b))
+                    ev_other["k_dec_pframe"].append((b, ev()))
 
     for _ in range(args.warmup):
         step(False)
@@ -277,6 +291,12 @@ def main():
         }
         res["pframe_encode"] = {"value": launch_mbs / (pe_ms * 1e-3), "unit": "macroblocks/s",
                                 "note": "k_enc_pframe alone (motion search + residual DCT + closed-loop reconstruction), HIP-event time"}
+        kern = {"k_enc_pframe": pe_ms}
+        kern.update({k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev_other.items() if v})
+        res["kernels"] = {k: {"avg_launch_ms": ms, "macroblocks_per_s": launch_mbs / (ms * 1e-3),
+                              "algorithmic_GBps": launch_mbs * BYTES_PER_MB[k] / (ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": launch_mbs * BYTES_PER_MB[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                          for k, ms in kern.items()}
         if ent:
             res["encode_to_payload"] = ent
         if not args.no_cpu_baseline and world == 1:
