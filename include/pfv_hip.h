@@ -199,6 +199,12 @@ PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const u
 PFV_API int pfv_dec_iframe(pfv_dec_session *s, const int16_t *coef, const uint8_t qidx[3]);
 PFV_API int pfv_dec_pframe(pfv_dec_session *s, const int8_t *mv, const uint8_t *has_coef, const int16_t *coef,
                            const uint8_t qidx[3]);
+/* Sparse forms: the non-zero coefficients as n (flat index into [stream][macroblock][256], value) pairs -- what the
+ * bit parser (src/dec.rs:261-296, 378-417) produces before it is spread into the dense vector; ~10x fewer bytes over
+ * PCIe.  Same result as the dense call on the expanded array; indices past the frame are ignored. */
+PFV_API int pfv_dec_iframe_sparse(pfv_dec_session *s, const uint32_t *idx, const int16_t *val, size_t n, const uint8_t qidx[3]);
+PFV_API int pfv_dec_pframe_sparse(pfv_dec_session *s, const int8_t *mv, const uint8_t *has_coef, const uint32_t *idx,
+                                  const int16_t *val, size_t n, const uint8_t qidx[3]);
 /* Decoder::advance_frame's crop of framebuffer into retframe (src/dec.rs:195-197,
  * 209-211): frames_out = n_streams unpadded frames (Y|U|V). */
 PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev);

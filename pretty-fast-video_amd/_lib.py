@@ -76,6 +76,8 @@ SIGNATURES = [
     ("pfv_enc_payload_dev", _P, [_P, c_int]),
     ("pfv_enc_payload_capacity", c_size_t, [_P]),
     ("pfv_enc_payload_fetch", c_int, [_P, c_int, _P, c_size_t]),
+    ("pfv_dec_iframe_sparse", c_int, [_P, _P, _P, c_size_t, _P]),
+    ("pfv_dec_pframe_sparse", c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),
     ("pfv_dec_session_create", c_int, [_P, c_int, c_int, _P, c_int, c_int, POINTER(_P)]),
     ("pfv_dec_session_destroy", None, [_P]),
     ("pfv_dec_iframe_dev", c_int, [_P, _P, _P]),

@@ -566,6 +566,9 @@ struct pfv_dec_session {
     int8_t *st_mv = nullptr;
     uint8_t *st_has = nullptr;
     uint8_t *st_frames = nullptr;
+    uint32_t *st_idx = nullptr;              // sparse coefficient upload (pfv_dec_*_sparse)
+    int16_t *st_val = nullptr;
+    size_t st_sparse_cap = 0;
 };
 
 extern "C" {
@@ -884,7 +887,7 @@ PFV_API void pfv_dec_session_destroy(pfv_dec_session *s)
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    void *bufs[] = {s->qtab_dev, s->fb[0], s->fb[1], s->flag_dev, s->st_coef, s->st_mv, s->st_has, s->st_frames};
+    void *bufs[] = {s->qtab_dev, s->fb[0], s->fb[1], s->flag_dev, s->st_coef, s->st_mv, s->st_has, s->st_frames, s->st_idx, s->st_val};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -1012,6 +1015,64 @@ PFV_API int pfv_dec_pframe(pfv_dec_session *s, const int8_t *mv, const uint8_t *
     return pfv_dec_check(s);
 }
 
+// Sparse forms of pfv_dec_iframe / pfv_dec_pframe: the non-zero coefficients as (flat index into
+// [stream][macroblock][256], value) pairs, everything else zero.  Same result as the dense call on the expanded array.
+static int dec_upload_sparse(pfv_dec_session *s, const uint32_t *idx, const int16_t *val, size_t n)
+{
+    pfv_ctx *ctx = s->ctx;
+    int rc = dec_staging(s);
+    if (rc) return rc;
+    const size_t total = (size_t)s->geom.mbs_per_frame * s->n_streams * 256;
+    if (n > total || total > 0xffffffffull) return fail(ctx, PFV_ERR_BAD_ARG, "sparse coefficient list longer than the frame");
+    if (n > s->st_sparse_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (s->st_idx) (void)hipFree(s->st_idx);
+        if (s->st_val) (void)hipFree(s->st_val);
+        s->st_idx = nullptr; s->st_val = nullptr; s->st_sparse_cap = 0;
+        const size_t cap = std::max(n, total / 8);
+        HIP_TRY(ctx, hipMalloc((void **)&s->st_idx, cap * 4));
+        HIP_TRY(ctx, hipMalloc((void **)&s->st_val, cap * 2));
+        s->st_sparse_cap = cap;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(s->st_coef, 0, total * 2, ctx->stream));
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(s->st_idx, idx, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(s->st_val, val, n * 2, hipMemcpyHostToDevice, ctx->stream));
+        const unsigned blocks = (unsigned)std::min<size_t>((n + kThreads - 1) / kThreads, 4096);
+        hipLaunchKernelGGL(k_scatter_coef, dim3(blocks), dim3(kThreads), 0, ctx->stream, s->st_idx, s->st_val, (uint32_t)n, (uint32_t)total,
+                           s->st_coef);
+        if ((rc = launch_check(ctx, "k_scatter_coef"))) return rc;
+    }
+    return PFV_OK;
+}
+PFV_API int pfv_dec_iframe_sparse(pfv_dec_session *s, const uint32_t *idx, const int16_t *val, size_t n, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (n && (!idx || !val)) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_sparse: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = dec_upload_sparse(s, idx, val, n);
+    if (rc) return rc;
+    if ((rc = pfv_dec_iframe_dev(s, s->st_coef, qidx))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PFV_OK;
+}
+PFV_API int pfv_dec_pframe_sparse(pfv_dec_session *s, const int8_t *mv, const uint8_t *has_coef, const uint32_t *idx,
+                                  const int16_t *val, size_t n, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!mv || !has_coef || (n && (!idx || !val))) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_sparse: null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = dec_upload_sparse(s, idx, val, n);
+    if (rc) return rc;
+    const size_t nmb = (size_t)s->geom.mbs_per_frame * s->n_streams;
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_mv, mv, nmb * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s->st_has, has_coef, nmb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pfv_dec_pframe_dev(s, s->st_mv, s->st_has, s->st_coef, qidx))) return rc;
+    return pfv_dec_check(s);
+}
+
 PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev)
 {
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
@@ -1103,9 +1164,13 @@ struct DecEvent {
     const uint8_t *payload = nullptr;
     uint32_t plen = 0;
     uint8_t qidx[3] = {0, 0, 0};
-    PinnedBuf<int16_t> coef;
+    PinnedBuf<int16_t> coef;             // dense form: only when the sparse list overflowed
     PinnedBuf<int8_t> mv;
     PinnedBuf<uint8_t> has;
+    PinnedBuf<uint32_t> idx;             // sparse form: non-zero coefficients as (flat index, value)
+    PinnedBuf<int16_t> val;
+    size_t n_sparse = 0;
+    bool dense = false;
 };
 
 struct pfv_decoder {
@@ -1340,8 +1405,21 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
 // ---- look-ahead machinery of pfv_decoder
 static void dec_parse(pfv_decoder *d, DecEvent *e)   // any thread; touches only the event and the immutable stream
 {
-    const size_t tb = (size_t)d->total_blocks;
-    if (!e->coef.resize(tb * 256) || (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb)))) {
+    const size_t tb = (size_t)d->total_blocks, cap = tb * 256 / 4;   // denser than 1 in 4: not worth a list
+    e->dense = false;
+    e->n_sparse = 0;
+    if (!e->idx.resize(cap) || !e->val.resize(cap) || (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb)))) {
+        e->rc = PFV_ERR_NOMEM;
+        return;
+    }
+    SparseSink sink{e->idx.data(), e->val.data(), cap};
+    e->rc = e->type == 1 ? parse_iframe_to(e->payload, e->plen, d->total_blocks, d->n_qtables, sink, e->qidx)
+                         : parse_pframe_to(e->payload, e->plen, d->total_blocks, d->n_qtables, e->mv.data(), e->has.data(), sink,
+                                           e->qidx);
+    e->n_sparse = sink.n;
+    if (e->rc != kSinkFull) return;
+    e->dense = true;
+    if (!e->coef.resize(tb * 256)) {
         e->rc = PFV_ERR_NOMEM;
         return;
     }
@@ -1517,8 +1595,13 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
         lk.unlock();   // workers keep parsing the packets behind this one while the device decodes it
         rc = e->rc;
         if (rc) rc = fail(d->ctx, rc, rc == PFV_ERR_NOMEM ? "pinned staging for a parsed packet" : "malformed packet payload");
-        if (!rc) rc = e->type == 1 ? pfv_dec_iframe(d->hot, e->coef.data(), e->qidx)
-                                   : pfv_dec_pframe(d->hot, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
+        if (!rc && e->dense)
+            rc = e->type == 1 ? pfv_dec_iframe(d->hot, e->coef.data(), e->qidx)
+                              : pfv_dec_pframe(d->hot, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
+        else if (!rc)
+            rc = e->type == 1 ? pfv_dec_iframe_sparse(d->hot, e->idx.data(), e->val.data(), e->n_sparse, e->qidx)
+                              : pfv_dec_pframe_sparse(d->hot, e->mv.data(), e->has.data(), e->idx.data(), e->val.data(),
+                                                      e->n_sparse, e->qidx);
         if (!rc) rc = pfv_dec_get_frame(d->hot, d->retframe.data());   // crop blits (:195-197, 209-211)
         lk.lock();
     }

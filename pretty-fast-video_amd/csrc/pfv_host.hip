@@ -353,8 +353,29 @@ inline int parse_head(BitSource &r, PacketHead &h, int n_qtables)
         if (q >= n_qtables) return -6;
     return 0;
 }
-// reads run symbols until `count` coefficients are covered, writing into out[0..count)
-inline int read_runs(BitSource &r, const HuffmanTree &tree, int16_t *out, size_t count)
+// Where parsed coefficients go: the dense [macroblock][256] array, or a list of (flat index, value) pairs -- after
+// quantisation ~9 in 10 coefficients are zero, so the list is what is worth sending over PCIe (pfv_dec_*_sparse).
+struct DenseSink {
+    int16_t *out;
+    bool put(size_t i, int16_t v) { out[i] = v; return true; }
+};
+struct SparseSink {
+    uint32_t *idx;
+    int16_t *val;
+    size_t cap, n = 0;
+    bool put(size_t i, int16_t v)
+    {
+        if (n >= cap) return false;
+        idx[n] = (uint32_t)i;
+        val[n++] = v;
+        return true;
+    }
+};
+constexpr int kSinkFull = 1;   // SparseSink ran out of room: the caller falls back to the dense form
+
+// reads run symbols until `count` coefficients are covered, handing values to sink.put(base + index, value)
+template <class Sink>
+inline int read_runs(BitSource &r, const HuffmanTree &tree, Sink &sink, size_t base, size_t count)
 {
     size_t idx = 0;
     while (idx < count) {
@@ -370,7 +391,8 @@ inline int read_runs(BitSource &r, const HuffmanTree &tree, int16_t *out, size_t
                 if (const unsigned nb = cn.symbol) {
                     if (idx >= count) return -6;
                     const uint32_t raw = (uint32_t)(win >> used) & ((1u << nb) - 1u);
-                    out[idx++] = (int16_t)(int32_t)((raw ^ (1u << (nb - 1))) - (1u << (nb - 1)));   // sign-extend nb bits
+                    const int16_t v = (int16_t)(int32_t)((raw ^ (1u << (nb - 1))) - (1u << (nb - 1)));   // sign-extend nb bits
+                    if (!sink.put(base + idx++, v)) return kSinkFull;
                     used += nb;
                 }
                 r.skip(used);
@@ -386,23 +408,24 @@ inline int read_runs(BitSource &r, const HuffmanTree &tree, int16_t *out, size_t
             int32_t c = r.get_signed((unsigned)nb);
             if (!r.ok()) return -8;
             if (idx >= count) return -6;   // the reference would index out of bounds here
-            out[idx++] = (int16_t)c;
+            if (!sink.put(base + idx++, (int16_t)c)) return kSinkFull;
         }
     }
     return 0;
 }
-inline int parse_iframe(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int16_t *coef, uint8_t qidx[3])
+template <class Sink>
+inline int parse_iframe_to(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, Sink &sink, uint8_t qidx[3])
 {
     BitSource r(payload, n);
     PacketHead h;
     if (int rc = parse_head(r, h, n_qtables)) return rc;
     HuffmanTree tree(h.table);
     std::memcpy(qidx, h.qidx, 3);
-    std::memset(coef, 0, (size_t)total_blocks * 512);
-    return read_runs(r, tree, coef, (size_t)total_blocks * 256);   // ONE run stream for the whole frame (dec.rs:261)
+    return read_runs(r, tree, sink, 0, (size_t)total_blocks * 256);   // ONE run stream for the whole frame (dec.rs:261)
 }
-inline int parse_pframe(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int8_t *mv, uint8_t *has,
-                        int16_t *coef, uint8_t qidx[3])
+template <class Sink>
+inline int parse_pframe_to(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int8_t *mv, uint8_t *has,
+                           Sink &sink, uint8_t qidx[3])
 {
     BitSource r(payload, n);
     PacketHead h;
@@ -419,11 +442,23 @@ inline int parse_pframe(const uint8_t *payload, size_t n, int total_blocks, int 
         }
     }
     if (!r.ok()) return -8;
-    std::memset(coef, 0, (size_t)total_blocks * 512);
     for (int b = 0; b < total_blocks; b++)     // dec.rs:378-417: 256 coefficients per coded macroblock
         if (has[b])
-            if (int rc = read_runs(r, tree, coef + (size_t)b * 256, 256)) return rc;
+            if (int rc = read_runs(r, tree, sink, (size_t)b * 256, 256)) return rc;
     return 0;
+}
+inline int parse_iframe(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int16_t *coef, uint8_t qidx[3])
+{
+    std::memset(coef, 0, (size_t)total_blocks * 512);
+    DenseSink sink{coef};
+    return parse_iframe_to(payload, n, total_blocks, n_qtables, sink, qidx);
+}
+inline int parse_pframe(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int8_t *mv, uint8_t *has,
+                        int16_t *coef, uint8_t qidx[3])
+{
+    std::memset(coef, 0, (size_t)total_blocks * 512);
+    DenseSink sink{coef};
+    return parse_pframe_to(payload, n, total_blocks, n_qtables, mv, has, sink, qidx);
 }
 
 }  // namespace pfv

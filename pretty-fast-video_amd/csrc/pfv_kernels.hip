@@ -1115,4 +1115,15 @@ __global__ __launch_bounds__(kThreads) void k_init_padded(FrameGeom g, uint8_t *
         dst[idx] = make_uint4(f, f, f, f);
 }
 
+// Sparse coefficient upload (pfv_dec_*_sparse): coef[idx[i]] = val[i] onto a zeroed coefficient buffer.  Indices of one
+// frame are distinct and ascending (the bit parser walks the frame front to back), so neighbouring lanes hit
+// neighbouring lines.
+__global__ void __launch_bounds__(kThreads) k_scatter_coef(const uint32_t *idx, const int16_t *val, uint32_t n, uint32_t limit, int16_t *coef)
+{
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const uint32_t at = idx[i];
+        if (at < limit) coef[at] = val[i];
+    }
+}
+
 }  // namespace pfv

@@ -147,6 +147,21 @@ class DecoderSession(_Geometry):
         assert c.size == self.n_streams * self.total_blocks * 256
         self.ctx.check(self.ctx._lib.pfv_dec_iframe(self.handle, ptr(c), ptr(self._qidx(qidx))))
 
+    def decode_iframe_sparse(self, idx, val, qidx=(0, 1, 1)):
+        """non-zero coefficients as (flat index into [stream][macroblock][256], value) pairs; the rest is zero"""
+        i = np.ascontiguousarray(idx, dtype=np.uint32)
+        v = np.ascontiguousarray(val, dtype=np.int16)
+        assert i.shape == v.shape and i.ndim == 1
+        self.ctx.check(self.ctx._lib.pfv_dec_iframe_sparse(self.handle, ptr(i), ptr(v), i.size, ptr(self._qidx(qidx))))
+
+    def decode_pframe_sparse(self, mv, has_coef, idx, val, qidx=(2, 3, 3)):
+        m = np.ascontiguousarray(mv, dtype=np.int8)
+        hc = np.ascontiguousarray(has_coef, dtype=np.uint8)
+        i = np.ascontiguousarray(idx, dtype=np.uint32)
+        v = np.ascontiguousarray(val, dtype=np.int16)
+        assert i.shape == v.shape and i.ndim == 1
+        self.ctx.check(self.ctx._lib.pfv_dec_pframe_sparse(self.handle, ptr(m), ptr(hc), ptr(i), ptr(v), i.size, ptr(self._qidx(qidx))))
+
     def decode_pframe(self, mv, has_coef, coef, qidx=(2, 3, 3)):
         m = np.ascontiguousarray(mv, dtype=np.int8)
         hc = np.ascontiguousarray(has_coef, dtype=np.uint8)

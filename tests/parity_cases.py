@@ -343,3 +343,31 @@ def check_device_entropy(pkg, ctx, oracle, w, h, n_streams, seed, kinds=("typica
         ctx.free(p)
     enc.close()
     return checked
+
+
+def check_sparse_decode(pkg, ctx, w=100, h=60, n_streams=2, seed=11):
+    """pfv_dec_*_sparse == pfv_dec_* on the expanded coefficient array (i-frame then p-frame, two sessions side by side)"""
+    rng = np.random.default_rng(seed)
+    q = np.stack(pkg.qtables_from_quality(5)[:4])
+    a = pkg.DecoderSession(ctx, w, h, q, n_streams)
+    b = pkg.DecoderSession(ctx, w, h, q, n_streams)
+    nb, S = a.total_blocks, n_streams
+    for frame in range(3):
+        kind = ("typical", "sparse", "zero")[frame]
+        coef = np.stack([_hostile_coefficients(rng, nb, kind) for _ in range(S)])
+        flat = coef.reshape(-1)
+        idx = np.flatnonzero(flat).astype(np.uint32)
+        val = flat[idx]
+        # entries the dense form cannot express must not matter: an explicit zero, an index past the frame
+        idx2 = np.concatenate([idx, np.array([flat.size + 5], np.uint32)])
+        val2 = np.concatenate([val, np.array([77], np.int16)])
+        if frame == 0:
+            a.decode_iframe(coef)
+            b.decode_iframe_sparse(idx2, val2)
+        else:
+            mv = np.zeros((S, nb, 2), np.int8)                 # zero motion is legal for every macroblock
+            has = (rng.random((S, nb)) < 0.7).astype(np.uint8)
+            a.decode_pframe(mv, has, coef)
+            b.decode_pframe_sparse(mv, has, idx2, val2)
+        assert np.array_equal(a.framebuffer(), b.framebuffer()), f"sparse != dense decode, frame {frame}"
+    a.close(); b.close()

@@ -70,3 +70,27 @@ def test_emu_device_entropy(pkg, emu_ctx, oracle):
     """k_ent_* (RLE + Huffman + bit packing on the device) vs the oracle's packet serialisers, byte for byte"""
     assert pc.check_device_entropy(pkg, emu_ctx, oracle, 48, 32, n_streams=2, seed=3) == 20
     assert pc.check_device_entropy(pkg, emu_ctx, oracle, 34, 18, n_streams=1, seed=4, kinds=("typical", "edges")) == 4
+
+
+def test_emu_sparse_decode(pkg, emu_ctx):
+    pc.check_sparse_decode(pkg, emu_ctx, 48, 32, n_streams=2)
+
+
+def test_emu_dense_stream_falls_back(pkg, emu_ctx, oracle):
+    """white noise at quality 10: more than 1 coefficient in 4 is non-zero, the decoder's sparse list overflows and the
+    packet is re-parsed into the dense form"""
+    import io
+    from oracle_bind import OracleStreamDecoder
+    w, h = 48, 32
+    rng = np.random.default_rng(2)
+    buf = io.BytesIO()
+    enc = pkg.Encoder(buf, w, h, 30, 10, emu_ctx)
+    for t in range(3):
+        fr = sc.frame_of(pkg, w, h, rng.integers(0, 256, w * h * 3 // 2).astype(np.uint8))
+        (enc.encode_iframe if t == 0 else enc.encode_pframe)(fr)
+    enc.finish(); enc.close()
+    data = buf.getvalue()
+    assert len(data) > w * h * 3 // 2          # dense indeed: bigger than a raw frame
+    a = [x for x in sc._outcomes_product(pkg, emu_ctx, data, lookahead=1)]
+    b = [x for x in sc._outcomes_oracle(oracle, data)]
+    assert a == b and sum(1 for x in a if x[0] == "frame") == 3

@@ -252,6 +252,11 @@ def test_stream_encoder_host_and_device_entropy_agree(pkg, gpu_ctx):
     assert outs[0] == outs[1] and len(outs[0]) > 1000
 
 
+def test_sparse_decode(pkg, gpu_ctx):
+    pc.check_sparse_decode(pkg, gpu_ctx, 100, 60, n_streams=2)
+    pc.check_sparse_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12)
+
+
 def test_colour_utils(pkg, gpu_ctx):
     pc.check_colour_utils(pkg, gpu_ctx)
 
