@@ -748,10 +748,11 @@ PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap)
         if (e == hipSuccess) s->ent_allocs.push_back(*p);
         return e;
     };
-    hipError_t e = grab((void **)&s->ent.mask, S * n_sb * 8);
+    const size_t n_groups = (n_sb + kEntThreads - 1) / kEntThreads;
+    hipError_t e = grab((void **)&s->ent.syms, S * n_groups * kEntGroupSyms * 4);
     if (e == hipSuccess) e = grab((void **)&s->ent.counts, S * n_sb * 16);
-    if (e == hipSuccess) e = grab((void **)&s->ent.sumsize, S * n_sb * 4);
-    if (e == hipSuccess) e = grab((void **)&s->ent.groups, S * ((n_sb + kEntThreads - 1) / kEntThreads) * sizeof(EntGroup));
+    if (e == hipSuccess) e = grab((void **)&s->ent.lanew, S * n_sb * 4);
+    if (e == hipSuccess) e = grab((void **)&s->ent.groups, S * n_groups * sizeof(EntGroup));
     if (e == hipSuccess) e = grab((void **)&s->ent.hist, S * 16 * 4);
     if (e == hipSuccess) e = grab((void **)&s->ent.codes, S * sizeof(EntCodes));
     if (e == hipSuccess) e = grab((void **)&s->ent.sizes, S * 4);

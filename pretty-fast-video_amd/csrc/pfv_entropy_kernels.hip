@@ -8,17 +8,19 @@
 //
 //   k_ent_scan   workgroup = 256 consecutive subblocks of one stream (64 macroblocks), lane = one 8x8 subblock.  The
 //                group's 32 KiB of coefficients come in with coalesced 16-byte loads and are staged in LDS (rows padded
-//                to 136 B); each lane builds its non-zero bitmap and walks the set bits: symbol counts (16 x 8-bit),
-//                sum of coefficient sizes.  Per lane -> HBM (bitmap, counts, size sum); per workgroup -> HBM (counts,
-//                size sum, block-header bits); per stream -> the frame histogram (atomics).
+//                to 136 B); each lane builds its non-zero bitmap and walks the set bits: one 32-bit word per run symbol
+//                (fillers, num_zeroes, coeff_size, value bits) appended to the group's symbol list -- the lanes' runs
+//                are contiguous in it --, symbol counts (16 x 8-bit), sum of coefficient sizes.  Per lane -> HBM
+//                (counts, packed size sum / list position); per workgroup -> HBM (counts, size sum, block-header
+//                bits); per stream -> the frame histogram (atomics).
 //   k_ent_codes  one workgroup per stream.  Wavefront 0 builds the reference's Huffman tree lane-parallel (stable
 //                rank sort, ballot-positioned merges, codes by walking the parent chain), all lanes fill the 256
 //                pre-joined (num_zeroes, coeff_size) code pairs; then bits per workgroup-of-scan = counts . code lengths
 //                + sizes, exclusive prefix over the workgroups -> base bit offsets and the payload size.
 //   k_ent_init   zeroes exactly the words the payload will occupy and writes the 19 header bytes.
 //   k_ent_pack   same tiling as k_ent_scan: bits per lane from its counts, workgroup exclusive scan + the workgroup's
-//                base = the lane's bit offset; the lane walks its bitmap again (values from LDS) and writes its bits:
-//                first and last word with atomicOr onto the zeroed payload, words in between with plain stores.
+//                base = the lane's bit offset; the lane reads its symbol words back (never the coefficients), looks the
+//                code pairs up and ORs its bits into an LDS window that leaves with coalesced stores.
 //
 // Run order inside a macroblock is the coefficient buffer's own (zigzag within a subblock, subblocks 0..3), runs cross
 // subblock boundaries and end at the macroblock (enc.rs:246-255), so lane (mb, sb) needs only the bitmaps of the
@@ -32,6 +34,7 @@ namespace pfv {
 
 constexpr int kEntThreads = 256;                    // subblocks per workgroup of k_ent_scan / k_ent_pack
 constexpr int kEntRow64 = 17;                       // LDS row of one subblock: 128 B of coefficients + 8 B pad, in 8-byte units
+constexpr int kEntGroupSyms = kEntThreads * 65;      // symbol words one group can produce: 64 values + the closing run, per lane
 constexpr uint32_t kEntErrOversize = 0xffffffffu;   // a coefficient needs more than 15 size bits (rle.rs:44 would panic)
 constexpr uint32_t kEntErrCapacity = 0xfffffffeu;   // payload larger than the per-stream capacity
 
@@ -67,9 +70,9 @@ struct EntBufs {
     const int16_t *coef;       // [S][total_blocks][256]
     const int8_t *mv;          // [S][total_blocks][2]   (p-frames)
     const uint8_t *has;        // [S][total_blocks]      (p-frames)
-    uint64_t *mask;            // [S][total_blocks*4] non-zero bitmap per subblock (0 for uncoded macroblocks)
+    uint32_t *syms;            // [S][n_groups][kEntGroupSyms] run symbols: fillers << 24 | value bits << 8 | coeff_size << 4 | num_zeroes
     uint4 *counts;             // [S][total_blocks*4] 16 x 8-bit symbol counts
-    uint32_t *sumsize;         // [S][total_blocks*4] sum of coeff_size over the subblock's values
+    uint32_t *lanew;           // [S][total_blocks*4] size sum (10 bits) | symbols << 10 (7 bits) | position in the group's list << 17
     EntGroup *groups;          // [S][n_groups]
     int32_t *hist;             // [S][16]
     EntCodes *codes;           // [S]
@@ -189,6 +192,7 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     __shared__ uint64_t rows[kEntThreads * kEntRow64];
     __shared__ uint4 cnt4[kEntThreads];
     __shared__ uint32_t blk[10];
+    __shared__ uint32_t wave_syms[kEntThreads / 64];
     const int stream = (int)blockIdx.y, n_sb = f.total_blocks * 4;
     const int sb0 = (int)blockIdx.x * kEntThreads;
     const int sbi = sb0 + (int)threadIdx.x;
@@ -215,8 +219,20 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     }
     int last = ent_prev_last(mask, sb);   // every lane of the wavefront takes part in the exchange
 
+    // place of this lane's symbols in the group's list: one per non-zero value, one more for the run that closes the
+    // macroblock (rle.rs:31-38) unless its last coefficient is non-zero
+    const int my_last = mask ? 64 * sb + 63 - __builtin_clzll(mask) : last;
+    const bool closing = coded && sb == 3 && my_last < 255;
+    const uint32_t n_sym = (uint32_t)__popcll(mask) + (closing ? 1u : 0u);
+    const uint32_t incl = ent_wave_scan(n_sym);
+    if ((threadIdx.x & 63u) == 63u) wave_syms[threadIdx.x >> 6] = incl;
     // symbol counts: 16 byte-wide counters per lane in LDS (ds_add without return: nothing to wait for in the loop)
     cnt4[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    uint32_t sym_off = incl - n_sym;
+    for (unsigned w = 0; w < (threadIdx.x >> 6); w++) sym_off += wave_syms[w];
+    uint32_t *out = b.syms + ((size_t)stream * f.n_groups + blockIdx.x) * kEntGroupSyms + sym_off;
+
     uint32_t *my_cnt = (uint32_t *)&cnt4[threadIdx.x];
     auto count = [&](unsigned bin, unsigned n) { atomicAdd(&my_cnt[bin >> 2], n << (8u * (bin & 3u))); };
     const int16_t *c = (const int16_t *)row;
@@ -230,10 +246,9 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
             const int nbit = mm ? __builtin_ctzll(mm) : 0;
             const int nv = c[nbit];   // next value on its way while this one is processed
             const int i = 64 * sb + bit;
-            unsigned run = (unsigned)(i - last - 1);
+            unsigned run = (unsigned)(i - last - 1), fillers = 0;
             last = i;
             if (run > 15u) {
-                unsigned fillers;
                 ent_split_run(run, fillers, run);
                 count(15u, fillers);
                 count(0u, fillers);
@@ -244,17 +259,20 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
             count(run, 1u);
             count(size & 15u, 1u);
             sumsize += size;
+            // write_signed keeps the low `size` bits of the two's complement (enc.rs:313-315)
+            *out++ = (fillers << 24) | (((uint32_t)v & ((1u << (size & 15u)) - 1u)) << 8) | ((size & 15u) << 4) | run;
             if (!mm) break;
             bit = nbit;
             v = nv;
         }
     }
-    if (coded && sb == 3 && last < 255) {   // the trailing run closes the macroblock (rle.rs:31-38)
+    if (closing) {   // the trailing run closes the macroblock (rle.rs:31-38): (rest, size 0) after its fillers
         unsigned fillers, rest;
         ent_split_run((unsigned)(255 - last), fillers, rest);
         count(15u, fillers);
         count(0u, fillers + 1u);
         count(rest, 1u);
+        *out++ = (fillers << 24) | rest;
     }
     uint32_t hdr_bits = 0;
     if (f.pframe && live && sb == 0)      // has_mvec, has_coeff, then two 7-bit components (enc.rs:414-451)
@@ -262,9 +280,8 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     ent_wave_lds_sync();
     const uint4 c4 = cnt4[threadIdx.x];
     if (live) {
-        b.mask[sbase + sbi] = mask;
         b.counts[sbase + sbi] = c4;
-        b.sumsize[sbase + sbi] = sumsize;
+        b.lanew[sbase + sbi] = (sumsize & 1023u) | (n_sym << 10) | (sym_off << 17);
     }
 
     // workgroup totals: counts widened to 16-bit fields (two symbols per word; at most 256 * 164 per field)
@@ -537,13 +554,13 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     const int mb = sbi >> 2, sb = sbi & 3;
     const size_t sbase = (size_t)stream * n_sb;
     const size_t bi = (size_t)stream * f.total_blocks + (live ? mb : 0);
-    const uint64_t mask = live ? b.mask[sbase + sbi] : 0;
     // this lane's symbol bits (counts . code lengths + sizes) and block-header bits, then their place in the workgroup
-    uint32_t my_bits = 0, my_hdr = 0;
+    uint32_t my_bits = 0, my_hdr = 0, lanew = 0;
     int mvx = 0, mvy = 0;
     if (live) {
         const uint4 c4 = b.counts[sbase + sbi];
-        my_bits = b.sumsize[sbase + sbi];
+        lanew = b.lanew[sbase + sbi];
+        my_bits = lanew & 1023u;
         my_bits = __builtin_amdgcn_udot4(c4.x, l0, my_bits, false);
         my_bits = __builtin_amdgcn_udot4(c4.y, l1, my_bits, false);
         my_bits = __builtin_amdgcn_udot4(c4.z, l2, my_bits, false);
@@ -554,10 +571,12 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
             my_hdr = (mvx != 0 || mvy != 0) ? 16u : 2u;
         }
     }
+    const uint32_t n_sym = (lanew >> 10) & 127u;
+    const uint32_t *sym = b.syms + ((size_t)stream * f.n_groups + blockIdx.x) * kEntGroupSyms + (lanew >> 17);
+    uint32_t w_next = n_sym ? sym[0] : 0;   // in flight across the offset computation
     const uint32_t si = ent_wave_scan(my_bits), hi = ent_wave_scan(my_hdr);
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     if (lane == 63) { wave_tot[0][wave] = si; wave_tot[1][wave] = hi; }
-    int last = ent_prev_last(mask, sb);
     __syncthreads();
     const EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
     const uint32_t sym_base = g->sym_base, hdr_base = g->hdr_base;
@@ -572,51 +591,24 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     if (!in_window && my_bits) atomicMin(&cutoff, sym_off);
 
     uint32_t *words = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
-    const bool has_coef = live && (!f.pframe || b.has[bi] != 0);
     if (my_hdr) {   // block header (enc.rs:414-451)
-        uint32_t bits = (my_hdr == 16u ? 1u : 0u) | (has_coef ? 2u : 0u);
+        uint32_t bits = (my_hdr == 16u ? 1u : 0u) | (b.has[bi] ? 2u : 0u);
         if (my_hdr == 16u) bits |= ((uint32_t)mvx & 0x7fu) << 2 | ((uint32_t)mvy & 0x7fu) << 9;
         LaneBits hw(hwin, words, hword0, hdr_off, true);
         hw.put(bits, my_hdr);
         hw.finish();
     }
-    if (has_coef) {
-        const int16_t *c = b.coef + ((size_t)stream * f.total_blocks + mb) * 256 + sb * 64;
+    if (n_sym) {
         LaneBits bw(win, words, word0, sym_off, in_window);
         const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
-        if (mask) {
-            uint64_t mm = mask;
-            int bit = __builtin_ctzll(mm);
-            int v = c[bit];
-            for (;;) {
-                mm &= mm - 1;
-                const int nbit = mm ? __builtin_ctzll(mm) : bit;
-                const int nv = c[nbit];   // next value on its way while this one is written
-                const int i = 64 * sb + bit;
-                unsigned run = (unsigned)(i - last - 1);
-                last = i;
-                if (run > 15u) {
-                    unsigned fillers;
-                    ent_split_run(run, fillers, run);
-                    for (; fillers; fillers--) bw.put(filler_bits, filler_len);
-                }
-                const unsigned mag = (unsigned)(v < 0 ? -v : v);
-                const unsigned size = (33u - (unsigned)__builtin_clz(mag)) & 15u;
-                const unsigned p = run | (size << 4);
-                const uint32_t pb = pair_bits[p], pl = pair_len[p];
-                const uint32_t vb = (uint32_t)v & ((1u << size) - 1u);   // write_signed: low `size` bits (enc.rs:313-315)
-                if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
-                else { bw.put(pb, pl); bw.put(vb, size); }
-                if (!mm) break;
-                bit = nbit;
-                v = nv;
-            }
-        }
-        if (sb == 3 && last < 255) {
-            unsigned fillers, rest;
-            ent_split_run((unsigned)(255 - last), fillers, rest);
-            for (; fillers; fillers--) bw.put(filler_bits, filler_len);
-            bw.put(pair_bits[rest], pair_len[rest]);   // (rest, size 0)
+        for (uint32_t k = 0; k < n_sym; k++) {
+            const uint32_t w = w_next;
+            if (k + 1 < n_sym) w_next = sym[k + 1];   // next symbol on its way while this one is written
+            for (uint32_t fl = w >> 24; fl; fl--) bw.put(filler_bits, filler_len);
+            const uint32_t p = w & 255u, size = (w >> 4) & 15u;
+            const uint32_t pb = pair_bits[p], pl = pair_len[p], vb = (w >> 8) & 0x7fffu;
+            if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
+            else { bw.put(pb, pl); bw.put(vb, size); }
         }
         bw.finish();
     }
