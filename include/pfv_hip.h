@@ -167,6 +167,12 @@ PFV_API int pfv_enc_prev_frame(pfv_enc_session *s, uint8_t *out_host);
 PFV_API size_t pfv_payload_worst_case(int width, int height);
 /* allocates the stage's buffers; payload_cap = bytes per stream (0: pfv_payload_worst_case).  Idempotent. */
 PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap);
+/* 1: the stage runs on its own HIP stream, so the (memory-bound) entropy kernels of frame t overlap the (VALU-bound)
+ * encode kernel of frame t+1.  The caller must then alternate between TWO sets of device buffers for the encode outputs
+ * it packs.  pfv_enc_payload_sizes / _fetch synchronise with the stage; pfv_enc_entropy_join makes the context's stream
+ * wait for it without blocking the host.  0 (default): everything on the context's stream. */
+PFV_API int pfv_enc_entropy_set_async(pfv_enc_session *s, int on);
+PFV_API int pfv_enc_entropy_join(pfv_enc_session *s);
 /* coef_dev / mv_dev / has_coef_dev: device buffers in the layout the encode entry points write (n_streams wide) */
 PFV_API int pfv_enc_pack_iframe_dev(pfv_enc_session *s, const int16_t *coef_dev);
 PFV_API int pfv_enc_pack_pframe_dev(pfv_enc_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev,

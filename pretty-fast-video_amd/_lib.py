@@ -70,6 +70,8 @@ SIGNATURES = [
     ("pfv_enc_prev_frame", c_int, [_P, _P]),
     ("pfv_payload_worst_case", c_size_t, [c_int, c_int]),
     ("pfv_enc_entropy_enable", c_int, [_P, c_size_t]),
+    ("pfv_enc_entropy_set_async", c_int, [_P, c_int]),
+    ("pfv_enc_entropy_join", c_int, [_P]),
     ("pfv_enc_pack_iframe_dev", c_int, [_P, _P]),
     ("pfv_enc_pack_pframe_dev", c_int, [_P, _P, _P, _P]),
     ("pfv_enc_payload_sizes", c_int, [_P, _P]),

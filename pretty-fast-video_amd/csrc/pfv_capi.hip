@@ -551,6 +551,13 @@ struct pfv_enc_session {
     EntBufs ent{};
     std::vector<void *> ent_allocs;
     std::vector<uint32_t> ent_sizes;         // last pfv_enc_payload_sizes result
+    // optional second HIP stream for the stage (pfv_enc_entropy_set_async): the memory-bound k_ent_* kernels of frame t
+    // overlap the VALU-bound encode kernel of frame t+1
+    hipStream_t ent_stream = nullptr;
+    hipEvent_t ev_encoded = nullptr;         // main stream: the buffers handed to pack are complete
+    hipEvent_t ev_packed[2] = {nullptr, nullptr};   // entropy stream: pack call t has finished with its inputs
+    int ev_cur = 0;
+    bool ev_prev_valid = false;
 };
 
 struct pfv_dec_session {
@@ -621,6 +628,13 @@ PFV_API void pfv_enc_session_destroy(pfv_enc_session *s)
         if (b) (void)hipFree(b);
     for (void *b : s->ent_allocs)
         if (b) (void)hipFree(b);
+    if (s->ent_stream) {
+        (void)hipStreamSynchronize(s->ent_stream);
+        (void)hipEventDestroy(s->ev_encoded);
+        (void)hipEventDestroy(s->ev_packed[0]);
+        (void)hipEventDestroy(s->ev_packed[1]);
+        (void)hipStreamDestroy(s->ent_stream);
+    }
     delete s;
 }
 
@@ -787,11 +801,59 @@ static int ent_pack(pfv_enc_session *s, bool pframe, const int8_t *mv_dev, const
     EntBufs b = s->ent;
     b.coef = coef_dev; b.mv = mv_dev; b.has = has_dev;
     const dim3 per_sb((unsigned)f.n_groups, (unsigned)f.n_streams);
-    hipLaunchKernelGGL(k_ent_scan, per_sb, dim3(kEntThreads), 0, ctx->stream, f, b);
-    hipLaunchKernelGGL(k_ent_codes, dim3((unsigned)f.n_streams), dim3(kEntThreads), 0, ctx->stream, f, b);
-    hipLaunchKernelGGL(k_ent_init, dim3(64, (unsigned)f.n_streams), dim3(kEntThreads), 0, ctx->stream, f, b);
-    hipLaunchKernelGGL(k_ent_pack, per_sb, dim3(kEntThreads), 0, ctx->stream, f, b);
-    return launch_check(ctx, "k_ent_*");
+    hipStream_t st = ctx->stream;
+    if (s->ent_stream) {   // inputs are complete once the main stream reaches this point
+        st = s->ent_stream;
+        HIP_TRY(ctx, hipEventRecord(s->ev_encoded, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_encoded, 0));
+    }
+    hipLaunchKernelGGL(k_ent_scan, per_sb, dim3(kEntThreads), 0, st, f, b);
+    hipLaunchKernelGGL(k_ent_codes, dim3((unsigned)f.n_streams), dim3(kEntThreads), 0, st, f, b);
+    hipLaunchKernelGGL(k_ent_init, dim3(64, (unsigned)f.n_streams), dim3(kEntThreads), 0, st, f, b);
+    hipLaunchKernelGGL(k_ent_pack, per_sb, dim3(kEntThreads), 0, st, f, b);
+    int rc = launch_check(ctx, "k_ent_*");
+    if (rc || !s->ent_stream) return rc;
+    // The caller alternates between two sets of coefficient / header buffers: the encode call after this one writes the
+    // other set and may overlap this stage; the one after that reuses this set, so the main stream waits here for the
+    // PREVIOUS pack call -- everything enqueued on it later is ordered behind that call's reads.
+    HIP_TRY(ctx, hipEventRecord(s->ev_packed[s->ev_cur], st));
+    if (s->ev_prev_valid) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_packed[s->ev_cur ^ 1], 0));
+    s->ev_cur ^= 1;
+    s->ev_prev_valid = true;
+    return PFV_OK;
+}
+// Runs the stage on its own HIP stream (1) or on the context's stream (0, default).  With 1 the caller must alternate
+// between TWO sets of device buffers for the encode outputs it packs; pfv_enc_payload_sizes / _fetch synchronise with the
+// stage, pfv_enc_entropy_join makes the context's stream wait for it without blocking the host.
+PFV_API int pfv_enc_entropy_set_async(pfv_enc_session *s, int on)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (on && !s->ent_stream) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&s->ent_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_encoded, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_packed[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_packed[1], hipEventDisableTiming));
+        s->ev_prev_valid = false;
+    } else if (!on && s->ent_stream) {
+        HIP_TRY(ctx, hipStreamSynchronize(s->ent_stream));
+        (void)hipEventDestroy(s->ev_encoded);
+        (void)hipEventDestroy(s->ev_packed[0]);
+        (void)hipEventDestroy(s->ev_packed[1]);
+        (void)hipStreamDestroy(s->ent_stream);
+        s->ent_stream = nullptr;
+    }
+    return PFV_OK;
+}
+PFV_API int pfv_enc_entropy_join(pfv_enc_session *s)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    pfv_ctx *ctx = s->ctx;
+    if (!s->ent_stream || !s->ev_prev_valid) return PFV_OK;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_packed[s->ev_cur ^ 1], 0));
+    return PFV_OK;
 }
 PFV_API int pfv_enc_pack_iframe_dev(pfv_enc_session *s, const int16_t *coef_dev)
 {
@@ -813,8 +875,9 @@ PFV_API int pfv_enc_payload_sizes(pfv_enc_session *s, uint32_t *sizes_out)
     if (!s || !sizes_out) return fail(s ? s->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_enc_payload_sizes: bad argument");
     pfv_ctx *ctx = s->ctx;
     if (!s->ent_on) return fail(ctx, PFV_ERR_STATE, "call pfv_enc_entropy_enable first");
-    HIP_TRY(ctx, hipMemcpyAsync(s->ent_sizes.data(), s->ent.sizes, (size_t)s->n_streams * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t st = s->ent_stream ? s->ent_stream : ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(s->ent_sizes.data(), s->ent.sizes, (size_t)s->n_streams * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     int rc = PFV_OK;
     for (int i = 0; i < s->n_streams; i++) {
         uint32_t v = s->ent_sizes[i];
@@ -839,8 +902,9 @@ PFV_API int pfv_enc_payload_fetch(pfv_enc_session *s, int stream, uint8_t *out, 
     pfv_ctx *ctx = s->ctx;
     if (!s->ent_on) return fail(ctx, PFV_ERR_STATE, "call pfv_enc_entropy_enable first");
     if (stream < 0 || stream >= s->n_streams || nbytes > s->ent_cap) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_payload_fetch: out of range");
-    if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(out, s->ent.payload + (size_t)stream * s->ent_cap, nbytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t st = s->ent_stream ? s->ent_stream : ctx->stream;
+    if (nbytes) HIP_TRY(ctx, hipMemcpyAsync(out, s->ent.payload + (size_t)stream * s->ent_cap, nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     return PFV_OK;
 }
 

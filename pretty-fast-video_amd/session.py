@@ -88,9 +88,15 @@ class EncoderSession(_Geometry):
                                                         ctypes.c_void_p(has_dev), ctypes.c_void_p(coef_dev)))
 
     # device entropy stage (RLE + Huffman + bit packing of enc.rs:237-470 on the device) ---------------
-    def enable_entropy(self, payload_cap: int = 0):
-        """allocate the stage; payload_cap = bytes per stream (0: worst case for the geometry)"""
+    def enable_entropy(self, payload_cap: int = 0, async_stream: bool = False):
+        """allocate the stage; payload_cap = bytes per stream (0: worst case for the geometry).  async_stream: run it
+        on its own HIP stream (the caller then alternates between two sets of encode output buffers)"""
         self.ctx.check(self.ctx._lib.pfv_enc_entropy_enable(self.handle, int(payload_cap)))
+        self.ctx.check(self.ctx._lib.pfv_enc_entropy_set_async(self.handle, 1 if async_stream else 0))
+
+    def entropy_join(self):
+        """the context's stream waits for the entropy stage (no host synchronisation)"""
+        self.ctx.check(self.ctx._lib.pfv_enc_entropy_join(self.handle))
 
     def pack_iframe_dev(self, coef_dev: int):
         self.ctx.check(self.ctx._lib.pfv_enc_pack_iframe_dev(self.handle, ctypes.c_void_p(coef_dev)))

@@ -371,3 +371,45 @@ def check_sparse_decode(pkg, ctx, w=100, h=60, n_streams=2, seed=11):
             b.decode_pframe_sparse(mv, has, idx2, val2)
         assert np.array_equal(a.framebuffer(), b.framebuffer()), f"sparse != dense decode, frame {frame}"
     a.close(); b.close()
+
+
+def check_async_entropy(pkg, ctx, oracle, w, h, n_streams, n_frames=6):
+    """entropy stage on its own HIP stream with two alternating sets of encode outputs: payloads equal the oracle's
+    serialisation of the same encode outputs, frame by frame"""
+    import ctypes
+    L = _oracle_serializers(oracle)
+    S = n_streams
+    enc = pkg.EncoderSession(ctx, w, h, 5, S)
+    enc.enable_entropy(async_stream=True)
+    nb, fb = enc.total_blocks, enc.frame_bytes
+    streams = [pkg.SyntheticStream(w, h, seed=pkg.synth.SEED + s) for s in range(S)]
+    d_frames = [ctx.alloc(S * fb) for _ in range(2)]
+    sets = [(ctx.alloc(S * nb * 512), ctx.alloc(S * nb * 2), ctx.alloc(S * nb)) for _ in range(2)]
+    cap = int(ctx._lib.pfv_payload_worst_case(w, h))
+    ref = np.zeros(cap + 64, np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for t in range(n_frames):
+        d_c, d_m, d_h = sets[t & 1]
+        ctx.upload(d_frames[t & 1], np.concatenate([st.frame(t) for st in streams]))
+        if t % 4 == 0:
+            enc.encode_iframe_dev(d_frames[t & 1], d_c)
+            enc.pack_iframe_dev(d_c)
+        else:
+            enc.encode_pframe_dev(d_frames[t & 1], d_m, d_h, d_c)
+            enc.pack_pframe_dev(d_m, d_h, d_c)
+        sizes = enc.payload_sizes()                       # synchronises with the entropy stream only
+        payloads = [enc.payload(s, int(sizes[s])) for s in range(S)]
+        ctx.sync()
+        coef, mv, has = np.empty((S, nb, 256), np.int16), np.empty((S, nb, 2), np.int8), np.empty((S, nb), np.uint8)
+        ctx.download(coef, d_c)
+        if t % 4:
+            ctx.download(mv, d_m); ctx.download(has, d_h)
+        for s in range(S):
+            n = (L.pfvo_serialize_pframe(P(mv[s]), P(has[s]), P(coef[s]), nb, P(ref), ref.size) if t % 4 else
+                 L.pfvo_serialize_iframe(P(coef[s]), nb, P(ref), ref.size))
+            assert n == int(sizes[s]) and payloads[s] == ref[:n].tobytes(), f"frame {t} stream {s}"
+    enc.entropy_join()
+    ctx.sync()
+    for p in d_frames + [x for st in sets for x in st]:
+        ctx.free(p)
+    enc.close()

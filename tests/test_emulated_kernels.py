@@ -94,3 +94,8 @@ def test_emu_dense_stream_falls_back(pkg, emu_ctx, oracle):
     a = [x for x in sc._outcomes_product(pkg, emu_ctx, data, lookahead=1)]
     b = [x for x in sc._outcomes_oracle(oracle, data)]
     assert a == b and sum(1 for x in a if x[0] == "frame") == 3
+
+
+def test_emu_async_entropy_api(pkg, emu_ctx, oracle):
+    """call sequence of the two-stream entropy mode (the emulator has one timeline; ordering is checked on the GPU)"""
+    pc.check_async_entropy(pkg, emu_ctx, oracle, 48, 32, n_streams=2, n_frames=5)

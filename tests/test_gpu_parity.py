@@ -252,6 +252,11 @@ def test_stream_encoder_host_and_device_entropy_agree(pkg, gpu_ctx):
     assert outs[0] == outs[1] and len(outs[0]) > 1000
 
 
+def test_async_entropy_stream(pkg, gpu_ctx, oracle):
+    pc.check_async_entropy(pkg, gpu_ctx, oracle, 320, 240, n_streams=3)
+    pc.check_async_entropy(pkg, gpu_ctx, oracle, 1920, 1080, n_streams=2, n_frames=4)
+
+
 def test_sparse_decode(pkg, gpu_ctx):
     pc.check_sparse_decode(pkg, gpu_ctx, 100, 60, n_streams=2)
     pc.check_sparse_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12)
