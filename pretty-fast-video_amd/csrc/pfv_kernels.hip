@@ -866,6 +866,10 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[kWinAlloc];
     __shared__ int qtab_lds[kQTabDwords];
+#ifdef PFV_PENC_LDS_PAD   // occupancy experiment: extra LDS per workgroup caps the resident workgroups per CU
+    __shared__ int lds_pad[PFV_PENC_LDS_PAD / 4];
+    if (g.n_streams < 0) lds_pad[threadIdx.x] = 0;
+#endif
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int m = lane >> 3, i = lane & 7;
