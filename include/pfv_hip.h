@@ -109,6 +109,12 @@ PFV_API int pfv_blit_dev(pfv_ctx *ctx, uint8_t *dst, int dst_w, int dst_h, const
  * VideoPlane::double (:538-556, nearest 2x upsampling, dst = 2 src_w x 2 src_h) on device-resident planes. */
 PFV_API int pfv_reduce_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int src_w, int src_h);
 PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int src_w, int src_h);
+/* The RGB <-> YCbCr helpers of the reference's tests (src/lib.rs:337-394; JPEG-conversion matrix in f32, `as u8`):
+ * interleaved RGB8 (width*height*3) -> packed Y|U|V 4:2:0 frame as load_frame + VideoFrame::from_planes produce it
+ * (chroma point-sampled at even pixels, src/frame.rs:51-59), and back as save_frame does (chroma doubled,
+ * src/common.rs:538-556).  width, height even.  Device-resident buffers. */
+PFV_API int pfv_rgb_to_yuv420_dev(pfv_ctx *ctx, const uint8_t *rgb_dev, int width, int height, uint8_t *frame_dev);
+PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int width, int height, uint8_t *rgb_dev);
 
 /* ------------------------------------------------------------------ device memory helpers */
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);

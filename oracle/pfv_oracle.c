@@ -721,3 +721,54 @@ PFVO_API int pfvo_decode_pframe(pfvo_decoder *d, const int8_t *mv, const uint8_t
     }
     return 0;
 }
+
+
+/* ------------------------------------------------------------------ colour helpers of the reference's tests
+ * load_frame (src/lib.rs:337-359) + VideoFrame::from_planes (src/frame.rs:51-59), save_frame (src/lib.rs:361-394).
+ * f32 arithmetic in source order; `as u8` = truncate toward zero, saturating, NaN -> 0. */
+static uint8_t f32_as_u8(float x) { return x >= 255.0f ? 255 : (x > 0.0f ? (uint8_t)(int)x : 0); }
+PFVO_API void pfvo_rgb_to_yuv420(const uint8_t *rgb, int w, int h, uint8_t *frame)
+{
+    size_t n = (size_t)w * h;
+    int cw = w / 2, ch = h / 2;
+    uint8_t *py = frame, *pu = frame + n, *pv = pu + (size_t)cw * ch;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t i = (size_t)y * w + x;
+            volatile float r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+            volatile float t0 = 0.299f * r, t1 = 0.587f * g, t2 = 0.114f * b;
+            volatile float yy = t0 + t1;
+            yy = yy + t2;
+            py[i] = f32_as_u8(yy);
+            if (!(x & 1) && !(y & 1) && x / 2 < cw && y / 2 < ch) {          /* reduce(): pixel (2x, 2y) (src/common.rs:523-536) */
+                volatile float u0 = 0.168736f * r, u1 = 0.331264f * g, u2 = 0.5f * b;
+                volatile float u = 128.0f - u0;
+                u = u - u1;
+                u = u + u2;
+                volatile float v0 = 0.5f * r, v1 = 0.418688f * g, v2 = 0.081312f * b;
+                volatile float v = 128.0f + v0;
+                v = v - v1;
+                v = v - v2;
+                pu[(size_t)(y / 2) * cw + x / 2] = f32_as_u8(u);
+                pv[(size_t)(y / 2) * cw + x / 2] = f32_as_u8(v);
+            }
+        }
+}
+PFVO_API void pfvo_yuv420_to_rgb(const uint8_t *frame, int w, int h, uint8_t *rgb)
+{
+    size_t n = (size_t)w * h;
+    int cw = w / 2, ch = h / 2;
+    const uint8_t *py = frame, *pu = frame + n, *pv = pu + (size_t)cw * ch;
+    (void)ch;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t i = (size_t)y * w + x, c = (size_t)(y / 2) * cw + x / 2;      /* double(): nearest (src/common.rs:538-556) */
+            volatile float yy = py[i], u = (float)pu[c] - 128.0f, v = (float)pv[c] - 128.0f;
+            volatile float r1 = 1.402f * v, g1 = 0.344136f * u, g2 = 0.714136f * v, b1 = 1.772f * u;
+            volatile float r = yy + r1, g = yy - g1, b = yy + b1;
+            g = g - g2;
+            rgb[3 * i] = f32_as_u8(r);
+            rgb[3 * i + 1] = f32_as_u8(g);
+            rgb[3 * i + 2] = f32_as_u8(b);
+        }
+}

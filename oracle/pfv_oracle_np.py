@@ -279,3 +279,35 @@ def qtables(quality: int):
 
     return (mk(Q_TABLE_INTRA, True), mk(Q_TABLE_INTRA, False), mk(Q_TABLE_INTER, True), mk(Q_TABLE_INTER, False),
             float(np.float32(quality) * np.float32(1.5)))
+
+
+# ------------------------------------------------------------------ colour helpers of the reference's tests
+def _as_u8(x):
+    """Rust `f32 as u8`: truncate toward zero, saturate"""
+    return np.clip(np.trunc(x), 0, 255).astype(np.uint8)
+
+
+def rgb_to_yuv420(rgb):
+    """load_frame (src/lib.rs:337-359) + VideoFrame::from_planes (src/frame.rs:51-59); rgb [h, w, 3] u8 -> packed Y|U|V"""
+    f = np.float32
+    r, g, b = (rgb[..., k].astype(f) for k in range(3))
+    y = (f(0.299) * r + f(0.587) * g) + f(0.114) * b
+    u = ((f(128.0) - f(0.168736) * r) - f(0.331264) * g) + f(0.5) * b
+    v = ((f(128.0) + f(0.5) * r) - f(0.418688) * g) - f(0.081312) * b
+    h, w = rgb.shape[:2]
+    return np.concatenate([_as_u8(y).reshape(-1), _as_u8(u)[0:h // 2 * 2:2, 0:w // 2 * 2:2].reshape(-1),
+                           _as_u8(v)[0:h // 2 * 2:2, 0:w // 2 * 2:2].reshape(-1)])
+
+
+def yuv420_to_rgb(frame, w, h):
+    """save_frame (src/lib.rs:361-394): chroma doubled (nearest), JPEG-conversion YCbCr -> RGB in f32"""
+    f = np.float32
+    n, cw, ch = w * h, w // 2, h // 2
+    y = frame[:n].reshape(h, w).astype(f)
+    up = lambda p: np.repeat(np.repeat(p.reshape(ch, cw), 2, axis=0), 2, axis=1)
+    u = up(frame[n:n + cw * ch]).astype(f) - f(128.0)
+    v = up(frame[n + cw * ch:]).astype(f) - f(128.0)
+    r = y + f(1.402) * v
+    g = (y - f(0.344136) * u) - f(0.714136) * v
+    b = y + f(1.772) * u
+    return np.stack([_as_u8(r), _as_u8(g), _as_u8(b)], axis=-1)

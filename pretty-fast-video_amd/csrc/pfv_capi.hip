@@ -458,6 +458,30 @@ PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int s
     return launch_check(ctx, "k_double2x");
 }
 
+// RGB8 <-> planar YUV 4:2:0 frames, the conversions of the reference's test helpers (src/lib.rs:337-394)
+PFV_API int pfv_rgb_to_yuv420_dev(pfv_ctx *ctx, const uint8_t *rgb_dev, int width, int height, uint8_t *frame_dev)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!rgb_dev || !frame_dev || width <= 0 || height <= 0 || (width & 1) || (height & 1))
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_rgb_to_yuv420_dev: null buffer or odd / non-positive size (src/frame.rs:13)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    long n = (long)width * height;
+    int blocks = (int)std::min<long>((n + kThreads - 1) / kThreads, 8192);
+    hipLaunchKernelGGL(k_rgb_to_yuv420, dim3(blocks), dim3(kThreads), 0, ctx->stream, rgb_dev, width, height, frame_dev);
+    return launch_check(ctx, "k_rgb_to_yuv420");
+}
+PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int width, int height, uint8_t *rgb_dev)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!rgb_dev || !frame_dev || width <= 0 || height <= 0 || (width & 1) || (height & 1))
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_yuv420_to_rgb_dev: null buffer or odd / non-positive size (src/frame.rs:13)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    long n = (long)width * height;
+    int blocks = (int)std::min<long>((n + kThreads - 1) / kThreads, 8192);
+    hipLaunchKernelGGL(k_yuv420_to_rgb, dim3(blocks), dim3(kThreads), 0, ctx->stream, frame_dev, width, height, rgb_dev);
+    return launch_check(ctx, "k_yuv420_to_rgb");
+}
+
 // ------------------------------------------------------------------ device memory helpers
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out)
 {

@@ -1107,6 +1107,48 @@ __global__ __launch_bounds__(kThreads) void k_double2x(uint8_t *__restrict__ dst
     }
 }
 
+// f32 -> u8 the way Rust's `as u8` does it: truncate toward zero, saturate, NaN -> 0
+__device__ __forceinline__ uint32_t f32_as_u8(float x)
+{
+    return x >= 255.0f ? 255u : (x > 0.0f ? (uint32_t)(int)x : 0u);
+}
+// load_frame of the reference's tests (src/lib.rs:337-359) + VideoFrame::from_planes (src/frame.rs:51-59): interleaved
+// RGB8 -> Y at full resolution, U and V from the pixels at even (x, y) (from_planes point-samples with reduce()).
+// JPEG-conversion YCbCr in f32, evaluated left to right without contraction, then `as u8`.
+__global__ __launch_bounds__(kThreads) void k_rgb_to_yuv420(const uint8_t *__restrict__ rgb, int w, int h, uint8_t *__restrict__ frame)
+{
+#pragma clang fp contract(off)
+    const long n = (long)w * h;
+    const int cw = w >> 1, ch = h >> 1;
+    uint8_t *py = frame, *pu = frame + n, *pv = pu + (long)cw * ch;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / w), x = (int)(idx - (long)y * w);
+        const float r = (float)rgb[3 * idx], g = (float)rgb[3 * idx + 1], b = (float)rgb[3 * idx + 2];
+        py[idx] = (uint8_t)f32_as_u8((0.299f * r) + (0.587f * g) + (0.114f * b));
+        if (!(x & 1) && !(y & 1) && (x >> 1) < cw && (y >> 1) < ch) {
+            const long c = (long)(y >> 1) * cw + (x >> 1);
+            pu[c] = (uint8_t)f32_as_u8(128.0f - (0.168736f * r) - (0.331264f * g) + (0.5f * b));
+            pv[c] = (uint8_t)f32_as_u8(128.0f + (0.5f * r) - (0.418688f * g) - (0.081312f * b));
+        }
+    }
+}
+// save_frame (src/lib.rs:361-394): chroma doubled (nearest), JPEG-conversion YCbCr -> RGB8 in f32, `as u8`.
+__global__ __launch_bounds__(kThreads) void k_yuv420_to_rgb(const uint8_t *__restrict__ frame, int w, int h, uint8_t *__restrict__ rgb)
+{
+#pragma clang fp contract(off)
+    const long n = (long)w * h;
+    const int cw = w >> 1, ch = h >> 1;
+    const uint8_t *py = frame, *pu = frame + n, *pv = pu + (long)cw * ch;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / w), x = (int)(idx - (long)y * w);
+        const long c = (long)(y >> 1) * cw + (x >> 1);
+        const float yy = (float)py[idx], u = (float)pu[c] - 128.0f, v = (float)pv[c] - 128.0f;
+        rgb[3 * idx] = (uint8_t)f32_as_u8(yy + (1.402f * v));
+        rgb[3 * idx + 1] = (uint8_t)f32_as_u8(yy - (0.344136f * u) - (0.714136f * v));
+        rgb[3 * idx + 2] = (uint8_t)f32_as_u8(yy + (1.772f * u));
+    }
+}
+
 // VideoFrame::new_padded initial state (src/frame.rs:38-43): Y = 0, U = V = 128.
 __global__ __launch_bounds__(kThreads) void k_init_padded(FrameGeom g, uint8_t *__restrict__ padded)
 {

@@ -37,6 +37,42 @@ class VideoFrame:
         return VideoFrame(width, height, plane_y, plane_u.reduce(), plane_v.reduce())
 
     # packing used by the session API: Y | U | V, tightly packed
+    # ---------------------------------------------------------------- src/lib.rs:337-394 (load_frame / save_frame)
+    @staticmethod
+    def from_rgb(ctx, rgb: np.ndarray) -> "VideoFrame":
+        """interleaved RGB8 [h, w, 3] -> 4:2:0 frame (JPEG-conversion YCbCr in f32, chroma point-sampled), on the device"""
+        import ctypes
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w = rgb.shape[:2]
+        assert rgb.shape == (h, w, 3) and w % 2 == 0 and h % 2 == 0
+        nbytes = w * h + 2 * (w // 2) * (h // 2)
+        d_rgb, d_frame = ctx.alloc(rgb.size), ctx.alloc(nbytes)
+        try:
+            ctx.upload(d_rgb, rgb)
+            ctx.check(ctx._lib.pfv_rgb_to_yuv420_dev(ctx.handle, ctypes.c_void_p(d_rgb), w, h, ctypes.c_void_p(d_frame)))
+            out = np.empty(nbytes, dtype=np.uint8)
+            ctx.download(out, d_frame)
+        finally:
+            ctx.free(d_rgb)
+            ctx.free(d_frame)
+        return VideoFrame.from_packed(w, h, out)
+
+    def to_rgb(self, ctx) -> np.ndarray:
+        """4:2:0 frame -> interleaved RGB8 [h, w, 3] (chroma doubled, JPEG-conversion YCbCr in f32), on the device"""
+        import ctypes
+        w, h = self.width, self.height
+        buf = self.packed()
+        d_rgb, d_frame = ctx.alloc(w * h * 3), ctx.alloc(buf.size)
+        try:
+            ctx.upload(d_frame, buf)
+            ctx.check(ctx._lib.pfv_yuv420_to_rgb_dev(ctx.handle, ctypes.c_void_p(d_frame), w, h, ctypes.c_void_p(d_rgb)))
+            out = np.empty((h, w, 3), dtype=np.uint8)
+            ctx.download(out, d_rgb)
+        finally:
+            ctx.free(d_rgb)
+            ctx.free(d_frame)
+        return out
+
     def packed(self) -> np.ndarray:
         return np.concatenate([self.plane_y.pixels, self.plane_u.pixels, self.plane_v.pixels])
 

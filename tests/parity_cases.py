@@ -413,3 +413,56 @@ def check_async_entropy(pkg, ctx, oracle, w, h, n_streams, n_frames=6):
     for p in d_frames + [x for st in sets for x in st]:
         ctx.free(p)
     enc.close()
+
+
+def _oracle_colour(oracle):
+    import ctypes
+    L = oracle.L
+    L.pfvo_rgb_to_yuv420.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.pfvo_yuv420_to_rgb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.pfvo_rgb_to_yuv420.restype = L.pfvo_yuv420_to_rgb.restype = None
+    return L
+
+
+def all_rgb_image():
+    """8192 x 8192 RGB image in which every one of the 2^24 colours fills one 2x2 block (so each is chroma-sampled)"""
+    idx = np.arange(1 << 24, dtype=np.uint32).reshape(4096, 4096)
+    big = np.repeat(np.repeat(idx, 2, axis=0), 2, axis=1)
+    return np.stack([(big & 255).astype(np.uint8), ((big >> 8) & 255).astype(np.uint8), (big >> 16).astype(np.uint8)], axis=-1)
+
+
+def all_yuv_frame():
+    """4096 x 4096 4:2:0 frame that contains every (Y, U, V) triple"""
+    w = h = 4096
+    x, y = np.meshgrid(np.arange(w, dtype=np.int32), np.arange(h, dtype=np.int32))
+    cx, cy = x >> 1, y >> 1
+    Y = (((cx >> 8) + 8 * (cy >> 8)) * 4 + (x & 1) + 2 * (y & 1)).astype(np.uint8)
+    c = np.arange(2048, dtype=np.int32)
+    U = np.broadcast_to((c & 255).astype(np.uint8)[None, :], (2048, 2048))
+    V = np.broadcast_to((c & 255).astype(np.uint8)[:, None], (2048, 2048))
+    return np.concatenate([Y.reshape(-1), U.reshape(-1), V.reshape(-1)]), w, h
+
+
+def check_colour_conversions(pkg, ctx, oracle, exhaustive):
+    """pfv_rgb_to_yuv420_dev / pfv_yuv420_to_rgb_dev == the oracle's restatement of the reference's test helpers"""
+    import ctypes
+    L = _oracle_colour(oracle)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(7)
+    cases = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for (w, h) in ((2, 2), (34, 18), (640, 360))]
+    if exhaustive:
+        cases.append(all_rgb_image())
+    for rgb in cases:
+        h, w = rgb.shape[:2]
+        ref = np.empty(w * h + 2 * (w // 2) * (h // 2), np.uint8)
+        L.pfvo_rgb_to_yuv420(P(rgb), w, h, P(ref))
+        fr = pkg.VideoFrame.from_rgb(ctx, rgb)
+        assert np.array_equal(fr.packed(), ref), f"rgb -> yuv420 differs ({w}x{h})"
+    frames = [(rng.integers(0, 256, w * h * 3 // 2).astype(np.uint8), w, h) for (w, h) in ((2, 2), (34, 18), (640, 360))]
+    if exhaustive:
+        frames.append(all_yuv_frame())
+    for buf, w, h in frames:
+        ref = np.empty((h, w, 3), np.uint8)
+        L.pfvo_yuv420_to_rgb(P(buf), w, h, P(ref))
+        got = pkg.VideoFrame.from_packed(w, h, buf).to_rgb(ctx)
+        assert np.array_equal(got, ref), f"yuv420 -> rgb differs ({w}x{h})"

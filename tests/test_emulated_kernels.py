@@ -99,3 +99,7 @@ def test_emu_dense_stream_falls_back(pkg, emu_ctx, oracle):
 def test_emu_async_entropy_api(pkg, emu_ctx, oracle):
     """call sequence of the two-stream entropy mode (the emulator has one timeline; ordering is checked on the GPU)"""
     pc.check_async_entropy(pkg, emu_ctx, oracle, 48, 32, n_streams=2, n_frames=5)
+
+
+def test_emu_colour_conversions(pkg, emu_ctx, oracle):
+    pc.check_colour_conversions(pkg, emu_ctx, oracle, exhaustive=False)

@@ -257,6 +257,11 @@ def test_async_entropy_stream(pkg, gpu_ctx, oracle):
     pc.check_async_entropy(pkg, gpu_ctx, oracle, 1920, 1080, n_streams=2, n_frames=4)
 
 
+def test_colour_conversions_exhaustive(pkg, gpu_ctx, oracle):
+    """every RGB colour and every (Y, U, V) triple through the device converters vs the oracle (src/lib.rs:337-394)"""
+    pc.check_colour_conversions(pkg, gpu_ctx, oracle, exhaustive=True)
+
+
 def test_sparse_decode(pkg, gpu_ctx):
     pc.check_sparse_decode(pkg, gpu_ctx, 100, 60, n_streams=2)
     pc.check_sparse_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12)

@@ -213,3 +213,24 @@ def test_config1_plumbing_161_frames_1080p(oracle, pkg):
             break
     assert n == N
     assert pw == pwy * phy + 2 * 960 * 544
+
+
+def test_colour_helpers_c_equals_numpy(oracle):
+    """src/lib.rs:337-394 restated twice (C with forced f32 rounding, numpy float32): same bytes, incl. saturation"""
+    import ctypes
+    import parity_cases as pc
+    L = pc._oracle_colour(oracle)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (512, 1024, 3)).astype(np.uint8)
+    rgb[:2, :4] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 0, 255]]
+    h, w = rgb.shape[:2]
+    out = np.empty(w * h * 3 // 2, np.uint8)
+    L.pfvo_rgb_to_yuv420(P(rgb), w, h, P(out))
+    assert np.array_equal(out, onp.rgb_to_yuv420(rgb))
+    assert out[0] == 0 and out[1] == 255                      # black, white
+    frame = rng.integers(0, 256, w * h * 3 // 2).astype(np.uint8)
+    back = np.empty((h, w, 3), np.uint8)
+    L.pfvo_yuv420_to_rgb(P(frame), w, h, P(back))
+    assert np.array_equal(back, onp.yuv420_to_rgb(frame, w, h))
+    assert back.min() == 0 and back.max() == 255              # the saturating casts are exercised
