@@ -12,7 +12,7 @@ echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | te
 echo "== bench"; timeout 900 python bench.py "$@" 2>$OUT/bench.err | tee $OUT/bench.json; tail -3 $OUT/bench.err
 echo "== rocprofv3 kernel stats"
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-two-stream "$@" > $OUT/prof.log 2>&1
 find $OUT/prof -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
 # keep only the small summaries (the raw trace can be large)

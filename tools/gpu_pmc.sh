@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $OUT/$name -o $name -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $OUT/$name -o $name -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-two-stream $BENCH_ARGS > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python $R/tools/pmc_summary.py "$f" > $OUT/$name.summary.txt; cat $OUT/$name.summary.txt; cp "$f" $OUT/$name.counters.csv; rm -rf $OUT/$name; fi
 }
