@@ -277,12 +277,21 @@ def main():
         achieved = launch_mbs * BYTES_PER_MB_PENC / (pe_ms * 1e-3) / 1e9
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
         # tools/gpu_pmc.sh); only quoted when it was collected on this exact configuration
-        traffic = None
+        traffic, valu = None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             c = pm["config"]
             if (int(c["streams"]), int(c["width"]), int(c["height"]), int(c["quality"])) == (S, W, H, Q):
                 traffic = pm["kernels"]["k_enc_pframe"]["traffic_bytes"]
+                n_valu = pm["kernels"]["k_enc_pframe"].get("valu_wave_instructions")
+                if n_valu:
+                    # what actually bounds the kernel: VALU issue.  1024 SIMDs at the 2.4 GHz maximum clock; a wave64
+                    # instruction occupies its SIMD for 2 (plain VOP2) to 4+ (VOP3 / DPP / SDWA / v_dot4) cycles
+                    valu = {"wave_instructions_per_launch": n_valu,
+                            "simd_cycles_per_instruction": pe_ms * 1e-3 * 2.4e9 * 1024 / n_valu,
+                            "note": "SQ_INSTS_VALU from the committed PMC pass (profiles/pmc_traffic.json), this run's launch "
+                                    "time, 1024 SIMDs x 2.4 GHz: the kernel retires one wave64 VALU instruction per ~4.5 SIMD "
+                                    "cycles, i.e. it is bound by VALU issue, not by the HBM roof quoted in frac"}
         except (OSError, KeyError, ValueError):
             pass
         res = {
@@ -305,7 +314,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": launch_mbs * BYTES_PER_MB_PENC,
                          "avg_launch_ms": pe_ms, "macroblocks_per_launch": launch_mbs,
-                         "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC},
+                         "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC, "valu": valu},
         }
         res["pframe_encode"] = {"value": launch_mbs / (pe_ms * 1e-3), "unit": "macroblocks/s",
                                 "note": "k_enc_pframe alone (motion search + residual DCT + closed-loop reconstruction), HIP-event time"}
