@@ -256,6 +256,17 @@ PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_block
 PFV_API size_t pfv_serialize_pframe_payload(const int8_t *mv, const uint8_t *has_coef, const int16_t *coef, int total_blocks,
                                             uint8_t *out, size_t cap);
 
+/* packet payload parsers alone (the bit-reading halves of decode_iframe / decode_pframe, src/dec.rs:226-296, 328-417; host
+ * only, no device): coef_out [total_blocks][256] is zero-filled first.  PFV_OK, PFV_ERR_FORMAT or PFV_ERR_IO. */
+PFV_API int pfv_parse_iframe_payload(const uint8_t *payload, size_t len, int total_blocks, int n_qtables, int16_t *coef_out,
+                                     uint8_t qidx_out[3]);
+PFV_API int pfv_parse_pframe_payload(const uint8_t *payload, size_t len, int total_blocks, int n_qtables, int8_t *mv_out,
+                                     uint8_t *has_coef_out, int16_t *coef_out, uint8_t qidx_out[3]);
+/* same, into the (flat index, value) list pfv_dec_*_sparse take; returns 1 when more than `cap` pairs would be needed */
+PFV_API int pfv_parse_payload_sparse(int is_pframe, const uint8_t *payload, size_t len, int total_blocks, int n_qtables,
+                                     int8_t *mv_out, uint8_t *has_coef_out, uint32_t *idx_out, int16_t *val_out, size_t cap,
+                                     size_t *n_out, uint8_t qidx_out[3]);
+
 /* `data` must stay valid while the decoder lives.  Errors: PFV_ERR_FORMAT / PFV_ERR_VERSION / PFV_ERR_IO
  * = DecodeError::{FormatError, VersionError, IOError} (src/dec.rs:30-35). */
 PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pfv_decoder **out);

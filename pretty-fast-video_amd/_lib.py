@@ -103,6 +103,9 @@ SIGNATURES = [
     ("pfv_encoder_set_device_entropy", c_int, [_P, c_int]),
     ("pfv_serialize_iframe_payload", c_size_t, [_P, c_int, _P, c_size_t]),
     ("pfv_serialize_pframe_payload", c_size_t, [_P, _P, _P, c_int, _P, c_size_t]),
+    ("pfv_parse_iframe_payload", c_int, [_P, c_size_t, c_int, c_int, _P, _P]),
+    ("pfv_parse_pframe_payload", c_int, [_P, c_size_t, c_int, c_int, _P, _P, _P, _P]),
+    ("pfv_parse_payload_sparse", c_int, [c_int, _P, c_size_t, c_int, c_int, _P, _P, _P, _P, c_size_t, POINTER(c_size_t), _P]),
     ("pfv_decoder_create", c_int, [_P, _P, c_size_t, POINTER(_P)]),
     ("pfv_decoder_destroy", None, [_P]),
     ("pfv_decoder_set_lookahead", c_int, [_P, c_int]),

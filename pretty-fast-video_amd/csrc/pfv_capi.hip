@@ -1450,6 +1450,39 @@ PFV_API size_t pfv_serialize_pframe_payload(const int8_t *mv, const uint8_t *has
     return p.size();
 }
 
+// payload parsers alone (decode_iframe / decode_pframe up to the plane decode, src/dec.rs:226-296, 328-417); host only.
+// coef_out: [total_blocks][256], zero-filled first.  Returns PFV_OK, PFV_ERR_FORMAT or PFV_ERR_IO.
+PFV_API int pfv_parse_iframe_payload(const uint8_t *payload, size_t len, int total_blocks, int n_qtables, int16_t *coef_out,
+                                     uint8_t qidx_out[3])
+{
+    if (!payload || !coef_out || !qidx_out || total_blocks <= 0) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_parse_iframe_payload: bad argument");
+    int rc = parse_iframe(payload, len, total_blocks, n_qtables, coef_out, qidx_out);
+    return rc ? fail(nullptr, rc, "malformed packet payload") : PFV_OK;
+}
+PFV_API int pfv_parse_pframe_payload(const uint8_t *payload, size_t len, int total_blocks, int n_qtables, int8_t *mv_out,
+                                     uint8_t *has_coef_out, int16_t *coef_out, uint8_t qidx_out[3])
+{
+    if (!payload || !mv_out || !has_coef_out || !coef_out || !qidx_out || total_blocks <= 0)
+        return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_parse_pframe_payload: bad argument");
+    int rc = parse_pframe(payload, len, total_blocks, n_qtables, mv_out, has_coef_out, coef_out, qidx_out);
+    return rc ? fail(nullptr, rc, "malformed packet payload") : PFV_OK;
+}
+// The sparse form the stream decoder uploads: up to `cap` (flat index, value) pairs; *n_out = pairs written.  Returns 1 when
+// the list would overflow (the caller then parses the dense form).
+PFV_API int pfv_parse_payload_sparse(int is_pframe, const uint8_t *payload, size_t len, int total_blocks, int n_qtables,
+                                     int8_t *mv_out, uint8_t *has_coef_out, uint32_t *idx_out, int16_t *val_out, size_t cap,
+                                     size_t *n_out, uint8_t qidx_out[3])
+{
+    if (!payload || !idx_out || !val_out || !n_out || !qidx_out || total_blocks <= 0 || (is_pframe && (!mv_out || !has_coef_out)))
+        return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_parse_payload_sparse: bad argument");
+    SparseSink sink{idx_out, val_out, cap};
+    int rc = is_pframe ? parse_pframe_to(payload, len, total_blocks, n_qtables, mv_out, has_coef_out, sink, qidx_out)
+                       : parse_iframe_to(payload, len, total_blocks, n_qtables, sink, qidx_out);
+    *n_out = sink.n;
+    if (rc == kSinkFull) return 1;
+    return rc ? fail(nullptr, rc, "malformed packet payload") : PFV_OK;
+}
+
 // Decoder::new (src/dec.rs:38-134).  `data` must stay valid for the decoder's lifetime (R: Read + Seek).
 PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pfv_decoder **out)
 {

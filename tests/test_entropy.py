@@ -111,3 +111,64 @@ def test_oracle_stream_self_consistency(oracle, pkg):
     for bad, code in ((b"X" + data[1:], -6), (data[:8] + (210).to_bytes(4, "little") + data[12:], -7), (data[:10], -8)):
         d = OracleStreamDecoder(oracle, bad)
         assert not d.h and d.err == code
+
+
+@pytest.mark.parametrize("density", [0.0, 0.03, 0.2, 1.0])
+def test_payload_parsers_invert_the_serialisers(graft, pkg, oracle, density):
+    """product parse(serialise(x)) == x, dense and sparse forms, on payloads from the product and from the oracle;
+    truncated payloads are reported, never read past"""
+    graft.build_hip()
+    os.environ.pop("PFV_HIP_LIB", None)
+    pkg._lib._lib = None
+    lib = pkg._lib.load()
+    L = _oracle_payloads(oracle)
+    rng = np.random.default_rng(int(density * 1000) + 1)
+    nb = 41
+    coef = (rng.integers(-16383, 16384, (nb, 256)) * (rng.random((nb, 256)) < density)).astype(np.int16)
+    coef[7] = 0
+    coef[9, 255] = 3
+    mv = rng.integers(-15, 16, (nb, 2)).astype(np.int8)
+    mv[::4] = 0
+    has = (rng.random(nb) < 0.7).astype(np.uint8)
+    cap = nb * 256 * 4 + 64
+    for pframe in (False, True):
+        a, b = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        if pframe:
+            na = lib.pfv_serialize_pframe_payload(_p(mv), _p(has), _p(coef), nb, _p(a), cap)
+            nbo = L.pfvo_serialize_pframe(_p(mv), _p(has), _p(coef), nb, _p(b), cap)
+        else:
+            na = lib.pfv_serialize_iframe_payload(_p(coef), nb, _p(a), cap)
+            nbo = L.pfvo_serialize_iframe(_p(coef), nb, _p(b), cap)
+        assert na == nbo
+        want = coef * has[:, None].astype(np.int16) if pframe else coef
+        for payload in (a[:na].copy(), b[:nbo].copy()):
+            out, q = np.full((nb, 256), 77, np.int16), np.zeros(3, np.uint8)
+            omv, ohas = np.zeros((nb, 2), np.int8), np.zeros(nb, np.uint8)
+            rc = (lib.pfv_parse_pframe_payload(_p(payload), payload.size, nb, 4, _p(omv), _p(ohas), _p(out), _p(q)) if pframe else
+                  lib.pfv_parse_iframe_payload(_p(payload), payload.size, nb, 4, _p(out), _p(q)))
+            assert rc == 0 and np.array_equal(out, want) and q.tolist() == ([2, 3, 3] if pframe else [0, 1, 1])
+            if pframe:
+                assert np.array_equal(omv, mv) and np.array_equal(ohas, has)
+            # sparse form: same non-zeros, ascending flat indices
+            idx, val, n = np.zeros(nb * 256, np.uint32), np.zeros(nb * 256, np.int16), ctypes.c_size_t()
+            rc = lib.pfv_parse_payload_sparse(int(pframe), _p(payload), payload.size, nb, 4, _p(omv), _p(ohas), _p(idx), _p(val),
+                                              idx.size, ctypes.byref(n), _p(q))
+            assert rc == 0
+            dense = np.zeros(nb * 256, np.int16)
+            dense[idx[:n.value]] = val[:n.value]
+            assert np.array_equal(dense.reshape(nb, 256), want) and np.all(np.diff(idx[:n.value].astype(np.int64)) > 0)
+            if n.value > 4:                                   # a list that is too short is reported, not overrun
+                rc = lib.pfv_parse_payload_sparse(int(pframe), _p(payload), payload.size, nb, 4, _p(omv), _p(ohas), _p(idx), _p(val),
+                                                  n.value - 1, ctypes.byref(n), _p(q))
+                assert rc == 1
+            # every truncation is an error (or, cut inside the final padding, still the full frame)
+            for cut in (0, 10, 18, 19, payload.size // 2, payload.size - 1):
+                out2 = np.zeros((nb, 256), np.int16)
+                rc = (lib.pfv_parse_pframe_payload(_p(payload), cut, nb, 4, _p(omv), _p(ohas), _p(out2), _p(q)) if pframe else
+                      lib.pfv_parse_iframe_payload(_p(payload), cut, nb, 4, _p(out2), _p(q)))
+                assert rc in (pkg._lib.PFV_ERR_IO, pkg._lib.PFV_ERR_FORMAT) or (rc == 0 and np.array_equal(out2, want))
+            # a q-table index past the header's table count fails at the head (dec.rs:244-246)
+            bad = payload.copy(); bad[17] = 9
+            rc = (lib.pfv_parse_pframe_payload(_p(bad), bad.size, nb, 4, _p(omv), _p(ohas), _p(out), _p(q)) if pframe else
+                  lib.pfv_parse_iframe_payload(_p(bad), bad.size, nb, 4, _p(out), _p(q)))
+            assert rc == pkg._lib.PFV_ERR_FORMAT
