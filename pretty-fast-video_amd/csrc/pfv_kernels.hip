@@ -564,7 +564,6 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
                                              int a2, int mbx, int mby, int pw, int ph, SearchState &st)
 {
     constexpr bool kAligned = (S >= 4);            // displacement is a multiple of 4 pixels: no byte shifts
-    constexpr int kN = kAligned ? (16 + 2 * S) / 4 : 7;   // dwords per span
     const int sh = st.cx & 3;                      // only used when !kAligned
     // span origin (bytes from the window row start): dword aligned
     const int col = kAligned ? (wcol0 + st.cx - S) : (wcol0 + (st.cx & ~3) - 4);
@@ -600,7 +599,6 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
             if (!FIRST && my == 0 && mx == 0) { part[1][1] = 0; continue; }   // centre already known (:176)
             unsigned ab = 0, bb = 0;
             if (kAligned) {
-                constexpr int dummy = 0; (void)dummy;
                 const int o = (mx + 1) * S / 4;
                 dot_row(top, dT[o], dT[o + 1], dT[o + 2], dT[o + 3], ab, bb);
                 dot_row(bot, dB[o], dB[o + 1], dB[o + 2], dB[o + 3], ab, bb);
