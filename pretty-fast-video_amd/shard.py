@@ -24,6 +24,43 @@ def streams_of_rank(table: np.ndarray, rank: int) -> np.ndarray:
     return table[table[:, 0] == rank]
 
 
+def assign_gops(n_frames: int, gop: int, world: int) -> np.ndarray:
+    """GOP-level sharding of ONE stream (granularity 2): an i-frame never reads prev_frame and overwrites
+    every plane (src/enc.rs:84-97), so each I P P ... run is independent.  int64 table [n_gops, 4] of
+    (rank, gop_index, first_frame, n_frames_in_gop); GOP g -> rank g % world."""
+    assert n_frames >= 0 and gop >= 1 and world >= 1
+    n_gops = (n_frames + gop - 1) // gop
+    g = np.arange(n_gops, dtype=np.int64)
+    first = g * gop
+    return np.stack([g % world, g, first, np.minimum(gop, n_frames - first)], axis=1)
+
+
+HEADER_BYTES = 20 + 4 * 128      # magic, version, w, h, fps, n_qtables, four 64 x u16 tables (src/enc.rs:190-219)
+
+
+def encode_gops(pkg, ctx, frame_of, width: int, height: int, framerate: int, quality: int, rows) -> list:
+    """Encode the GOPs listed in `rows` (rows of assign_gops owned by this rank) with fresh Encoders; returns
+    [(gop_index, packet bytes)] -- the stream's packets for those frames, without header and EOF."""
+    import io
+    out = []
+    for _, g, first, n in np.asarray(rows, dtype=np.int64):
+        buf = io.BytesIO()
+        enc = pkg.Encoder(buf, width, height, framerate, quality, ctx)
+        for t in range(int(first), int(first + n)):
+            (enc.encode_iframe if t == first else enc.encode_pframe)(frame_of(t))
+        data = buf.getvalue()            # header + packets so far; finish() would append the EOF packet
+        enc.finished = True              # the packets are spliced into a longer stream: no EOF here
+        enc.close()
+        out.append((int(g), data[HEADER_BYTES:]))
+    return out
+
+
+def splice_stream(header: bytes, gop_packets) -> bytes:
+    """header + the GOPs' packets in order + EOF packet (src/enc.rs:221-227)"""
+    body = b"".join(p for _, p in sorted(gop_packets))
+    return header + body + bytes([0, 0, 0, 0, 0])
+
+
 def broadcast_table(table, rank: int, dist, device=None) -> np.ndarray:
     """rank 0's table to everyone (a few hundred bytes)"""
     import torch

@@ -80,3 +80,61 @@ def test_stream_sharding_gloo_world2(pkg, oracle):
     assert max_s == 2.0                      # max over ranks
     assert tot_cs == ref_cs % (1 << 40) or tot_cs == ref_cs   # checksum of checksums
     assert rank0_ids == [0, 2, 4]
+
+
+def _gop_worker(rank, world, port, emu_lib, geom, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PFV_HIP_LIB"] = emu_lib          # the product's own sources on the CPU emulator (kernels need a GPU)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    from importlib import import_module
+    shard = import_module("pretty_fast_video_amd.shard")
+    import stream_cases as sc
+    w, h, fps, quality, n_frames, gop = geom
+    table = shard.assign_gops(n_frames, gop, world) if rank == 0 else np.zeros(((n_frames + gop - 1) // gop, 4), np.int64)
+    table = shard.broadcast_table(table, rank, dist)          # the only scatter: frame index ranges
+    st = pkg.SyntheticStream(w, h)
+    with pkg.Context(0) as ctx:
+        mine = shard.encode_gops(pkg, ctx, lambda t: sc.frame_of(pkg, w, h, st.frame(t)), w, h, fps, quality, table[table[:, 0] == rank])
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)                  # packets are host bytes: concatenated in order on rank 0
+    if rank == 0:
+        q.put([x for part in gathered for x in part])
+    dist.destroy_process_group()
+
+
+def test_gop_sharding_gloo_world2(pkg, oracle):
+    """one stream, GOPs dealt to two ranks, packets spliced on rank 0 == the single-process stream == the oracle's"""
+    import io
+    from importlib import import_module
+    import conftest
+    import stream_cases as sc
+    from oracle_bind import OracleStreamEncoder
+    shard = import_module("pretty_fast_video_amd.shard")
+    geom = (48, 32, 30, 5, 8, 3)                               # 8 frames, GOP 3 -> GOPs of 3, 3, 2 frames
+    w, h, fps, quality, n_frames, gop = geom
+    table = shard.assign_gops(n_frames, gop, 2)
+    assert table.tolist() == [[0, 0, 0, 3], [1, 1, 3, 3], [0, 2, 6, 2]]
+    emu_lib = conftest.build_emulator()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gop_worker, args=(r, 2, port, emu_lib, geom, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g for g, _ in parts) == [0, 1, 2]
+    # the oracle's stream of the same frames with the same i-frame positions
+    st = pkg.SyntheticStream(w, h)
+    oenc = OracleStreamEncoder(oracle, w, h, fps, quality)
+    for t in range(n_frames):
+        (oenc.encode_iframe if t % gop == 0 else oenc.encode_pframe)(st.frame(t))
+    oenc.finish()
+    want = oenc.bytes()
+    assert shard.splice_stream(want[:shard.HEADER_BYTES], parts) == want
