@@ -17,5 +17,5 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY
-python $R/tools/pmc_traffic.py $OUT/fetch.counters.csv $OUT/write.counters.csv $OUT/pmc_traffic.json sq=$OUT/sq1.counters.csv streams=32 width=1920 height=1080 quality=5
+python $R/tools/pmc_traffic.py $OUT/fetch.counters.csv $OUT/write.counters.csv $OUT/pmc_traffic.json sq=$OUT/sq1.counters.csv streams=96 width=1920 height=1080 quality=5
 rm -f $OUT/*.counters.csv
