@@ -187,6 +187,10 @@ PFV_API int pfv_enc_pack_pframe_dev(pfv_enc_session *s, const int8_t *mv_dev, co
  * than 15 size bits (the reference panics, rle.rs:44); PFV_ERR_NOMEM: a payload exceeds the capacity.  sizes_out is
  * filled either way (0 for failed streams). */
 PFV_API int pfv_enc_payload_sizes(pfv_enc_session *s, uint32_t *sizes_out);
+/* every stream's payload with one device-to-host copy: gathered back to back on the device (16-byte aligned starts) into
+ * `out` (cap bytes, ideally from pfv_host_alloc); stream s occupies out[offsets_out[s] .. + sizes_out[s]).  Synchronises;
+ * errors as pfv_enc_payload_sizes, PFV_ERR_NOMEM when cap is too small. */
+PFV_API int pfv_enc_payloads_fetch(pfv_enc_session *s, uint8_t *out, size_t cap, uint32_t *sizes_out, uint64_t *offsets_out);
 PFV_API const uint8_t *pfv_enc_payload_dev(pfv_enc_session *s, int stream);
 PFV_API size_t pfv_enc_payload_capacity(pfv_enc_session *s);
 /* first nbytes of one stream's payload to the host (synchronises) */

@@ -77,6 +77,7 @@ SIGNATURES = [
     ("pfv_enc_pack_iframe_dev", c_int, [_P, _P]),
     ("pfv_enc_pack_pframe_dev", c_int, [_P, _P, _P, _P]),
     ("pfv_enc_payload_sizes", c_int, [_P, _P]),
+    ("pfv_enc_payloads_fetch", c_int, [_P, _P, c_size_t, _P, _P]),
     ("pfv_enc_payload_dev", _P, [_P, c_int]),
     ("pfv_enc_payload_capacity", c_size_t, [_P]),
     ("pfv_enc_payload_fetch", c_int, [_P, c_int, _P, c_size_t]),

@@ -577,6 +577,9 @@ struct pfv_enc_session {
     std::vector<uint32_t> ent_sizes;         // last pfv_enc_payload_sizes result
     // optional second HIP stream for the stage (pfv_enc_entropy_set_async): the memory-bound k_ent_* kernels of frame t
     // overlap the VALU-bound encode kernel of frame t+1
+    uint8_t *ent_packed = nullptr;           // all payloads back to back (pfv_enc_payloads_fetch)
+    uint32_t *ent_offsets_dev = nullptr;
+    size_t ent_packed_cap = 0;
     hipStream_t ent_stream = nullptr;
     hipEvent_t ev_encoded = nullptr;         // main stream: the buffers handed to pack are complete
     hipEvent_t ev_packed[2] = {nullptr, nullptr};   // entropy stream: pack call t has finished with its inputs
@@ -652,6 +655,8 @@ PFV_API void pfv_enc_session_destroy(pfv_enc_session *s)
         if (b) (void)hipFree(b);
     for (void *b : s->ent_allocs)
         if (b) (void)hipFree(b);
+    if (s->ent_packed) (void)hipFree(s->ent_packed);
+    if (s->ent_offsets_dev) (void)hipFree(s->ent_offsets_dev);
     if (s->ent_stream) {
         (void)hipStreamSynchronize(s->ent_stream);
         (void)hipEventDestroy(s->ev_encoded);
@@ -777,7 +782,8 @@ PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap)
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (s->ent_on) return PFV_OK;
-    size_t cap = payload_cap ? ((payload_cap + 3) & ~(size_t)3) : pfv_payload_worst_case(s->width, s->height);
+    size_t cap = payload_cap ? payload_cap : pfv_payload_worst_case(s->width, s->height);
+    cap = (cap + 15) & ~(size_t)15;   // 16-byte stride: k_ent_gather moves uint4s
     if (cap < 24 || cap > 0xfffffff0u) return fail(ctx, PFV_ERR_BAD_ARG, "payload capacity must be in [24, 2^32)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t S = (size_t)s->n_streams, tb = (size_t)s->geom.mbs_per_frame, n_sb = tb * 4;
@@ -913,6 +919,46 @@ PFV_API int pfv_enc_payload_sizes(pfv_enc_session *s, uint32_t *sizes_out)
     if (rc == PFV_ERR_NOMEM) return fail(ctx, rc, "payload exceeds the capacity given to pfv_enc_entropy_enable");
     return PFV_OK;
 }
+// Every stream's payload with ONE device-to-host copy: the payloads are gathered back to back on the device (starts
+// 16-byte aligned) and land in `out` (ideally page-locked, pfv_host_alloc); offsets_out[s] / sizes_out[s] locate stream
+// s in it.  `cap` must hold the sum of the sizes rounded up to 16 each.  Synchronises; errors as pfv_enc_payload_sizes.
+PFV_API int pfv_enc_payloads_fetch(pfv_enc_session *s, uint8_t *out, size_t cap, uint32_t *sizes_out, uint64_t *offsets_out)
+{
+    if (!s || !out || !sizes_out || !offsets_out) return fail(s ? s->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_enc_payloads_fetch: bad argument");
+    pfv_ctx *ctx = s->ctx;
+    int rc = pfv_enc_payload_sizes(s, sizes_out);
+    if (rc) return rc;
+    const int S = s->n_streams;
+    std::vector<uint32_t> off((size_t)S);
+    size_t total = 0;
+    for (int i = 0; i < S; i++) {
+        off[(size_t)i] = (uint32_t)total;
+        offsets_out[i] = total;
+        total += ((size_t)sizes_out[i] + 15) & ~(size_t)15;
+    }
+    if (total > cap || total > 0xfffffff0u) return fail(ctx, PFV_ERR_NOMEM, "pfv_enc_payloads_fetch: output buffer too small");
+    if (total == 0) return PFV_OK;
+    hipStream_t st = s->ent_stream ? s->ent_stream : ctx->stream;
+    if (total > s->ent_packed_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (s->ent_packed) (void)hipFree(s->ent_packed);
+        s->ent_packed = nullptr; s->ent_packed_cap = 0;
+        const size_t want = total + total / 2;
+        HIP_TRY(ctx, hipMalloc((void **)&s->ent_packed, want));
+        s->ent_packed_cap = want;
+    }
+    if (!s->ent_offsets_dev) HIP_TRY(ctx, hipMalloc((void **)&s->ent_offsets_dev, (size_t)S * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(s->ent_offsets_dev, off.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+    EntFrame f{};
+    f.n_streams = S;
+    f.cap_bytes = s->ent_cap;
+    hipLaunchKernelGGL(k_ent_gather, dim3(32, (unsigned)S), dim3(kEntThreads), 0, st, f, s->ent, s->ent_offsets_dev, s->ent_packed);
+    if ((rc = launch_check(ctx, "k_ent_gather"))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, s->ent_packed, total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));   // also keeps `off` alive long enough
+    return PFV_OK;
+}
+
 PFV_API const uint8_t *pfv_enc_payload_dev(pfv_enc_session *s, int stream)
 {
     if (!s || !s->ent_on || stream < 0 || stream >= s->n_streams) return nullptr;

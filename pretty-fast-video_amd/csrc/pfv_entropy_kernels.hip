@@ -617,4 +617,18 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     ent_flush_window(hwin, words, hword0, hdr_base + hdr_all);
 }
 
+// ---------------------------------------------------------------------------------------------------- k_ent_gather
+// All streams' payloads back to back (each start 16-byte aligned) so that ONE device-to-host copy fetches them.
+// offsets[s] = start of stream s in `packed`; sizes as left by k_ent_codes (error markers copy nothing).
+__global__ void __launch_bounds__(kEntThreads) k_ent_gather(EntFrame f, EntBufs b, const uint32_t *offsets, uint8_t *packed)
+{
+    const int stream = (int)blockIdx.y;
+    const uint32_t bytes = b.sizes[stream];
+    if (bytes >= kEntErrCapacity) return;
+    const uint4 *src = (const uint4 *)(b.payload + (size_t)stream * f.cap_bytes);
+    uint4 *dst = (uint4 *)(packed + offsets[stream]);
+    const uint32_t n = (bytes + 15u) >> 4;   // the tail of the last 16 bytes is payload padding / stale words: harmless
+    for (uint32_t i = blockIdx.x * kEntThreads + threadIdx.x; i < n; i += gridDim.x * kEntThreads) dst[i] = src[i];
+}
+
 }  // namespace pfv

@@ -77,3 +77,73 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+
+class BatchEncoder:
+    """``n`` independent streams of one geometry encoded together: one upload, one kernel launch per stage and one
+    download per frame step for all of them (the reference runs one ``Encoder`` per stream, src/enc.rs:12-26).  Each
+    writer receives exactly the bytes an ``Encoder`` of its own would have written.
+
+    The caller fills ``frames`` -- a page-locked ``[n, frame_bytes]`` uint8 array, one packed Y|U|V frame per stream --
+    and calls ``encode_iframes()`` / ``encode_pframes()``; ``finish()`` writes the EOF packets."""
+
+    def __init__(self, writers, width: int, height: int, framerate: int, quality: int, ctx: Context):
+        import numpy as np
+        from .session import EncoderSession, qtables_from_quality
+        assert 0 <= quality <= 10 and len(writers) >= 1
+        self.ctx, self.writers, self.n = ctx, list(writers), len(writers)
+        self.width, self.height = int(width), int(height)
+        self.session = EncoderSession(ctx, width, height, quality, self.n)
+        self.session.enable_entropy()
+        s = self.session
+        self.frames = ctx.host_array(self.n * s.frame_bytes).reshape(self.n, s.frame_bytes)
+        cap = int(ctx._lib.pfv_payload_worst_case(width, height))
+        self._payloads = ctx.host_array(min(self.n * cap, max(self.n * s.frame_bytes * 2, 1 << 20)))
+        self._d_frames = ctx.alloc(self.n * s.frame_bytes)
+        self._d_coef, self._d_mv, self._d_has = (ctx.alloc(self.n * s.total_blocks * 512), ctx.alloc(self.n * s.total_blocks * 2),
+                                                 ctx.alloc(self.n * s.total_blocks))
+        self.finished = False
+        # header (src/enc.rs:190-219): magic, version, geometry, the four q-tables
+        q = qtables_from_quality(quality)
+        head = (b"PFVIDEO\x00" + (211).to_bytes(4, "little") + self.width.to_bytes(2, "little") + self.height.to_bytes(2, "little")
+                + int(framerate).to_bytes(2, "little") + (4).to_bytes(2, "little")
+                + b"".join(np.asarray(t, dtype="<u2").tobytes() for t in q[:4]))
+        for w in self.writers:
+            w.write(head)
+
+    def _step(self, pframe: bool):
+        assert not self.finished
+        s, ctx = self.session, self.ctx
+        ctx.upload(self._d_frames, self.frames)
+        if pframe:
+            s.encode_pframe_dev(self._d_frames, self._d_mv, self._d_has, self._d_coef)
+            s.pack_pframe_dev(self._d_mv, self._d_has, self._d_coef)
+        else:
+            s.encode_iframe_dev(self._d_frames, self._d_coef)
+            s.pack_iframe_dev(self._d_coef)
+        sizes, offsets = s.payloads(self._payloads)
+        kind = bytes([2 if pframe else 1])
+        for w, n, o in zip(self.writers, sizes.tolist(), offsets.tolist()):
+            w.write(kind + int(n).to_bytes(4, "little"))             # packet header (src/enc.rs:301-305, :453-457)
+            w.write(self._payloads[o:o + n].data)
+
+    def encode_iframes(self):
+        self._step(False)
+
+    def encode_pframes(self):
+        self._step(True)
+
+    def finish(self):
+        assert not self.finished
+        self.finished = True
+        for w in self.writers:
+            w.write(bytes(5))                                        # EOF packet (src/enc.rs:221-227)
+
+    def close(self):
+        if getattr(self, "session", None) is not None:
+            if not self.finished:
+                self.finish()
+            for p in (self._d_frames, self._d_coef, self._d_mv, self._d_has):
+                self.ctx.free(p)
+            self.session.close()
+            self.session = None

@@ -116,6 +116,14 @@ class EncoderSession(_Geometry):
         self.ctx.check(self.ctx._lib.pfv_enc_payload_fetch(self.handle, int(stream), ptr(out), int(nbytes)))
         return out[:nbytes].tobytes()
 
+    def payloads(self, out: np.ndarray):
+        """all streams' payloads of the last pack call with one device-to-host copy into `out` (uint8, ideally from
+        Context.host_array); returns (sizes, offsets): stream s is out[offsets[s] : offsets[s] + sizes[s]]"""
+        sizes = np.zeros(self.n_streams, dtype=np.uint32)
+        offsets = np.zeros(self.n_streams, dtype=np.uint64)
+        self.ctx.check(self.ctx._lib.pfv_enc_payloads_fetch(self.handle, ptr(out), out.size, ptr(sizes), ptr(offsets)))
+        return sizes, offsets
+
     def payload_dev(self, stream: int) -> int:
         return int(self.ctx._lib.pfv_enc_payload_dev(self.handle, int(stream)) or 0)
 

@@ -199,3 +199,22 @@ def check_lookahead_reset(pkg, ctx, data, n_frames):
         pass
     assert got == ref[:2] + ref
     dec.close()
+
+
+def check_batch_encoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, gop):
+    """BatchEncoder: every writer receives exactly the bytes the oracle's Encoder produces for that stream"""
+    bufs = [io.BytesIO() for _ in range(n_streams)]
+    enc = pkg.BatchEncoder(bufs, w, h, 30, quality, ctx)
+    streams = [pkg.SyntheticStream(w, h, seed=pkg.synth.SEED + 5 * s) for s in range(n_streams)]
+    oencs = [OracleStreamEncoder(oracle, w, h, 30, quality) for _ in range(n_streams)]
+    for t in range(n_frames):
+        for s, st in enumerate(streams):
+            f = st.frame(t)
+            enc.frames[s] = f
+            (oencs[s].encode_iframe if t % gop == 0 else oencs[s].encode_pframe)(f)
+        (enc.encode_iframes if t % gop == 0 else enc.encode_pframes)()
+    enc.finish()
+    enc.close()
+    for s in range(n_streams):
+        oencs[s].finish()
+        assert bufs[s].getvalue() == oencs[s].bytes(), f"stream {s}: batch encoder bytes differ from the oracle's stream"

@@ -103,3 +103,7 @@ def test_emu_async_entropy_api(pkg, emu_ctx, oracle):
 
 def test_emu_colour_conversions(pkg, emu_ctx, oracle):
     pc.check_colour_conversions(pkg, emu_ctx, oracle, exhaustive=False)
+
+
+def test_emu_batch_encoder(pkg, emu_ctx, oracle):
+    sc.check_batch_encoder(pkg, emu_ctx, oracle, 48, 32, 5, n_streams=3, n_frames=4, gop=3)

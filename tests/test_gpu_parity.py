@@ -262,6 +262,11 @@ def test_colour_conversions_exhaustive(pkg, gpu_ctx, oracle):
     pc.check_colour_conversions(pkg, gpu_ctx, oracle, exhaustive=True)
 
 
+def test_batch_encoder(pkg, gpu_ctx, oracle):
+    sc.check_batch_encoder(pkg, gpu_ctx, oracle, 176, 144, 5, n_streams=5, n_frames=5, gop=3)
+    sc.check_batch_encoder(pkg, gpu_ctx, oracle, 640, 360, 8, n_streams=2, n_frames=3, gop=15)
+
+
 def test_sparse_decode(pkg, gpu_ctx):
     pc.check_sparse_decode(pkg, gpu_ctx, 100, 60, n_streams=2)
     pc.check_sparse_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12)

@@ -71,6 +71,21 @@ with pkg.Context(0) as ctx:
             d.close()
             assert n == NG * GOP
         res[f"end_to_end_decode_{name}_mb_per_s"] = best
+    # (iv) batch encoder: S streams per step, one upload / launch set / download; frames written straight into the
+    # page-locked array, writers are in-memory
+    for SB in (8, 32):
+        bufs = [io.BytesIO() for _ in range(SB)]
+        be = pkg.BatchEncoder(bufs, W, H, 30, Q, ctx)
+        fr = [np.tile(f, (SB, 1)) for f in frames1]
+        best = 0.0
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for t in range(GOP):
+                be.frames[...] = fr[t]                      # stands for the producer writing into the pinned array
+                (be.encode_iframes if t == 0 else be.encode_pframes)()
+            best = max(best, GOP * SB * 12240 / (time.perf_counter() - t0))
+        be.close()
+        res[f"batch_encoder_{SB}_streams_mb_per_s"] = best
     res.update({"stream_bytes": len(data),
                 "end_to_end_note": "one 1080p stream, 4 x GOP-15, pinned staging; encode = upload + kernels (+ device entropy | + "
                                    "coefficient download + host entropy) + packet assembly; decode = host bit parser (inline or on "
