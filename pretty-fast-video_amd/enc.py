@@ -111,10 +111,12 @@ class BatchEncoder:
         for w in self.writers:
             w.write(head)
 
-    def _step(self, pframe: bool):
+    def _step(self, pframe: bool, frames=None):
         assert not self.finished
         s, ctx = self.session, self.ctx
-        ctx.upload(self._d_frames, self.frames)
+        src = self.frames if frames is None else frames      # any [n, frame_bytes] uint8 array; page-locked ones upload fastest
+        assert src.size == self.n * s.frame_bytes
+        ctx.upload(self._d_frames, src)
         if pframe:
             s.encode_pframe_dev(self._d_frames, self._d_mv, self._d_has, self._d_coef)
             s.pack_pframe_dev(self._d_mv, self._d_has, self._d_coef)
@@ -127,11 +129,11 @@ class BatchEncoder:
             w.write(kind + int(n).to_bytes(4, "little"))             # packet header (src/enc.rs:301-305, :453-457)
             w.write(self._payloads[o:o + n].data)
 
-    def encode_iframes(self):
-        self._step(False)
+    def encode_iframes(self, frames=None):
+        self._step(False, frames)
 
-    def encode_pframes(self):
-        self._step(True)
+    def encode_pframes(self, frames=None):
+        self._step(True, frames)
 
     def finish(self):
         assert not self.finished
