@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 
+from . import _lib
 from .context import Context, ptr
 from .frame import VideoFrame
 
@@ -97,8 +98,8 @@ class BatchEncoder:
         self.session.enable_entropy()
         s = self.session
         self.frames = ctx.host_array(self.n * s.frame_bytes).reshape(self.n, s.frame_bytes)
-        cap = int(ctx._lib.pfv_payload_worst_case(width, height))
-        self._payloads = ctx.host_array(min(self.n * cap, max(self.n * s.frame_bytes * 2, 1 << 20)))
+        self._cap = cap = (int(ctx._lib.pfv_payload_worst_case(width, height)) + 15) & ~15
+        self._payloads = ctx.host_array(min(self.n * cap, max(self.n * s.frame_bytes, 1 << 20)))
         self._d_frames = ctx.alloc(self.n * s.frame_bytes)
         self._d_coef, self._d_mv, self._d_has = (ctx.alloc(self.n * s.total_blocks * 512), ctx.alloc(self.n * s.total_blocks * 2),
                                                  ctx.alloc(self.n * s.total_blocks))
@@ -123,7 +124,13 @@ class BatchEncoder:
         else:
             s.encode_iframe_dev(self._d_frames, self._d_coef)
             s.pack_iframe_dev(self._d_coef)
-        sizes, offsets = s.payloads(self._payloads)
+        try:
+            sizes, offsets = s.payloads(self._payloads)
+        except _lib.PfvError as e:                                   # very dense content: retry with the worst-case buffer
+            if e.code != _lib.PFV_ERR_NOMEM or self._payloads.size >= self.n * self._cap:
+                raise
+            self._payloads = ctx.host_array(self.n * self._cap)
+            sizes, offsets = s.payloads(self._payloads)
         kind = bytes([2 if pframe else 1])
         for w, n, o in zip(self.writers, sizes.tolist(), offsets.tolist()):
             w.write(kind + int(n).to_bytes(4, "little"))             # packet header (src/enc.rs:301-305, :453-457)

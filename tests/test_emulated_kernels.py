@@ -107,3 +107,26 @@ def test_emu_colour_conversions(pkg, emu_ctx, oracle):
 
 def test_emu_batch_encoder(pkg, emu_ctx, oracle):
     sc.check_batch_encoder(pkg, emu_ctx, oracle, 48, 32, 5, n_streams=3, n_frames=4, gop=3)
+
+
+def test_emu_batch_encoder_dense_content_grows_its_buffer(pkg, emu_ctx, oracle):
+    """white noise at quality 10 needs more payload bytes than a raw frame: the first download reports NOMEM, the
+    encoder retries with the worst-case buffer and still writes the oracle's bytes"""
+    import io
+    from oracle_bind import OracleStreamEncoder
+    w, h, n = 64, 48, 2
+    rng = np.random.default_rng(8)
+    bufs = [io.BytesIO() for _ in range(n)]
+    enc = pkg.BatchEncoder(bufs, w, h, 30, 10, emu_ctx)
+    enc._payloads = emu_ctx.host_array(4096)                      # start far too small
+    oencs = [OracleStreamEncoder(oracle, w, h, 30, 10) for _ in range(n)]
+    for t in range(2):
+        for s_ in range(n):
+            f = rng.integers(0, 256, w * h * 3 // 2).astype(np.uint8)
+            enc.frames[s_] = f
+            (oencs[s_].encode_iframe if t == 0 else oencs[s_].encode_pframe)(f)
+        (enc.encode_iframes if t == 0 else enc.encode_pframes)()
+    enc.finish(); enc.close()
+    for s_ in range(n):
+        oencs[s_].finish()
+        assert bufs[s_].getvalue() == oencs[s_].bytes()
