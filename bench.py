@@ -120,11 +120,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # developer dry-run of the N > 1 control flow on a one-GPU box: PFV_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # uses gloo (RCCL refuses two ranks on one device); never set by the driver
+    share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as graft
     graft.build_hip()
