@@ -100,7 +100,7 @@ def cpu_baseline(pkg, width, height, quality, frames_one_stream):
     for th in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
         trials[th] = run(th, 1, 5.0)[0]
     best = max(trials, key=trials.get)
-    rate, reps, el = run(best, 6, 10.0, record=True)
+    rate, reps, el = run(best, 40, 3.0, record=True)     # ~3 s of wall time on the best pool size
     n_mb = reps * len(frames_one_stream) * pkg._lib.load().pfv_total_blocks(width, height)
     return {"value": rate, "unit": "macroblocks/s", "cores": best, "kind": "port",
             "pframe_encode_value": penc["n"] / penc["s"] if penc["s"] > 0 else None,
