@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU box (not part of the test suite): many more geometries / contents / qualities than
+tests/test_gpu_parity.py runs, same checkers, product vs oracle.  usage: python tools/soak.py [minutes]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import __graft_entry__ as g   # noqa: E402
+
+g.build()
+pkg = g.load_package()
+import parity_cases as pc      # noqa: E402
+import stream_cases as sc      # noqa: E402
+from oracle_bind import Oracle  # noqa: E402
+
+budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 300.0
+oracle = Oracle()
+stats = {"plane_cases": 0, "sessions": 0, "entropy_payloads": 0, "corrupted_trials": 0, "stream_roundtrips": 0, "batch": 0}
+t_end = time.time() + budget
+rng = np.random.default_rng(int(time.time()))
+seed0 = int(rng.integers(1 << 30))
+print("seed", seed0, flush=True)
+it = 0
+with pkg.Context(0) as ctx:
+    while time.time() < t_end:
+        s = seed0 + it
+        r = np.random.default_rng(s)
+        pc.fuzz_plane_ops(pkg, ctx, oracle, n_cases=25, seed=s, max_w=700, max_h=300)
+        stats["plane_cases"] += 25
+        w, h = 2 * int(r.integers(1, 200)), 2 * int(r.integers(1, 120))
+        q = int(r.integers(0, 11))
+        S = int(r.integers(1, 4))
+        pc.check_session(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=int(r.integers(2, 6)), gop=int(r.integers(1, 5)))
+        stats["sessions"] += 1
+        stats["entropy_payloads"] += pc.check_device_entropy(pkg, ctx, oracle, w, h, n_streams=S, seed=s)
+        nf, gop = int(r.integers(2, 7)), int(r.integers(1, 4))
+        data = sc.check_stream_roundtrip(pkg, ctx, oracle, w, h, q, n_frames=nf, gop=gop)
+        stats["stream_roundtrips"] += 1
+        stats["corrupted_trials"] += sc.check_corrupted_streams(pkg, ctx, oracle, data, n_trials=40, seed=s)["trials"]
+        sc.check_batch_encoder(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=3, gop=2)
+        stats["batch"] += 1
+        pc.check_sparse_decode(pkg, ctx, w, h, n_streams=S, seed=s)
+        it += 1
+        if it % 10 == 0:
+            print(it, json.dumps(stats), flush=True)
+print("OK", json.dumps(stats))
