@@ -70,6 +70,10 @@ static_assert(kXchgDwords * 4 <= 4 * 1024, "exchange region must fit a wavefront
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 __device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+// The same wrapping product for operands known to fit 24 signed bits (v_mul_i32_i24 instead of v_mul_lo_u32): transform
+// outputs of 8-bit pixels (|m| < 2^22) times DCT_SCALE_FACTOR (<= 43), and i16 coefficients times SCALE*q (< 2^22 for
+// q <= 65535, which make_qtab enforces).
+__device__ __forceinline__ int wmul24(int a, int b) { return __mul24(a, b); }
 
 // Rust `/` by 2, 4, 16 on i32 (truncation toward zero).  trunc(x / 2^k) = (x + bias) >> k with
 // bias = (2^k - 1) for negative x; truncating divisions compose (trunc(trunc(x/a)/b) = trunc(x/(ab)))
@@ -421,7 +425,7 @@ __device__ __forceinline__ void forward_half(int (&v)[2][8], int *xw, int m, int
         const float rcp = lq.rcp(k);
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            int n = wmul(v[s][k], scale) >> 16;
+            int n = wmul24(v[s][k], scale) >> 16;
             v[s][k] = (int)((float)n * rcp) & keepmask;
             stage[s * 64 + zz] = (int16_t)v[s][k];
         }
@@ -442,8 +446,8 @@ __device__ __forceinline__ void inverse_half(int (&v)[2][8], int *xw, int m, int
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int deq = lq.deq(k);
-        v[0][k] = wmul(v[0][k], deq);
-        v[1][k] = wmul(v[1][k], deq);
+        v[0][k] = wmul24(v[0][k], deq);
+        v[1][k] = wmul24(v[1][k], deq);
     }
     idct8(v[0]);   // dct_inverse_transform_columns
     idct8(v[1]);

@@ -74,6 +74,11 @@ static inline unsigned long long __ballot(bool p)
     return m;
 }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __mul24(int a, int b)   // v_mul_i32_i24: low 32 bits of the product of the operands' low 24 bits, sign-extended
+{
+    const long long x = ((long long)a << 40) >> 40, y = ((long long)b << 40) >> 40;
+    return (int)(unsigned)(unsigned long long)(x * y);
+}
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int __shfl(int v, int src_lane) { return hipemu::wave_exchange(v, src_lane); }
