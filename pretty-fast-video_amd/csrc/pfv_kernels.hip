@@ -73,7 +73,11 @@ __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (
 // The same wrapping product for operands known to fit 24 signed bits (v_mul_i32_i24 instead of v_mul_lo_u32): transform
 // outputs of 8-bit pixels (|m| < 2^22) times DCT_SCALE_FACTOR (<= 43), and i16 coefficients times SCALE*q (< 2^22 for
 // q <= 65535, which make_qtab enforces).
+#ifdef PFV_NO_MUL24   // A/B switch
+__device__ __forceinline__ int wmul24(int a, int b) { return wmul(a, b); }
+#else
 __device__ __forceinline__ int wmul24(int a, int b) { return __mul24(a, b); }
+#endif
 
 // Rust `/` by 2, 4, 16 on i32 (truncation toward zero).  trunc(x / 2^k) = (x + bias) >> k with
 // bias = (2^k - 1) for negative x; truncating divisions compose (trunc(trunc(x/a)/b) = trunc(x/(ab)))
