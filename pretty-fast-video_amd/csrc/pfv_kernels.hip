@@ -73,12 +73,6 @@ __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (
 // The same wrapping product for operands known to fit 24 signed bits (v_mul_i32_i24 instead of v_mul_lo_u32): transform
 // outputs of 8-bit pixels (|m| < 2^22) times DCT_SCALE_FACTOR (<= 43), and i16 coefficients times SCALE*q (< 2^22 for
 // q <= 65535, which make_qtab enforces).
-// Byte offset of pixel (x, y) inside one plane as an unsigned 32-bit value: planes are at most 65536 x 65536 bytes and
-// rows / pitches fit 17 bits, so v_mul_u32_u24 is exact and the 64-bit arithmetic stays in the (scalar) plane base.
-__device__ __forceinline__ unsigned pix_off(int y, int pitch, int x)
-{
-    return __umul24((unsigned)y, (unsigned)pitch) + (unsigned)x;
-}
 #ifdef PFV_NO_MUL24   // A/B switch
 __device__ __forceinline__ int wmul24(int a, int b) { return wmul(a, b); }
 #else
@@ -349,7 +343,7 @@ __device__ __forceinline__ uint4 load_src16(const uint8_t *plane, const PlaneGeo
     unsigned fill = (unsigned)p.clear * 0x01010101u;
     uint4 val = make_uint4(fill, fill, fill, fill);
     if (y < p.h && x < p.w) {
-        const uint8_t *src = plane + pix_off(y, p.w, x);
+        const uint8_t *src = plane + (long)y * p.w + x;
         if (p.fast_src && x + 16 <= p.w) {
             val = *reinterpret_cast<const uint4 *>(src);
         } else {
@@ -378,7 +372,7 @@ __device__ __forceinline__ uint4 load_src16(const uint8_t *plane, const PlaneGeo
 // geometries run the separate k_crop_frames pass.
 __device__ __forceinline__ void store_cropped16(uint8_t *plane, const PlaneGeom &p, int x, int y, const uint4 &val)
 {
-    if (y < p.h && x < p.w) st_stream(reinterpret_cast<uint4 *>(plane + pix_off(y, p.w, x)), val);
+    if (y < p.h && x < p.w) st_stream(reinterpret_cast<uint4 *>(plane + (long)y * p.w + x), val);
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -510,7 +504,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
     wave_lds_sync();
     const LaneQ lq{qtab_lds[wave], i};
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
-    uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + pix_off(sp.y0 + i, p.pw, sp.x0 + m * 16)
+    uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16
                          : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -530,7 +524,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
             for (int s = 0; s < 2; s++)
 #pragma unroll
                 for (int k = 0; k < 8; k++) v[s][k] = min(max(v[s][k] + 128, 0), 255);   // src/common.rs:321
-            if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (unsigned)(8 * h) * (unsigned)p.pw) = pack_row(v);
+            if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(v);
         }
     }
 }
@@ -707,7 +701,7 @@ __device__ __forceinline__ void issue_window(const PlaneGeom &p, const uint8_t *
         const int c = q * 64 + lane;
         const int row = c / kWinChunksPerRow, col = c - row * kWinChunksPerRow;
         const int y = min(max(t.winy0 + row, 0), p.ph - 1), x = min(max(t.winx0 + col * 16, 0), p.pw - 16);
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(refp + pix_off(y, p.pw, x)), (lds_void_t *)(winbuf + c * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(refp + (long)y * p.pw + x), (lds_void_t *)(winbuf + c * 16), 16, 0, 0);
     }
 }
 
@@ -811,7 +805,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
     uint8_t *dst = recon ? recon + (((long)(sp.y0 + i) * p.pw + mbx) & 0xfffff) : nullptr;
 #else
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
-    uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + pix_off(sp.y0 + i, p.pw, mbx) : nullptr;
+    uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
 #endif
 
     if (__any(coded)) {   // wavefront-uniform: the LDS transposes need all lanes
@@ -843,9 +837,9 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                         pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
                 }
 #ifdef PFV_ABL_NOSTORE   // ablation experiment only (results invalid): one dword per lane instead of the row
-                if (mb_valid && pp[0][0] == 999) *reinterpret_cast<uint4 *>(dst + (unsigned)(8 * h) * (unsigned)p.pw) = pack_row(pp);
+                if (mb_valid && pp[0][0] == 999) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
 #else
-                if (mb_valid) *reinterpret_cast<uint4 *>(dst + (unsigned)(8 * h) * (unsigned)p.pw) = pack_row(pp);
+                if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
 #endif
             }
         }
@@ -858,7 +852,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
         }
         if (recon && mb_valid) {
             *reinterpret_cast<uint4 *>(dst) = so.patch[0];
-            *reinterpret_cast<uint4 *>(dst + 8u * (unsigned)p.pw) = so.patch[1];
+            *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = so.patch[1];
         }
     }
 }
@@ -935,7 +929,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
     fill_qtable<false>(qtab_lds[wave], qtabs + p.qsel, lane);
     wave_lds_sync();
     const LaneQ lq{qtab_lds[wave], i};
-    uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + pix_off(sp.y0 + i, p.pw, sp.x0 + m * 16);
+    uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         stage_coef_half(xw, cbuf[h], lane);
@@ -949,7 +943,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
             for (int k = 0; k < 8; k++) v[s][k] = min(max(v[s][k] + 128, 0), 255);   // src/common.rs:321
         if (m < sp.n_mb) {
             const uint4 o = pack_row(v);
-            *reinterpret_cast<uint4 *>(dst + (unsigned)(8 * h) * (unsigned)p.pw) = o;
+            *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = o;
             if (frames_out)
                 store_cropped16(frames_out + (long)sp.stream * g.src_frame_bytes + p.src_off, p, sp.x0 + m * 16, sp.y0 + i + 8 * h, o);
         }
@@ -1016,11 +1010,11 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     uint4 patch[2];
     patch[0] = patch[1] = make_uint4(0, 0, 0, 0);
     if (mb_valid) {   // the lane's two rows of the motion-compensated patch (get_block, :327-339)
-        const uint8_t *rp = ref + (long)sp.stream * g.pad_frame_bytes + p.pad_off + pix_off(mby + my + i, p.pw, mbx + mx);
+        const uint8_t *rp = ref + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(mby + my + i) * p.pw + (mbx + mx);
         patch[0] = load_unaligned16(rp);
-        patch[1] = load_unaligned16(rp + 8u * (unsigned)p.pw);
+        patch[1] = load_unaligned16(rp + 8 * (long)p.pw);
     }
-    uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + pix_off(sp.y0 + i, p.pw, mbx);
+    uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx;
     uint8_t *crop = frames_out ? frames_out + (long)sp.stream * g.src_frame_bytes + p.src_off : nullptr;
 
     if (any_coded) {
@@ -1042,13 +1036,13 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
                     pp[s][k] = min(max(pp[s][k] + 2 * (v[s][k] & codedmask), 0), 255);
             if (mb_valid) {
                 const uint4 o = pack_row(pp);
-                *reinterpret_cast<uint4 *>(dst + (unsigned)(8 * h) * (unsigned)p.pw) = o;
+                *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = o;
                 if (crop) store_cropped16(crop, p, mbx, sp.y0 + i + 8 * h, o);
             }
         }
     } else if (mb_valid) {
         *reinterpret_cast<uint4 *>(dst) = patch[0];
-        *reinterpret_cast<uint4 *>(dst + 8u * (unsigned)p.pw) = patch[1];
+        *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = patch[1];
         if (crop) {
             store_cropped16(crop, p, mbx, sp.y0 + i, patch[0]);
             store_cropped16(crop, p, mbx, sp.y0 + i + 8, patch[1]);

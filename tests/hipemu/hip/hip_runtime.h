@@ -79,7 +79,6 @@ static inline int __mul24(int a, int b)   // v_mul_i32_i24: low 32 bits of the p
     const long long x = ((long long)a << 40) >> 40, y = ((long long)b << 40) >> 40;
     return (int)(unsigned)(unsigned long long)(x * y);
 }
-static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int __shfl(int v, int src_lane) { return hipemu::wave_exchange(v, src_lane); }
