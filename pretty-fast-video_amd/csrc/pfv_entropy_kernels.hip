@@ -485,19 +485,23 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_init(EntFrame f, EntBufs b)
 constexpr int kEntWinWords = 2048;
 constexpr int kEntHdrWords = 64 * 16 / 32 + 2;   // 64 macroblocks x 16 header bits, plus unaligned ends
 
+// LSB-first bit writer of one lane.  kWindow: words are ORed into the workgroup's LDS window (ds_or_b32, nothing
+// returned, no branches); otherwise straight to memory, where the first and the last word a lane touches may be shared
+// with its neighbours (atomicOr onto the zeroed payload) and the words in between are its own (plain stores).
+template <bool kWindow>
 struct LaneBits {
-    uint32_t *lds;        // window word, or nullptr: straight to memory
-    uint32_t *mem;
+    uint32_t *w;
     uint64_t acc = 0;
     unsigned fill;
     bool first = true;
-    __device__ __forceinline__ LaneBits(uint32_t *window, uint32_t *words, uint32_t word0, uint32_t bit_off, bool in_window)
-        : lds(in_window ? window + ((bit_off >> 5) - word0) : nullptr), mem(words + (bit_off >> 5)), fill(bit_off & 31u) {}
+    __device__ __forceinline__ LaneBits(uint32_t *window, uint32_t *words, uint32_t word0, uint32_t bit_off)
+        : w(kWindow ? window + ((bit_off >> 5) - word0) : words + (bit_off >> 5)), fill(bit_off & 31u) {}
     __device__ __forceinline__ void word_out(uint32_t x, bool last)
     {
-        if (lds) atomicOr(lds++, x);                     // ds_or_b32, nothing returned
-        else if (first || last) atomicOr(mem++, x);      // may share the word with a neighbour
-        else *mem++ = x;
+        if (kWindow) atomicOr(w, x);
+        else if (first || last) atomicOr(w, x);
+        else *w = x;
+        w++;
         first = false;
     }
     __device__ __forceinline__ void put(uint32_t bits, unsigned len)   // len <= 32, bits < 2^len
@@ -515,6 +519,24 @@ struct LaneBits {
         if (fill && (uint32_t)acc) word_out((uint32_t)acc, true);
     }
 };
+
+// One lane's run symbols -> bits (enc.rs:307-316, :459-466): fillers, the pre-joined code pair, the value bits.
+template <bool kWindow>
+__device__ __forceinline__ void ent_emit_symbols(LaneBits<kWindow> &bw, const uint32_t *sym, uint32_t n_sym, uint32_t w_next,
+                                                 const uint32_t *pair_bits, const uint8_t *pair_len)
+{
+    const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
+    for (uint32_t k = 0; k < n_sym; k++) {
+        const uint32_t w = w_next;
+        if (k + 1 < n_sym) w_next = sym[k + 1];   // next symbol on its way while this one is written
+        for (uint32_t fl = w >> 24; fl; fl--) bw.put(filler_bits, filler_len);
+        const uint32_t p = w & 255u, size = (w >> 4) & 15u;
+        const uint32_t pb = pair_bits[p], pl = pair_len[p], vb = (w >> 8) & 0x7fffu;
+        if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
+        else { bw.put(pb, pl); bw.put(vb, size); }
+    }
+    bw.finish();
+}
 
 __device__ __forceinline__ void ent_flush_window(const uint32_t *win, uint32_t *words, uint32_t word0, uint32_t end_bit)
 {
@@ -594,23 +616,16 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     if (my_hdr) {   // block header (enc.rs:414-451)
         uint32_t bits = (my_hdr == 16u ? 1u : 0u) | (b.has[bi] ? 2u : 0u);
         if (my_hdr == 16u) bits |= ((uint32_t)mvx & 0x7fu) << 2 | ((uint32_t)mvy & 0x7fu) << 9;
-        LaneBits hw(hwin, words, hword0, hdr_off, true);
+        LaneBits<true> hw(hwin, words, hword0, hdr_off);
         hw.put(bits, my_hdr);
         hw.finish();
     }
-    if (n_sym) {
-        LaneBits bw(win, words, word0, sym_off, in_window);
-        const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
-        for (uint32_t k = 0; k < n_sym; k++) {
-            const uint32_t w = w_next;
-            if (k + 1 < n_sym) w_next = sym[k + 1];   // next symbol on its way while this one is written
-            for (uint32_t fl = w >> 24; fl; fl--) bw.put(filler_bits, filler_len);
-            const uint32_t p = w & 255u, size = (w >> 4) & 15u;
-            const uint32_t pb = pair_bits[p], pl = pair_len[p], vb = (w >> 8) & 0x7fffu;
-            if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
-            else { bw.put(pb, pl); bw.put(vb, size); }
-        }
-        bw.finish();
+    if (n_sym && in_window) {
+        LaneBits<true> bw(win, words, word0, sym_off);
+        ent_emit_symbols(bw, sym, n_sym, w_next, pair_bits, pair_len);
+    } else if (n_sym) {   // dense content: past the window, straight to memory
+        LaneBits<false> bw(win, words, word0, sym_off);
+        ent_emit_symbols(bw, sym, n_sym, w_next, pair_bits, pair_len);
     }
     __syncthreads();
     ent_flush_window(win, words, word0, min(cutoff, sym_base + sym_all));
