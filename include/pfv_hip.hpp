@@ -1,0 +1,216 @@
+// pfv_hip.hpp -- C++ host classes over the C ABI of pfv_hip.h, with the reference's public surface:
+//   pfv::VideoPlane  (src/plane.rs:1-36)     width, height, pixels  (public fields, tightly packed rows)
+//   pfv::VideoFrame  (src/frame.rs:3-59)     width, height, plane_y / plane_u / plane_v
+//   pfv::Encoder     (src/enc.rs:12-188)     new(writer, w, h, framerate, quality, num_threads) -> Encoder(writer, ..., Context&)
+//   pfv::Decoder     (src/dec.rs:15-224)     new(reader, num_threads)                            -> Decoder(reader, Context&)
+// The reference's `num_threads` slot (its rayon pool) is the pfv::Context: one device + one HIP stream.  Writers are
+// std::ostream, readers std::istream (read to the end on construction; the reference needs Read + Seek).  Errors of the
+// C ABI become pfv::Error (what() = pfv_last_error); DecodeError::{FormatError, VersionError, IOError} keep their codes.
+// Header-only; link against libpfv_hip.so.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <istream>
+#include <iterator>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pfv_hip.h"
+
+namespace pfv {
+
+class Error : public std::runtime_error {
+  public:
+    Error(int code, const std::string &what) : std::runtime_error(what), code_(code) {}
+    int code() const { return code_; }   // a pfv_status value
+
+  private:
+    int code_;
+};
+
+class Context {
+  public:
+    explicit Context(int device = 0)
+    {
+        int rc = pfv_ctx_create(device, &h_);
+        if (rc != PFV_OK) throw Error(rc, last(nullptr));
+    }
+    ~Context() { pfv_ctx_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    pfv_ctx *handle() const { return h_; }
+    void check(int rc) const
+    {
+        if (rc != PFV_OK) throw Error(rc, last(h_));
+    }
+
+  private:
+    static std::string last(pfv_ctx *h)
+    {
+        const char *m = pfv_last_error(h);
+        return m ? m : "pfv_hip error";
+    }
+    pfv_ctx *h_ = nullptr;
+};
+
+// src/plane.rs:1-36
+struct VideoPlane {
+    size_t width = 0, height = 0;
+    std::vector<uint8_t> pixels;
+    VideoPlane() = default;
+    VideoPlane(size_t w, size_t h) : width(w), height(h), pixels(w * h, 0) {}                    // VideoPlane::new
+    static VideoPlane from_slice(size_t w, size_t h, const uint8_t *data, size_t len)           // VideoPlane::from_slice
+    {
+        if (len != w * h) throw std::invalid_argument("VideoPlane::from_slice: len != width * height (src/plane.rs:14)");
+        VideoPlane p;
+        p.width = w; p.height = h;
+        p.pixels.assign(data, data + len);
+        return p;
+    }
+};
+
+// src/frame.rs:3-26
+struct VideoFrame {
+    size_t width = 0, height = 0;
+    VideoPlane plane_y, plane_u, plane_v;
+    VideoFrame() = default;
+    VideoFrame(size_t w, size_t h) : width(w), height(h), plane_y(w, h), plane_u(w / 2, h / 2), plane_v(w / 2, h / 2)   // VideoFrame::new
+    {
+        if (w % 2 || h % 2) throw std::invalid_argument("VideoFrame: width and height must be even (src/frame.rs:13)");
+        plane_u.pixels.assign(plane_u.pixels.size(), 128);
+        plane_v.pixels.assign(plane_v.pixels.size(), 128);
+    }
+};
+
+// src/enc.rs:12-188
+class Encoder {
+  public:
+    Encoder(std::ostream &writer, size_t width, size_t height, uint32_t framerate, int quality, Context &ctx)
+        : ctx_(ctx), out_(writer), width_(width), height_(height)
+    {
+        ctx_.check(pfv_encoder_create(ctx.handle(), (int)width, (int)height, (int)framerate, quality, &h_));
+        flush();   // the header (src/enc.rs:70)
+    }
+    ~Encoder()   // impl Drop (src/enc.rs:28-34): finish if the caller did not
+    {
+        if (h_) {
+            if (!finished_ && pfv_encoder_finish(h_) == PFV_OK) {
+                try { flush(); } catch (...) {}
+            }
+            pfv_encoder_destroy(h_);
+        }
+    }
+    Encoder(const Encoder &) = delete;
+    Encoder &operator=(const Encoder &) = delete;
+
+    void encode_iframe(const VideoFrame &f)   // src/enc.rs:75-123
+    {
+        check_frame(f);
+        ctx_.check(pfv_encoder_encode_iframe(h_, f.plane_y.pixels.data(), f.plane_u.pixels.data(), f.plane_v.pixels.data()));
+        flush();
+    }
+    void encode_pframe(const VideoFrame &f)   // src/enc.rs:125-173
+    {
+        check_frame(f);
+        ctx_.check(pfv_encoder_encode_pframe(h_, f.plane_y.pixels.data(), f.plane_u.pixels.data(), f.plane_v.pixels.data()));
+        flush();
+    }
+    void encode_dropframe()                   // src/enc.rs:175-180
+    {
+        ctx_.check(pfv_encoder_encode_dropframe(h_));
+        flush();
+    }
+    void finish()                             // src/enc.rs:182-188
+    {
+        ctx_.check(pfv_encoder_finish(h_));
+        finished_ = true;
+        flush();
+    }
+    // packet payloads from the device entropy stage (default) or the host serialisers: same bytes
+    void set_device_entropy(bool on) { ctx_.check(pfv_encoder_set_device_entropy(h_, on ? 1 : 0)); }
+
+  private:
+    void check_frame(const VideoFrame &f) const   // the asserts of src/enc.rs:76-80
+    {
+        if (f.width != width_ || f.height != height_ || f.plane_y.pixels.size() != width_ * height_ ||
+            f.plane_u.pixels.size() != (width_ / 2) * (height_ / 2) || f.plane_v.pixels.size() != (width_ / 2) * (height_ / 2))
+            throw std::invalid_argument("Encoder: frame geometry does not match the encoder (src/enc.rs:76-79)");
+    }
+    void flush()
+    {
+        const uint8_t *data = nullptr;
+        size_t len = 0;
+        ctx_.check(pfv_encoder_bytes(h_, &data, &len));
+        if (len > flushed_) {
+            out_.write(reinterpret_cast<const char *>(data) + flushed_, (std::streamsize)(len - flushed_));
+            flushed_ = len;
+        }
+    }
+    Context &ctx_;
+    std::ostream &out_;
+    size_t width_, height_, flushed_ = 0;
+    bool finished_ = false;
+    pfv_encoder *h_ = nullptr;
+};
+
+// src/dec.rs:15-224
+class Decoder {
+  public:
+    using OnVideo = std::function<void(const VideoFrame &)>;
+
+    Decoder(std::istream &reader, Context &ctx)
+        : ctx_(ctx), data_((std::istreambuf_iterator<char>(reader)), std::istreambuf_iterator<char>())
+    {
+        int rc = pfv_decoder_create(ctx.handle(), reinterpret_cast<const uint8_t *>(data_.data()), data_.size(), &h_);
+        if (rc != PFV_OK) ctx_.check(rc);   // DecodeError::{FormatError, VersionError, IOError} (src/dec.rs:30-35)
+        frame_ = VideoFrame((size_t)width(), (size_t)height());
+    }
+    ~Decoder() { pfv_decoder_destroy(h_); }
+    Decoder(const Decoder &) = delete;
+    Decoder &operator=(const Decoder &) = delete;
+
+    uint32_t width() const { return (uint32_t)pfv_decoder_width(h_); }          // src/dec.rs:136-138
+    uint32_t height() const { return (uint32_t)pfv_decoder_height(h_); }        // :140-142
+    uint32_t framerate() const { return (uint32_t)pfv_decoder_framerate(h_); }  // :144-146
+    void reset() { ctx_.check(pfv_decoder_reset(h_)); }                         // :148-152
+    void set_lookahead(int n_threads) { ctx_.check(pfv_decoder_set_lookahead(h_, n_threads)); }
+
+    // false at the end of the stream (Ok(false)), true otherwise; onvideo is called for every decoded frame
+    bool advance_delta(double delta, const OnVideo &onvideo)                    // src/dec.rs:154-167
+    {
+        cb_ = &onvideo;
+        return result(pfv_decoder_advance_delta(h_, delta, &Decoder::trampoline, this));
+    }
+    bool advance_frame(const OnVideo &onvideo)                                  // src/dec.rs:169-224
+    {
+        cb_ = &onvideo;
+        return result(pfv_decoder_advance_frame(h_, &Decoder::trampoline, this));
+    }
+
+  private:
+    bool result(int rc)
+    {
+        cb_ = nullptr;
+        if (rc < 0) ctx_.check(rc);
+        return rc == 1;
+    }
+    static void trampoline(void *user, const uint8_t *y, const uint8_t *u, const uint8_t *v, int w, int h)
+    {
+        Decoder *d = static_cast<Decoder *>(user);
+        const size_t ny = (size_t)w * h, nc = (size_t)(w / 2) * (h / 2);
+        d->frame_.plane_y.pixels.assign(y, y + ny);
+        d->frame_.plane_u.pixels.assign(u, u + nc);
+        d->frame_.plane_v.pixels.assign(v, v + nc);
+        if (d->cb_ && *d->cb_) (*d->cb_)(d->frame_);
+    }
+    Context &ctx_;
+    std::string data_;              // the whole stream: the native decoder reads from it for its lifetime
+    pfv_decoder *h_ = nullptr;
+    VideoFrame frame_;              // retframe (src/dec.rs:22)
+    const OnVideo *cb_ = nullptr;
+};
+
+}  // namespace pfv

@@ -1,0 +1,67 @@
+// Exercise of include/pfv_hip.hpp (the C++ mirror of pfv_rs::enc::Encoder / dec::Decoder): reads raw 4:2:0 frames,
+// writes the .pfv stream and the decoded frames.  usage: roundtrip W H FPS QUALITY GOP DROP_AT in.yuv out.pfv out.yuv
+// (frame DROP_AT becomes a drop frame; -1: none).  The Python test compares both outputs with the oracle's.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "pfv_hip.hpp"
+
+int main(int argc, char **argv)
+{
+    if (argc != 10) { std::fprintf(stderr, "usage: %s W H FPS QUALITY GOP DROP_AT in.yuv out.pfv out.yuv\n", argv[0]); return 2; }
+    const size_t w = std::strtoul(argv[1], nullptr, 10), h = std::strtoul(argv[2], nullptr, 10);
+    const unsigned fps = (unsigned)std::atoi(argv[3]);
+    const int quality = std::atoi(argv[4]), gop = std::atoi(argv[5]), drop_at = std::atoi(argv[6]);
+    try {
+        pfv::Context ctx(0);
+        std::ifstream in(argv[7], std::ios::binary);
+        std::stringstream stream(std::ios::in | std::ios::out | std::ios::binary);
+        int n_in = 0;
+        {
+            pfv::Encoder enc(stream, w, h, fps, quality, ctx);
+            pfv::VideoFrame f(w, h);
+            for (int t = 0;; t++) {
+                in.read(reinterpret_cast<char *>(f.plane_y.pixels.data()), (std::streamsize)f.plane_y.pixels.size());
+                in.read(reinterpret_cast<char *>(f.plane_u.pixels.data()), (std::streamsize)f.plane_u.pixels.size());
+                in.read(reinterpret_cast<char *>(f.plane_v.pixels.data()), (std::streamsize)f.plane_v.pixels.size());
+                if (!in) break;
+                if (t == drop_at) enc.encode_dropframe();
+                else if (t % gop == 0) enc.encode_iframe(f);
+                else enc.encode_pframe(f);
+                n_in++;
+            }
+        }   // ~Encoder writes the EOF packet (impl Drop, src/enc.rs:28-34)
+        const std::string bytes = stream.str();
+        std::ofstream(argv[8], std::ios::binary).write(bytes.data(), (std::streamsize)bytes.size());
+
+        std::istringstream reader(bytes, std::ios::binary);
+        pfv::Decoder dec(reader, ctx);
+        if (dec.width() != w || dec.height() != h || dec.framerate() != fps) { std::fprintf(stderr, "header mismatch\n"); return 1; }
+        std::ofstream out(argv[9], std::ios::binary);
+        int n_out = 0;
+        auto sink = [&](const pfv::VideoFrame &fr) {
+            out.write(reinterpret_cast<const char *>(fr.plane_y.pixels.data()), (std::streamsize)fr.plane_y.pixels.size());
+            out.write(reinterpret_cast<const char *>(fr.plane_u.pixels.data()), (std::streamsize)fr.plane_u.pixels.size());
+            out.write(reinterpret_cast<const char *>(fr.plane_v.pixels.data()), (std::streamsize)fr.plane_v.pixels.size());
+            n_out++;
+        };
+        while (dec.advance_frame(sink)) {}
+        // a bad stream must surface as pfv::Error with the DecodeError code
+        try {
+            std::istringstream bad(std::string("NOTPFV!!") + bytes.substr(8), std::ios::binary);
+            pfv::Decoder d2(bad, ctx);
+            std::fprintf(stderr, "bad magic accepted\n");
+            return 1;
+        } catch (const pfv::Error &e) {
+            if (e.code() != PFV_ERR_FORMAT) { std::fprintf(stderr, "wrong error code %d\n", e.code()); return 1; }
+        }
+        std::printf("frames in %d, decoded %d, stream %zu bytes\n", n_in, n_out, bytes.size());
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,66 @@
+"""include/pfv_hip.hpp -- the C++ mirror of pfv_rs::enc::Encoder / dec::Decoder -- driven by tests/cpp/roundtrip.cpp:
+the .pfv bytes it writes and the frames it decodes must equal the oracle's.  The CPU run links the program against the
+emulator build of the product sources; the GPU run (-m gpu) against libpfv_hip.so."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(lib_path, exe):
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "roundtrip.cpp"), "-o", exe, lib_path,
+                    "-Wl,-rpath," + os.path.dirname(lib_path)], check=True)
+
+
+def _run(pkg, oracle, exe, tmp_path, w, h, quality, n_frames, gop, drop_at):
+    from oracle_bind import OracleStreamDecoder, OracleStreamEncoder
+    st = pkg.SyntheticStream(w, h)
+    frames = [st.frame(t) for t in range(n_frames)]
+    yuv_in, pfv_out, yuv_out = (str(tmp_path / n) for n in ("in.yuv", "out.pfv", "out.yuv"))
+    np.concatenate(frames).tofile(yuv_in)
+    r = subprocess.run([exe, str(w), str(h), "30", str(quality), str(gop), str(drop_at), yuv_in, pfv_out, yuv_out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    oenc = OracleStreamEncoder(oracle, w, h, 30, quality)
+    for t, f in enumerate(frames):
+        if t == drop_at:
+            oenc.encode_dropframe()
+        elif t % gop == 0:
+            oenc.encode_iframe(f)
+        else:
+            oenc.encode_pframe(f)
+    oenc.finish()
+    want = oenc.bytes()
+    assert open(pfv_out, "rb").read() == want, "C++ Encoder bytes differ from the oracle's stream"
+    odec = OracleStreamDecoder(oracle, want)
+    decoded = []
+    while True:
+        rc, fr = odec.advance_frame()
+        assert rc >= 0
+        if fr is not None:
+            decoded.append(fr)
+        if rc == 0:
+            break
+    got = np.fromfile(yuv_out, dtype=np.uint8)
+    assert got.size == sum(d.size for d in decoded) and np.array_equal(got, np.concatenate(decoded))
+    assert f"decoded {len(decoded)}" in r.stdout
+
+
+def test_cpp_mirror_on_emulator(pkg, oracle, tmp_path):
+    import conftest
+    exe = str(tmp_path / "roundtrip_emu")
+    _build(conftest.build_emulator(), exe)
+    _run(pkg, oracle, exe, tmp_path, 48, 32, 5, n_frames=5, gop=3, drop_at=2)
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_on_gpu(graft, pkg, oracle, tmp_path):
+    exe = str(tmp_path / "roundtrip")
+    _build(graft.build_hip(), exe)
+    _run(pkg, oracle, exe, tmp_path, 320, 240, 6, n_frames=7, gop=3, drop_at=4)
+    _run(pkg, oracle, exe, tmp_path, 1920, 1080, 5, n_frames=3, gop=15, drop_at=-1)
