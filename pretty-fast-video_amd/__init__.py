@@ -16,8 +16,8 @@ from .plane import VideoPlane, EncodedIPlane, EncodedPPlane
 from .frame import VideoFrame
 from .session import EncoderSession, DecoderSession, qtables_from_quality
 from .enc import BatchEncoder, Encoder
-from .dec import Decoder, DecodeError
+from .dec import BatchDecoder, Decoder, DecodeError
 from .synth import SyntheticStream
 
 __all__ = ["Context", "VideoPlane", "VideoFrame", "EncodedIPlane", "EncodedPPlane", "EncoderSession",
-           "DecoderSession", "Encoder", "BatchEncoder", "Decoder", "DecodeError", "qtables_from_quality", "PfvError", "SyntheticStream", "_lib"]
+           "DecoderSession", "Encoder", "BatchEncoder", "Decoder", "BatchDecoder", "DecodeError", "qtables_from_quality", "PfvError", "SyntheticStream", "_lib"]

@@ -218,3 +218,32 @@ def check_batch_encoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, go
     for s in range(n_streams):
         oencs[s].finish()
         assert bufs[s].getvalue() == oencs[s].bytes(), f"stream {s}: batch encoder bytes differ from the oracle's stream"
+
+
+def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, gop):
+    """BatchDecoder over the streams a BatchEncoder wrote: every step's frames equal the oracle decoder's, stream by stream"""
+    bufs = [io.BytesIO() for _ in range(n_streams)]
+    enc = pkg.BatchEncoder(bufs, w, h, 30, quality, ctx)
+    streams = [pkg.SyntheticStream(w, h, seed=pkg.synth.SEED + 3 * s) for s in range(n_streams)]
+    for t in range(n_frames):
+        for s, st in enumerate(streams):
+            enc.frames[s] = st.frame(t)
+        (enc.encode_iframes if t % gop == 0 else enc.encode_pframes)()
+    enc.finish(); enc.close()
+    data = [b.getvalue() for b in bufs]
+    odecs = [OracleStreamDecoder(oracle, d) for d in data]
+    dec = pkg.BatchDecoder(data, ctx, threads=3)
+    assert (dec.width, dec.height, dec.framerate) == (w, h, 30)
+    steps = 0
+    while True:
+        fr = dec.advance_frames()
+        if fr is False:
+            break
+        for s in range(n_streams):
+            rc, want = odecs[s].advance_frame()
+            assert rc == 1 and np.array_equal(fr[s], want), f"step {steps} stream {s}"
+        steps += 1
+    assert steps == n_frames and dec.advance_frames() is False
+    for od in odecs:
+        assert od.advance_frame()[0] == 0            # the oracle is at EOF too
+    dec.close()

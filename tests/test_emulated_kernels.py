@@ -130,3 +130,7 @@ def test_emu_batch_encoder_dense_content_grows_its_buffer(pkg, emu_ctx, oracle):
     for s_ in range(n):
         oencs[s_].finish()
         assert bufs[s_].getvalue() == oencs[s_].bytes()
+
+
+def test_emu_batch_decoder(pkg, emu_ctx, oracle):
+    sc.check_batch_decoder(pkg, emu_ctx, oracle, 48, 32, 5, n_streams=3, n_frames=4, gop=3)

@@ -276,6 +276,11 @@ def test_batch_encoder(pkg, gpu_ctx, oracle):
     sc.check_batch_encoder(pkg, gpu_ctx, oracle, 640, 360, 8, n_streams=2, n_frames=3, gop=15)
 
 
+def test_batch_decoder(pkg, gpu_ctx, oracle):
+    sc.check_batch_decoder(pkg, gpu_ctx, oracle, 176, 144, 5, n_streams=5, n_frames=5, gop=3)
+    sc.check_batch_decoder(pkg, gpu_ctx, oracle, 640, 360, 7, n_streams=2, n_frames=3, gop=15)
+
+
 def test_sparse_decode(pkg, gpu_ctx):
     pc.check_sparse_decode(pkg, gpu_ctx, 100, 60, n_streams=2)
     pc.check_sparse_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12)

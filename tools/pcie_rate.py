@@ -89,6 +89,16 @@ with pkg.Context(0) as ctx:
             best = max(best, GOP * SB * 12240 / (time.perf_counter() - t0))
         be.close()
         res[f"batch_encoder_{SB}_streams_mb_per_s"] = best
+        # (v) batch decoder over those streams: per-stream bit parsing on a thread pool, one sparse upload + one launch per step
+        for th in (8, 16):
+            bd = pkg.BatchDecoder([b.getvalue() for b in bufs], ctx, threads=th)
+            t0 = time.perf_counter()
+            steps = 0
+            while bd.advance_frames() is not False:
+                steps += 1
+            el = time.perf_counter() - t0
+            bd.close()
+            res[f"batch_decoder_{SB}_streams_{th}_threads_mb_per_s"] = steps * SB * 12240 / el
     res.update({"stream_bytes": len(data),
                 "end_to_end_note": "one 1080p stream, 4 x GOP-15, pinned staging; encode = upload + kernels (+ device entropy | + "
                                    "coefficient download + host entropy) + packet assembly; decode = host bit parser (inline or on "
