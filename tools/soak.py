@@ -43,6 +43,7 @@ with pkg.Context(0) as ctx:
         stats["stream_roundtrips"] += 1
         stats["corrupted_trials"] += sc.check_corrupted_streams(pkg, ctx, oracle, data, n_trials=40, seed=s)["trials"]
         sc.check_batch_encoder(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=3, gop=2)
+        sc.check_batch_decoder(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=4, gop=3)
         stats["batch"] += 1
         pc.check_sparse_decode(pkg, ctx, w, h, n_streams=S, seed=s)
         it += 1
