@@ -146,7 +146,7 @@ class BatchDecoder:
         rc = lib.pfv_parse_payload_sparse(int(typ == 2), P(payload), payload.size, tb, self.n_qtables, P(self._mv[k]), P(self._has[k]),
                                           P(idx), P(val), self._cap, ctypes.byref(n), P(qidx))
         if rc == 1:
-            raise DecodeError(_lib.PFV_ERR_NOMEM, "BatchDecoder: packet too dense for the sparse upload; decode this stream with Decoder")
+            return None, qidx.tobytes()                               # denser than 1 in 4: this step goes the dense way
         if rc:
             raise DecodeError(rc, "malformed packet payload")
         idx[:n.value] += np.uint32(k * tb * 256)                      # flat index into [stream][macroblock][256]
@@ -170,6 +170,8 @@ class BatchDecoder:
         res = list(self._pool.map(lambda k: self._parse(k, typ, pk[k][1]), range(self.n)))
         if len({q for _, q in res}) != 1:
             raise ValueError("BatchDecoder: the streams use different q-table indices in this step")
+        if any(c is None for c, _ in res):
+            return self._dense_step(typ, pk, np.frombuffer(res[0][1], np.uint8))
         # compact the per-stream lists into one (they are ascending within and across streams)
         counts = [c for c, _ in res]
         at = 0
@@ -185,6 +187,29 @@ class BatchDecoder:
         else:
             s.decode_pframe_sparse(self._mv, self._has, self._idx[:at], self._val[:at], qidx)
         self.ctx.check(self.ctx._lib.pfv_dec_get_frame(s.handle, self._frames.ctypes.data_as(ctypes.c_void_p)))
+        return self._frames
+
+    def _dense_step(self, typ, pk, qidx):
+        """some packet overflowed its sparse list: parse every stream into the dense [macroblock][256] form instead"""
+        lib, s, tb = self.ctx._lib, self.session, self.session.total_blocks
+        if getattr(self, "_coef", None) is None:
+            self._coef = self.ctx.host_array(self.n * tb * 512).view(np.int16).reshape(self.n, tb, 256)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+        def parse(k):
+            q = np.zeros(3, np.uint8)
+            payload = pk[k][1]
+            rc = (lib.pfv_parse_pframe_payload(P(payload), payload.size, tb, self.n_qtables, P(self._mv[k]), P(self._has[k]),
+                                               P(self._coef[k]), P(q)) if typ == 2 else
+                  lib.pfv_parse_iframe_payload(P(payload), payload.size, tb, self.n_qtables, P(self._coef[k]), P(q)))
+            if rc:
+                raise DecodeError(rc, "malformed packet payload")
+        list(self._pool.map(parse, range(self.n)))
+        if typ == 1:
+            s.decode_iframe(self._coef, qidx)
+        else:
+            s.decode_pframe(self._mv, self._has, self._coef, qidx)
+        self.ctx.check(lib.pfv_dec_get_frame(s.handle, self._frames.ctypes.data_as(ctypes.c_void_p)))
         return self._frames
 
     def close(self):

@@ -220,14 +220,16 @@ def check_batch_encoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, go
         assert bufs[s].getvalue() == oencs[s].bytes(), f"stream {s}: batch encoder bytes differ from the oracle's stream"
 
 
-def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, gop):
-    """BatchDecoder over the streams a BatchEncoder wrote: every step's frames equal the oracle decoder's, stream by stream"""
+def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, gop, noise=False):
+    """BatchDecoder over the streams a BatchEncoder wrote: every step's frames equal the oracle decoder's, stream by stream.
+    noise=True feeds white noise (dense coefficients: the decoder's sparse lists overflow and it parses the dense form)."""
     bufs = [io.BytesIO() for _ in range(n_streams)]
     enc = pkg.BatchEncoder(bufs, w, h, 30, quality, ctx)
     streams = [pkg.SyntheticStream(w, h, seed=pkg.synth.SEED + 3 * s) for s in range(n_streams)]
+    rng = np.random.default_rng(w * h + quality)
     for t in range(n_frames):
         for s, st in enumerate(streams):
-            enc.frames[s] = st.frame(t)
+            enc.frames[s] = rng.integers(0, 256, w * h * 3 // 2).astype(np.uint8) if noise else st.frame(t)
         (enc.encode_iframes if t % gop == 0 else enc.encode_pframes)()
     enc.finish(); enc.close()
     data = [b.getvalue() for b in bufs]
@@ -246,4 +248,5 @@ def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, go
     assert steps == n_frames and dec.advance_frames() is False
     for od in odecs:
         assert od.advance_frame()[0] == 0            # the oracle is at EOF too
+    assert not noise or getattr(dec, "_coef", None) is not None
     dec.close()

@@ -134,3 +134,8 @@ def test_emu_batch_encoder_dense_content_grows_its_buffer(pkg, emu_ctx, oracle):
 
 def test_emu_batch_decoder(pkg, emu_ctx, oracle):
     sc.check_batch_decoder(pkg, emu_ctx, oracle, 48, 32, 5, n_streams=3, n_frames=4, gop=3)
+
+
+def test_emu_batch_decoder_dense_fallback(pkg, emu_ctx, oracle):
+    """quality 10 on small frames: more than 1 coefficient in 4 is non-zero, the step is parsed into the dense form"""
+    sc.check_batch_decoder(pkg, emu_ctx, oracle, 48, 32, 10, n_streams=2, n_frames=3, gop=2, noise=True)

@@ -279,6 +279,7 @@ def test_batch_encoder(pkg, gpu_ctx, oracle):
 def test_batch_decoder(pkg, gpu_ctx, oracle):
     sc.check_batch_decoder(pkg, gpu_ctx, oracle, 176, 144, 5, n_streams=5, n_frames=5, gop=3)
     sc.check_batch_decoder(pkg, gpu_ctx, oracle, 640, 360, 7, n_streams=2, n_frames=3, gop=15)
+    sc.check_batch_decoder(pkg, gpu_ctx, oracle, 64, 48, 10, n_streams=3, n_frames=3, gop=2, noise=True)
 
 
 def test_sparse_decode(pkg, gpu_ctx):
