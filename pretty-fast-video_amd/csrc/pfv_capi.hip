@@ -1250,21 +1250,34 @@ PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host)
 // enc::Encoder<W> (src/enc.rs:12-188) with W = an in-memory byte vector (the reference's tests use
 // Cursor<Vec<u8>>, src/lib.rs:319-321), dec::Decoder<R> (src/dec.rs:15-224) with R = a caller-owned byte slice.
 // Page-locked host staging (hipHostMalloc): PCIe copies from / to these run at link rate without the runtime's
-// bounce through its own pinned chunks; falls back to nothing -- an allocation failure is reported by the caller.
+// bounce through its own pinned chunks; where page-locking is refused the buffer is ordinary memory.
 template <class T>
 struct PinnedBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool pinned = false;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
     PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    ~PinnedBuf() { release(); }
+    void release()
+    {
+        if (p && pinned) (void)hipHostFree(p);
+        else if (p) free(p);
+        p = nullptr; n = 0;
+    }
     bool resize(size_t count)
     {
         if (count <= n) return true;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; n = 0;
-        if (hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        release();
+        if (hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) == hipSuccess) {
+            pinned = true;
+        } else {   // locked-memory limits: pageable memory still works, the copies just bounce through the runtime
+            (void)hipGetLastError();
+            p = (T *)malloc(count * sizeof(T));
+            pinned = false;
+            if (!p) return false;
+        }
         n = count;
         return true;
     }
