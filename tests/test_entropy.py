@@ -172,3 +172,19 @@ def test_payload_parsers_invert_the_serialisers(graft, pkg, oracle, density):
             rc = (lib.pfv_parse_pframe_payload(_p(bad), bad.size, nb, 4, _p(omv), _p(ohas), _p(out), _p(q)) if pframe else
                   lib.pfv_parse_iframe_payload(_p(bad), bad.size, nb, 4, _p(out), _p(q)))
             assert rc == pkg._lib.PFV_ERR_FORMAT
+
+
+def test_stream_layout_regression_pins(pkg, oracle):
+    """the oracle's .pfv bytes for four small clips still hash to the committed digests (tests/golden/stream_digests.json)"""
+    import hashlib
+    import json
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_stream_digests", os.path.join(sys_path, "make_stream_digests.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pins = json.load(open(os.path.join(sys_path, "stream_digests.json")))
+    assert [tuple(p["clip"]) for p in pins] == mod.CLIPS
+    for p in pins:
+        b = mod.stream_bytes(pkg, oracle, tuple(p["clip"]))
+        assert len(b) == p["bytes"] and hashlib.sha256(b).hexdigest() == p["sha256"], p["clip"]
