@@ -161,6 +161,22 @@ class HuffmanTree {
     const std::array<uint8_t, 16> &table() const { return table_; }
     const HuffCode &code(uint8_t sym) const { return codes_[sym & 15]; }
     const HuffCode &fast(uint32_t low8) const { return fast_[low8 & 255]; }   // len == 0: no code of <= 8 bits matches
+    // (num_zeroes, coeff_size) decoded together from the low 12 bits of the window: used = total code bits (0: one of the
+    // two codes is longer than 8 bits or the pair longer than 12 -- take the one-at-a-time path)
+    struct PairEntry { uint8_t used, zeros, size; };
+    const PairEntry &pair(uint32_t low12) const { return pair_[low12 & 4095]; }
+    void build_pair_table()   // once per packet that is worth it (the run parser of whole frames)
+    {
+        for (uint32_t v = 0; v < 4096; v++) {
+            PairEntry e{0, 0, 0};
+            const HuffCode &a = fast_[v & 255];
+            if (a.len) {
+                const HuffCode &b = fast_[(v >> a.len) & 255];
+                if (b.len && a.len + b.len <= 12) e = PairEntry{(uint8_t)(a.len + b.len), a.symbol, b.symbol};
+            }
+            pair_[v] = e;
+        }
+    }
 
     // HuffmanTree::read (huffman.rs:156-197); -1 = DecodeError, -2 = I/O error
     int read(BitSource &r, uint64_t max_bits) const
@@ -209,6 +225,7 @@ class HuffmanTree {
     std::array<uint8_t, 16> table_;
     std::array<HuffCode, 16> codes_{};
     std::array<HuffCode, 256> fast_{};
+    std::array<PairEntry, 4096> pair_{};
     std::vector<Node> nodes_;
     int root_ = -1;
 };
@@ -383,12 +400,11 @@ inline int read_runs(BitSource &r, const HuffmanTree &tree, Sink &sink, size_t b
             // whole symbol from one 64-bit window when both codes hit the 8-bit table (the same lookups
             // HuffmanTree::read makes, huffman.rs:156-197, minus the per-field refills)
             const uint64_t win = r.peek();
-            const HuffCode &cz = tree.fast((uint32_t)win);
-            const HuffCode &cn = tree.fast((uint32_t)(win >> cz.len));
-            if (cz.len && cn.len) {
-                unsigned used = cz.len + cn.len;
-                idx += cz.symbol;
-                if (const unsigned nb = cn.symbol) {
+            const HuffmanTree::PairEntry &pe = tree.pair((uint32_t)win);
+            if (pe.used) {
+                unsigned used = pe.used;
+                idx += pe.zeros;
+                if (const unsigned nb = pe.size) {
                     if (idx >= count) return -6;
                     const uint32_t raw = (uint32_t)(win >> used) & ((1u << nb) - 1u);
                     const int16_t v = (int16_t)(int32_t)((raw ^ (1u << (nb - 1))) - (1u << (nb - 1)));   // sign-extend nb bits
@@ -420,6 +436,7 @@ inline int parse_iframe_to(const uint8_t *payload, size_t n, int total_blocks, i
     PacketHead h;
     if (int rc = parse_head(r, h, n_qtables)) return rc;
     HuffmanTree tree(h.table);
+    tree.build_pair_table();
     std::memcpy(qidx, h.qidx, 3);
     return read_runs(r, tree, sink, 0, (size_t)total_blocks * 256);   // ONE run stream for the whole frame (dec.rs:261)
 }
@@ -431,6 +448,7 @@ inline int parse_pframe_to(const uint8_t *payload, size_t n, int total_blocks, i
     PacketHead h;
     if (int rc = parse_head(r, h, n_qtables)) return rc;
     HuffmanTree tree(h.table);
+    tree.build_pair_table();
     std::memcpy(qidx, h.qidx, 3);
     for (int b = 0; b < total_blocks; b++) {   // dec.rs:361-372
         bool has_mvec = r.get(1) != 0;
