@@ -451,6 +451,19 @@ inline int parse_pframe_to(const uint8_t *payload, size_t n, int total_blocks, i
     tree.build_pair_table();
     std::memcpy(qidx, h.qidx, 3);
     for (int b = 0; b < total_blocks; b++) {   // dec.rs:361-372
+        if (r.can_peek()) {   // the whole block header (2 or 16 bits) from one window
+            const uint32_t w = (uint32_t)r.peek();
+            has[b] = (uint8_t)((w >> 1) & 1u);
+            if (w & 1u) {
+                mv[2 * b] = (int8_t)((int32_t)(w << 23) >> 25);       // bits 2..8, two's complement
+                mv[2 * b + 1] = (int8_t)((int32_t)(w << 16) >> 25);   // bits 9..15
+                r.skip(16);
+            } else {
+                mv[2 * b] = mv[2 * b + 1] = 0;
+                r.skip(2);
+            }
+            continue;
+        }
         bool has_mvec = r.get(1) != 0;
         has[b] = (uint8_t)r.get(1);
         mv[2 * b] = mv[2 * b + 1] = 0;
