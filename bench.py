@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic streams generated on the host per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy", action="store_true", help="skip the extra encode_to_payload measurement (device entropy stage)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the decoder == encoder check (ablation builds of the kernels produce invalid results by construction)")
     ap.add_argument("--no-two-stream", action="store_true",
                     help="skip the two-stream variant of that measurement (profiling runs: keeps per-kernel durations free of time-slicing)")
     return ap.parse_args()
@@ -218,10 +220,11 @@ def main():
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
-    dec.check()
+    if not args.no_verify:
+        dec.check()
 
     # sanity inside the bench: decoder output == encoder reconstruction, and the p-frames did real work
-    assert np.array_equal(enc.prev_frame(), dec.framebuffer()), "decoder framebuffer != encoder reconstruction"
+    assert args.no_verify or np.array_equal(enc.prev_frame(), dec.framebuffer()), "decoder framebuffer != encoder reconstruction"
     coded_frac = float(has.float().mean().item())
 
     pe_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")

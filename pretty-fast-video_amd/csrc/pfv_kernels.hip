@@ -879,7 +879,14 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int m = lane >> 3, i = lane & 7;
-    const TilePos cur = locate_tile(g, xcd_remap((int)blockIdx.x, (int)gridDim.x), wave);
+#ifndef PFV_PENC_TILES
+#define PFV_PENC_TILES 1   // tiles a workgroup encodes one after the other (experiment: >1 lets a tile's stores drain under the next tile)
+#endif
+    const int n_tiles = g.tiles_per_frame * g.n_streams;
+    for (int rep = 0; rep < PFV_PENC_TILES; rep++) {
+    const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x) * PFV_PENC_TILES + rep;
+    if (vt >= n_tiles) break;   // uniform over the workgroup
+    const TilePos cur = locate_tile(g, vt, wave);
     const PlaneGeom &p = g.p[cur.sp.plane];
     if (wave == 0) fill_qtable<true>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
 
@@ -902,6 +909,10 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     if (cur.wave_valid)
         penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
                        recon, qtab_lds);
+#if PFV_PENC_TILES > 1
+    __syncthreads();   // exchange regions and the quantiser table are free again
+#endif
+    }
 }
 
 // ================================================================== I-frame decode
