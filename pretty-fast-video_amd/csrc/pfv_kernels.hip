@@ -318,18 +318,6 @@ __device__ __forceinline__ uint4 pack_row(const int (&px)[2][8])
                       pack4(px[1][0], px[1][1], px[1][2], px[1][3]), pack4(px[1][4], px[1][5], px[1][6], px[1][7]));
 }
 
-// Row-owner lanes and memory coalescing.  Lane 8m + i holds row i of macroblock m (16 B); a wave-wide 16-byte access in
-// that order touches eight different rows with every group of eight neighbouring lanes, and the texture addresser then
-// handles it as 64 separate 16-byte requests (the p-frame encoder's two reconstruction stores alone cost 125 us of a
-// 700 us launch that way).  lane_transpose16 moves the data of lane 8m + i to lane 8i + m (an involution: the same call
-// maps back), so that eight neighbouring lanes cover one 128-byte row segment.
-__device__ __forceinline__ uint4 lane_transpose16(const uint4 &v, int lane)
-{
-    const int src = (((lane & 7) << 3) | (lane >> 3)) << 2;   // ds_bpermute addresses are in bytes
-    return make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)v.x), (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)v.y),
-                      (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)v.z), (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)v.w));
-}
-
 // ------------------------------------------------------------------ strip I/O
 // streaming (read-once / write-once) global accesses: non-temporal, so that coefficient and retframe traffic does
 // not evict the reference planes that neighbouring strips re-read from L2 (measured +1.3 % on the GOP bench)
@@ -398,12 +386,7 @@ __device__ __forceinline__ void store_coef_half(const int *stage, int16_t *coef_
     for (int j = 0; j < 2; j++) {
         int ch = j * 64 + lane;   // 16-byte chunk of the stage; 16 chunks per macroblock half
         int mb = ch >> 4;
-#ifdef PFV_ABL_COEF_NOISSUE   // ablation experiment only (results invalid): stage read back, store never issued
-        const uint4 val = reinterpret_cast<const uint4 *>(stage)[ch];
-        if (mb < n_mb && val.x == 0x7ffe7ffdu && val.w == 0x12345u) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], val);
-#else
         if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(stage)[ch]);
-#endif
     }
 }
 __device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int h)
@@ -824,9 +807,6 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
 #endif
-    // the same plane position for the transposed lane order (lane 8i' + m': row i', macroblock m')
-    uint8_t *dst_t = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + (lane >> 3)) * p.pw + sp.x0 + (lane & 7) * 16
-                           : nullptr;
 
     if (__any(coded)) {   // wavefront-uniform: the LDS transposes need all lanes
         const LaneQ lq{qtab_lds, i};
@@ -856,19 +836,10 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                     for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
                         pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
                 }
-#if defined(PFV_ABL_NOSTORE) || defined(PFV_ABL_RECON_NOISSUE)   // ablation experiment only (results invalid)
+#ifdef PFV_ABL_NOSTORE   // ablation experiment only (results invalid): one dword per lane instead of the row
                 if (mb_valid && pp[0][0] == 999) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
 #else
-#ifdef PFV_RECON_ROWOWNER   // A/B switch: the old store, eight rows per eight lanes
                 if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
-#else
-                {   // lane 8i' + m' stores row i' of macroblock m': eight neighbouring lanes = one 128-byte segment
-                    const uint4 o = lane_transpose16(pack_row(pp), lane);
-                    const int ti = lane >> 3, tm = lane & 7;
-                    if (tm < sp.n_mb) *reinterpret_cast<uint4 *>(dst_t + (long)(8 * h) * p.pw) = o;
-                    (void)ti;
-                }
-#endif
 #endif
             }
         }
@@ -938,14 +909,6 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     if (cur.wave_valid)
         penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
                        recon, qtab_lds);
-#ifdef PFV_ABL_TAILWORK   // experiment: PFV_ABL_TAILWORK dependent VALU instructions after the last store of the wavefront
-    {
-        unsigned t = (unsigned)lane;
-#pragma unroll 16
-        for (int k = 0; k < PFV_ABL_TAILWORK; k++) t = __builtin_amdgcn_udot4(t, 0x01020304u, t, false);
-        if (t == 0x9e3779b9u) has_out[0] = 1;   // never true in practice; keeps the chain alive
-    }
-#endif
 #if PFV_PENC_TILES > 1
     __syncthreads();   // exchange regions and the quantiser table are free again
 #endif
