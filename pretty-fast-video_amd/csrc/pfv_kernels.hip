@@ -386,7 +386,12 @@ __device__ __forceinline__ void store_coef_half(const int *stage, int16_t *coef_
     for (int j = 0; j < 2; j++) {
         int ch = j * 64 + lane;   // 16-byte chunk of the stage; 16 chunks per macroblock half
         int mb = ch >> 4;
+#ifdef PFV_ABL_COEF_NOISSUE   // ablation experiment only (results invalid): stage read back, store never issued
+        const uint4 val = reinterpret_cast<const uint4 *>(stage)[ch];
+        if (mb < n_mb && val.x == 0x7ffe7ffdu && val.w == 0x12345u) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], val);
+#else
         if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(stage)[ch]);
+#endif
     }
 }
 __device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int h)
@@ -836,8 +841,14 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                     for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
                         pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
                 }
-#ifdef PFV_ABL_NOSTORE   // ablation experiment only (results invalid): one dword per lane instead of the row
-                if (mb_valid && pp[0][0] == 999) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
+#if defined(PFV_ABL_NOSTORE) || defined(PFV_ABL_RECON_NOISSUE)   // ablation experiment only (results invalid)
+                // the row is fully computed and packed; the store hangs on a value the packed row never has, so that the
+                // compiler can neither drop nor sink the arithmetic behind it (an earlier form of this switch tested one
+                // pixel only: the rest of the inverse row pass moved into the never-taken branch and the "store cost" it
+                // reported was that arithmetic)
+                const uint4 o_abl = pack_row(pp);
+                if (mb_valid && (o_abl.x ^ o_abl.y ^ o_abl.z ^ o_abl.w) == 0x9e3779b9u && o_abl.x == 0x01020304u)
+                    *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = o_abl;
 #else
                 if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
 #endif
@@ -909,6 +920,14 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     if (cur.wave_valid)
         penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
                        recon, qtab_lds);
+#ifdef PFV_ABL_TAILWORK   // experiment: PFV_ABL_TAILWORK dependent VALU instructions after the last store of the wavefront
+    {
+        unsigned t = (unsigned)lane;
+#pragma unroll 16
+        for (int k = 0; k < PFV_ABL_TAILWORK; k++) t = __builtin_amdgcn_udot4(t, 0x01020304u, t, false);
+        if (t == 0x9e3779b9u) has_out[0] = 1;   // never true in practice; keeps the chain alive
+    }
+#endif
 #if PFV_PENC_TILES > 1
     __syncthreads();   // exchange regions and the quantiser table are free again
 #endif

@@ -117,6 +117,8 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool)
 // global_load_lds: per-lane copy global -> LDS (the emulator has no lane-linear restriction; the kernels keep to it)
 static inline void hipemu_global_load_lds(const void *g, void *l, unsigned size, int offset, int) { memcpy((char *)l + offset, (const char *)g + offset, size); }
 #define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
+static inline int hipemu_ds_bpermute(int byte_addr, int v) { return hipemu::wave_exchange(v, (byte_addr >> 2) & 63); }
+#define __builtin_amdgcn_ds_bpermute hipemu_ds_bpermute
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
