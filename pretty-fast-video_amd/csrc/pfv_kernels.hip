@@ -818,7 +818,10 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             int v[2][8], pp[2][8];
-            unpack_row(rows[h], v);
+            // a skipped macroblock (None in the reference, zero coefficients here) takes its prediction as its source:
+            // zero residual -> zero coefficients -> reconstruction = prediction, without masking 16 values per pass
+            const uint4 srow = coded ? rows[h] : so.patch[h];
+            unpack_row(srow, v);
             unpack_row(so.patch[h], pp);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
@@ -828,7 +831,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                     v[s][k] = (int)((unsigned)tdiv2(d) << 8);         // (:304)
                 }
             }
-            forward_half(v, xw, m, i, lq, coded);
+            forward_half(v, xw, m, i, lq, true);
 #ifndef PFV_ABL_NOSTORE
             store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
 #endif
