@@ -116,6 +116,13 @@ PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int s
 PFV_API int pfv_rgb_to_yuv420_dev(pfv_ctx *ctx, const uint8_t *rgb_dev, int width, int height, uint8_t *frame_dev);
 PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int width, int height, uint8_t *rgb_dev);
 
+/* ------------------------------------------------------------------ synthetic workload (not a reference interface)
+ * The reference's fixtures are Git-LFS stubs; tests and benchmarks run on an integer-only synthetic video (SURVEY.md
+ * section 8d) that is generated where it is consumed: frame `t` of n_streams streams (stream s seeded with seeds[s], a HOST
+ * array) as packed Y|U|V frames back to back in frames_dev.  Byte-identical to synth.SyntheticStream(w, h, seed).frame(t). */
+PFV_API int pfv_synth_frames_dev(pfv_ctx *ctx, int width, int height, int n_streams, const uint64_t *seeds, int t,
+                                 uint8_t *frames_dev);
+
 /* ------------------------------------------------------------------ device memory helpers */
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);
 PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p);

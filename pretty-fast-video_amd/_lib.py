@@ -53,6 +53,7 @@ SIGNATURES = [
     ("pfv_double_dev", c_int, [_P, _P, _P, c_int, c_int]),
     ("pfv_rgb_to_yuv420_dev", c_int, [_P, _P, c_int, c_int, _P]),
     ("pfv_yuv420_to_rgb_dev", c_int, [_P, _P, c_int, c_int, _P]),
+    ("pfv_synth_frames_dev", c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     ("pfv_dev_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
     ("pfv_dev_free", c_int, [_P, _P]),
     ("pfv_host_alloc", c_int, [_P, c_size_t, POINTER(_P)]),

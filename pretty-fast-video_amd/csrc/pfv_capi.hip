@@ -5,6 +5,7 @@
 // a negative status.
 #include "pfv_kernels.hip"
 #include "pfv_entropy_kernels.hip"
+#include "pfv_synth_kernels.hip"
 #include "pfv_host.hip"
 
 #include <math.h>
@@ -487,6 +488,25 @@ PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int wi
 }
 
 // ------------------------------------------------------------------ device memory helpers
+// Synthetic workload generator: frame `t` of n_streams streams, stream s seeded with seeds[s], written as
+// packed Y|U|V frames back to back into frames_dev.  Same bytes as synth.SyntheticStream(width, height, seed).frame(t).
+PFV_API int pfv_synth_frames_dev(pfv_ctx *ctx, int width, int height, int n_streams, const uint64_t *seeds, int t, uint8_t *frames_dev)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (!seeds || !frames_dev || width <= 0 || height <= 0 || (width & 1) || (height & 1) || n_streams <= 0 || n_streams > 65535 || t < 0)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_synth_frames_dev: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *sd = nullptr;
+    int rc = ensure_scratch(ctx, 7, (size_t)n_streams * sizeof(uint64_t), &sd);
+    if (rc) return rc;
+    // pageable source: the runtime stages the few bytes before returning, the caller's array is free again
+    HIP_TRY(ctx, hipMemcpyAsync(sd, seeds, (size_t)n_streams * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    const long n = (long)width * height;
+    hipLaunchKernelGGL(k_synth_frames, dim3((unsigned)((n + kThreads - 1) / kThreads), 3, (unsigned)n_streams), dim3(kThreads), 0, ctx->stream,
+                       width, height, t, (const uint64_t *)sd, frames_dev, (long)pfv_frame_bytes(width, height));
+    return launch_check(ctx, "k_synth_frames");
+}
+
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dev_alloc: bad argument");

@@ -1,0 +1,31 @@
+"""The device-side synthetic generator (k_synth_frames) against synth.py, byte for byte:
+on the CPU emulator here, on the MI355X under -m gpu."""
+import numpy as np
+import pytest
+
+
+def _check(pkg, ctx, w, h, seeds, ts):
+    fb = int(pkg._lib.load().pfv_frame_bytes(w, h))
+    dev = ctx.alloc(fb * len(seeds))
+    try:
+        for t in ts:
+            ctx.synth_frames_dev(w, h, seeds, t, dev)
+            got = np.empty((len(seeds), fb), np.uint8)
+            ctx.download(got, dev)
+            for k, s in enumerate(seeds):
+                want = pkg.SyntheticStream(w, h, seed=int(s)).frame(t)
+                assert np.array_equal(got[k], want), (w, h, s, t)
+    finally:
+        ctx.free(dev)
+
+
+def test_emu_synth_matches_numpy(pkg, emu_ctx):
+    _check(pkg, emu_ctx, 64, 48, [pkg.synth.SEED, pkg.synth.SEED + 17], [0, 1, 9])
+    _check(pkg, emu_ctx, 50, 38, [12345], [4, 23])      # odd chroma width, negative floor-halved chroma motion
+
+
+@pytest.mark.gpu
+def test_gpu_synth_matches_numpy(pkg, gpu_ctx):
+    _check(pkg, gpu_ctx, 64, 48, [pkg.synth.SEED, 1, 2 ** 40 + 5], [0, 1, 9, 299])
+    _check(pkg, gpu_ctx, 50, 38, [12345], [4, 23])
+    _check(pkg, gpu_ctx, 1920, 1080, [pkg.synth.SEED + 17 * 3], [7])
