@@ -1,32 +1,41 @@
 #!/usr/bin/env python
-"""bench.py -- macroblocks/s (encode+decode) on synthetic 1080p YUV 4:2:0, MI355X.
+"""bench.py -- macroblocks/s (encode+decode) on synthetic YUV 4:2:0, MI355X.
 
-One "step" = one GOP-15 (1 i-frame + 14 p-frames, README.md:34-41 pattern) of S independent
-synthetic 1080p streams per GPU, each frame ENCODED (with closed-loop reconstruction) and then
-DECODED from the coefficients just produced, all streams batched into one kernel launch per
-frame operation.  Inputs (the raw frames) are resident in HBM before the timed region starts;
-coefficients / motion vectors / reconstructed frames never leave HBM.  Entropy coding (host)
-is outside this path.
+    python bench.py --gpus N --steps K --warmup W [--workload gop1080p|config5] [--streams S]
 
-    python bench.py --gpus N --steps K --warmup W [--streams S] [--width 1920 --height 1080]
+Workloads (BASELINE.json `configs`):
+  gop1080p (default; the configuration the metric is quoted on): one step = one GOP-15 (1 i-frame + 14 p-frames,
+      README.md:34-41 pattern) of S independent synthetic 1080p streams per GPU, every frame ENCODED (with closed-loop
+      reconstruction) and then DECODED from the coefficients just produced, all streams batched into one kernel launch
+      per frame operation.  Every stream is distinct (its own seed), generated on the device.
+  config5: one 3840x2160, 300-frame, GOP-15 stream per GPU (seed = base + rank), one step = the whole stream encoded +
+      decoded, one launch per frame operation (48 720 macroblocks per launch).  At N = 1 this is config #4.
+Inputs (the raw frames) are resident in HBM before the timed region starts; coefficients / motion vectors /
+reconstructed frames never leave HBM.  Entropy coding is outside `value` (reported beside it).
 
-N > 1: one process per GPU (torchrun); the streams are independent, so they are sharded
-across ranks with NO data-path collective ("weak" scaling: S streams per GPU).  RCCL is used
-only for the stream-assignment broadcast and the final counter gather.
+N > 1: one process per GPU.  `python bench.py --gpus N` launches its own N ranks (re-executes itself under
+torch.distributed.run on 127.0.0.1); when it is already running under torchrun (RANK / WORLD_SIZE set, which is how the
+driver starts it) it uses those.  Streams are independent (src/enc.rs:12-26: an Encoder shares nothing with another), so
+they are sharded across ranks with NO data-path collective ("weak" scaling: fixed work per GPU); RCCL carries only the
+assignment-table broadcast and the final counter reduction.  With fewer GPUs than ranks (developer dry run on a one-GPU
+box) every rank uses device 0 and the control plane runs on gloo; the JSON says so (`rccl_ranks`: 0).
 
 The JSON line also carries
-  roofline     -- dominant kernel (k_enc_pframe): algorithmic bytes per launch (1284 B per
-                  macroblock) / its average HIP-event duration on the
-                  context's own stream, against the 8 TB/s HBM peak;
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm with its fork/join
-                  structure; the Rust reference itself cannot be built here) timed on this
-                  node's host cores on one GOP of one stream of the same workload.
+  roofline     -- dominant kernel (k_enc_pframe): algorithmic bytes per launch (1284 B per macroblock, SURVEY.md
+                  section 8d) / its average HIP-event duration on the context's own stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm with its fork/join structure; the Rust reference
+                  itself cannot be built here) timed on this node's host cores on GOPs of one stream of the workload;
+  extra        -- (N = 1) single-stream figures (S = 1, S = 8; per-frame launches vs one HIP graph per GOP) and BASELINE
+                  config #4 (4K x 300 frames) at kernel / +PCIe / end-to-end scope.
 """
 from __future__ import annotations
 
 import argparse
+import io
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,6 +51,7 @@ BYTES_PER_MB_PENC = 1284        # src 256 + ref 256 + coef 512 + mv/flag 4 + rec
 # algorithmic bytes per macroblock of the other three codec kernels + 256 for the retframe crop the
 # decode kernels fuse (src/dec.rs:195-197, 209-211)
 BYTES_PER_MB = {"k_enc_iframe": 1024, "k_enc_pframe": BYTES_PER_MB_PENC, "k_dec_iframe": 768 + 256, "k_dec_pframe": 1028 + 256}
+EMU = os.environ.get("PFV_BENCH_EMU") == "1"    # test-only: kernel sources on the CPU emulator, no GPU (tests/test_sharding.py)
 
 
 def parse():
@@ -49,32 +59,66 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=96, help="independent streams per GPU, batched per launch")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--workload", choices=["gop1080p", "config5"], default="gop1080p")
+    ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU, batched per launch (gop1080p: 96)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None, help="frames per step (gop1080p: 15; config5: 300)")
     ap.add_argument("--quality", type=int, default=5)
-    ap.add_argument("--unique", type=int, default=2, help="distinct synthetic streams generated on the host per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy", action="store_true", help="skip the extra encode_to_payload measurement (device entropy stage)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the single-stream and config-4 side measurements")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the decoder == encoder check (ablation builds of the kernels produce invalid results by construction)")
     ap.add_argument("--no-two-stream", action="store_true",
-                    help="skip the two-stream variant of that measurement (profiling runs: keeps per-kernel durations free of time-slicing)")
+                    help="skip the two-stream variant of the entropy measurement (profiling runs: keeps per-kernel durations free of time-slicing)")
     return ap.parse_args()
 
 
-def cpu_baseline(pkg, width, height, quality, frames_one_stream):
-    """encode+decode GOPs of one stream with the CPU oracle on the host cores.  The reference sizes its rayon
-    pool from a caller-chosen num_threads (src/enc.rs:54); several pool sizes are tried on one GOP each and the
-    best one is then timed for a few more GOPs, so the baseline is not handicapped by a bad thread count."""
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU on this node)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------- helpers
+def host_cpu_facts():
+    facts = {"host_cpus": os.cpu_count() or 1, "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+             "cgroup_cpu_quota": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                facts["cgroup_cpu_quota"] = "max" if txt[0] == "max" else round(int(txt[0]) / int(txt[1]), 2)
+            else:
+                q = int(txt[0])
+                facts["cgroup_cpu_quota"] = "max" if q < 0 else round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return facts
+
+
+def cpu_baseline(width, height, quality, frames_one_stream, n_mb, budget_s=12.0):
+    """encode+decode GOPs of one stream with the CPU oracle on the host cores.  The reference sizes its rayon pool from a
+    caller-chosen num_threads (src/enc.rs:54); several pool sizes are tried on one GOP each and the best one is then
+    timed for a few more GOPs, so the baseline is not handicapped by a bad thread count.  The 1-thread figure, the host's
+    CPU count, the cgroup quota and the affinity mask are reported beside it: a container rarely owns the node."""
     from oracle_bind import Oracle, OracleDecoder
     ora = Oracle()
-    ncpu = os.cpu_count() or 1
+    facts = host_cpu_facts()
+    ncpu = facts["affinity_cpus"] or facts["host_cpus"]
     tabs = np.stack(ora.qtables(quality)[:4])
-
     penc = {"s": 0.0, "n": 0}
 
-    def run(threads, max_reps, budget_s, record=False):
+    def run(threads, max_reps, budget, record=False):
         ora.L.pfvo_pool_shutdown()          # fresh pool of exactly `threads` workers
         enc = ora.encoder(width, height, quality, threads=threads)
         dec = OracleDecoder(ora, width, height, tabs, threads=threads)
@@ -93,220 +137,434 @@ def cpu_baseline(pkg, width, height, quality, frames_one_stream):
                     dec.decode_pframe(*r)
             reps += 1
             el = time.perf_counter() - t0
-            if el > budget_s or reps >= max_reps:
+            if el > budget or reps >= max_reps:
                 break
         assert np.array_equal(dec.framebuffer(), enc.prev_frame())
         return reps * len(frames_one_stream) * enc.total_blocks / el, reps, el
 
     trials = {}
-    for th in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
-        trials[th] = run(th, 1, 5.0)[0]
+    for th in sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+        trials[th] = run(th, 1, 4.0)[0]
     best = max(trials, key=trials.get)
-    rate, reps, el = run(best, 40, 3.0, record=True)     # ~3 s of wall time on the best pool size
-    n_mb = reps * len(frames_one_stream) * pkg._lib.load().pfv_total_blocks(width, height)
+    rate, reps, el = run(best, 40, max(2.0, budget_s / 4), record=True)
+    ora.L.pfvo_pool_shutdown()
     return {"value": rate, "unit": "macroblocks/s", "cores": best, "kind": "port",
+            "value_best": rate, "threads_best": best, "value_1thread": trials[1],
+            "trials_threads_to_value": {str(k): round(v) for k, v in trials.items()}, **facts,
             "pframe_encode_value": penc["n"] / penc["s"] if penc["s"] > 0 else None,
-            "sample": f"{reps} x GOP-{len(frames_one_stream)} encode+decode of one {width}x{height} stream ({n_mb} macroblocks, "
-                      f"{el:.1f} s); C oracle = port of the reference's algorithm with its per-plane fork/join, persistent "
-                      f"pool of {best} threads (best of {dict((k, round(v)) for k, v in trials.items())} on {ncpu} host CPUs)"}
+            "sample": f"{reps} x GOP-{len(frames_one_stream)} encode+decode of one {width}x{height} stream ({reps * len(frames_one_stream) * n_mb} "
+                      f"macroblocks, {el:.1f} s) on the best pool size; C oracle = port of the reference's algorithm with its per-plane "
+                      f"fork/join over a persistent pool (`cores` = threads used; host_cpus / cgroup_cpu_quota / affinity_cpus = what "
+                      f"this container may use of the node)"}
 
 
+class Timer:
+    """HIP events on the kernels' own stream (GPU) or wall-clock stamps (CPU emulator runs of the control flow)."""
+
+    def __init__(self, ctx, dev):
+        self.ctx = ctx
+        if EMU:
+            self.stream = None
+        else:
+            import torch
+            self.torch = torch
+            self.stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+
+    def stamp(self):
+        if EMU:
+            return time.perf_counter()
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record(self.stream)
+        return e
+
+    @staticmethod
+    def ms(a, b):
+        return (b - a) * 1e3 if EMU else a.elapsed_time(b)
+
+
+class StreamSet:
+    """S independent streams of one geometry resident in HBM: `n_frames` synthetic frames per stream (generated on the
+    device from (seed, t)), an encoder session and a decoder session S streams wide, and the buffers between them."""
+
+    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, fused_crop=True):
+        self.pkg, self.ctx, self.W, self.H, self.Q, self.S, self.n_frames = pkg, ctx, W, H, Q, len(seeds), n_frames
+        self.seeds = [int(s) for s in seeds]
+        lib = pkg._lib.load()
+        self.fb = int(lib.pfv_frame_bytes(W, H))
+        S = self.S
+        self.enc = pkg.EncoderSession(ctx, W, H, Q, S)
+        self.dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), S)
+        self.n_mb = self.enc.total_blocks
+        self._bufs = []
+        self.frames = self._alloc(n_frames * S * self.fb)
+        self.coef, self.mv, self.has = self._alloc(S * self.n_mb * 512), self._alloc(S * self.n_mb * 2), self._alloc(S * self.n_mb)
+        self.out_frames = self._alloc(S * self.fb)
+        if fused_crop:
+            self.dec.set_output_dev(self.out_frames)       # retframe crop (src/dec.rs:209-211) fused into decode
+        for t in range(n_frames):
+            ctx.synth_frames_dev(W, H, self.seeds, t, self.frame_ptr(t))
+        ctx.sync()
+
+    def _alloc(self, n):
+        p = self.ctx.alloc(max(int(n), 16))
+        self._bufs.append(p)
+        return p
+
+    def frame_ptr(self, t):
+        return self.frames + t * self.S * self.fb
+
+    def host_frames(self, stream, count):
+        out = []
+        for t in range(count):
+            a = np.empty(self.fb, np.uint8)
+            self.ctx.download(a, self.frame_ptr(t) + stream * self.fb)
+            out.append(a)
+        return out
+
+    def step(self, gop=GOP, on_launch=None):
+        """encode + decode every resident frame once; i-frame when t % gop == 0 (README.md:34-41)"""
+        enc, dec = self.enc, self.dec
+        for t in range(self.n_frames):
+            f = self.frame_ptr(t)
+            if t % gop == 0:
+                a = on_launch and on_launch()
+                enc.encode_iframe_dev(f, self.coef)
+                b = on_launch and on_launch()
+                dec.decode_iframe_dev(self.coef)
+                if on_launch:
+                    on_launch("k_enc_iframe", a, b)
+                    on_launch("k_dec_iframe", b, on_launch())
+            else:
+                a = on_launch and on_launch()
+                enc.encode_pframe_dev(f, self.mv, self.has, self.coef)
+                b = on_launch and on_launch()
+                dec.decode_pframe_dev(self.mv, self.has, self.coef)
+                if on_launch:
+                    on_launch("k_enc_pframe", a, b)
+                    on_launch("k_dec_pframe", b, on_launch())
+
+    def verify(self):
+        self.dec.check()
+        assert np.array_equal(self.enc.prev_frame(), self.dec.framebuffer()), "decoder framebuffer != encoder reconstruction"
+
+    def coded_fraction(self):
+        h = np.empty(self.S * self.n_mb, np.uint8)
+        self.ctx.download(h, self.has)
+        return float(h.mean())
+
+    def wall(self, reps, gop=GOP):
+        """macroblocks/s of `reps` passes by the host clock (sync on both sides)"""
+        self.step(gop)
+        self.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.step(gop)
+        self.ctx.sync()
+        el = time.perf_counter() - t0
+        return reps * self.n_frames * self.S * self.n_mb / el
+
+    def close(self):
+        self.enc.close()
+        self.dec.close()
+        for p in self._bufs:
+            self.ctx.free(p)
+        self._bufs = []
+
+
+def entropy_side(ss, timer, args):
+    """beside the headline (never part of `value`): the encoder alone with its entropy stage on the device, i.e. frames in
+    HBM -> packet payloads in HBM (k_enc_* + k_ent_*), whole passes timed with HIP events"""
+    enc, ctx, S, n_mb = ss.enc, ss.ctx, ss.S, ss.n_mb
+    # two sets of encode outputs: with the stage on its own HIP stream the k_ent_* kernels of frame t overlap k_enc_pframe
+    # of frame t+1; pack(t+1) orders later main-stream work behind pack(t)'s reads
+    second = (ctx.alloc(S * n_mb * 512), ctx.alloc(S * n_mb * 2), ctx.alloc(S * n_mb))
+    sets = [(ss.coef, ss.mv, ss.has), second]
+
+    def encode_pass():
+        for t in range(ss.n_frames):
+            f = ss.frame_ptr(t)
+            c, m, h = sets[t & 1]
+            if t % GOP == 0:
+                enc.encode_iframe_dev(f, c)
+                enc.pack_iframe_dev(c)
+            else:
+                enc.encode_pframe_dev(f, m, h, c)
+                enc.pack_pframe_dev(m, h, c)
+
+    def measure(async_stream):
+        enc.enable_entropy(async_stream=async_stream)
+        encode_pass()
+        enc.entropy_join()
+        ctx.sync()
+        reps = max(1, min(args.steps, 5))
+        e0 = timer.stamp()
+        for _ in range(reps):
+            encode_pass()
+        enc.entropy_join()          # the kernels' stream waits for the entropy stream before the closing event
+        e1 = timer.stamp()
+        ctx.sync()
+        return Timer.ms(e0, e1) / reps, enc.payload_sizes()
+
+    serial_ms, sizes = measure(False)
+    two_ms = None
+    if not args.no_two_stream:
+        two_ms, sizes_b = measure(True)
+        assert np.array_equal(sizes, sizes_b), "entropy stage: two-stream and same-stream runs disagree"
+        enc.enable_entropy(async_stream=False)
+    for p in second:
+        ctx.free(p)
+    total = ss.n_frames * S * n_mb
+    return {"value": total / (serial_ms * 1e-3), "unit": "macroblocks/s", "ms_per_pass": serial_ms,
+            "two_stream_value": total / (two_ms * 1e-3) if two_ms else None, "two_stream_ms_per_pass": two_ms,
+            "last_pframe_payload_bytes_per_stream": float(np.mean(sizes)),
+            "note": "encode only, frames in HBM -> .pfv packet payloads in HBM: k_enc_iframe/k_enc_pframe + the device entropy "
+                    "stage, HIP-event time over whole passes; two_stream_*: the stage on a second HIP stream with "
+                    "double-buffered encode outputs"}
+
+
+def single_stream_side(pkg, ctx, Q, reps=6):
+    """The reference's caller is ONE Encoder per stream (src/enc.rs:125-173): what a single 1080p stream (and 8 of them)
+    gets at kernel scope, with one launch per frame operation and with a whole GOP replayed as one HIP graph."""
+    out = {}
+    for S in (1, 8):
+        ss = StreamSet(pkg, ctx, 1920, 1080, Q, [pkg.synth.SEED + 17 * k for k in range(S)], GOP)
+        r = {"launches": ss.wall(reps)}
+        ss.verify()
+        graph = getattr(ss.enc, "gop_graph", None)
+        if graph is not None:
+            try:
+                r["hip_graph"] = graph_rate(ss, reps)
+                ss.verify()
+            except Exception as e:      # noqa: BLE001 -- side measurement: report, do not fail the bench
+                r["hip_graph_error"] = str(e)[:200]
+        out[f"streams_{S}"] = r
+        ss.close()
+    out["unit"] = "macroblocks/s (encode+decode, 1080p GOP-15, kernel scope, host clock incl. launch overhead)"
+    return out
+
+
+def graph_rate(ss, reps):
+    g = ss.pkg.GopGraph(ss.enc, ss.dec, ss.frames, ss.n_frames, GOP, ss.coef, ss.mv, ss.has)
+    g.launch()
+    ss.ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.launch()
+    ss.ctx.sync()
+    el = time.perf_counter() - t0
+    g.close()
+    return reps * ss.n_frames * ss.S * ss.n_mb / el
+
+
+def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, e2e_frames=45, ss=None):
+    """BASELINE config #4 at the three scopes of SURVEY.md section 8d: one 3840x2160 GOP-15 stream; (i) kernels only, frames
+    and coefficients resident in HBM; (ii) + PCIe through the host-buffer session entry points; (iii) end to end through
+    Encoder -> .pfv bytes -> Decoder (device entropy stage on the encoder side, host bit parser on the decoder side)."""
+    W, H = 3840, 2160
+    own = ss is None
+    if own:
+        ss = StreamSet(pkg, ctx, W, H, Q, [seed], n_frames)
+    res = {"config": f"{W}x{H}, GOP-{GOP}, quality {Q}, seed {seed}", "macroblocks_per_frame": ss.n_mb}
+    res["kernel_only"] = {"value": ss.wall(2), "frames": ss.n_frames,
+                          "note": "one launch per frame operation, 48 720 macroblocks per launch"}
+    ss.verify()
+    host = ss.host_frames(0, max(pcie_frames, e2e_frames))
+    if own:
+        ss.close()
+    # (ii)
+    enc = pkg.EncoderSession(ctx, W, H, Q, 1)
+    dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), 1)
+    t0 = time.perf_counter()
+    for t in range(pcie_frames):
+        if t % GOP == 0:
+            dec.decode_iframe(enc.encode_iframe(host[t]))
+        else:
+            dec.decode_pframe(*enc.encode_pframe(host[t]))
+        dec.get_frame()
+    el = time.perf_counter() - t0
+    res["pcie_inclusive"] = {"value": pcie_frames * ss.n_mb / el, "frames": pcie_frames,
+                             "note": "host-buffer session entry points, pageable numpy buffers, synchronous per frame"}
+    recon_last = enc.prev_frame()[0]
+    enc.close()
+    dec.close()
+    # (iii)
+    buf = io.BytesIO()
+    e = pkg.Encoder(buf, W, H, 30, Q, ctx)
+    vfs = [pkg.VideoFrame.from_packed(W, H, host[t]) for t in range(e2e_frames)]
+    t0 = time.perf_counter()
+    for t, vf in enumerate(vfs):
+        (e.encode_iframe if t % GOP == 0 else e.encode_pframe)(vf)
+    e.finish()
+    t_enc = time.perf_counter() - t0
+    e.close()
+    data = buf.getvalue()
+    d = pkg.Decoder(data, ctx)
+    n = [0]
+    last = [None]
+
+    def onvideo(fr):
+        n[0] += 1
+        if n[0] == pcie_frames:
+            last[0] = fr.packed()
+    t0 = time.perf_counter()
+    while d.advance_frame(onvideo):
+        pass
+    t_dec = time.perf_counter() - t0
+    d.close()
+    assert n[0] == e2e_frames
+    if pcie_frames <= e2e_frames:       # decoded frame == the closed-loop reconstruction of the session path, cropped
+        pf = pkg.VideoFrame.from_packed(W, H, recon_last, padded=True)
+        want = np.concatenate([pf.plane_y.image()[:H, :W].reshape(-1), pf.plane_u.image()[:H // 2, :W // 2].reshape(-1),
+                               pf.plane_v.image()[:H // 2, :W // 2].reshape(-1)])
+        assert np.array_equal(last[0], want), "decoded .pfv frame != encoder reconstruction"
+    res["end_to_end"] = {"frames": e2e_frames, "stream_bytes": len(data), "bits_per_pixel": round(len(data) * 8 / (e2e_frames * W * H), 3),
+                         "encode_value": e2e_frames * ss.n_mb / t_enc, "decode_value": e2e_frames * ss.n_mb / t_dec,
+                         "value": e2e_frames * ss.n_mb / (t_enc + t_dec),
+                         "note": "Encoder -> .pfv bytes -> Decoder objects (single stream, synchronous per frame, pinned staging; "
+                                 "decoded frames checked against the encoder's reconstruction)"}
+    res["unit"] = "macroblocks/s"
+    return res
+
+
+def traffic_from_profiles(S, W, H, Q):
+    """HBM traffic per k_enc_pframe launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+    tools/gpu_pmc.sh).  PMC counters cannot be collected inside this process; the value is quoted only when it was
+    collected on this exact configuration, and the line says where it came from."""
+    try:
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pm = json.load(open(path))
+        c = pm["config"]
+        if (int(c["streams"]), int(c["width"]), int(c["height"]), int(c["quality"])) != (S, W, H, Q):
+            return None, None, None
+        k = pm["kernels"]["k_enc_pframe"]
+        sha = "unknown"
+        try:
+            sha = subprocess.run(["git", "log", "-1", "--format=%h", "--", "profiles/pmc_traffic.json"], cwd=ROOT, capture_output=True,
+                                 text=True, timeout=10).stdout.strip() or pm.get("source_commit", "unknown")
+        except (OSError, subprocess.SubprocessError):
+            sha = pm.get("source_commit", "unknown")
+        return k["traffic_bytes"], k.get("valu_wave_instructions"), f"profiles/pmc_traffic.json @{sha} (committed PMC pass, not measured in this run)"
+    except (OSError, KeyError, ValueError):
+        return None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    # developer dry-run of the N > 1 control flow on a one-GPU box: PFV_BENCH_SHARE_GPU=1 puts every rank on device 0 and
-    # uses gloo (RCCL refuses two ranks on one device); never set by the driver
-    share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1"
-    if share:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+
+    if EMU:
+        import conftest                               # tests/conftest.py: g++ build of the kernel sources on the fiber emulator
+        os.environ["PFV_HIP_LIB"] = conftest.build_emulator()
+        dev, backend, share, local_rank = None, "gloo", False, 0
+    else:
+        n_dev = torch.cuda.device_count()
+        # fewer devices than ranks (developer dry run of the N > 1 control flow on a one-GPU box): every rank on device 0,
+        # control plane on gloo (RCCL refuses two ranks on one device)
+        share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1" or (world > 1 and n_dev < world)
+        if share:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        backend = "gloo" if share else "nccl"
+        graft.build_hip()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else None         # where control-plane tensors live
 
-    import __graft_entry__ as graft
-    graft.build_hip()
     pkg = graft.load_package()
     from importlib import import_module
     shard = import_module("pretty_fast_video_amd.shard")
 
-    W, H, S, Q = args.width, args.height, args.streams, args.quality
+    Q = args.quality
+    if args.workload == "config5":
+        W, H, S, NF = args.width or 3840, args.height or 2160, args.streams or 1, args.frames or 300
+    else:
+        W, H, S, NF = args.width or 1920, args.height or 1080, args.streams or 96, args.frames or GOP
 
-    # ---- stream assignment: rank 0 decides, everyone learns it through one tiny broadcast
-    # (the only "scatter" this path has: stream ids / seeds, a few hundred bytes)
-    table = shard.assign_streams(n_streams_total=S * world, world=world, base_seed=pkg.synth.SEED)
+    # ---- stream assignment: rank 0 decides, everyone learns it through one tiny broadcast (the only "scatter" this path
+    # has: stream ids / seeds, a few hundred bytes); config5: seed = base + stream id = base + rank
+    if args.workload == "config5":
+        sid = np.arange(S * world, dtype=np.int64)
+        table = np.stack([sid % world, pkg.synth.SEED + sid, sid], axis=1)
+    else:
+        table = shard.assign_streams(n_streams_total=S * world, world=world, base_seed=pkg.synth.SEED)
     if world > 1:
-        t = torch.tensor(table if rank == 0 else np.zeros_like(table), device=dev)
-        dist.broadcast(t, src=0)
-        table = t.cpu().numpy()
+        table = shard.broadcast_table(table, rank, dist, cdev)
     mine = shard.streams_of_rank(table, rank)
     assert len(mine) == S
 
-    # ---- synthetic input, resident in HBM: [GOP][S][frame_bytes]
-    uniq = max(1, min(args.unique, S))
-    fb = int(pkg._lib.load().pfv_frame_bytes(W, H))
-    host = np.empty((GOP, uniq, fb), dtype=np.uint8)
-    for u in range(uniq):
-        st = pkg.SyntheticStream(W, H, seed=int(mine[u][1]))
-        for t in range(GOP):
-            host[t, u] = st.frame(t)
-    frames = torch.from_numpy(host).to(dev)                              # [GOP, uniq, fb]
-    frames = frames[:, torch.arange(S, device=dev) % uniq].contiguous()  # [GOP, S, fb]
-
     ctx = pkg.Context(local_rank)
-    enc = pkg.EncoderSession(ctx, W, H, Q, S)
-    dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), S)
-    n_mb = enc.total_blocks
-    coef = torch.empty((S, n_mb, 256), dtype=torch.int16, device=dev)
-    mv = torch.empty((S, n_mb, 2), dtype=torch.int8, device=dev)
-    has = torch.empty((S, n_mb), dtype=torch.uint8, device=dev)
-    out_frames = torch.empty((S, fb), dtype=torch.uint8, device=dev)
-    dec.set_output_dev(out_frames.data_ptr())                            # retframe crop (src/dec.rs:209-211) fused into decode
-    stream = torch.cuda.ExternalStream(ctx.stream, device=dev)           # HIP events on the kernels' own stream
-    torch.cuda.synchronize()
+    timer = Timer(ctx, dev)
+    ss = StreamSet(pkg, ctx, W, H, Q, [int(r[1]) for r in mine], NF)      # synthetic input generated in HBM: [NF][S][frame_bytes]
+    n_mb = ss.n_mb
+    if not EMU:
+        torch.cuda.synchronize()
 
-    ev_pairs = []
-    ev_other = {"k_enc_iframe": [], "k_dec_iframe": [], "k_dec_pframe": []}
+    ev = {k: [] for k in BYTES_PER_MB}
 
-    def step(timed: bool):
-        # HIP events on the kernels' own stream bracket every launch of the timed steps: k_enc_pframe for the roofline
-        # object, the other three for the per-kernel table (one event = ~1 us of host time, inside the timed region)
-        def ev():
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(stream)
-            return e
-        for t in range(GOP):
-            f = frames[t].data_ptr()
-            if t == 0:
-                a = ev() if timed else None
-                enc.encode_iframe_dev(f, coef.data_ptr())
-                b = ev() if timed else None
-                dec.decode_iframe_dev(coef.data_ptr())
-                if timed:
-                    ev_other["k_enc_iframe"].append((a, b))
-                    ev_other["k_dec_iframe"].append((b, ev()))
-            else:
-                a = ev() if timed else None
-                enc.encode_pframe_dev(f, mv.data_ptr(), has.data_ptr(), coef.data_ptr())
-                b = ev() if timed else None
-                dec.decode_pframe_dev(mv.data_ptr(), has.data_ptr(), coef.data_ptr())
-                if timed:
-                    ev_pairs.append((a, b))
-                    ev_other["k_dec_pframe"].append((b, ev()))
+    def on_launch(name=None, a=None, b=None):
+        # HIP events on the kernels' own stream bracket every launch of the timed steps (one event = ~1 us of host time,
+        # inside the timed region)
+        if name is None:
+            return timer.stamp()
+        ev[name].append((a, b))
+        return None
+
+    def barrier():
+        ctx.sync()
+        if not EMU:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
     for _ in range(args.warmup):
-        step(False)
-    ctx.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+        ss.step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
-    ctx.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+        ss.step(on_launch=on_launch)
+    barrier()
     el = time.perf_counter() - t0
     if not args.no_verify:
-        dec.check()
+        ss.verify()                                   # decoder output == encoder reconstruction, no bad motion vector
+    coded_frac = ss.coded_fraction()
+    kern_ms = {k: float(np.mean([Timer.ms(a, b) for a, b in v])) for k, v in ev.items() if v}
+    pe_ms = kern_ms.get("k_enc_pframe", float("nan"))
 
-    # sanity inside the bench: decoder output == encoder reconstruction, and the p-frames did real work
-    assert args.no_verify or np.array_equal(enc.prev_frame(), dec.framebuffer()), "decoder framebuffer != encoder reconstruction"
-    coded_frac = float(has.float().mean().item())
+    ent = None if args.no_entropy else entropy_side(ss, timer, args)
 
-    pe_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
-
-    # ---- beside the headline (never part of `value`): the encoder alone with its entropy stage on the device, i.e.
-    # frames in HBM -> packet payloads in HBM (k_enc_* + k_ent_*), one GOP per pass
-    ent = None
-    if not args.no_entropy:
-        # two sets of encode outputs: with the stage on its own HIP stream the k_ent_* kernels of frame t (memory-bound)
-        # overlap k_enc_pframe of frame t+1 (VALU-bound); pack(t+1) orders later main-stream work behind pack(t)'s reads
-        sets = [(coef, mv, has), (torch.empty_like(coef), torch.empty_like(mv), torch.empty_like(has))]
-
-        def encode_gop():
-            for t in range(GOP):
-                f = frames[t].data_ptr()
-                c, m, h = sets[t & 1]
-                if t == 0:
-                    enc.encode_iframe_dev(f, c.data_ptr())
-                    enc.pack_iframe_dev(c.data_ptr())
-                else:
-                    enc.encode_pframe_dev(f, m.data_ptr(), h.data_ptr(), c.data_ptr())
-                    enc.pack_pframe_dev(m.data_ptr(), h.data_ptr(), c.data_ptr())
-
-        def measure(async_stream):
-            enc.enable_entropy(async_stream=async_stream)
-            encode_gop()
-            enc.entropy_join()
-            ctx.sync()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = max(1, min(args.steps, 5))
-            e0.record(stream)
-            for _ in range(reps):
-                encode_gop()
-            enc.entropy_join()          # the kernels' stream waits for the entropy stream before the closing event
-            e1.record(stream)
-            ctx.sync()
-            return e0.elapsed_time(e1) / reps, enc.payload_sizes()
-
-        serial_ms, sizes = measure(False)
-        gop_ms = None
-        if not args.no_two_stream:
-            gop_ms, sizes_b = measure(True)
-            assert np.array_equal(sizes, sizes_b), "entropy stage: two-stream and same-stream runs disagree"
-        ent = {"value": GOP * S * n_mb / (serial_ms * 1e-3), "unit": "macroblocks/s", "ms_per_gop": serial_ms,
-               "two_stream_value": GOP * S * n_mb / (gop_ms * 1e-3) if gop_ms else None, "two_stream_ms_per_gop": gop_ms,
-               "last_pframe_payload_bytes_per_stream": float(np.mean(sizes)),
-               "note": "encode only, frames in HBM -> .pfv packet payloads in HBM: k_enc_iframe/k_enc_pframe + the device "
-                       "entropy stage (k_ent_scan/codes/init/pack), HIP-event time over whole GOPs; two_stream_*: the stage "
-                       "on a second HIP stream with double-buffered encode outputs (k_enc_pframe's 5 wavefronts/SIMD fill "
-                       "the VGPR file, so the kernels time-slice instead of co-residing: no gain expected)"}
-
-    elt = torch.tensor([el], device=dev, dtype=torch.float64)
-    cnt = torch.tensor([float(args.steps) * GOP * S * n_mb], device=dev, dtype=torch.float64)
+    total_mb, el_max = float(args.steps) * NF * S * n_mb, el
     if world > 1:
-        dist.all_reduce(elt, op=dist.ReduceOp.MAX)       # max over ranks
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)       # counter gather
-    el_max, total_mb = float(elt.item()), float(cnt.item())
+        total_mb, el_max, _ = shard.gather_counters(total_mb, el, 0, dist, cdev)      # sum of macroblocks, max of seconds
 
     if rank == 0:
         launch_mbs = S * n_mb
         achieved = launch_mbs * BYTES_PER_MB_PENC / (pe_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-        # tools/gpu_pmc.sh); only quoted when it was collected on this exact configuration
-        traffic, valu = None, None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            c = pm["config"]
-            if (int(c["streams"]), int(c["width"]), int(c["height"]), int(c["quality"])) == (S, W, H, Q):
-                traffic = pm["kernels"]["k_enc_pframe"]["traffic_bytes"]
-                n_valu = pm["kernels"]["k_enc_pframe"].get("valu_wave_instructions")
-                if n_valu:
-                    # what actually bounds the kernel: VALU issue.  1024 SIMDs at the 2.4 GHz maximum clock; a wave64
-                    # instruction occupies its SIMD for 2 (plain VOP2) to 4+ (VOP3 / DPP / SDWA / v_dot4) cycles
-                    valu = {"wave_instructions_per_launch": n_valu,
-                            "simd_cycles_per_instruction": pe_ms * 1e-3 * 2.4e9 * 1024 / n_valu,
-                            "note": "SQ_INSTS_VALU from the committed PMC pass (profiles/pmc_traffic.json), this run's launch "
-                                    "time, 1024 SIMDs x 2.4 GHz: the kernel retires one wave64 VALU instruction per ~4.5 SIMD "
-                                    "cycles, i.e. it is bound by VALU issue, not by the HBM roof quoted in frac"}
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, n_valu, traffic_source = traffic_from_profiles(S, W, H, Q)
+        valu = None
+        if n_valu:
+            valu = {"wave_instructions_per_launch": n_valu, "simd_cycles_per_instruction": pe_ms * 1e-3 * 2.4e9 * 1024 / n_valu,
+                    "note": "SQ_INSTS_VALU from the committed PMC pass, this run's launch time, 1024 SIMDs x 2.4 GHz"}
+        if args.workload == "config5":
+            name = f"config5: one {W}x{H} {NF}-frame GOP-{GOP} stream per GPU (seed = base + rank), encode+decode, one launch per frame operation"
+        else:
+            name = f"{W}x{H} YUV420 GOP-{GOP} encode+decode, {S} independent streams per GPU batched per launch"
         res = {
-            "metric": "macroblocks/s (encode+decode) 1080p YUV420",
+            "metric": "macroblocks/s (encode+decode) 1080p YUV420" if (W, H) == (1920, 1080) else f"macroblocks/s (encode+decode) {W}x{H} YUV420",
             "value": total_mb / el_max,
             "unit": "macroblocks/s",
             "n_gpus": world,
@@ -317,38 +575,49 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "i32",
-            "data": f"synthetic ({uniq} distinct integer-hash texture streams per GPU tiled to {S}; quality {Q})",
-            "config": {"workload": f"{W}x{H} YUV420 GOP-{GOP} encode+decode, {S} independent streams per GPU batched per launch",
-                       "streams_per_gpu": S, "macroblocks_per_frame": n_mb, "quality": Q,
+            "data": f"synthetic, generated on the device ({S} distinct integer-hash texture streams per GPU, seed per stream; quality {Q})",
+            "rccl_ranks": world if backend == "nccl" and world > 1 else 0,
+            "control_plane": {"backend": backend if world > 1 else None, "shared_gpu": bool(share), "emulated": EMU,
+                              "collectives": "assignment-table broadcast + counter all-reduce only (no data-path collective)"},
+            "config": {"workload": name, "streams_per_gpu": S, "frames_per_step": NF, "macroblocks_per_frame": n_mb, "quality": Q,
                        "pframe_coded_fraction": round(coded_frac, 4), "parallelism": f"streams sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "k_enc_pframe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": launch_mbs * BYTES_PER_MB_PENC,
                          "avg_launch_ms": pe_ms, "macroblocks_per_launch": launch_mbs,
                          "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC, "valu": valu},
         }
         res["pframe_encode"] = {"value": launch_mbs / (pe_ms * 1e-3), "unit": "macroblocks/s",
                                 "note": "k_enc_pframe alone (motion search + residual DCT + closed-loop reconstruction), HIP-event time"}
-        kern = {"k_enc_pframe": pe_ms}
-        kern.update({k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev_other.items() if v})
         res["kernels"] = {k: {"avg_launch_ms": ms, "macroblocks_per_s": launch_mbs / (ms * 1e-3),
                               "algorithmic_GBps": launch_mbs * BYTES_PER_MB[k] / (ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": launch_mbs * BYTES_PER_MB[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                          for k, ms in kern.items()}
+                          for k, ms in kern_ms.items()}
         if ent:
             res["encode_to_payload"] = ent
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(pkg, W, H, Q, [host[t, 0] for t in range(GOP)])
+        host_gop = ss.host_frames(0, min(GOP, NF)) if (world == 1 and not args.no_cpu_baseline) else None
+        if world == 1 and not args.no_extra and not EMU:
+            extra = {}
+            if args.workload == "config5":
+                extra["config4"] = stream_4k_side(pkg, ctx, Q, ss.seeds[0], ss=ss) if (W, H) == (3840, 2160) else None
+                ss.close()
+            else:
+                ss.close()                            # give the 4.5 GB of resident input back first
+                extra["single_stream"] = single_stream_side(pkg, ctx, Q)
+                extra["config4"] = stream_4k_side(pkg, ctx, Q, pkg.synth.SEED)
+            res["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(W, H, Q, host_gop, n_mb, budget_s=4.0 if EMU else 12.0)
             if res["cpu_baseline"].get("pframe_encode_value"):
                 res["pframe_encode"]["vs_cpu_baseline"] = res["pframe_encode"]["value"] / res["cpu_baseline"]["pframe_encode_value"]
         elif not args.no_cpu_baseline:
-            res["cpu_baseline"] = None
+            res["cpu_baseline"] = None                # rank 0 at N = 1 only
         print(json.dumps(res), flush=True)
 
-    enc.close()
-    dec.close()
+    ss.close()
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

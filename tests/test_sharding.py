@@ -138,3 +138,41 @@ def test_gop_sharding_gloo_world2(pkg, oracle):
     oenc.finish()
     want = oenc.bytes()
     assert shard.splice_stream(want[:shard.HEADER_BYTES], parts) == want
+
+
+def _run_bench(extra_args, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ, PFV_BENCH_EMU="1", **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra_args], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run, both ranks
+    run the product's session path (kernel sources on the CPU emulator; PFV_BENCH_EMU=1 is test-only) on their own streams,
+    the control plane (table broadcast, counter reduction) runs on gloo, rank 0 prints the line."""
+    res = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--streams", "2", "--width", "64", "--height", "48", "--frames", "3",
+                      "--no-entropy"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["control_plane"]["backend"] == "gloo"
+    assert res["rccl_ranks"] == 0 and res["control_plane"]["emulated"] is True
+    # whole-job count: 2 ranks x 2 streams x 3 frames x 20 macroblocks per step
+    assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 2 * 2 * 3 * 20) < 1e-6
+    assert res["cpu_baseline"] is None and "roofline" in res and res["config"]["streams_per_gpu"] == 2
+
+
+def test_bench_config5_single_rank_fields():
+    """config-5 workload (one stream per GPU, seed = base + rank) and the cpu_baseline fields, at a toy geometry"""
+    res = _run_bench(["--workload", "config5", "--steps", "1", "--warmup", "0", "--width", "64", "--height", "48", "--frames", "4",
+                      "--no-entropy"])
+    assert res["n_gpus"] == 1 and res["config"]["workload"].startswith("config5") and res["config"]["streams_per_gpu"] == 1
+    cb = res["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cgroup_cpu_quota", "affinity_cpus", "value_1thread", "value_best",
+              "threads_best"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] == cb["threads_best"] and cb["value_best"] >= cb["value_1thread"] * 0.999
