@@ -155,6 +155,34 @@ def check_golden(pkg, ctx, oracle):
     assert np.array_equal(r1.image(), gold["pf_rec1"])
 
 
+def check_trap_vectors(pkg, ctx, oracle):
+    """the HIP path against tests/golden/trap_vectors.npz: the vectors aimed at the bit-exactness traps of SURVEY.md section 8c
+    (pad colour on a ragged plane, exact ties, skip threshold met with equality, last legal search position, i32 wrap in
+    decode); tests/test_mutation_sensitivity.py shows which rule each of them notices"""
+    import os
+    t = np.load(os.path.join(os.path.dirname(__file__), "golden", "trap_vectors.npz"))
+    _, ic, pl, pcq, px_err = oracle.qtables(5)
+    f0 = pkg.VideoPlane.from_slice(50, 38, t["rag_f0"])
+    e0 = f0.encode_plane(ic, 128, ctx)
+    assert np.array_equal(e0.blocks, t["rag_c0"])
+    r0 = pkg.VideoPlane.decode_plane(e0, ic, ctx)
+    assert np.array_equal(r0.image(), t["rag_rec0"])
+    e1 = pkg.VideoPlane.from_slice(50, 38, t["rag_f1"]).encode_plane_delta(r0, pcq, px_err, 128, ctx)
+    assert np.array_equal(e1.motion, t["rag_mv"]) and np.array_equal(e1.has_coeff, t["rag_has"]) and np.array_equal(e1.blocks, t["rag_c1"])
+    assert np.array_equal(pkg.VideoPlane.decode_plane_delta(e1, r0, pcq, ctx).image(), t["rag_rec1"])
+    for name in ("tie", "diag", "edge"):
+        src, ref = t[f"{name}_src"], t[f"{name}_ref"]
+        h, w = src.shape
+        e = pkg.VideoPlane.from_slice(w, h, src).encode_plane_delta(pkg.VideoPlane.from_slice(w, h, ref), pl, px_err, 0, ctx)
+        assert np.array_equal(e.motion, t[f"{name}_mv"]), name
+        assert np.array_equal(e.has_coeff, t[f"{name}_has"]), name
+        assert np.array_equal(e.blocks, t[f"{name}_c1"]), name
+    enc = pkg.EncodedIPlane(32, 64, 2, 4, t["host_coef"])
+    rec = pkg.VideoPlane.decode_plane(enc, t["host_q"], ctx).image()
+    want = t["host_rec"].reshape(4, 2, 16, 16).transpose(0, 2, 1, 3).reshape(64, 32)
+    assert np.array_equal(rec, want)
+
+
 def check_colour_utils(pkg, ctx):
     """VideoPlane::reduce / double on the device vs the host container ops (src/common.rs:523-556)"""
     import ctypes

@@ -13,13 +13,15 @@ def frame_of(pkg, w, h, packed):
     return pkg.VideoFrame.from_packed(w, h, packed)
 
 
-def encode_clip(pkg, ctx, oracle, w, h, fps, quality, n_frames, gop, drop_at=()):
-    st = pkg.SyntheticStream(w, h)
+def encode_clip(pkg, ctx, oracle, w, h, fps, quality, n_frames, gop, drop_at=(), frame_src=None, threads=1):
+    """frame_src: t -> packed Y|U|V frame (default: synth.SyntheticStream); threads: the oracle's pool size"""
+    if frame_src is None:
+        frame_src = pkg.SyntheticStream(w, h).frame
     buf = io.BytesIO()
     enc = pkg.Encoder(buf, w, h, fps, quality, ctx)
-    oenc = OracleStreamEncoder(oracle, w, h, fps, quality)
+    oenc = OracleStreamEncoder(oracle, w, h, fps, quality, threads=threads)
     for t in range(n_frames):
-        f = st.frame(t)
+        f = frame_src(t)
         if t in drop_at:
             enc.encode_dropframe(); oenc.encode_dropframe()
         elif t % gop == 0:
@@ -31,15 +33,15 @@ def encode_clip(pkg, ctx, oracle, w, h, fps, quality, n_frames, gop, drop_at=())
     return buf.getvalue(), oenc.bytes()
 
 
-def check_stream_roundtrip(pkg, ctx, oracle, w, h, quality, n_frames, gop, drop_at=()):
-    data, odata = encode_clip(pkg, ctx, oracle, w, h, 30, quality, n_frames, gop, drop_at)
+def check_stream_roundtrip(pkg, ctx, oracle, w, h, quality, n_frames, gop, drop_at=(), frame_src=None, threads=1):
+    data, odata = encode_clip(pkg, ctx, oracle, w, h, 30, quality, n_frames, gop, drop_at, frame_src, threads)
     assert data[:8] == b"PFVIDEO\x00" and int.from_bytes(data[8:12], "little") == 211      # common.rs:1-2
     assert data[-5:] == b"\x00\x00\x00\x00\x00"                                              # EOF packet (enc.rs:221-227)
     assert data == odata, "product .pfv stream differs from the oracle's"
     # decode with the product and with the oracle: same frames, same count, both hit EOF
     dec = pkg.Decoder(io.BytesIO(data), ctx)
     assert (dec.width(), dec.height(), dec.framerate()) == (w, h, 30)
-    odec = OracleStreamDecoder(oracle, data)
+    odec = OracleStreamDecoder(oracle, data, threads=threads)
     frames = []
     n_calls = 0
     while True:

@@ -24,6 +24,10 @@ def test_emu_golden_vectors(pkg, emu_ctx, oracle):
     pc.check_golden(pkg, emu_ctx, oracle)
 
 
+def test_emu_trap_vectors(pkg, emu_ctx, oracle):
+    pc.check_trap_vectors(pkg, emu_ctx, oracle)
+
+
 def test_emu_session_two_streams(pkg, emu_ctx, oracle):
     stats = pc.check_session(pkg, emu_ctx, oracle, 64, 48, 5, n_streams=2, n_frames=3)
     assert 0 < stats["coded"] < stats["mbs"]

@@ -25,6 +25,10 @@ def test_golden_vectors(pkg, gpu_ctx, oracle):
     pc.check_golden(pkg, gpu_ctx, oracle)
 
 
+def test_trap_vectors(pkg, gpu_ctx, oracle):
+    pc.check_trap_vectors(pkg, gpu_ctx, oracle)
+
+
 @pytest.mark.parametrize("quality", list(range(0, 11)))
 def test_iframe_plane_all_qualities(pkg, gpu_ctx, oracle, quality):
     il, ic, _, _, _ = oracle.qtables(quality)
@@ -298,3 +302,30 @@ def test_misaligned_device_frames(pkg, gpu_ctx, oracle):
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_fuzz_plane_operators(pkg, gpu_ctx, oracle, seed):
     pc.fuzz_plane_ops(pkg, gpu_ctx, oracle, n_cases=40, seed=seed)
+
+
+def test_config4_4k_gop15_stream_vs_oracle(pkg, gpu_ctx, oracle):
+    """BASELINE config #4 at its stated geometry and GOP pattern, under the driver's eyes: 3840x2160, 31 frames (i-frames at
+    0, 15 and 30 -> two full GOP boundaries, README.md:34-41), quality 5, product Encoder -> .pfv bytes -> product Decoder
+    (src/dec.rs:169-224 loop) against OracleStreamEncoder / OracleStreamDecoder: the stream bytes and every decoded frame.
+    Frames come from the device-side generator (one of them is also checked against synth.py here)."""
+    W, H, N = 3840, 2160, 31
+    fb = int(pkg._lib.load().pfv_frame_bytes(W, H))
+    dev = gpu_ctx.alloc(fb)
+    frames = []
+    for t in range(N):
+        gpu_ctx.synth_frames_dev(W, H, [pkg.synth.SEED], t, dev)
+        a = np.empty(fb, np.uint8)
+        gpu_ctx.download(a, dev)
+        frames.append(a)
+    gpu_ctx.free(dev)
+    assert np.array_equal(frames[16], pkg.SyntheticStream(W, H).frame(16))
+    threads = min(32, len(os.sched_getaffinity(0)))
+    data = sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, W, H, 5, n_frames=N, gop=15, frame_src=lambda t: frames[t], threads=threads)
+    oracle.L.pfvo_pool_shutdown()
+    # packet walk: types 1, 2 x 14, 1, 2 x 14, 1, then EOF
+    pos, kinds = 20 + 4 * 128, []
+    while pos < len(data):
+        kinds.append(data[pos])
+        pos += 5 + int.from_bytes(data[pos + 1:pos + 5], "little")
+    assert kinds == ([1] + [2] * 14) * 2 + [1, 0]
