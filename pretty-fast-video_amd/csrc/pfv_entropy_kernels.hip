@@ -155,20 +155,18 @@ __device__ __forceinline__ void ent_stage_rows(uint64_t *rows, const int16_t *gr
     }
 }
 
-// v_pk_min_u16: unsigned minimum of the two 16-bit halves (the CPU emulator supplies its own primitive, same semantics)
-#ifndef PFV_HIPEMU
-typedef unsigned short ent_us2 __attribute__((ext_vector_type(2)));
+// v_pk_min_u16: unsigned minimum of the two 16-bit halves (generic vector form; hipcc selects v_pk_min_u16 for it)
+typedef unsigned short ent_us2 __attribute__((vector_size(4)));
 __device__ __forceinline__ uint32_t ent_pk_min_u16(uint32_t a, uint32_t b)
 {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ent_us2, a), __builtin_bit_cast(ent_us2, b)));
+    ent_us2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const ent_us2 m = x < y ? x : y;
+    uint32_t r;
+    __builtin_memcpy(&r, &m, 4);
+    return r;
 }
-#else
-static inline uint32_t ent_pk_min_u16(uint32_t a, uint32_t b)
-{
-    const uint32_t lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
-    return lo | (hi << 16);
-}
-#endif
 // bit 0 / bit 1: the low / high 16-bit half of d is non-zero
 __device__ __forceinline__ uint32_t ent_nz2(uint32_t d)
 {
