@@ -253,10 +253,15 @@ typedef void (*pfv_video_cb)(void *user, const uint8_t *y, const uint8_t *u, con
 
 PFV_API int pfv_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, pfv_encoder **out);
 PFV_API int pfv_encoder_encode_iframe(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+/* PFV_ERR_STATE when the previous frame failed after prev_frame had advanced (oversize coefficient, out of memory, HIP
+ * error while fetching the payload): the stream no longer matches the encoder's reference; an i-frame clears this. */
 PFV_API int pfv_encoder_encode_pframe(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 PFV_API int pfv_encoder_encode_dropframe(pfv_encoder *e);
 PFV_API int pfv_encoder_finish(pfv_encoder *e);
-/* the bytes written so far (header + packets); valid until the next call on this encoder */
+/* Writer side (the reference's `W: Write`, src/enc.rs:12-26): pfv_encoder_drain hands over the bytes produced since the last
+ * drain (header after create, one packet per encode call) and forgets them -- valid until the next call on this encoder;
+ * nothing accumulates in the library.  pfv_encoder_bytes peeks at the bytes not yet drained without consuming them. */
+PFV_API int pfv_encoder_drain(pfv_encoder *e, const uint8_t **data, size_t *len);
 PFV_API int pfv_encoder_bytes(pfv_encoder *e, const uint8_t **data, size_t *len);
 PFV_API void pfv_encoder_destroy(pfv_encoder *e);
 /* 1 (default): packet payloads come from the device entropy stage; 0: from the host serialisers.  Same bytes. */

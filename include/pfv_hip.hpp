@@ -143,15 +143,12 @@ class Encoder {
     {
         const uint8_t *data = nullptr;
         size_t len = 0;
-        ctx_.check(pfv_encoder_bytes(h_, &data, &len));
-        if (len > flushed_) {
-            out_.write(reinterpret_cast<const char *>(data) + flushed_, (std::streamsize)(len - flushed_));
-            flushed_ = len;
-        }
+        ctx_.check(pfv_encoder_drain(h_, &data, &len));   // hands the pending bytes over; the library keeps nothing
+        if (len) out_.write(reinterpret_cast<const char *>(data), (std::streamsize)len);
     }
     Context &ctx_;
     std::ostream &out_;
-    size_t width_, height_, flushed_ = 0;
+    size_t width_, height_;
     bool finished_ = false;
     pfv_encoder *h_ = nullptr;
 };

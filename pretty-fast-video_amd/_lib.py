@@ -101,6 +101,7 @@ SIGNATURES = [
     ("pfv_encoder_encode_dropframe", c_int, [_P]),
     ("pfv_encoder_finish", c_int, [_P]),
     ("pfv_encoder_bytes", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
+    ("pfv_encoder_drain", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_encoder_destroy", None, [_P]),
     ("pfv_encoder_set_device_entropy", c_int, [_P, c_int]),
     ("pfv_serialize_iframe_payload", c_size_t, [_P, c_int, _P, c_size_t]),

@@ -84,7 +84,11 @@ static inline int pad16(int x) { return x + (16 - (x % 16)) % 16; }
 
 extern "C" {
 
-PFV_API const char *pfv_version(void) { return "pfv-hip 0.1 (gfx950; pfv-rs 0.2.2 / codec 2.1.1 hot path)"; }
+// PFV_BUILD_ID: hash of the sources this binary was compiled from, passed by __graft_entry__.build_hip() (hipcc -DPFV_BUILD_ID=...)
+#ifndef PFV_BUILD_ID
+#define PFV_BUILD_ID "unstamped"
+#endif
+PFV_API const char *pfv_version(void) { return "pfv-hip 0.2 (gfx950; pfv-rs 0.2.2 / codec 2.1.1 hot path; src " PFV_BUILD_ID ")"; }
 PFV_API int pfv_pad16(int x) { return pad16(x); }
 
 PFV_API const char *pfv_last_error(pfv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
@@ -1315,7 +1319,9 @@ struct pfv_encoder {
     int width = 0, height = 0, framerate = 0, total_blocks = 0;
     bool finished = false;
     bool device_entropy = true;            // payloads built by the k_ent_* kernels instead of serialize_*frame on the host
-    std::vector<uint8_t> out;              // the writer
+    bool poisoned = false;                 // a frame failed after prev_frame had moved on: the next frame must be an i-frame
+    std::vector<uint8_t> out;              // the writer: bytes produced and not yet handed over (pfv_encoder_drain)
+    std::vector<uint8_t> drained;          // what the last pfv_encoder_drain handed over
     PinnedBuf<uint8_t> frame;              // packed Y|U|V staging
     PinnedBuf<int16_t> coef;               // host entropy path only
     PinnedBuf<int8_t> mv;
@@ -1434,12 +1440,16 @@ static int encode_on_device(pfv_encoder *e, bool pframe)
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s->st_frames, e->frame.data(), (size_t)s->geom.src_frame_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = pframe ? pfv_enc_pframe_dev(s, s->st_frames, s->st_mv, s->st_has, s->st_coef) : pfv_enc_iframe_dev(s, s->st_frames, s->st_coef);
-    if (!rc) rc = pframe ? pfv_enc_pack_pframe_dev(s, s->st_mv, s->st_has, s->st_coef) : pfv_enc_pack_iframe_dev(s, s->st_coef);
+    if (rc) return rc;
+    // from here on prev_frame has moved to this frame: a failure leaves the encoder's reference ahead of the stream
+    e->poisoned = true;
+    rc = pframe ? pfv_enc_pack_pframe_dev(s, s->st_mv, s->st_has, s->st_coef) : pfv_enc_pack_iframe_dev(s, s->st_coef);
     uint32_t nbytes = 0;
     if (!rc) rc = pfv_enc_payload_sizes(s, &nbytes);
     if (rc) return rc;
     if (!e->payload.resize(std::max<size_t>(nbytes, 1 << 20))) return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
     if ((rc = pfv_enc_payload_fetch(s, 0, e->payload.data(), nbytes))) return rc;
+    e->poisoned = false;
     e->out.push_back(pframe ? 2 : 1);
     put_u32(e->out, nbytes);
     e->out.insert(e->out.end(), e->payload.data(), e->payload.data() + nbytes);
@@ -1461,13 +1471,15 @@ PFV_API int pfv_encoder_encode_iframe(pfv_encoder *e, const uint8_t *y, const ui
     if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
     int rc = pack_frame(e, y, u, v);
     if (rc) return rc;
-    if (e->device_entropy) return encode_on_device(e, false);
+    if (e->device_entropy) return encode_on_device(e, false);      // an i-frame replaces prev_frame entirely: clears a poisoned state
     if ((rc = host_entropy_staging(e))) return rc;
     if ((rc = pfv_enc_iframe(e->hot, e->frame.data(), e->coef.data()))) return rc;
+    e->poisoned = true;
     std::vector<uint8_t> payload;
     if (!serialize_iframe(payload, e->coef.data(), e->total_blocks))
         return fail(e->ctx, PFV_ERR_FORMAT, "coefficient needs more than 15 size bits (src/rle.rs:44)");
     put_packet(e->out, 1, &payload);
+    e->poisoned = false;
     return PFV_OK;
 }
 // Encoder::encode_pframe (src/enc.rs:125-173)
@@ -1476,13 +1488,18 @@ PFV_API int pfv_encoder_encode_pframe(pfv_encoder *e, const uint8_t *y, const ui
     if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
     int rc = pack_frame(e, y, u, v);
     if (rc) return rc;
+    // a previous frame failed after the encoder's reference had advanced but before its packet was written: a p-frame
+    // now would predict from a frame the decoder never saw (the reference panics in that situation and the Encoder is gone)
+    if (e->poisoned) return fail(e->ctx, PFV_ERR_STATE, "the previous frame failed after prev_frame had advanced: encode an i-frame next");
     if (e->device_entropy) return encode_on_device(e, true);
     if ((rc = host_entropy_staging(e))) return rc;
     if ((rc = pfv_enc_pframe(e->hot, e->frame.data(), e->mv.data(), e->has.data(), e->coef.data()))) return rc;
+    e->poisoned = true;
     std::vector<uint8_t> payload;
     if (!serialize_pframe(payload, e->mv.data(), e->has.data(), e->coef.data(), e->total_blocks))
         return fail(e->ctx, PFV_ERR_FORMAT, "coefficient needs more than 15 size bits (src/rle.rs:44)");
     put_packet(e->out, 2, &payload);
+    e->poisoned = false;
     return PFV_OK;
 }
 // Encoder::encode_dropframe (src/enc.rs:175-180): an i-frame packet with an empty payload
@@ -1507,6 +1524,17 @@ PFV_API int pfv_encoder_bytes(pfv_encoder *e, const uint8_t **data, size_t *len)
     if (!e || !data || !len) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_encoder_bytes: bad argument");
     *data = e->out.data();
     *len = e->out.size();
+    return PFV_OK;
+}
+// The reference streams every packet to its writer and keeps nothing (src/enc.rs:190-235); so does this: the bytes produced
+// since the last drain are handed over and forgotten, only the current packet is ever resident.
+PFV_API int pfv_encoder_drain(pfv_encoder *e, const uint8_t **data, size_t *len)
+{
+    if (!e || !data || !len) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_encoder_drain: bad argument");
+    e->drained.swap(e->out);
+    e->out.clear();
+    *data = e->drained.data();
+    *len = e->drained.size();
     return PFV_OK;
 }
 // Drop for Encoder (src/enc.rs:28-34): finishes the stream if the caller did not

@@ -24,17 +24,16 @@ class Encoder:
         self.handle = h
         # packet payloads from the device entropy stage (default) or the host serialisers: same bytes
         ctx.check(ctx._lib.pfv_encoder_set_device_entropy(h, 1 if device_entropy else 0))
-        self._flushed = 0
         self.finished = False
         ctx._sessions.add(self)
         self._flush()                                               # header (src/enc.rs:70)
 
     def _flush(self):
+        # the library keeps only what has not been handed over yet (the reference writes each packet through, src/enc.rs:190-235)
         data, n = ctypes.c_void_p(), ctypes.c_size_t()
-        self.ctx.check(self.ctx._lib.pfv_encoder_bytes(self.handle, ctypes.byref(data), ctypes.byref(n)))
-        if n.value > self._flushed:
-            self.writer.write(ctypes.string_at(data.value + self._flushed, n.value - self._flushed))
-            self._flushed = n.value
+        self.ctx.check(self.ctx._lib.pfv_encoder_drain(self.handle, ctypes.byref(data), ctypes.byref(n)))
+        if n.value:
+            self.writer.write(ctypes.string_at(data.value, n.value))
 
     def _check_frame(self, frame: VideoFrame):
         assert frame.width == self.width and frame.height == self.height                                  # src/enc.rs:76-79

@@ -252,3 +252,24 @@ def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, go
         assert od.advance_frame()[0] == 0            # the oracle is at EOF too
     assert not noise or getattr(dec, "_coef", None) is not None
     dec.close()
+
+
+def check_encoder_keeps_nothing(pkg, ctx, w=48, h=32):
+    """the native encoder must not accumulate the stream.  After every call the writer has received the packet
+    and the library holds zero pending bytes (the reference writes each packet through, src/enc.rs:190-235)."""
+    import ctypes
+    st = pkg.SyntheticStream(w, h)
+    buf = io.BytesIO()
+    enc = pkg.Encoder(buf, w, h, 30, 5, ctx)
+    sizes = [len(buf.getvalue())]
+    assert sizes[0] == 20 + 4 * 128
+    for t in range(4):
+        (enc.encode_iframe if t == 0 else enc.encode_pframe)(frame_of(pkg, w, h, st.frame(t)))
+        data, n = ctypes.c_void_p(), ctypes.c_size_t()
+        ctx.check(ctx._lib.pfv_encoder_bytes(enc.handle, ctypes.byref(data), ctypes.byref(n)))
+        assert n.value == 0                                  # nothing pending inside the library
+        sizes.append(len(buf.getvalue()))
+        assert sizes[-1] > sizes[-2]
+    enc.finish()
+    enc.close()
+    assert buf.getvalue()[-5:] == bytes(5)

@@ -25,6 +25,8 @@ def test_header_symbols_are_all_bound_and_exported(graft, pkg):
     for name in declared:
         assert hasattr(lib, name)
     assert b"gfx950" in lib.pfv_version()
+    # the binary is attributable to the sources in the tree: build_hip() stamps their hash into pfv_version()
+    assert graft.source_hash().encode() in lib.pfv_version() and graft.hip_build_id() == graft.source_hash()
     assert lib.pfv_pad16(1080) == 1088 and lib.pfv_pad16(1920) == 1920
     assert lib.pfv_total_blocks(1920, 1080) == 12240 and lib.pfv_total_blocks(3840, 2160) == 48720
     assert lib.pfv_frame_bytes(1920, 1080) == 3110400 and lib.pfv_padded_frame_bytes(1920, 1080) == 3133440

@@ -19,6 +19,8 @@ def test_native_library_is_the_one_loaded(pkg, gpu_ctx):
     with open("/proc/self/maps") as f:
         assert "libpfv_hip.so" in f.read()
     assert b"gfx950" in pkg._lib.load().pfv_version()
+    import __graft_entry__ as graft
+    assert graft.source_hash().encode() in pkg._lib.load().pfv_version(), "libpfv_hip.so was not built from the sources in this tree"
 
 
 def test_golden_vectors(pkg, gpu_ctx, oracle):
@@ -210,6 +212,7 @@ def test_stream_encoder_decoder_vs_oracle(pkg, gpu_ctx, oracle):
     sc.check_header_errors(pkg, gpu_ctx, data)
     sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 100, 60, 2, n_frames=3, gop=15)
     sc.check_stream_roundtrip(pkg, gpu_ctx, oracle, 64, 48, 10, n_frames=3, gop=15)
+    sc.check_encoder_keeps_nothing(pkg, gpu_ctx)
 
 
 @pytest.mark.parametrize("geom", [(176, 144, 5, 5, 3), (34, 18, 2, 3, 3), (100, 60, 8, 4, 4)])
