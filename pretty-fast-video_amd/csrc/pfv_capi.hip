@@ -271,8 +271,7 @@ static FrameGeom with_base_alignment(FrameGeom g, const void *src_base)
 // p-frame encoder: one workgroup per 128 x 64 tile
 static inline unsigned penc_blocks(const pfv_ctx *, const FrameGeom &g)
 {
-    const long tiles = (long)g.tiles_per_frame * g.n_streams;
-    return (unsigned)((tiles + PFV_PENC_TILES - 1) / PFV_PENC_TILES);
+    return (unsigned)((long)g.tiles_per_frame * g.n_streams);
 }
 
 // one strip per wavefront, kStripsPerWG strips per workgroup

@@ -73,11 +73,7 @@ __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (
 // The same wrapping product for operands known to fit 24 signed bits (v_mul_i32_i24 instead of v_mul_lo_u32): transform
 // outputs of 8-bit pixels (|m| < 2^22) times DCT_SCALE_FACTOR (<= 43), and i16 coefficients times SCALE*q (< 2^22 for
 // q <= 65535, which make_qtab enforces).
-#ifdef PFV_NO_MUL24   // A/B switch
-__device__ __forceinline__ int wmul24(int a, int b) { return wmul(a, b); }
-#else
 __device__ __forceinline__ int wmul24(int a, int b) { return __mul24(a, b); }
-#endif
 
 // Rust `/` by 2, 4, 16 on i32 (truncation toward zero).  trunc(x / 2^k) = (x + bias) >> k with
 // bias = (2^k - 1) for negative x; truncating divisions compose (trunc(trunc(x/a)/b) = trunc(x/(ab)))
@@ -328,12 +324,8 @@ __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 }
 __device__ __forceinline__ void st_stream(uint4 *p, const uint4 &v)
 {
-#ifdef PFV_V_PLAINST   // A/B switch
-    *p = v;
-#else
     __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
-#endif
 }
 
 // 16 source pixels (x .. x+15, row y) of an unpadded plane with the reference's pad rule
@@ -386,12 +378,7 @@ __device__ __forceinline__ void store_coef_half(const int *stage, int16_t *coef_
     for (int j = 0; j < 2; j++) {
         int ch = j * 64 + lane;   // 16-byte chunk of the stage; 16 chunks per macroblock half
         int mb = ch >> 4;
-#ifdef PFV_ABL_COEF_NOISSUE   // ablation experiment only (results invalid): stage read back, store never issued
-        const uint4 val = reinterpret_cast<const uint4 *>(stage)[ch];
-        if (mb < n_mb && val.x == 0x7ffe7ffdu && val.w == 0x12345u) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], val);
-#else
         if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(stage)[ch]);
-#endif
     }
 }
 __device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int h)
@@ -554,17 +541,52 @@ struct SearchState {
     int err;        // error of the current centre = best so far (:164, :191)
 };
 
-__device__ __forceinline__ void dot_row(const uint4 &a, unsigned b0, unsigned b1, unsigned b2, unsigned b3, unsigned &ab,
-                                        unsigned &bb)
+// sum a.b over one 16-pixel row (4 dwords)
+__device__ __forceinline__ unsigned dot_ab(const uint4 &a, unsigned b0, unsigned b1, unsigned b2, unsigned b3, unsigned acc)
 {
-    ab = __builtin_amdgcn_udot4(a.x, b0, ab, false);
-    ab = __builtin_amdgcn_udot4(a.y, b1, ab, false);
-    ab = __builtin_amdgcn_udot4(a.z, b2, ab, false);
-    ab = __builtin_amdgcn_udot4(a.w, b3, ab, false);
-    bb = __builtin_amdgcn_udot4(b0, b0, bb, false);
-    bb = __builtin_amdgcn_udot4(b1, b1, bb, false);
-    bb = __builtin_amdgcn_udot4(b2, b2, bb, false);
-    bb = __builtin_amdgcn_udot4(b3, b3, bb, false);
+    acc = __builtin_amdgcn_udot4(a.x, b0, acc, false);
+    acc = __builtin_amdgcn_udot4(a.y, b1, acc, false);
+    acc = __builtin_amdgcn_udot4(a.z, b2, acc, false);
+    return __builtin_amdgcn_udot4(a.w, b3, acc, false);
+}
+// sum of squares of two dwords (8 pixels) on top of acc
+__device__ __forceinline__ unsigned sq2(unsigned x, unsigned y, unsigned acc)
+{
+    return __builtin_amdgcn_udot4(y, y, __builtin_amdgcn_udot4(x, x, acc, false), false);
+}
+__device__ __forceinline__ unsigned sq4(unsigned b0, unsigned b1, unsigned b2, unsigned b3, unsigned acc) { return sq2(b2, b3, sq2(b0, b1, acc)); }
+
+// What one lane of a macroblock needs to finalise "its" candidate of a search level: after the dot products every
+// lane holds a partial sum (its two rows) for each of the 8 neighbours; the partials are transposed through a small
+// wavefront-private LDS region (8 ds_write_b32 + 2 ds_read_b128 per lane: LDS-pipe work) so that lane c ends up with
+// the 8 row-pair partials of candidate c and adds them with plain VALU adds -- instead of all-reducing all 8 values over
+// the 8 lanes with 24 DPP adds and building 8 keys in every lane.
+constexpr int kRedPitch = 72;   // dwords per macroblock: 64 used; 72 = 8 (mod 32) spreads the 4 macroblocks of a 32-lane group over the banks
+constexpr int kRedDwords = kStripMB * kRedPitch;
+struct SearchLane {
+    int ord;            // visiting order 1..8 of this lane's candidate: my outer, mx inner, centre skipped (src/common.rs:168-179)
+    int dy, dx;         // its position in the 3 x 3 pattern (-1, 0, 1)
+    int *wr;            // &red[m][0][i]: the lane's partial for candidate c goes to wr[c * 8]
+    const int4 *rd;     // &red[m][i][0]: the 8 lanes' partials of this lane's candidate
+};
+__device__ __forceinline__ SearchLane make_search_lane(int *red, int m, int i)
+{
+    SearchLane sl;
+    sl.ord = i + 1;
+    const int b9 = i < 4 ? i : i + 1;           // index in the full 3 x 3 pattern
+    sl.dy = b9 / 3 - 1;
+    sl.dx = b9 - (b9 / 3) * 3 - 1;
+    sl.wr = red + m * kRedPitch + i;
+    sl.rd = reinterpret_cast<const int4 *>(red + m * kRedPitch + i * 8);
+    return sl;
+}
+// minimum over the 8 lanes of one macroblock
+__device__ __forceinline__ unsigned mb_min(unsigned v)
+{
+    v = min(v, (unsigned)dpp<kQuadXor1>((int)v));
+    v = min(v, (unsigned)dpp<kQuadXor2>((int)v));
+    v = min(v, (unsigned)dpp<kRowHalfMirror>((int)v));
+    return v;
 }
 
 // One search level with step S.  wrow0 / wcol0: window coordinates of the macroblock origin
@@ -572,9 +594,12 @@ __device__ __forceinline__ void dot_row(const uint4 &a, unsigned b0, unsigned b1
 // (st.cx + mx*S, st.cy + my*S).  FIRST: the centre's error is not known yet (first level).
 // BOUNDS: check every candidate against the plane (src/common.rs:171, :182); false for wavefronts whose whole
 // strip lies at least 15 pixels inside the plane, where no candidate can leave it.
+// Per candidate the lane accumulates  sum b^2 - 2 sum ab  over its two rows.  In the aligned levels (S = 8, 4) the three
+// horizontal candidates of one row read overlapping dwords of the same span, so their sums of squares share the dwords
+// they have in common (16 instead of 24 v_dot4 per row pair at S = 8, 12 instead of 24 at S = 4).
 template <int S, bool FIRST, bool BOUNDS>
 __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int wcol0, const uint4 &top, const uint4 &bot,
-                                             int a2, int mbx, int mby, int pw, int ph, SearchState &st)
+                                             int a2, int mbx, int mby, int pw, int ph, SearchState &st, const SearchLane &sl)
 {
     constexpr bool kAligned = (S >= 4);            // displacement is a multiple of 4 pixels: no byte shifts
     const int sh = st.cx & 3;                      // only used when !kAligned
@@ -583,22 +608,64 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
     int part[3][3];
 #pragma unroll
     for (int my = -1; my <= 1; my++) {
+#ifdef PFV_ABL_LDSLINEAR   // ablation experiment only (results invalid): lane-linear addresses, 16 bytes apart -> (almost) no bank conflicts
+        const uint8_t *rp = win + ((threadIdx.x & 63) * 16 + (my + 1) * 4096 + (col & 12));
+#else
         const uint8_t *rp = win + (wrow0 + st.cy + my * S) * kWinStride + col;
-        unsigned dT[8], dB[8];
-        if (S == 8) {   // col = 16m + 8 (mod 16 == 8): 8-byte, 16-byte, 8-byte pieces
+#endif
+        const bool centre_known = !FIRST && my == 0;   // (0,0) is not evaluated again (:176)
+        unsigned ab[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
+        if (S == 8) {   // col = 16m + 8 (mod 16 == 8): 8-byte, 16-byte, 8-byte pieces; candidates at dwords 0, 2, 4
             uint2 t0 = *reinterpret_cast<const uint2 *>(rp), b0 = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride);
             uint4 t1 = *reinterpret_cast<const uint4 *>(rp + 8), b1 = *reinterpret_cast<const uint4 *>(rp + 8 * kWinStride + 8);
             uint2 t2 = *reinterpret_cast<const uint2 *>(rp + 24), b2 = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride + 24);
-            dT[0] = t0.x; dT[1] = t0.y; dT[2] = t1.x; dT[3] = t1.y; dT[4] = t1.z; dT[5] = t1.w; dT[6] = t2.x; dT[7] = t2.y;
-            dB[0] = b0.x; dB[1] = b0.y; dB[2] = b1.x; dB[3] = b1.y; dB[4] = b1.z; dB[5] = b1.w; dB[6] = b2.x; dB[7] = b2.y;
-        } else if (S == 4) {   // col == 12 (mod 16): dword, 16-byte, dword
+            const unsigned dT[8] = {t0.x, t0.y, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y};
+            const unsigned dB[8] = {b0.x, b0.y, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (centre_known && c == 1) continue;
+                ab[c] = dot_ab(bot, dB[2 * c], dB[2 * c + 1], dB[2 * c + 2], dB[2 * c + 3],
+                               dot_ab(top, dT[2 * c], dT[2 * c + 1], dT[2 * c + 2], dT[2 * c + 3], 0));
+            }
+            if (centre_known) {   // windows 0..3 and 4..7: disjoint
+                bb[0] = sq4(dB[0], dB[1], dB[2], dB[3], sq4(dT[0], dT[1], dT[2], dT[3], 0));
+                bb[2] = sq4(dB[4], dB[5], dB[6], dB[7], sq4(dT[4], dT[5], dT[6], dT[7], 0));
+            } else {
+                const unsigned q23 = sq2(dB[2], dB[3], sq2(dT[2], dT[3], 0)), q45 = sq2(dB[4], dB[5], sq2(dT[4], dT[5], 0));
+                bb[0] = sq2(dB[0], dB[1], sq2(dT[0], dT[1], q23));
+                bb[1] = q23 + q45;
+                bb[2] = sq2(dB[6], dB[7], sq2(dT[6], dT[7], q45));
+            }
+        } else if (S == 4) {   // dword, 16-byte, dword; candidates at dwords 0, 1, 2 of a 6-dword span
             const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);
-            uint4 t1 = *reinterpret_cast<const uint4 *>(rp + 4), b1 = *reinterpret_cast<const uint4 *>(rp + 8 * kWinStride + 4);
-            dT[0] = t[0]; dT[1] = t1.x; dT[2] = t1.y; dT[3] = t1.z; dT[4] = t1.w; dT[5] = t[5];
-            dB[0] = b[0]; dB[1] = b1.x; dB[2] = b1.y; dB[3] = b1.z; dB[4] = b1.w; dB[5] = b[5];
+            uint4 t1, b1;     // col + 4 is a multiple of 8 only: two 8-byte reads each (no 16-byte access at an 8-byte aligned address)
+            {
+                const uint2 ta = *reinterpret_cast<const uint2 *>(rp + 4), tb = *reinterpret_cast<const uint2 *>(rp + 12);
+                const uint2 ba = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride + 4), bc = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride + 12);
+                t1 = make_uint4(ta.x, ta.y, tb.x, tb.y);
+                b1 = make_uint4(ba.x, ba.y, bc.x, bc.y);
+            }
+            const unsigned dT[6] = {t[0], t1.x, t1.y, t1.z, t1.w, t[5]};
+            const unsigned dB[6] = {b[0], b1.x, b1.y, b1.z, b1.w, b[5]};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (centre_known && c == 1) continue;
+                ab[c] = dot_ab(bot, dB[c], dB[c + 1], dB[c + 2], dB[c + 3], dot_ab(top, dT[c], dT[c + 1], dT[c + 2], dT[c + 3], 0));
+            }
+            const unsigned q23 = sq2(dB[2], dB[3], sq2(dT[2], dT[3], 0));                 // common to all three windows
+            if (centre_known) {
+                bb[0] = sq2(dB[0], dB[1], sq2(dT[0], dT[1], q23));
+                bb[2] = sq2(dB[4], dB[5], sq2(dT[4], dT[5], q23));
+            } else {
+                const unsigned y = __builtin_amdgcn_udot4(dB[1], dB[1], __builtin_amdgcn_udot4(dT[1], dT[1], q23, false), false);   // q23 + s1
+                const unsigned z = __builtin_amdgcn_udot4(dB[4], dB[4], __builtin_amdgcn_udot4(dT[4], dT[4], 0, false), false);     // s4
+                bb[0] = __builtin_amdgcn_udot4(dB[0], dB[0], __builtin_amdgcn_udot4(dT[0], dT[0], y, false), false);
+                bb[1] = y + z;
+                bb[2] = __builtin_amdgcn_udot4(dB[5], dB[5], __builtin_amdgcn_udot4(dT[5], dT[5], q23 + z, false), false);
+            }
         } else {
             const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);
-            unsigned rt[7], rb[7];
+            unsigned rt[7], rb[7], dT[6], dB[6];
 #pragma unroll
             for (int k = 0; k < 7; k++) { rt[k] = t[k]; rb[k] = b[k]; }
 #pragma unroll
@@ -606,52 +673,48 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
                 dT[k] = __builtin_amdgcn_alignbyte(rt[k + 1], rt[k], sh);
                 dB[k] = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
             }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (centre_known && c == 1) continue;
+                const int ob = 4 + (c - 1) * S, o = ob >> 2, bs = ob & 3;   // compile-time byte offset from the rebased origin
+                unsigned eT[4], eB[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    eT[k] = bs ? __builtin_amdgcn_alignbyte(dT[o + k + 1], dT[o + k], bs) : dT[o + k];
+                    eB[k] = bs ? __builtin_amdgcn_alignbyte(dB[o + k + 1], dB[o + k], bs) : dB[o + k];
+                }
+                ab[c] = dot_ab(bot, eB[0], eB[1], eB[2], eB[3], dot_ab(top, eT[0], eT[1], eT[2], eT[3], 0));
+                bb[c] = sq4(eB[0], eB[1], eB[2], eB[3], sq4(eT[0], eT[1], eT[2], eT[3], 0));
+            }
         }
 #pragma unroll
-        for (int mx = -1; mx <= 1; mx++) {
-            if (!FIRST && my == 0 && mx == 0) { part[1][1] = 0; continue; }   // centre already known (:176)
-            unsigned ab = 0, bb = 0;
-            if (kAligned) {
-                const int o = (mx + 1) * S / 4;
-                dot_row(top, dT[o], dT[o + 1], dT[o + 2], dT[o + 3], ab, bb);
-                dot_row(bot, dB[o], dB[o + 1], dB[o + 2], dB[o + 3], ab, bb);
-            } else {
-                const int ob = 4 + mx * S, o = ob >> 2, bs = ob & 3;   // compile-time byte offset from the rebased origin
-                if (bs == 0) {
-                    dot_row(top, dT[o], dT[o + 1], dT[o + 2], dT[o + 3], ab, bb);
-                    dot_row(bot, dB[o], dB[o + 1], dB[o + 2], dB[o + 3], ab, bb);
-                } else {
-                    dot_row(top, __builtin_amdgcn_alignbyte(dT[o + 1], dT[o], bs), __builtin_amdgcn_alignbyte(dT[o + 2], dT[o + 1], bs),
-                            __builtin_amdgcn_alignbyte(dT[o + 3], dT[o + 2], bs), __builtin_amdgcn_alignbyte(dT[o + 4], dT[o + 3], bs),
-                            ab, bb);
-                    dot_row(bot, __builtin_amdgcn_alignbyte(dB[o + 1], dB[o], bs), __builtin_amdgcn_alignbyte(dB[o + 2], dB[o + 1], bs),
-                            __builtin_amdgcn_alignbyte(dB[o + 3], dB[o + 2], bs), __builtin_amdgcn_alignbyte(dB[o + 4], dB[o + 3], bs),
-                            ab, bb);
-                }
-            }
-            part[my + 1][mx + 1] = (int)bb - 2 * (int)ab;
-        }
+        for (int c = 0; c < 3; c++) part[my + 1][c] = (int)bb[c] + __mul24((int)ab[c], -2);   // sum ab < 2^22
     }
-    // all-reduce every candidate's partial sum over the macroblock's 8 lanes, then the
-    // sequential accept rule of the reference: strict `<`, first visited wins (:189), centre first
-    unsigned best = FIRST ? 0xffffffffu : ((unsigned)st.err << 4);
-    if (FIRST) best = ((unsigned)(a2 + mb_sum(part[1][1])) << 4);
+    // transposed reduction: lane c of the macroblock collects the 8 row-pair partials of candidate c
     int ord = 0;
 #pragma unroll
     for (int my = -1; my <= 1; my++) {
-        const int oy = mby + st.cy + my * S;
-        const bool vy = oy >= 0 && oy <= ph - 16;                       // :171
 #pragma unroll
         for (int mx = -1; mx <= 1; mx++) {
             if (my == 0 && mx == 0) continue;
+            sl.wr[ord * 8] = part[my + 1][mx + 1];
             ord++;
-            const int ox = mbx + st.cx + mx * S;
-            const bool valid = !BOUNDS || (vy && ox >= 0 && ox <= pw - 16);          // :182
-            int err = a2 + mb_sum(part[my + 1][mx + 1]);
-            unsigned key = valid ? (((unsigned)err << 4) | (unsigned)ord) : 0xffffffffu;
-            best = min(best, key);
         }
     }
+    wave_lds_sync();
+    const int4 x = sl.rd[0], y = sl.rd[1];
+    wave_lds_sync();
+    const int err = a2 + ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+    // this lane's candidate against the plane, then the sequential accept rule of the reference: strict `<`, first
+    // visited wins (:189), centre first -- the lexicographic minimum of (error, visiting order)
+    bool valid = true;
+    if (BOUNDS) {
+        const int oy = mby + st.cy + sl.dy * S, ox = mbx + st.cx + sl.dx * S;
+        valid = oy >= 0 && oy <= ph - 16 && ox >= 0 && ox <= pw - 16;        // :171, :182
+    }
+    const unsigned key = valid ? (((unsigned)err << 4) | (unsigned)sl.ord) : 0xffffffffu;
+    const unsigned centre = FIRST ? ((unsigned)(a2 + mb_sum(part[1][1])) << 4) : ((unsigned)st.err << 4);
+    const unsigned best = min(mb_min(key), centre);
     const int bo = (int)(best & 15u);
     st.err = (int)(best >> 4);
     if (bo) {
@@ -664,7 +727,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
 
 // Geometry of one p-frame tile (128 x 64 px = 4 vertically stacked strips) as seen by one wavefront.
 #ifndef PFV_PENC_WAVES
-#define PFV_PENC_WAVES 5   // wavefronts per SIMD the p-frame encoder is compiled for (VGPR budget 96; measured best of 4/5/6)
+#define PFV_PENC_WAVES 5   // wavefronts per SIMD the p-frame encoder is compiled for (tuning constant: VGPR budget 96; measured best of 4/5/6)
 #endif
 struct TilePos {
     StripPos sp;        // this wavefront's strip
@@ -719,7 +782,7 @@ struct SearchOut {
 
 // Phase 1 of a tile for one wavefront: motion search, skip decision, fetch of the chosen patch rows.
 // Reads the window; issues no global memory operation.
-__device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &tp, const uint8_t *win, const uint4 (&rows)[2], int lane,
+__device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &tp, const uint8_t *win, int *red, const uint4 (&rows)[2], int lane,
                                             float min_err, SearchOut &so)
 {
     const StripPos &sp = tp.sp;
@@ -744,25 +807,22 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
     // 4-step search (reference src/common.rs:154-204, steps 8, 4, 2, 1)
     SearchState st;
     st.cx = 0; st.cy = 0; st.err = 0;
+    const SearchLane sl = make_search_lane(red, m, i);
     // strips at least 15 px inside the plane on every side (84 % of a 1080p luma plane) skip the bounds tests
-#ifdef PFV_NO_INTERIOR   // A/B switch
-    const bool interior = false;
-#else
     const bool interior = sp.x0 >= 16 && sp.x0 + kStripMB * 16 + 16 <= p.pw && sp.y0 >= 16 && sp.y0 + 32 <= p.ph;   // wave-uniform
-#endif
     if (interior) {
-        search_level<8, true, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<8, true, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
 #ifndef PFV_ABL_SEARCH1   // ablation experiment only (results invalid): first search level alone
-        search_level<4, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
-        search_level<2, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
-        search_level<1, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<4, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<2, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<1, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
 #endif
     } else {
-        search_level<8, true, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<8, true, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
 #ifndef PFV_ABL_SEARCH1
-        search_level<4, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
-        search_level<2, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
-        search_level<1, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st);
+        search_level<4, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<2, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<1, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
 #endif
     }
 
@@ -797,21 +857,14 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
     const int m = lane >> 3, i = lane & 7;
     const bool mb_valid = m < sp.n_mb, coded = so.coded;
     const int mbx = sp.x0 + m * 16;
-#ifndef PFV_ABL_NOHDR   // ablation experiment only (results invalid)
     if (i == 0 && mb_valid) {
         long mbi = (long)sp.stream * g.mbs_per_frame + sp.mb_first + m;
         mv_out[mbi * 2 + 0] = (int8_t)so.cx;
         mv_out[mbi * 2 + 1] = (int8_t)so.cy;
         has_out[mbi] = coded ? 1 : 0;
     }
-#endif
-#ifdef PFV_ABL_STORE_SMALL   // ablation experiment only (results invalid): all stores land in one L2-resident megabyte
-    int16_t *coef_mb0 = coef + (((long)sp.stream * g.mbs_per_frame + sp.mb_first) & 1023) * 256;
-    uint8_t *dst = recon ? recon + (((long)(sp.y0 + i) * p.pw + mbx) & 0xfffff) : nullptr;
-#else
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
-#endif
 
     if (__any(coded)) {   // wavefront-uniform: the LDS transposes need all lanes
         const LaneQ lq{qtab_lds, i};
@@ -832,9 +885,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                 }
             }
             forward_half(v, xw, m, i, lq, true);
-#ifndef PFV_ABL_NOSTORE
             store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
-#endif
             wave_lds_sync();
             if (recon) {
                 inverse_half(v, xw, m, i, lq);
@@ -844,17 +895,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                     for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
                         pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
                 }
-#if defined(PFV_ABL_NOSTORE) || defined(PFV_ABL_RECON_NOISSUE)   // ablation experiment only (results invalid)
-                // the row is fully computed and packed; the store hangs on a value the packed row never has, so that the
-                // compiler can neither drop nor sink the arithmetic behind it (an earlier form of this switch tested one
-                // pixel only: the rest of the inverse row pass moved into the never-taken branch and the "store cost" it
-                // reported was that arithmetic)
-                const uint4 o_abl = pack_row(pp);
-                if (mb_valid && (o_abl.x ^ o_abl.y ^ o_abl.z ^ o_abl.w) == 0x9e3779b9u && o_abl.x == 0x01020304u)
-                    *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = o_abl;
-#else
                 if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
-#endif
             }
         }
     } else {
@@ -874,39 +915,30 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
 // One workgroup per tile (128 x 64 px = 4 vertically stacked strips).  Per wavefront:
 //     LDS-DMA of the tile's window (each wavefront its own 5 KiB slice), source rows -> registers
 //     ---- workgroup barrier: window complete ----
-//     search, fetch the chosen patch rows
+//     search (partial sums transposed through the wavefront's reduction region), fetch the chosen patch rows
 //     ---- workgroup barrier: window released ----
 //     transform + reconstruct + store; the exchange region lives in the wavefront's own window slice
-// so the kernel needs one 20 KiB LDS buffer per workgroup.
+// LDS per workgroup: 17 KiB window (+ 16 bytes in front of it: the 1-pixel level reads one dword to the left of the
+// leftmost candidate of the first window row) + 9 KiB reduction regions + 1 KiB quantiser tables.
 __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs,
                                                           float min_err)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t win[kWinAlloc];
+    __shared__ __attribute__((aligned(16))) uint8_t win_lds[16 + kWinAlloc];
+    __shared__ __attribute__((aligned(16))) int red_lds[kStripsPerWG][kRedDwords];
     __shared__ int qtab_lds[kQTabDwords];
-#ifdef PFV_PENC_LDS_PAD   // occupancy experiment: extra LDS per workgroup caps the resident workgroups per CU
-    __shared__ int lds_pad[PFV_PENC_LDS_PAD / 4];
-    if (g.n_streams < 0) lds_pad[threadIdx.x] = 0;
-#endif
+    uint8_t *win = win_lds + 16;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int m = lane >> 3, i = lane & 7;
-#ifndef PFV_PENC_TILES
-#define PFV_PENC_TILES 1   // tiles a workgroup encodes one after the other (experiment: >1 lets a tile's stores drain under the next tile)
-#endif
-    const int n_tiles = g.tiles_per_frame * g.n_streams;
-    for (int rep = 0; rep < PFV_PENC_TILES; rep++) {
-    const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x) * PFV_PENC_TILES + rep;
-    if (vt >= n_tiles) break;   // uniform over the workgroup
+    const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const TilePos cur = locate_tile(g, vt, wave);
     const PlaneGeom &p = g.p[cur.sp.plane];
     if (wave == 0) fill_qtable<true>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
 
-#ifndef PFV_ABL_NOWIN   // ablation experiment only (results invalid): search in whatever the LDS holds
     issue_window(p, ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off, cur, win, wave, lane);
-#endif
     uint4 rows[2];
     rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) {
@@ -918,23 +950,11 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     SearchOut so;
     so.cx = so.cy = 0; so.coded = false;
     so.patch[0] = so.patch[1] = make_uint4(0, 0, 0, 0);
-    if (cur.wave_valid) penc_search(g, cur, win, rows, lane, min_err, so);
+    if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, so);
     __syncthreads();   // window released by every wavefront
     if (cur.wave_valid)
         penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
                        recon, qtab_lds);
-#ifdef PFV_ABL_TAILWORK   // experiment: PFV_ABL_TAILWORK dependent VALU instructions after the last store of the wavefront
-    {
-        unsigned t = (unsigned)lane;
-#pragma unroll 16
-        for (int k = 0; k < PFV_ABL_TAILWORK; k++) t = __builtin_amdgcn_udot4(t, 0x01020304u, t, false);
-        if (t == 0x9e3779b9u) has_out[0] = 1;   // never true in practice; keeps the chain alive
-    }
-#endif
-#if PFV_PENC_TILES > 1
-    __syncthreads();   // exchange regions and the quantiser table are free again
-#endif
-    }
 }
 
 // ================================================================== I-frame decode
