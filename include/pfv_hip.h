@@ -67,6 +67,19 @@ PFV_API void *pfv_ctx_stream(pfv_ctx *ctx);
 PFV_API const char *pfv_last_error(pfv_ctx *ctx);
 PFV_API const char *pfv_version(void);
 
+/* HIP graphs over the `*_dev` entry points.  The reference's caller is one Encoder per stream, one call per frame
+ * (src/enc.rs:125-173); for a single stream the launches, not the kernels, are the cost.  Every `*_dev` call made between
+ * pfv_graph_begin and pfv_graph_end on this context is recorded instead of executed (stream capture); pfv_graph_launch
+ * replays the whole sequence -- e.g. the 30 launches of a GOP-15 encode + decode -- as one launch.  Device pointers are baked
+ * into the graph.  The recorded sequence must start with an i-frame step of every session it touches (an i-frame reads no
+ * previous state, src/enc.rs:84-97), or contain an even number of frame steps per session, so that the sessions' ping-pong
+ * state after a replay equals the state after the recording.  Host-pointer entry points cannot be recorded. */
+typedef struct pfv_graph pfv_graph;
+PFV_API int pfv_graph_begin(pfv_ctx *ctx);
+PFV_API int pfv_graph_end(pfv_ctx *ctx, pfv_graph **out);
+PFV_API int pfv_graph_launch(pfv_graph *g);
+PFV_API void pfv_graph_destroy(pfv_graph *g);
+
 /* x + (16 - x%16)%16  (src/common.rs:352-353, src/frame.rs:29-36) */
 PFV_API int pfv_pad16(int x);
 
@@ -266,6 +279,28 @@ PFV_API int pfv_encoder_bytes(pfv_encoder *e, const uint8_t **data, size_t *len)
 PFV_API void pfv_encoder_destroy(pfv_encoder *e);
 /* 1 (default): packet payloads come from the device entropy stage; 0: from the host serialisers.  Same bytes. */
 PFV_API int pfv_encoder_set_device_entropy(pfv_encoder *e, int on);
+/* ------------------------------------------------------------------ batch encoder (n streams per step, pipelined)
+ * n independent streams of one geometry encoded together -- the reference runs one Encoder per stream (src/enc.rs:12-26);
+ * every writer receives exactly the bytes an Encoder of its own would have written.  Per frame step: ONE upload of all
+ * frames (on a copy stream, overlapping the host-side collection of the previous step), one kernel launch per stage for
+ * all streams, one download of all payloads.  Packets reach the writers one step late; finish flushes.
+ *   write != NULL: called with each stream's header / packets in stream order (from the thread calling encode / finish);
+ *   write == NULL: the library keeps each stream's bytes until pfv_batch_encoder_take hands them over. */
+typedef struct pfv_batch_encoder pfv_batch_encoder;
+typedef void (*pfv_write_cb)(void *user, int stream, const uint8_t *data, size_t len);
+PFV_API int pfv_batch_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int n_streams,
+                                     pfv_write_cb write, void *user, pfv_batch_encoder **out);
+/* page-locked [n_streams][pfv_frame_bytes] array to fill for the NEXT encode call (two alternate; valid for that call only) */
+PFV_API uint8_t *pfv_batch_encoder_frames(pfv_batch_encoder *b);
+/* one frame step for all streams.  frames == NULL: the array from pfv_batch_encoder_frames; else the caller's own
+ * [n_streams][frame_bytes] buffer (ideally from pfv_host_alloc), free again when the call returns.  pframe: 0 = i-frames
+ * (Encoder::encode_iframe, src/enc.rs:75-123), 1 = p-frames (:125-173).  Returns when the step is enqueued. */
+PFV_API int pfv_batch_encoder_encode(pfv_batch_encoder *b, int pframe, const uint8_t *frames);
+PFV_API int pfv_batch_encoder_flush(pfv_batch_encoder *b);
+PFV_API int pfv_batch_encoder_finish(pfv_batch_encoder *b);
+PFV_API int pfv_batch_encoder_take(pfv_batch_encoder *b, int stream, const uint8_t **data, size_t *len);
+PFV_API void pfv_batch_encoder_destroy(pfv_batch_encoder *b);
+
 /* packet payload serialisers alone (write_iframe_packet / write_pframe_packet bodies, src/enc.rs:237-320, 332-470);
  * return the payload size (0 on error); the payload is copied to `out` when it fits `cap` */
 PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap);

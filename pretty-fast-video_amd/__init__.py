@@ -11,7 +11,7 @@ The directory name contains a hyphen, so import it through
 """
 from . import _lib
 from ._lib import PfvError
-from .context import Context
+from .context import Context, Graph
 from .plane import VideoPlane, EncodedIPlane, EncodedPPlane
 from .frame import VideoFrame
 from .session import EncoderSession, DecoderSession, qtables_from_quality
@@ -19,5 +19,5 @@ from .enc import BatchEncoder, Encoder
 from .dec import BatchDecoder, Decoder, DecodeError
 from .synth import SyntheticStream
 
-__all__ = ["Context", "VideoPlane", "VideoFrame", "EncodedIPlane", "EncodedPPlane", "EncoderSession",
+__all__ = ["Context", "Graph", "VideoPlane", "VideoFrame", "EncodedIPlane", "EncodedPPlane", "EncoderSession",
            "DecoderSession", "Encoder", "BatchEncoder", "Decoder", "BatchDecoder", "DecodeError", "qtables_from_quality", "PfvError", "SyntheticStream", "_lib"]

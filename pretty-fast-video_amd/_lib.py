@@ -41,6 +41,10 @@ SIGNATURES = [
     ("pfv_ctx_stream", _P, [_P]),
     ("pfv_last_error", c_char_p, [_P]),
     ("pfv_version", c_char_p, []),
+    ("pfv_graph_begin", c_int, [_P]),
+    ("pfv_graph_end", c_int, [_P, POINTER(_P)]),
+    ("pfv_graph_launch", c_int, [_P]),
+    ("pfv_graph_destroy", None, [_P]),
     ("pfv_pad16", c_int, [c_int]),
     ("pfv_qtables_from_quality", c_int, [c_int, _P, _P, _P, _P, POINTER(c_float)]),
     ("pfv_encode_plane", c_int, [_P, _P, c_int, c_int, _P, c_uint8, _P]),
@@ -104,6 +108,13 @@ SIGNATURES = [
     ("pfv_encoder_drain", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_encoder_destroy", None, [_P]),
     ("pfv_encoder_set_device_entropy", c_int, [_P, c_int]),
+    ("pfv_batch_encoder_create", c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, POINTER(_P)]),
+    ("pfv_batch_encoder_frames", _P, [_P]),
+    ("pfv_batch_encoder_encode", c_int, [_P, c_int, _P]),
+    ("pfv_batch_encoder_flush", c_int, [_P]),
+    ("pfv_batch_encoder_finish", c_int, [_P]),
+    ("pfv_batch_encoder_take", c_int, [_P, c_int, POINTER(_P), POINTER(c_size_t)]),
+    ("pfv_batch_encoder_destroy", None, [_P]),
     ("pfv_serialize_iframe_payload", c_size_t, [_P, c_int, _P, c_size_t]),
     ("pfv_serialize_pframe_payload", c_size_t, [_P, _P, _P, c_int, _P, c_size_t]),
     ("pfv_parse_iframe_payload", c_int, [_P, c_size_t, c_int, c_int, _P, _P]),

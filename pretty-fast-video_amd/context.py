@@ -94,5 +94,41 @@ class Context:
                                               dst.nbytes))
 
 
+class Graph:
+    """A recorded sequence of ``*_dev`` calls (HIP graph): ``with Graph(ctx) as g: ...dev calls...`` records, ``g.launch()``
+    replays them as one launch.  See include/pfv_hip.h (pfv_graph_begin) for the ping-pong rule."""
+
+    def __init__(self, ctx: Context):
+        self.ctx, self.handle = ctx, None
+
+    def __enter__(self):
+        self.ctx.check(self.ctx._lib.pfv_graph_begin(self.ctx.handle))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        h = ctypes.c_void_p()
+        rc = self.ctx._lib.pfv_graph_end(self.ctx.handle, ctypes.byref(h))
+        if exc_type is None:
+            self.ctx.check(rc)
+            self.handle = h
+        elif rc == _lib.PFV_OK:
+            self.ctx._lib.pfv_graph_destroy(h)
+        return False
+
+    def launch(self):
+        self.ctx.check(self.ctx._lib.pfv_graph_launch(self.handle))
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle:
+            self.ctx._lib.pfv_graph_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def ptr(a: np.ndarray) -> ctypes.c_void_p:
     return a.ctypes.data_as(ctypes.c_void_p)

@@ -58,6 +58,7 @@ struct pfv_ctx {
     QTab *qtab_host = nullptr;   // pinned mirror
     int *flag_dev = nullptr;
     int n_cus = 256;             // compute units of the device (persistent-kernel grid sizing)
+    bool capturing = false;      // a pfv_graph_begin is open on the stream
 };
 
 static thread_local std::string g_tls_err;
@@ -146,6 +147,60 @@ PFV_API int pfv_ctx_sync(pfv_ctx *ctx)
     return PFV_OK;
 }
 PFV_API void *pfv_ctx_stream(pfv_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ------------------------------------------------------------------ HIP graphs over the device-pointer entry points
+// One Encoder = one stream is the reference's calling pattern (src/enc.rs:125-173): 30 small launches per GOP, each of
+// which costs more host time than device time for a single 1080p stream.  Every *_dev entry point only enqueues kernels on
+// the context's stream, so a whole GOP can be recorded once (stream capture) and replayed as ONE graph launch.
+struct pfv_graph {
+    pfv_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+PFV_API int pfv_graph_begin(pfv_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    if (ctx->capturing) return fail(ctx, PFV_ERR_STATE, "pfv_graph_begin: a capture is already open on this context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = true;
+    return PFV_OK;
+}
+PFV_API int pfv_graph_end(pfv_ctx *ctx, pfv_graph **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_graph_end: bad argument");
+    *out = nullptr;
+    if (!ctx->capturing) return fail(ctx, PFV_ERR_STATE, "pfv_graph_end: no capture is open");
+    ctx->capturing = false;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return hip_fail(ctx, e, "hipGraphInstantiate");
+    }
+    pfv_graph *g = new pfv_graph();
+    g->ctx = ctx; g->graph = graph; g->exec = exec;
+    *out = g;
+    return PFV_OK;
+}
+PFV_API int pfv_graph_launch(pfv_graph *g)
+{
+    if (!g) return fail(nullptr, PFV_ERR_BAD_ARG, "null graph");
+    HIP_TRY(g->ctx, hipSetDevice(g->ctx->device));
+    HIP_TRY(g->ctx, hipGraphLaunch(g->exec, g->ctx->stream));
+    return PFV_OK;
+}
+PFV_API void pfv_graph_destroy(pfv_graph *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
 
 // Encoder::new, src/enc.rs:40-51
 PFV_API int pfv_qtables_from_quality(int quality, int32_t intra_l[64], int32_t intra_c[64], int32_t inter_l[64],
@@ -1543,6 +1598,202 @@ PFV_API void pfv_encoder_destroy(pfv_encoder *e)
     pfv_enc_session_destroy(e->hot);
     delete e;
 }
+// ------------------------------------------------------------------ batch encoder: n streams, pipelined
+// n independent streams of one geometry encoded together (the reference runs one Encoder per stream, src/enc.rs:12-26):
+// per frame step ONE upload, one launch per stage for all streams, one download of all payloads.  The upload of step t runs
+// on its own copy stream while the host collects step t-1 (payload download, packet assembly, writers) and before the
+// kernels of step t are enqueued, so PCIe, the kernels and the host work of neighbouring steps overlap:
+//     encode(t):  [copy stream] frames(t) -> HBM      [host] finish step t-1: payloads -> writers
+//                 [main stream] wait upload(t); k_enc_*; k_ent_*       (returns without waiting for them)
+// Every writer receives exactly the bytes an Encoder of its own would have written (packets arrive one step late; finish
+// flushes).
+struct pfv_batch_encoder {
+    pfv_ctx *ctx = nullptr;
+    pfv_enc_session *hot = nullptr;
+    int n = 0, width = 0, height = 0;
+    size_t frame_bytes = 0, total_blocks = 0;
+    pfv_write_cb write = nullptr;
+    void *user = nullptr;
+    std::vector<std::vector<uint8_t>> kept;   // write == NULL: per-stream bytes until pfv_batch_encoder_take
+    std::vector<std::vector<uint8_t>> taken;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
+    uint8_t *in_host[2] = {nullptr, nullptr};   // page-locked [n][frame_bytes], filled by the caller
+    uint8_t *in_dev[2] = {nullptr, nullptr};
+    int16_t *coef = nullptr;
+    int8_t *mv = nullptr;
+    uint8_t *has = nullptr;
+    PinnedBuf<uint8_t> payloads;
+    std::vector<uint32_t> sizes;
+    std::vector<uint64_t> offsets;
+    std::vector<uint8_t> packet;
+    long step = 0;
+    int pending = -1;          // packet type of the step whose kernels are in flight, -1: none
+    bool finished = false, poisoned = false;
+};
+
+static void be_emit(pfv_batch_encoder *b, int stream, const uint8_t *data, size_t len)
+{
+    if (b->write) b->write(b->user, stream, data, len);
+    else b->kept[(size_t)stream].insert(b->kept[(size_t)stream].end(), data, data + len);
+}
+// the step in flight: wait for it, fetch every payload with one copy, hand the packets to the writers
+static int be_collect(pfv_batch_encoder *b)
+{
+    if (b->pending < 0) return PFV_OK;
+    const int type = b->pending;
+    b->pending = -1;
+    int rc = pfv_enc_payloads_fetch(b->hot, b->payloads.data(), b->payloads.size(), b->sizes.data(), b->offsets.data());
+    if (rc == PFV_ERR_NOMEM) {   // very dense content: retry with the worst-case landing zone
+        const size_t worst = (size_t)b->n * ((pfv_payload_worst_case(b->width, b->height) + 15) & ~(size_t)15);
+        if (b->payloads.size() < worst && b->payloads.resize(worst))
+            rc = pfv_enc_payloads_fetch(b->hot, b->payloads.data(), b->payloads.size(), b->sizes.data(), b->offsets.data());
+    }
+    if (rc) { b->poisoned = true; return rc; }
+    for (int s = 0; s < b->n; s++) {
+        const uint32_t nbytes = b->sizes[(size_t)s];
+        uint8_t head[5] = {(uint8_t)type, (uint8_t)nbytes, (uint8_t)(nbytes >> 8), (uint8_t)(nbytes >> 16), (uint8_t)(nbytes >> 24)};
+        if (b->write) {   // packet header (src/enc.rs:301-305, :453-457) + payload as one write
+            b->packet.assign(head, head + 5);
+            b->packet.insert(b->packet.end(), b->payloads.data() + b->offsets[(size_t)s], b->payloads.data() + b->offsets[(size_t)s] + nbytes);
+            b->write(b->user, s, b->packet.data(), b->packet.size());
+        } else {
+            be_emit(b, s, head, 5);
+            be_emit(b, s, b->payloads.data() + b->offsets[(size_t)s], nbytes);
+        }
+    }
+    return PFV_OK;
+}
+
+PFV_API void pfv_batch_encoder_destroy(pfv_batch_encoder *b)
+{
+    if (!b) return;
+    pfv_ctx *ctx = b->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+    for (int i = 0; i < 2; i++) {
+        if (b->ev_up[i]) (void)hipEventDestroy(b->ev_up[i]);
+        if (b->in_host[i]) (void)hipHostFree(b->in_host[i]);
+        if (b->in_dev[i]) (void)hipFree(b->in_dev[i]);
+    }
+    if (b->coef) (void)hipFree(b->coef);
+    if (b->mv) (void)hipFree(b->mv);
+    if (b->has) (void)hipFree(b->has);
+    if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
+    pfv_enc_session_destroy(b->hot);
+    delete b;
+}
+
+PFV_API int pfv_batch_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int n_streams, pfv_write_cb write,
+                                     void *user, pfv_batch_encoder **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_batch_encoder_create: bad argument");
+    *out = nullptr;
+    if (framerate < 0 || framerate > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "framerate must fit u16 (src/enc.rs:197)");
+    pfv_enc_session *hot = nullptr;
+    int rc = pfv_enc_session_create(ctx, width, height, quality, n_streams, &hot);
+    if (rc) return rc;
+    pfv_batch_encoder *b = new pfv_batch_encoder();
+    b->ctx = ctx; b->hot = hot; b->n = n_streams; b->width = width; b->height = height;
+    b->write = write; b->user = user;
+    b->frame_bytes = pfv_frame_bytes(width, height);
+    b->total_blocks = (size_t)pfv_total_blocks(width, height);
+    b->sizes.assign((size_t)n_streams, 0);
+    b->offsets.assign((size_t)n_streams, 0);
+    if (!write) { b->kept.resize((size_t)n_streams); b->taken.resize((size_t)n_streams); }
+    const size_t in_bytes = (size_t)n_streams * b->frame_bytes, nmb = (size_t)n_streams * b->total_blocks;
+    hipError_t e = hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&b->ev_up[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b->in_host[i], in_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->in_dev[i], in_bytes);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&b->coef, nmb * 512);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->mv, nmb * 2);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->has, nmb);
+    if (e != hipSuccess) {
+        rc = hip_fail(ctx, e, "pfv_batch_encoder_create");
+        pfv_batch_encoder_destroy(b);
+        return rc;
+    }
+    rc = pfv_enc_entropy_enable(hot, 0);
+    // landing zone for one step's payloads: typical content needs a fraction of the worst case; it grows on demand
+    if (!rc && !b->payloads.resize(std::max<size_t>(in_bytes, 1 << 20))) rc = fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
+    if (rc) { pfv_batch_encoder_destroy(b); return rc; }
+    // header (src/enc.rs:190-219): magic, version, geometry, the four q-tables -- to every writer
+    int32_t q[4][64];
+    pfv_qtables_from_quality(quality, q[0], q[1], q[2], q[3], nullptr);
+    std::vector<uint8_t> head;
+    static const char magic[8] = {'P', 'F', 'V', 'I', 'D', 'E', 'O', 0};
+    head.insert(head.end(), magic, magic + 8);
+    put_u32(head, 211);
+    put_u16(head, (unsigned)width); put_u16(head, (unsigned)height); put_u16(head, (unsigned)framerate);
+    put_u16(head, 4);
+    for (int t = 0; t < 4; t++)
+        for (int i = 0; i < 64; i++) put_u16(head, (unsigned)q[t][i]);
+    for (int s = 0; s < n_streams; s++) be_emit(b, s, head.data(), head.size());
+    *out = b;
+    return PFV_OK;
+}
+
+// the page-locked [n_streams][frame_bytes] array to fill for the NEXT encode call (two of them alternate)
+PFV_API uint8_t *pfv_batch_encoder_frames(pfv_batch_encoder *b) { return b ? b->in_host[b->step & 1] : nullptr; }
+
+PFV_API int pfv_batch_encoder_encode(pfv_batch_encoder *b, int pframe, const uint8_t *frames)
+{
+    if (!b) return fail(nullptr, PFV_ERR_BAD_ARG, "null batch encoder");
+    pfv_ctx *ctx = b->ctx;
+    if (b->finished) return fail(ctx, PFV_ERR_STATE, "batch encoder already finished (src/enc.rs:80)");
+    if (pframe && b->poisoned) return fail(ctx, PFV_ERR_STATE, "a previous step failed after prev_frame had advanced: encode i-frames next");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int slot = (int)(b->step & 1);
+    const uint8_t *src = frames ? frames : b->in_host[slot];
+    // in_dev[slot] was last read by the kernels of step t-2, which the collect of step t-1's call has waited for
+    HIP_TRY(ctx, hipMemcpyAsync(b->in_dev[slot], src, (size_t)b->n * b->frame_bytes, hipMemcpyHostToDevice, b->copy_stream));
+    HIP_TRY(ctx, hipEventRecord(b->ev_up[slot], b->copy_stream));
+    int rc = be_collect(b);            // step t-1 -> writers, while the upload of step t is on the wire
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, b->ev_up[slot], 0));
+    rc = pframe ? pfv_enc_pframe_dev(b->hot, b->in_dev[slot], b->mv, b->has, b->coef) : pfv_enc_iframe_dev(b->hot, b->in_dev[slot], b->coef);
+    if (rc) return rc;
+    b->poisoned = true;                // until this step's packets have been written
+    rc = pframe ? pfv_enc_pack_pframe_dev(b->hot, b->mv, b->has, b->coef) : pfv_enc_pack_iframe_dev(b->hot, b->coef);
+    if (rc) return rc;
+    if (frames) HIP_TRY(ctx, hipStreamSynchronize(b->copy_stream));   // the caller's buffer is free again when this returns
+    b->pending = pframe ? 2 : 1;
+    b->poisoned = false;
+    b->step++;
+    return PFV_OK;
+}
+// packets of the step in flight -> writers (encode does this for the previous step by itself)
+PFV_API int pfv_batch_encoder_flush(pfv_batch_encoder *b)
+{
+    if (!b) return fail(nullptr, PFV_ERR_BAD_ARG, "null batch encoder");
+    return be_collect(b);
+}
+PFV_API int pfv_batch_encoder_finish(pfv_batch_encoder *b)
+{
+    if (!b) return fail(nullptr, PFV_ERR_BAD_ARG, "null batch encoder");
+    if (b->finished) return fail(b->ctx, PFV_ERR_STATE, "batch encoder already finished (src/enc.rs:183)");
+    int rc = be_collect(b);
+    if (rc) return rc;
+    b->finished = true;
+    const uint8_t eof[5] = {0, 0, 0, 0, 0};                                    // src/enc.rs:221-227
+    for (int s = 0; s < b->n; s++) be_emit(b, s, eof, 5);
+    return PFV_OK;
+}
+// write == NULL at creation: the bytes produced for one stream since the last take (valid until the next call on `b`)
+PFV_API int pfv_batch_encoder_take(pfv_batch_encoder *b, int stream, const uint8_t **data, size_t *len)
+{
+    if (!b || !data || !len || stream < 0 || stream >= b->n || b->write) return fail(b ? b->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_batch_encoder_take: bad argument");
+    b->taken[(size_t)stream].swap(b->kept[(size_t)stream]);
+    b->kept[(size_t)stream].clear();
+    *data = b->taken[(size_t)stream].data();
+    *len = b->taken[(size_t)stream].size();
+    return PFV_OK;
+}
+
 // payload serialisers alone (for tests: product vs oracle on identical coefficient input)
 PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap)
 {

@@ -82,58 +82,45 @@ class Encoder:
 class BatchEncoder:
     """``n`` independent streams of one geometry encoded together: one upload, one kernel launch per stage and one
     download per frame step for all of them (the reference runs one ``Encoder`` per stream, src/enc.rs:12-26).  Each
-    writer receives exactly the bytes an ``Encoder`` of its own would have written.
+    writer receives exactly the bytes an ``Encoder`` of its own would have written.  The orchestration (copy stream for
+    the next step's upload, payload collection, packet assembly) is the C++ ``pfv_batch_encoder``; this class marshals.
 
-    The caller fills ``frames`` -- a page-locked ``[n, frame_bytes]`` uint8 array, one packed Y|U|V frame per stream --
-    and calls ``encode_iframes()`` / ``encode_pframes()``; ``finish()`` writes the EOF packets."""
+    The caller fills ``frames`` -- a page-locked ``[n, frame_bytes]`` uint8 array, one packed Y|U|V frame per stream; two
+    such arrays alternate, fetch the attribute again after every step -- and calls ``encode_iframes()`` /
+    ``encode_pframes()``; or passes its own ``[n, frame_bytes]`` array to them.  Packets reach the writers one step late;
+    ``finish()`` flushes and writes the EOF packets."""
 
     def __init__(self, writers, width: int, height: int, framerate: int, quality: int, ctx: Context):
         import numpy as np
-        from .session import EncoderSession, qtables_from_quality
         assert 0 <= quality <= 10 and len(writers) >= 1
         self.ctx, self.writers, self.n = ctx, list(writers), len(writers)
         self.width, self.height = int(width), int(height)
-        self.session = EncoderSession(ctx, width, height, quality, self.n)
-        self.session.enable_entropy()
-        s = self.session
-        self.frames = ctx.host_array(self.n * s.frame_bytes).reshape(self.n, s.frame_bytes)
-        self._cap = cap = (int(ctx._lib.pfv_payload_worst_case(width, height)) + 15) & ~15
-        self._payloads = ctx.host_array(min(self.n * cap, max(self.n * s.frame_bytes, 1 << 20)))
-        self._d_frames = ctx.alloc(self.n * s.frame_bytes)
-        self._d_coef, self._d_mv, self._d_has = (ctx.alloc(self.n * s.total_blocks * 512), ctx.alloc(self.n * s.total_blocks * 2),
-                                                 ctx.alloc(self.n * s.total_blocks))
+        self.frame_bytes = int(ctx._lib.pfv_frame_bytes(width, height))
         self.finished = False
-        # header (src/enc.rs:190-219): magic, version, geometry, the four q-tables
-        q = qtables_from_quality(quality)
-        head = (b"PFVIDEO\x00" + (211).to_bytes(4, "little") + self.width.to_bytes(2, "little") + self.height.to_bytes(2, "little")
-                + int(framerate).to_bytes(2, "little") + (4).to_bytes(2, "little")
-                + b"".join(np.asarray(t, dtype="<u2").tobytes() for t in q[:4]))
-        for w in self.writers:
-            w.write(head)
+        self._np = np
+
+        def on_write(_user, stream, data, length):
+            self.writers[stream].write(ctypes.string_at(data, length))
+        self._cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t)(on_write)
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.pfv_batch_encoder_create(ctx.handle, self.width, self.height, int(framerate), int(quality), self.n,
+                                                    ctypes.cast(self._cb, ctypes.c_void_p), None, ctypes.byref(h)))
+        self.handle = h
+        ctx._sessions.add(self)
+
+    @property
+    def frames(self):
+        """the page-locked [n, frame_bytes] array to fill for the next step"""
+        p = self.ctx._lib.pfv_batch_encoder_frames(self.handle)
+        return self._np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(self.n, self.frame_bytes))
 
     def _step(self, pframe: bool, frames=None):
         assert not self.finished
-        s, ctx = self.session, self.ctx
-        src = self.frames if frames is None else frames      # any [n, frame_bytes] uint8 array; page-locked ones upload fastest
-        assert src.size == self.n * s.frame_bytes
-        ctx.upload(self._d_frames, src)
-        if pframe:
-            s.encode_pframe_dev(self._d_frames, self._d_mv, self._d_has, self._d_coef)
-            s.pack_pframe_dev(self._d_mv, self._d_has, self._d_coef)
-        else:
-            s.encode_iframe_dev(self._d_frames, self._d_coef)
-            s.pack_iframe_dev(self._d_coef)
-        try:
-            sizes, offsets = s.payloads(self._payloads)
-        except _lib.PfvError as e:                                   # very dense content: retry with the worst-case buffer
-            if e.code != _lib.PFV_ERR_NOMEM or self._payloads.size >= self.n * self._cap:
-                raise
-            self._payloads = ctx.host_array(self.n * self._cap)
-            sizes, offsets = s.payloads(self._payloads)
-        kind = bytes([2 if pframe else 1])
-        for w, n, o in zip(self.writers, sizes.tolist(), offsets.tolist()):
-            w.write(kind + int(n).to_bytes(4, "little"))             # packet header (src/enc.rs:301-305, :453-457)
-            w.write(self._payloads[o:o + n].data)
+        src = None
+        if frames is not None:
+            src = self._np.ascontiguousarray(frames, dtype=self._np.uint8)
+            assert src.size == self.n * self.frame_bytes
+        self.ctx.check(self.ctx._lib.pfv_batch_encoder_encode(self.handle, 1 if pframe else 0, ptr(src) if src is not None else None))
 
     def encode_iframes(self, frames=None):
         self._step(False, frames)
@@ -141,17 +128,23 @@ class BatchEncoder:
     def encode_pframes(self, frames=None):
         self._step(True, frames)
 
+    def flush(self):
+        self.ctx.check(self.ctx._lib.pfv_batch_encoder_flush(self.handle))
+
     def finish(self):
         assert not self.finished
+        self.ctx.check(self.ctx._lib.pfv_batch_encoder_finish(self.handle))
         self.finished = True
-        for w in self.writers:
-            w.write(bytes(5))                                        # EOF packet (src/enc.rs:221-227)
 
     def close(self):
-        if getattr(self, "session", None) is not None:
+        if getattr(self, "handle", None) and self.ctx.handle:
             if not self.finished:
                 self.finish()
-            for p in (self._d_frames, self._d_coef, self._d_mv, self._d_has):
-                self.ctx.free(p)
-            self.session.close()
-            self.session = None
+            self.ctx._lib.pfv_batch_encoder_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -154,8 +154,28 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
+// ---- stream capture / graphs: while a capture is open, kernel launches are recorded (not executed); hipGraphLaunch runs them
+namespace hipemu {
+struct Graph { std::vector<std::function<void()>> nodes; };
+extern Graph *g_capture;
+}
+typedef hipemu::Graph *hipGraph_t;
+typedef hipemu::Graph *hipGraphExec_t;
+typedef void *hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { hipemu::g_capture = new hipemu::Graph(); return hipSuccess; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = hipemu::g_capture; hipemu::g_capture = nullptr; return hipSuccess; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, hipGraphNode_t *, char *, size_t) { *e = new hipemu::Graph(*g); return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto &n : e->nodes) n(); return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+
 template <class K, class... A>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args)
 {
+    if (hipemu::g_capture) {
+        hipemu::g_capture->nodes.push_back([=]() { hipemu::launch(grid, block, [=]() { kernel(args...); }); });
+        return;
+    }
     hipemu::launch(grid, block, [=]() { kernel(args...); });
 }

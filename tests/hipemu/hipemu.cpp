@@ -5,6 +5,7 @@
 
 namespace hipemu {
 
+Graph *g_capture = nullptr;
 Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 namespace {

@@ -494,3 +494,59 @@ def check_colour_conversions(pkg, ctx, oracle, exhaustive):
         L.pfvo_yuv420_to_rgb(P(buf), w, h, P(ref))
         got = pkg.VideoFrame.from_packed(w, h, buf).to_rgb(ctx)
         assert np.array_equal(got, ref), f"yuv420 -> rgb differs ({w}x{h})"
+
+
+def check_gop_graph(pkg, ctx, oracle, w=64, h=48, n_streams=2, n_frames=4, quality=5):
+    """A GOP recorded once as a HIP graph (pfv_graph_begin / _end) and replayed: the buffers after every replay equal the
+    oracle's for the same frames -- the replay really re-runs encode + decode, and the sessions' ping-pong state is consistent."""
+    fb = int(pkg._lib.load().pfv_frame_bytes(w, h))
+    seeds = [pkg.synth.SEED + 5 * k for k in range(n_streams)]
+    enc = pkg.EncoderSession(ctx, w, h, quality, n_streams)
+    dec = pkg.DecoderSession(ctx, w, h, np.stack(pkg.qtables_from_quality(quality)[:4]), n_streams)
+    n_mb = enc.total_blocks
+    d_frames = ctx.alloc(n_frames * n_streams * fb)
+    d_coef, d_mv, d_has = ctx.alloc(n_streams * n_mb * 512), ctx.alloc(n_streams * n_mb * 2), ctx.alloc(n_streams * n_mb)
+    d_out = ctx.alloc(n_streams * fb)
+    dec.set_output_dev(d_out)
+
+    def fill(t0):
+        for t in range(n_frames):
+            ctx.synth_frames_dev(w, h, seeds, t0 + t, d_frames + t * n_streams * fb)
+
+    fill(0)
+    with pkg.Graph(ctx) as g:
+        for t in range(n_frames):
+            f = d_frames + t * n_streams * fb
+            if t == 0:
+                enc.encode_iframe_dev(f, d_coef)
+                dec.decode_iframe_dev(d_coef)
+            else:
+                enc.encode_pframe_dev(f, d_mv, d_has, d_coef)
+                dec.decode_pframe_dev(d_mv, d_has, d_coef)
+    for rep, t0 in enumerate((0, 7, 3)):          # every replay on different content: stale results cannot pass
+        fill(t0)
+        g.launch()
+        dec.check()
+        recon, fbuf = enc.prev_frame(), dec.framebuffer()
+        coef = np.empty((n_streams, n_mb, 256), np.int16)
+        ctx.download(coef, d_coef)
+        out = np.empty((n_streams, fb), np.uint8)
+        ctx.download(out, d_out)
+        for s, seed in enumerate(seeds):
+            st = pkg.SyntheticStream(w, h, seed=seed)
+            oenc = oracle.encoder(w, h, quality)
+            oenc.encode_iframe(st.frame(t0))
+            for t in range(1, n_frames):
+                _, _, ocoef = oenc.encode_pframe(st.frame(t0 + t))
+            assert np.array_equal(coef[s], ocoef), (rep, s)
+            assert np.array_equal(recon[s], oenc.prev_frame()), (rep, s)
+            assert np.array_equal(fbuf[s], recon[s]), (rep, s)
+            pf = pkg.VideoFrame.from_packed(w, h, recon[s], padded=True)
+            want = np.concatenate([pf.plane_y.image()[:h, :w].reshape(-1), pf.plane_u.image()[:h // 2, :w // 2].reshape(-1),
+                                   pf.plane_v.image()[:h // 2, :w // 2].reshape(-1)])
+            assert np.array_equal(out[s], want), (rep, s)
+    g.close()
+    enc.close()
+    dec.close()
+    for p in (d_frames, d_coef, d_mv, d_has, d_out):
+        ctx.free(p)

@@ -50,6 +50,10 @@ def test_emu_stream_encoder_decoder(pkg, emu_ctx, oracle):
     sc.check_header_errors(pkg, emu_ctx, data)
 
 
+def test_emu_gop_graph(pkg, emu_ctx, oracle):
+    pc.check_gop_graph(pkg, emu_ctx, oracle, n_frames=3)
+
+
 def test_emu_encoder_keeps_nothing(pkg, emu_ctx):
     sc.check_encoder_keeps_nothing(pkg, emu_ctx)
 

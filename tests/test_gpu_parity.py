@@ -27,6 +27,11 @@ def test_golden_vectors(pkg, gpu_ctx, oracle):
     pc.check_golden(pkg, gpu_ctx, oracle)
 
 
+def test_gop_graph_replay(pkg, gpu_ctx, oracle):
+    pc.check_gop_graph(pkg, gpu_ctx, oracle, 64, 48, n_streams=2, n_frames=4)
+    pc.check_gop_graph(pkg, gpu_ctx, oracle, 320, 240, n_streams=1, n_frames=15)
+
+
 def test_trap_vectors(pkg, gpu_ctx, oracle):
     pc.check_trap_vectors(pkg, gpu_ctx, oracle)
 
