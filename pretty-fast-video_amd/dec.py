@@ -163,8 +163,10 @@ class BatchDecoder:
         if typ == 0:
             self.eof = True
             return False
-        if all(p.size == 0 for _, p in pk):                           # drop frames (src/dec.rs:190)
+        if typ == 1 and all(p.size == 0 for _, p in pk):              # drop frames: an i-frame packet without payload (src/dec.rs:188-202)
             return None
+        if typ == 2 and any(p.size == 0 for _, p in pk):              # an empty p-frame packet is a truncated read in the reference (src/dec.rs:204-214)
+            raise DecodeError(_lib.PFV_ERR_IO, "p-frame packet without payload")
         if any(p.size == 0 for _, p in pk):
             raise ValueError("BatchDecoder: drop frames must line up across the streams")
         res = list(self._pool.map(lambda k: self._parse(k, typ, pk[k][1]), range(self.n)))

@@ -273,3 +273,28 @@ def check_encoder_keeps_nothing(pkg, ctx, w=48, h=32):
     enc.finish()
     enc.close()
     assert buf.getvalue()[-5:] == bytes(5)
+
+
+def check_empty_pframe_packet(pkg, ctx, oracle, w=48, h=32):
+    """a type-2 packet with length 0 is not a drop frame (only type 1 is, src/dec.rs:188-202); the reference fails
+    reading its payload.  Single-stream decoder, batch decoder and the oracle's decoder must agree that it is an error."""
+    import pytest
+    data, _ = encode_clip(pkg, ctx, oracle, w, h, 30, 5, n_frames=2, gop=15)
+    hdr = 20 + 4 * 128
+    n0 = int.from_bytes(data[hdr + 1:hdr + 5], "little")
+    bad = data[:hdr + 5 + n0] + bytes([2, 0, 0, 0, 0]) + bytes(5)       # i-frame, empty p-frame packet, EOF
+    odec = OracleStreamDecoder(oracle, bad)
+    assert odec.advance_frame()[0] == 1
+    assert odec.advance_frame()[0] < 0
+    dec = pkg.Decoder(bad, ctx)
+    assert dec.advance_frame(lambda fr: None) is True
+    with pytest.raises(pkg.PfvError) as e:
+        dec.advance_frame(lambda fr: None)
+    assert e.value.code in (pkg._lib.PFV_ERR_IO, pkg._lib.PFV_ERR_FORMAT)
+    dec.close()
+    bd = pkg.BatchDecoder([bad, bad], ctx, threads=1)
+    assert bd.advance_frames() is not None
+    with pytest.raises(pkg.DecodeError) as e:
+        bd.advance_frames()
+    assert e.value.code == pkg._lib.PFV_ERR_IO
+    bd.close()

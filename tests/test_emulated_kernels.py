@@ -54,6 +54,10 @@ def test_emu_gop_graph(pkg, emu_ctx, oracle):
     pc.check_gop_graph(pkg, emu_ctx, oracle, n_frames=3)
 
 
+def test_emu_empty_pframe_packet_is_an_error(pkg, emu_ctx, oracle):
+    sc.check_empty_pframe_packet(pkg, emu_ctx, oracle)
+
+
 def test_emu_encoder_keeps_nothing(pkg, emu_ctx):
     sc.check_encoder_keeps_nothing(pkg, emu_ctx)
 
