@@ -221,10 +221,14 @@ class StreamSet:
             out.append(a)
         return out
 
-    def step(self, gop=GOP, on_launch=None):
-        """encode + decode every resident frame once; i-frame when t % gop == 0 (README.md:34-41)"""
+    def step(self, gop=GOP, on_launch=None, sample_frames=2 * GOP):
+        """encode + decode every resident frame once; i-frame when t % gop == 0 (README.md:34-41).  on_launch: HIP-event
+        brackets around the launches of the first `sample_frames` frames of the pass (every launch of the default
+        workload; a 2-GOP sample of a 300-frame stream, whose 20-microsecond launches the event calls would otherwise slow)"""
         enc, dec = self.enc, self.dec
+        ev = on_launch
         for t in range(self.n_frames):
+            on_launch = ev if t < sample_frames else None
             f = self.frame_ptr(t)
             if t % gop == 0:
                 a = on_launch and on_launch()
@@ -474,13 +478,11 @@ def traffic_from_profiles(S, W, H, Q):
         if (int(c["streams"]), int(c["width"]), int(c["height"]), int(c["quality"])) != (S, W, H, Q):
             return None, None, None
         k = pm["kernels"]["k_enc_pframe"]
-        sha = "unknown"
-        try:
-            sha = subprocess.run(["git", "log", "-1", "--format=%h", "--", "profiles/pmc_traffic.json"], cwd=ROOT, capture_output=True,
-                                 text=True, timeout=10).stdout.strip() or pm.get("source_commit", "unknown")
-        except (OSError, subprocess.SubprocessError):
-            sha = pm.get("source_commit", "unknown")
-        return k["traffic_bytes"], k.get("valu_wave_instructions"), f"profiles/pmc_traffic.json @{sha} (committed PMC pass, not measured in this run)"
+        import __graft_entry__ as graft
+        built, here = pm.get("build_id"), graft.hip_build_id()
+        src = f"profiles/pmc_traffic.json (rocprofv3 --pmc passes on build {built}; this run's library is build {here}" + \
+              (")" if built == here else " -- a different build of the kernels)")
+        return k["traffic_bytes"], k.get("valu_wave_instructions"), src + "; quoted, not measured in this run"
     except (OSError, KeyError, ValueError):
         return None, None, None
 

@@ -21,7 +21,8 @@ sq = kv.pop("sq", None)
 valu = means(sq, "SQ_INSTS_VALU") if sq else {}
 waves = means(sq, "SQ_WAVES") if sq else {}
 out = {"note": "HBM bytes per launch = FETCH_SIZE[KiB]*1024*2 (gfx950 half-count correction) + WRITE_SIZE[KiB]*1024; "
-               "valu_wave_instructions = SQ_INSTS_VALU per launch (a wave64 VALU instruction occupies its SIMD for 2 cycles as plain VOP2, 4 or more as VOP3 / DPP / SDWA / v_dot4)",
+               "valu_wave_instructions = SQ_INSTS_VALU per launch (issue cost per instruction: profiles/r02_ubench_valu_rates2.txt, r02_ubench_issue_patterns.txt)",
+       "build_id": kv.pop("build", None),      # source hash of the libpfv_hip.so the counters were collected on (pfv_version())
        "config": kv, "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     rd, wr = fetch.get(k, 0.0) * 1024 * 2, write.get(k, 0.0) * 1024
