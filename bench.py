@@ -462,9 +462,32 @@ def batch_encoder_side(pkg, ctx, Q, n_streams=32, reps=3):
         be.flush()
         best = max(best, GOP * n_streams * 12240 / (time.perf_counter() - t0))
     be.close()
-    return {"value": best, "unit": "macroblocks/s", "streams": n_streams, "stream_bytes_per_gop": sinks[0].n // reps,
-            "upload_GBps_equivalent": best / 12240 * fb / 1e9,
-            "note": "1080p GOP-15, encode only, best of %d passes; never part of `value`" % reps}
+    res = {"value": best, "unit": "macroblocks/s", "streams": n_streams, "stream_bytes_per_gop": sinks[0].n // reps,
+           "upload_GBps_equivalent": best / 12240 * fb / 1e9,
+           "note": "1080p GOP-15, encode only, best of %d passes; never part of `value`" % reps}
+    # the way back: the same n streams (2 GOPs each, kept in memory this time) through the C++ batch decoder
+    bufs = [io.BytesIO() for _ in range(n_streams)]
+    be = pkg.BatchEncoder(bufs, W, H, 30, Q, ctx)
+    for t in range(2 * GOP):
+        (be.encode_iframes if t % GOP == 0 else be.encode_pframes)(host[t % GOP])
+    be.close()
+    data = [b.getvalue() for b in bufs]
+    dec = {}
+    for th in (8, 16, 32):
+        bd = pkg.BatchDecoder(data, ctx, threads=th)
+        t0 = time.perf_counter()
+        steps = 0
+        while bd.advance_frames() is not False:
+            steps += 1
+        el = time.perf_counter() - t0
+        assert steps == 2 * GOP and bd.dense_steps == 0
+        bd.close()
+        dec[str(th)] = steps * n_streams * 12240 / el
+    res["batch_decoder"] = {"value": max(dec.values()), "unit": "macroblocks/s", "by_parse_threads": dec,
+                            "note": ".pfv bytes in host memory -> host bit parser on a worker pool (step t+1 under the device work of "
+                                    "step t) -> coefficient lists read by the scatter kernel from page-locked memory -> k_dec_* -> "
+                                    "frames back in page-locked host memory"}
+    return res
 
 
 def traffic_from_profiles(S, W, H, Q):

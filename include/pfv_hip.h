@@ -301,6 +301,25 @@ PFV_API int pfv_batch_encoder_finish(pfv_batch_encoder *b);
 PFV_API int pfv_batch_encoder_take(pfv_batch_encoder *b, int stream, const uint8_t **data, size_t *len);
 PFV_API void pfv_batch_encoder_destroy(pfv_batch_encoder *b);
 
+/* ------------------------------------------------------------------ batch decoder (n streams per step, pipelined)
+ * n `.pfv` byte streams of one geometry and one packet-type pattern decoded together: per step the packets are bit-parsed on
+ * n_threads worker threads (one task per stream; 0 = on the calling thread), one kernel launch decodes all streams, one copy
+ * brings the frames back; the parse of step t+1 overlaps the device work of step t.  `streams[k]` must stay valid while the
+ * decoder lives (the reference's R: Read + Seek).  Frames, their order and the error codes are those of n independent
+ * Decoder::advance_frame loops (src/dec.rs:169-224) run in lockstep. */
+typedef struct pfv_batch_decoder pfv_batch_decoder;
+PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams, const size_t *lens, int n_streams, int n_threads,
+                                     pfv_batch_decoder **out);
+PFV_API int pfv_batch_decoder_width(const pfv_batch_decoder *b);
+PFV_API int pfv_batch_decoder_height(const pfv_batch_decoder *b);
+PFV_API int pfv_batch_decoder_framerate(const pfv_batch_decoder *b);
+/* steps so far whose coefficient lists overflowed (more than 1 non-zero in 4) and were parsed / uploaded in the dense form */
+PFV_API long pfv_batch_decoder_dense_steps(const pfv_batch_decoder *b);
+/* 1: *frames_out = [n_streams][pfv_frame_bytes] decoded frames (page-locked, valid until the call after next); 2: a step of drop
+ * frames; 0: end of the streams; negative: error (PFV_ERR_FORMAT also when packet types or q-table indices diverge between streams) */
+PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **frames_out);
+PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
+
 /* packet payload serialisers alone (write_iframe_packet / write_pframe_packet bodies, src/enc.rs:237-320, 332-470);
  * return the payload size (0 on error); the payload is copied to `out` when it fits `cap` */
 PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap);

@@ -115,6 +115,13 @@ SIGNATURES = [
     ("pfv_batch_encoder_finish", c_int, [_P]),
     ("pfv_batch_encoder_take", c_int, [_P, c_int, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_batch_encoder_destroy", None, [_P]),
+    ("pfv_batch_decoder_create", c_int, [_P, _P, _P, c_int, c_int, POINTER(_P)]),
+    ("pfv_batch_decoder_width", c_int, [_P]),
+    ("pfv_batch_decoder_height", c_int, [_P]),
+    ("pfv_batch_decoder_framerate", c_int, [_P]),
+    ("pfv_batch_decoder_dense_steps", ctypes.c_long, [_P]),
+    ("pfv_batch_decoder_advance", c_int, [_P, POINTER(_P)]),
+    ("pfv_batch_decoder_destroy", None, [_P]),
     ("pfv_serialize_iframe_payload", c_size_t, [_P, c_int, _P, c_size_t]),
     ("pfv_serialize_pframe_payload", c_size_t, [_P, _P, _P, c_int, _P, c_size_t]),
     ("pfv_parse_iframe_payload", c_int, [_P, c_size_t, c_int, c_int, _P, _P]),

@@ -1794,6 +1794,266 @@ PFV_API int pfv_batch_encoder_take(pfv_batch_encoder *b, int stream, const uint8
     return PFV_OK;
 }
 
+// ------------------------------------------------------------------ batch decoder: n streams, pipelined
+// n .pfv streams of one geometry and one packet-type pattern (e.g. what a pfv_batch_encoder wrote) decoded together.  The
+// packets of a step are bit-parsed (src/dec.rs:226-296, 328-417) on a worker pool, one task per stream, into (index, value)
+// lists in page-locked memory; ONE segmented scatter kernel reads the lists straight from host memory, ONE decode launch
+// serves all streams, ONE copy brings the frames back.  The parse of step t+1 runs while the device works on step t.
+struct BdSet {   // host staging of one step (two sets alternate)
+    PinnedBuf<uint32_t> idx;
+    PinnedBuf<int16_t> val;
+    PinnedBuf<uint32_t> counts;
+    PinnedBuf<int8_t> mv;
+    PinnedBuf<uint8_t> has;
+    std::vector<int> rc;               // per stream: 0, kSinkFull, PFV_ERR_*
+    std::vector<uint8_t> qidx;         // per stream x 3
+    std::vector<const uint8_t *> payload;
+    std::vector<size_t> len;
+    int type = 0;                      // 0 EOF, 1 i-frames, 2 p-frames, 3 drop frames; negative: error found by the scanner
+};
+struct pfv_batch_decoder {
+    pfv_ctx *ctx = nullptr;
+    pfv_dec_session *hot = nullptr;
+    int n = 0, width = 0, height = 0, framerate = 0, n_qtables = 0;
+    size_t total_blocks = 0, frame_bytes = 0, cap = 0;
+    std::vector<const uint8_t *> data;
+    std::vector<size_t> len, pos;
+    BdSet set[2];
+    PinnedBuf<int16_t> dense;          // fallback for steps whose lists overflow
+    PinnedBuf<uint8_t> frames[2];
+    uint8_t *frames_dev = nullptr;
+    long step = 0, dense_steps = 0;
+    bool eof = false;
+    // worker pool
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    BdSet *job = nullptr;
+    int next = 0, done = 0, generation = 0;
+    bool quit = false;
+};
+
+static void bd_parse_one(pfv_batch_decoder *b, BdSet *s, int k)
+{
+    const size_t tb = b->total_blocks;
+    SparseSink sink{s->idx.data() + (size_t)k * b->cap, s->val.data() + (size_t)k * b->cap, b->cap};
+    sink.offset = (size_t)k * tb * 256;
+    uint8_t *q = &s->qidx[(size_t)k * 3];
+    int rc = s->type == 2 ? parse_pframe_to(s->payload[(size_t)k], s->len[(size_t)k], (int)tb, b->n_qtables, s->mv.data() + (size_t)k * tb * 2,
+                                            s->has.data() + (size_t)k * tb, sink, q)
+                          : parse_iframe_to(s->payload[(size_t)k], s->len[(size_t)k], (int)tb, b->n_qtables, sink, q);
+    s->counts.data()[k] = (uint32_t)sink.n;
+    s->rc[(size_t)k] = rc;
+}
+static void bd_worker(pfv_batch_decoder *b)
+{
+    std::unique_lock<std::mutex> lk(b->m);
+    int seen = 0;
+    for (;;) {
+        b->cv_work.wait(lk, [&] { return b->quit || b->generation != seen; });
+        if (b->quit) return;
+        seen = b->generation;
+        BdSet *s = b->job;
+        while (s && b->next < b->n) {
+            const int k = b->next++;
+            lk.unlock();
+            bd_parse_one(b, s, k);
+            lk.lock();
+            if (++b->done == b->n) b->cv_done.notify_all();
+        }
+    }
+}
+// next frame packet of every stream (unknown packet types are skipped, src/dec.rs:216-219); starts the parse on the pool
+static void bd_scan_and_start(pfv_batch_decoder *b, BdSet *s)
+{
+    s->type = 0;
+    int first = -1;
+    bool all_empty = true, any_empty = false;
+    for (int k = 0; k < b->n; k++) {
+        const uint8_t *d = b->data[(size_t)k];
+        size_t p = b->pos[(size_t)k];
+        int typ;
+        size_t n = 0;
+        for (;;) {
+            if (p + 5 > b->len[(size_t)k]) { s->type = PFV_ERR_IO; return; }
+            typ = d[p];
+            n = (size_t)d[p + 1] | ((size_t)d[p + 2] << 8) | ((size_t)d[p + 3] << 16) | ((size_t)d[p + 4] << 24);
+            if (typ == 0) break;
+            if (p + 5 + n > b->len[(size_t)k]) { s->type = PFV_ERR_IO; return; }
+            p += 5 + n;
+            if (typ == 1 || typ == 2) break;
+        }
+        b->pos[(size_t)k] = p;
+        if (first < 0) first = typ;
+        else if (typ != first) { s->type = PFV_ERR_FORMAT; return; }     // the streams' packet types diverge at this step
+        s->payload[(size_t)k] = typ ? d + p - n : nullptr;
+        s->len[(size_t)k] = n;
+        all_empty = all_empty && n == 0;
+        any_empty = any_empty || n == 0;
+    }
+    if (first == 0) { s->type = 0; return; }
+    if (first == 1 && all_empty) { s->type = 3; return; }                 // drop frames (src/dec.rs:188-202)
+    if (any_empty) { s->type = first == 2 ? PFV_ERR_IO : PFV_ERR_FORMAT; return; }   // empty p-frame packet: truncated read (:204-214)
+    s->type = first;
+    std::lock_guard<std::mutex> lk(b->m);
+    b->job = s; b->next = 0; b->done = 0; b->generation++;
+    b->cv_work.notify_all();
+}
+static void bd_join(pfv_batch_decoder *b, BdSet *s)
+{
+    if (s->type != 1 && s->type != 2) return;
+    std::unique_lock<std::mutex> lk(b->m);
+    while (b->job == s && b->next < b->n) {       // the caller helps (and is the whole pool when there are no workers)
+        const int k = b->next++;
+        lk.unlock();
+        bd_parse_one(b, s, k);
+        lk.lock();
+        ++b->done;
+    }
+    b->cv_done.wait(lk, [&] { return b->done >= b->n; });
+    b->job = nullptr;
+}
+
+PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b)
+{
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->m);
+        b->quit = true;
+        b->cv_work.notify_all();
+    }
+    for (auto &t : b->workers) t.join();
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->frames_dev) (void)hipFree(b->frames_dev);
+    pfv_dec_session_destroy(b->hot);
+    delete b;
+}
+
+PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams, const size_t *lens, int n_streams, int n_threads,
+                                     pfv_batch_decoder **out)
+{
+    if (!ctx || !streams || !lens || !out || n_streams <= 0 || n_threads < 0) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_batch_decoder_create: bad argument");
+    *out = nullptr;
+    static const char magic[8] = {'P', 'F', 'V', 'I', 'D', 'E', 'O', 0};
+    const uint8_t *d0 = streams[0];
+    if (!d0 || lens[0] < 8) return fail(ctx, PFV_ERR_IO, "stream shorter than the magic");
+    if (memcmp(d0, magic, 8) != 0) return fail(ctx, PFV_ERR_FORMAT, "bad magic (src/dec.rs:50-52)");
+    if (lens[0] < 20) return fail(ctx, PFV_ERR_IO, "truncated header");
+    const uint32_t ver = (uint32_t)d0[8] | ((uint32_t)d0[9] << 8) | ((uint32_t)d0[10] << 16) | ((uint32_t)d0[11] << 24);
+    if (ver != 211) return fail(ctx, PFV_ERR_VERSION, "codec version is not 2.1.1 (src/dec.rs:57-59)");
+    auto u16 = [&](size_t o) { return (int)d0[o] | ((int)d0[o + 1] << 8); };
+    const int w = u16(12), h = u16(14), fps = u16(16), nq = u16(18);
+    const size_t head = 20 + (size_t)nq * 128;
+    for (int k = 0; k < n_streams; k++) {
+        if (!streams[k] || lens[k] < head) return fail(ctx, PFV_ERR_IO, "truncated header");
+        if (memcmp(streams[k], d0, head) != 0) return fail(ctx, PFV_ERR_FORMAT, "the streams must share one header (geometry, frame rate, q-tables)");
+    }
+    std::vector<int32_t> q((size_t)std::max(nq, 1) * 64, 1);
+    for (int i = 0; i < nq * 64; i++) q[(size_t)i] = u16(20 + 2 * (size_t)i);
+    pfv_dec_session *hot = nullptr;
+    int rc = pfv_dec_session_create(ctx, w, h, q.data(), nq, n_streams, &hot);
+    if (rc) return rc;
+    pfv_batch_decoder *b = new pfv_batch_decoder();
+    b->ctx = ctx; b->hot = hot; b->n = n_streams; b->width = w; b->height = h; b->framerate = fps; b->n_qtables = nq;
+    b->total_blocks = (size_t)pfv_total_blocks(w, h);
+    b->frame_bytes = pfv_frame_bytes(w, h);
+    b->cap = b->total_blocks * 256 / 4;                       // per stream: denser than 1 in 4 -> dense fallback
+    b->data.assign(streams, streams + n_streams);
+    b->len.assign(lens, lens + n_streams);
+    b->pos.assign((size_t)n_streams, head);
+    const size_t S = (size_t)n_streams, tb = b->total_blocks;
+    bool ok = true;
+    for (auto &s : b->set) {
+        ok = ok && s.idx.resize(S * b->cap) && s.val.resize(S * b->cap) && s.counts.resize(S) && s.mv.resize(S * tb * 2) && s.has.resize(S * tb);
+        s.rc.assign(S, 0); s.qidx.assign(S * 3, 0); s.payload.assign(S, nullptr); s.len.assign(S, 0);
+    }
+    ok = ok && b->frames[0].resize(S * b->frame_bytes) && b->frames[1].resize(S * b->frame_bytes);
+    hipError_t e = ok ? hipMalloc((void **)&b->frames_dev, S * b->frame_bytes) : hipErrorOutOfMemory;
+    if (e == hipSuccess && (rc = dec_staging(hot)) == PFV_OK) rc = pfv_dec_set_output_dev(hot, b->frames_dev);
+    if (e != hipSuccess) rc = hip_fail(ctx, e, "pfv_batch_decoder_create");
+    if (rc) { pfv_batch_decoder_destroy(b); return rc; }
+    for (int t = 0; t < n_threads; t++) b->workers.emplace_back(bd_worker, b);
+    bd_scan_and_start(b, &b->set[0]);                         // the first step is being parsed when create returns
+    *out = b;
+    return PFV_OK;
+}
+PFV_API int pfv_batch_decoder_width(const pfv_batch_decoder *b) { return b ? b->width : 0; }
+PFV_API int pfv_batch_decoder_height(const pfv_batch_decoder *b) { return b ? b->height : 0; }
+PFV_API int pfv_batch_decoder_framerate(const pfv_batch_decoder *b) { return b ? b->framerate : 0; }
+// steps so far whose coefficient lists overflowed (denser than 1 non-zero in 4) and went up in the dense form
+PFV_API long pfv_batch_decoder_dense_steps(const pfv_batch_decoder *b) { return b ? b->dense_steps : 0; }
+
+// One step for all streams: 1 = *frames_out points at [n_streams][frame_bytes] decoded frames (page-locked, valid until the
+// call after next), 2 = a step of drop frames (no frames), 0 = end of the streams, negative = error (PFV_ERR_FORMAT also when
+// the streams' packet types or q-table indices diverge).
+PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **frames_out)
+{
+    if (!b || !frames_out) return fail(b ? b->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_batch_decoder_advance: bad argument");
+    pfv_ctx *ctx = b->ctx;
+    *frames_out = nullptr;
+    if (b->eof) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int slot = (int)(b->step & 1);
+    BdSet *s = &b->set[slot];
+    bd_join(b, s);
+    if (s->type < 0) { b->eof = true; return fail(ctx, s->type, "batch decoder: truncated stream or diverging packet types"); }
+    if (s->type == 0) { b->eof = true; return 0; }
+    b->step++;
+    if (s->type == 3) {
+        bd_scan_and_start(b, &b->set[slot ^ 1]);
+        return 2;
+    }
+    const size_t S = (size_t)b->n, tb = b->total_blocks;
+    bool dense = false;
+    for (size_t k = 0; k < S; k++) {
+        if (s->rc[k] == kSinkFull) dense = true;
+        else if (s->rc[k]) { b->eof = true; return fail(ctx, s->rc[k], "malformed packet payload"); }
+        if (memcmp(&s->qidx[k * 3], &s->qidx[0], 3) != 0) { b->eof = true; return fail(ctx, PFV_ERR_FORMAT, "the streams use different q-table indices in this step"); }
+    }
+    pfv_dec_session *hot = b->hot;
+    const size_t total = tb * S * 256;
+    int rc = PFV_OK;
+    const bool lists_on_device_bus = s->idx.pinned && s->val.pinned && s->counts.pinned;   // page-locked: the kernel can read them
+    if (!dense && !lists_on_device_bus) {   // pageable staging (locked-memory limit): expand the lists on the host instead
+        if (!b->dense.resize(total)) return fail(ctx, PFV_ERR_NOMEM, "dense staging");
+        memset(b->dense.data(), 0, total * 2);
+        for (size_t k = 0; k < S; k++)
+            for (uint32_t i = 0; i < s->counts.data()[k]; i++) b->dense.data()[s->idx.data()[k * b->cap + i]] = s->val.data()[k * b->cap + i];
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_coef, b->dense.data(), total * 2, hipMemcpyHostToDevice, ctx->stream));
+    } else if (dense) {   // some list overflowed (very dense content): parse every stream into the dense form on this thread
+        b->dense_steps++;
+        if (!b->dense.resize(total)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
+        memset(b->dense.data(), 0, total * 2);
+        for (size_t k = 0; k < S && !rc; k++) {
+            DenseSink sink{b->dense.data() + k * tb * 256};
+            uint8_t q[3];
+            rc = s->type == 2 ? parse_pframe_to(s->payload[k], s->len[k], (int)tb, b->n_qtables, s->mv.data() + k * tb * 2, s->has.data() + k * tb, sink, q)
+                              : parse_iframe_to(s->payload[k], s->len[k], (int)tb, b->n_qtables, sink, q);
+        }
+        if (rc) { b->eof = true; return fail(ctx, rc, "malformed packet payload"); }
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_coef, b->dense.data(), total * 2, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(hot->st_coef, 0, total * 2, ctx->stream));
+        hipLaunchKernelGGL(k_scatter_coef_seg, dim3(64, (unsigned)S), dim3(kThreads), 0, ctx->stream, s->idx.data(), s->val.data(),
+                           s->counts.data(), (uint32_t)b->cap, (uint32_t)total, hot->st_coef);
+        if ((rc = launch_check(ctx, "k_scatter_coef_seg"))) return rc;
+    }
+    if (s->type == 2) {
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_mv, s->mv.data(), S * tb * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_has, s->has.data(), S * tb, hipMemcpyHostToDevice, ctx->stream));
+        rc = pfv_dec_pframe_dev(hot, hot->st_mv, hot->st_has, hot->st_coef, &s->qidx[0]);
+    } else {
+        rc = pfv_dec_iframe_dev(hot, hot->st_coef, &s->qidx[0]);
+    }
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(b->frames[slot].data(), b->frames_dev, S * b->frame_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    bd_scan_and_start(b, &b->set[slot ^ 1]);       // parse of step t+1 under the device work of step t
+    if ((rc = pfv_dec_check(hot))) return rc;      // synchronises; bad-motion-vector flag (src/common.rs:258-259)
+    *frames_out = b->frames[slot].data();
+    return 1;
+}
+
 // payload serialisers alone (for tests: product vs oracle on identical coefficient input)
 PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap)
 {

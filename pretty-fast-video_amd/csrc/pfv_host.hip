@@ -380,10 +380,11 @@ struct SparseSink {
     uint32_t *idx;
     int16_t *val;
     size_t cap, n = 0;
+    size_t offset = 0;   // added to every index: the frame's position in a wider [stream][macroblock][256] array
     bool put(size_t i, int16_t v)
     {
         if (n >= cap) return false;
-        idx[n] = (uint32_t)i;
+        idx[n] = (uint32_t)(i + offset);
         val[n++] = v;
         return true;
     }

@@ -1231,4 +1231,19 @@ __global__ void __launch_bounds__(kThreads) k_scatter_coef(const uint32_t *idx, 
     }
 }
 
+// The same for n_streams lists at once (pfv_batch_decoder): stream k's pairs are idx[k * cap .. k * cap + counts[k]); indices are
+// already absolute.  The lists may live in page-locked HOST memory: the kernel then reads them over PCIe (coalesced, read once)
+// and no staging copy is needed.
+__global__ void __launch_bounds__(kThreads) k_scatter_coef_seg(const uint32_t *idx, const int16_t *val, const uint32_t *counts, uint32_t cap,
+                                                               uint32_t limit, int16_t *coef)
+{
+    const uint32_t k = blockIdx.y, n = counts[k];
+    const uint32_t *ik = idx + (size_t)k * cap;
+    const int16_t *vk = val + (size_t)k * cap;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const uint32_t at = ik[i];
+        if (at < limit) coef[at] = vk[i];
+    }
+}
+
 }  // namespace pfv

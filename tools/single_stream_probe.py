@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Single 1080p stream (the reference's calling pattern, one Encoder per stream): GOP-15 encode+decode at kernel scope with one launch
+per frame operation, no event calls; run under `rocprofv3 --kernel-trace --stats` to split the GOP time into kernel execution and gaps.
+    python tools/single_stream_probe.py [streams=1] [reps=20]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, __graft_entry__ as g
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+g.build_hip()
+pkg = g.load_package()
+ctx = pkg.Context(0)
+ss = bench.StreamSet(pkg, ctx, 1920, 1080, 5, [pkg.synth.SEED + 17 * k for k in range(S)], bench.GOP)
+rate = ss.wall(reps)
+ss.verify()
+print(json.dumps({"streams": S, "macroblocks_per_s": rate, "us_per_gop": bench.GOP * S * ss.n_mb / rate * 1e6}))
+ss.close(); ctx.close()
