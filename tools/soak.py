@@ -46,6 +46,9 @@ with pkg.Context(0) as ctx:
         sc.check_batch_decoder(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=4, gop=3)
         stats["batch"] += 1
         pc.check_sparse_decode(pkg, ctx, w, h, n_streams=S, seed=s)
+        if w % 32 == 0:     # the fused retframe crop needs 16-byte rows in every plane
+            pc.check_gop_graph(pkg, ctx, oracle, w, h, n_streams=S, n_frames=int(r.integers(2, 5)), quality=q)
+            stats["graphs"] = stats.get("graphs", 0) + 1
         it += 1
         if it % 10 == 0:
             print(it, json.dumps(stats), flush=True)
