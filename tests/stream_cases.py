@@ -250,7 +250,7 @@ def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, go
     assert steps == n_frames and dec.advance_frames() is False
     for od in odecs:
         assert od.advance_frame()[0] == 0            # the oracle is at EOF too
-    assert (dec.dense_steps > 0) == bool(noise)
+    assert not noise or dec.dense_steps > 0          # white noise must have taken the dense path (other content may, too)
     dec.close()
 
 
