@@ -16,6 +16,7 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "pfv_hip.h"
@@ -208,6 +209,81 @@ class Decoder {
     pfv_decoder *h_ = nullptr;
     VideoFrame frame_;              // retframe (src/dec.rs:22)
     const OnVideo *cb_ = nullptr;
+};
+
+// n Encoders of one geometry stepped together (pfv_batch_encoder): every writer receives exactly the bytes an Encoder of
+// its own would have written (src/enc.rs:12-188); packets arrive one step late, finish() / the destructor flush.
+class BatchEncoder {
+  public:
+    BatchEncoder(std::vector<std::ostream *> writers, size_t width, size_t height, uint32_t framerate, int quality, Context &ctx)
+        : ctx_(ctx), writers_(std::move(writers))
+    {
+        ctx_.check(pfv_batch_encoder_create(ctx.handle(), (int)width, (int)height, (int)framerate, quality, (int)writers_.size(), &on_write, this, &h_));
+        frame_bytes_ = pfv_frame_bytes((int)width, (int)height);
+    }
+    ~BatchEncoder()
+    {
+        if (h_) {
+            if (!finished_) {
+                try { finish(); } catch (...) {}
+            }
+            pfv_batch_encoder_destroy(h_);
+        }
+    }
+    BatchEncoder(const BatchEncoder &) = delete;
+    BatchEncoder &operator=(const BatchEncoder &) = delete;
+    size_t frame_bytes() const { return frame_bytes_; }
+    // page-locked [n][frame_bytes] array to fill for the next encode call (packed Y|U|V per stream)
+    uint8_t *frames() { return pfv_batch_encoder_frames(h_); }
+    void encode_iframes() { ctx_.check(pfv_batch_encoder_encode(h_, 0, nullptr)); }
+    void encode_pframes() { ctx_.check(pfv_batch_encoder_encode(h_, 1, nullptr)); }
+    void finish()
+    {
+        ctx_.check(pfv_batch_encoder_finish(h_));
+        finished_ = true;
+    }
+
+  private:
+    static void on_write(void *user, int stream, const uint8_t *data, size_t len)
+    {
+        auto *self = static_cast<BatchEncoder *>(user);
+        self->writers_[(size_t)stream]->write(reinterpret_cast<const char *>(data), (std::streamsize)len);
+    }
+    Context &ctx_;
+    std::vector<std::ostream *> writers_;
+    size_t frame_bytes_ = 0;
+    bool finished_ = false;
+    pfv_batch_encoder *h_ = nullptr;
+};
+
+// n Decoders in lockstep (pfv_batch_decoder): advance_frames() -> 1 frames (page-locked [n][frame_bytes], valid until the call
+// after next), 2 a step of drop frames, 0 end of the streams; errors as pfv::Error with the DecodeError codes.
+class BatchDecoder {
+  public:
+    BatchDecoder(std::vector<std::string> streams, Context &ctx, int n_threads = 8) : ctx_(ctx), data_(std::move(streams))
+    {
+        std::vector<const uint8_t *> p;
+        std::vector<size_t> n;
+        for (const auto &s : data_) { p.push_back(reinterpret_cast<const uint8_t *>(s.data())); n.push_back(s.size()); }
+        ctx_.check(pfv_batch_decoder_create(ctx.handle(), p.data(), n.data(), (int)data_.size(), n_threads, &h_));
+    }
+    ~BatchDecoder() { pfv_batch_decoder_destroy(h_); }
+    BatchDecoder(const BatchDecoder &) = delete;
+    BatchDecoder &operator=(const BatchDecoder &) = delete;
+    size_t width() const { return (size_t)pfv_batch_decoder_width(h_); }
+    size_t height() const { return (size_t)pfv_batch_decoder_height(h_); }
+    uint32_t framerate() const { return (uint32_t)pfv_batch_decoder_framerate(h_); }
+    int advance_frames(const uint8_t **frames)
+    {
+        const int rc = pfv_batch_decoder_advance(h_, frames);
+        if (rc < 0) ctx_.check(rc);
+        return rc;
+    }
+
+  private:
+    Context &ctx_;
+    std::vector<std::string> data_;
+    pfv_batch_decoder *h_ = nullptr;
 };
 
 }  // namespace pfv

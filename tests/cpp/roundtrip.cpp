@@ -6,6 +6,8 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <algorithm>
+#include <vector>
 
 #include "pfv_hip.hpp"
 
@@ -57,6 +59,46 @@ int main(int argc, char **argv)
             return 1;
         } catch (const pfv::Error &e) {
             if (e.code() != PFV_ERR_FORMAT) { std::fprintf(stderr, "wrong error code %d\n", e.code()); return 1; }
+        }
+        // the batch classes on the same clip: both streams carry the clip itself, so each writer must receive `bytes`
+        // and every decoded step must equal the frames the single Decoder wrote (when no drop frame was asked for)
+        if (drop_at < 0) {
+            std::ifstream in2(argv[7], std::ios::binary);
+            std::stringstream w0(std::ios::in | std::ios::out | std::ios::binary), w1(std::ios::in | std::ios::out | std::ios::binary);
+            {
+                pfv::BatchEncoder be({&w0, &w1}, w, h, fps, quality, ctx);
+                const size_t fb = be.frame_bytes();
+                std::vector<char> frame(fb);
+                for (int t = 0; t < n_in; t++) {
+                    in2.read(frame.data(), (std::streamsize)fb);
+                    uint8_t *dst = be.frames();
+                    std::copy(frame.begin(), frame.end(), reinterpret_cast<char *>(dst));
+                    std::copy(frame.begin(), frame.end(), reinterpret_cast<char *>(dst) + fb);
+                    if (t % gop == 0) be.encode_iframes();
+                    else be.encode_pframes();
+                }
+            }   // ~BatchEncoder flushes and writes the EOF packets
+            if (w0.str() != bytes || w1.str() != bytes) { std::fprintf(stderr, "BatchEncoder bytes differ from Encoder bytes\n"); return 1; }
+            pfv::BatchDecoder bd({w0.str(), w1.str()}, ctx, 2);
+            if (bd.width() != w || bd.height() != h) { std::fprintf(stderr, "batch header mismatch\n"); return 1; }
+            out.flush();
+            std::ifstream ref(argv[9], std::ios::binary);      // the frames the single Decoder just wrote
+            const size_t fb = w * h * 3 / 2;
+            std::vector<char> want(fb);
+            const uint8_t *frames = nullptr;
+            int steps = 0, rc;
+            while ((rc = bd.advance_frames(&frames)) != 0) {
+                if (rc != 1) { std::fprintf(stderr, "unexpected drop step\n"); return 1; }
+                ref.read(want.data(), (std::streamsize)fb);
+                if (!ref || !std::equal(want.begin(), want.end(), reinterpret_cast<const char *>(frames)) ||
+                    !std::equal(want.begin(), want.end(), reinterpret_cast<const char *>(frames) + fb)) {
+                    std::fprintf(stderr, "BatchDecoder frame %d differs from Decoder's\n", steps);
+                    return 1;
+                }
+                steps++;
+            }
+            if (steps != n_out) { std::fprintf(stderr, "BatchDecoder decoded %d steps, Decoder %d\n", steps, n_out); return 1; }
+            std::printf("batch: 2 streams x %d steps identical to the single-stream objects\n", steps);
         }
         std::printf("frames in %d, decoded %d, stream %zu bytes\n", n_in, n_out, bytes.size());
         return 0;

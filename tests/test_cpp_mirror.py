@@ -49,6 +49,8 @@ def _run(pkg, oracle, exe, tmp_path, w, h, quality, n_frames, gop, drop_at):
     got = np.fromfile(yuv_out, dtype=np.uint8)
     assert got.size == sum(d.size for d in decoded) and np.array_equal(got, np.concatenate(decoded))
     assert f"decoded {len(decoded)}" in r.stdout
+    if drop_at < 0:                      # the program also ran pfv::BatchEncoder / BatchDecoder on two copies of the clip
+        assert "batch: 2 streams" in r.stdout
 
 
 def test_cpp_mirror_on_emulator(pkg, oracle, tmp_path):
@@ -56,6 +58,7 @@ def test_cpp_mirror_on_emulator(pkg, oracle, tmp_path):
     exe = str(tmp_path / "roundtrip_emu")
     _build(conftest.build_emulator(), exe)
     _run(pkg, oracle, exe, tmp_path, 48, 32, 5, n_frames=5, gop=3, drop_at=2)
+    _run(pkg, oracle, exe, tmp_path, 48, 32, 7, n_frames=4, gop=2, drop_at=-1)
 
 
 @pytest.mark.gpu
