@@ -372,7 +372,8 @@ PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, cons
     if ((rc = ensure_scratch(ctx, 0, (size_t)w * h, &d_src))) return rc;
     if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_enc_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
+    // encode only: the forward transform is exact in f32 for any table
+    hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
                                                                    ctx->qtab_dev);
     if ((rc = launch_check(ctx, "k_enc_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -402,7 +403,7 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
     float min_err = px_err * px_err * 256.0f;   // src/common.rs:209
-    hipLaunchKernelGGL(k_enc_pframe, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
+    hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
                                                                    (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
                                                                    nullptr, ctx->qtab_dev, min_err);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
@@ -638,12 +639,62 @@ static int init_padded(pfv_ctx *ctx, const FrameGeom &g, uint8_t *buf)
     return launch_check(ctx, "k_init_padded");
 }
 
+// ------------------------------------------------------------------ may the encoder run its transforms in f32?
+// The float kernels (k_enc_*<true>) are exact as long as every intermediate is an integer below 2^24 (pfv_kernels.hip, "the
+// same transforms in f32").  The forward transform is: |fdct2d| <= 128 * 256 * (row norm)^2 = 2.5 M for any 8-bit input.  For
+// the closed-loop inverse the bound depends on the tables: with M(u,v) = that forward bound, the largest coefficient is
+// floor(floor(M * SCALE / 65536) / q), decode multiplies it by SCALE[z] * q[z] at its zigzag position z (src/dct.rs:78-82), and an L1
+// bound pushes all 64 such maxima through |idct| columns and rows at once (with slack for the truncations).  Quality-derived
+// tables give 1.9 M; a table for which the bound reaches 2^23 keeps the integer kernels.
+static bool enc_float_exact(const int32_t q[64], double amplitude)
+{
+    static double F1[8], Iabs[8][8];
+    static bool init = false;
+    if (!init) {
+        for (int k = 0; k < 8; k++) {
+            int e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            e[k] = 1 << 20;
+            int f[8], t[8];
+            memcpy(f, e, sizeof e); memcpy(t, e, sizeof e);
+            int (&fr)[8] = f; int (&tr)[8] = t;
+            fdct8(fr);
+            idct8(tr);
+            for (int u = 0; u < 8; u++) { if (k == 0) F1[u] = 0; F1[u] += fabs((double)f[u]) / (1 << 20); Iabs[u][k] = fabs((double)t[u]) / (1 << 20); }
+        }
+        init = true;
+    }
+    double D[8][8], worst = 0;
+    for (int i = 0; i < 64; i++) {
+        const int u = i >> 3, v = i & 7, z = H_INV_ZIGZAG[i];
+        const double M = amplitude * F1[u] * F1[v];
+        const double n = floor(M * H_SCALE[i] / 65536.0), c = floor(n / (double)q[i]);
+        D[u][v] = c * (double)H_SCALE[z] * (double)q[z];
+        worst = std::max(worst, std::max(M, D[u][v]));
+    }
+    double col[8][8];
+    for (int u = 0; u < 8; u++)
+        for (int v = 0; v < 8; v++) {
+            double a = 16;
+            for (int k = 0; k < 8; k++) a += Iabs[u][k] * D[k][v];     // columns first (src/common.rs:315)
+            col[u][v] = a;
+            worst = std::max(worst, a);
+        }
+    for (int u = 0; u < 8; u++)
+        for (int v = 0; v < 8; v++) {
+            double a = 16;
+            for (int k = 0; k < 8; k++) a += col[u][k] * Iabs[v][k];   // then rows
+            worst = std::max(worst, a);
+        }
+    return worst < 8388608.0;   // 2^23: a factor 2 below what f32 holds exactly
+}
+
 struct pfv_enc_session {
     pfv_ctx *ctx = nullptr;
     int width = 0, height = 0, n_streams = 0;
     FrameGeom geom;
     QTab *qtab_dev = nullptr;       // intra_l, intra_c, inter_l, inter_c
     float px_err = 0.0f;
+    bool flt = false;                        // the closed loop may run in f32 (enc_float_exact holds for all four tables)
     uint8_t *prev[2] = {nullptr, nullptr};   // ping-pong prev_frame, padded, n_streams wide
     int cur = 0;                             // prev[cur] is the current prev_frame
     // staging for the host-buffer entry points
@@ -709,6 +760,8 @@ PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int qual
         int rc = make_qtab(ctx, q[i], &tabs[i]);
         if (rc) { delete s; return rc; }
     }
+    s->flt = getenv("PFV_ENC_INT_TRANSFORM") == nullptr && enc_float_exact(q[0], 128.0 * 256.0) && enc_float_exact(q[1], 128.0 * 256.0) &&
+             enc_float_exact(q[2], 127.0 * 256.0) && enc_float_exact(q[3], 127.0 * 256.0);
     size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
     hipError_t e = hipMalloc((void **)&s->qtab_dev, sizeof tabs);
     if (e == hipSuccess) e = hipMemcpy(s->qtab_dev, tabs, sizeof tabs, hipMemcpyHostToDevice);
@@ -757,8 +810,10 @@ PFV_API int pfv_enc_iframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
-    hipLaunchKernelGGL(k_enc_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt],
-                                                                                 s->qtab_dev + 0);
+    if (s->flt)
+        hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0);
+    else
+        hipLaunchKernelGGL(k_enc_iframe<false>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0);
     int rc = launch_check(ctx, "k_enc_iframe");
     if (rc) return rc;
     s->cur = nxt;
@@ -775,8 +830,12 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
     float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
-    hipLaunchKernelGGL(k_enc_pframe, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, 
-        g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err);
+    if (s->flt)
+        hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
+            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err);
+    else
+        hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
+            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err);
     int rc = launch_check(ctx, "k_enc_pframe");
     if (rc) return rc;
     s->cur = nxt;

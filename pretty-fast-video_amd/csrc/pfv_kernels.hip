@@ -67,9 +67,9 @@ constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 1024 dwords
 static_assert(kXchgDwords * 4 <= 4 * 1024, "exchange region must fit a wavefront's smallest window slice");
 
 // ------------------------------------------------------------------ small helpers
-__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
-__device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
-__device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+__host__ __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__host__ __device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__host__ __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 // The same wrapping product for operands known to fit 24 signed bits (v_mul_i32_i24 instead of v_mul_lo_u32): transform
 // outputs of 8-bit pixels (|m| < 2^22) times DCT_SCALE_FACTOR (<= 43), and i16 coefficients times SCALE*q (< 2^22 for
 // q <= 65535, which make_qtab enforces).
@@ -81,7 +81,7 @@ __device__ __forceinline__ int wmul24(int a, int b) { return __mul24(a, b); }
 // from x/4 with the SAME one- or two-bit bias: one sign extraction + one mask per operand.
 struct TDiv24 {   // operand needing x/2 and x/4
     int x, h, q;
-    __device__ __forceinline__ explicit TDiv24(int v) : x(v)
+    __host__ __device__ __forceinline__ explicit TDiv24(int v) : x(v)
     {
         unsigned b = (unsigned)v >> 31;
         h = (int)((unsigned)v + b) >> 1;
@@ -90,14 +90,14 @@ struct TDiv24 {   // operand needing x/2 and x/4
 };
 struct TDiv416 {   // operand needing x/4 and x/16
     int x, q, s;
-    __device__ __forceinline__ explicit TDiv416(int v) : x(v)
+    __host__ __device__ __forceinline__ explicit TDiv416(int v) : x(v)
     {
         unsigned b = (unsigned)(v >> 31) & 3u;
         q = (int)((unsigned)v + b) >> 2;
         s = (int)((unsigned)q + b) >> 2;
     }
 };
-__device__ __forceinline__ int tdiv2(int x) { return (int)((unsigned)x + ((unsigned)x >> 31)) >> 1; }
+__host__ __device__ __forceinline__ int tdiv2(int x) { return (int)((unsigned)x + ((unsigned)x >> 31)) >> 1; }
 
 // Intra-wavefront LDS hand-off: DS operations of one wavefront execute in issue order, so
 // only the compiler has to be kept from moving accesses across this point.
@@ -182,7 +182,7 @@ __device__ __forceinline__ StripPos locate_strip(const FrameGeom &g, int gstrip)
 // divisions are exact again.  Truncation toward zero therefore never happens in an fdct, and `x / 2^k` is a
 // plain arithmetic shift -- no sign bias needed (tests/test_oracle.py::test_forward_dct_is_exact checks the
 // claim against the truncating form; the GPU parity tests check the kernels bit for bit).
-__device__ __forceinline__ void fdct8(int (&v)[8])
+__host__ __device__ __forceinline__ void fdct8(int (&v)[8])
 {
     int a0 = wadd(v[0], v[7]), a1 = wadd(v[1], v[6]), a2 = wadd(v[2], v[5]), a3 = wadd(v[3], v[4]);
     int a4 = wsub(v[0], v[7]), a5 = wsub(v[1], v[6]), a6 = wsub(v[2], v[5]), a7 = wsub(v[3], v[4]);
@@ -201,7 +201,7 @@ __device__ __forceinline__ void fdct8(int (&v)[8])
 }
 
 // reference src/dct.rs:241-293  DctMatrix8x8::idct
-__device__ __forceinline__ void idct8(int (&v)[8])
+__host__ __device__ __forceinline__ void idct8(int (&v)[8])
 {
     int c0 = v[0], d4 = v[1], d6 = v[3], c1 = v[4], d5 = v[5], d7 = v[7];
     TDiv24 c2(v[2]), c3(v[6]);
@@ -275,6 +275,7 @@ struct LaneQ {
     int c;            // the lane's column
     __device__ __forceinline__ int zz(int k) const { return tab[k * 8 + c]; }             // INV_ZIGZAG[k*8+c]
     __device__ __forceinline__ int deq(int k) const { return tab[64 + k * 8 + c]; }       // SCALE[z]*q[z], z = zz (decode)
+    __device__ __forceinline__ float deqf(int k) const { return __int_as_float(tab[64 + k * 8 + c]); }   // the same as f32 bits (fill_qtable<true, true>)
     __device__ __forceinline__ int scale(int k) const { return tab[128 + k * 8 + c]; }    // DCT_SCALE_FACTOR[k*8+c] (encode)
     __device__ __forceinline__ float rcp(int k) const { return __int_as_float(tab[192 + k * 8 + c]); }   // biased 1/q (encode)
 };
@@ -283,11 +284,11 @@ struct LaneQ {
 // memory loads per lane (which would put more bytes through the CU's texture-addresser path than the pixels
 // and coefficients themselves).  Layout: [0] zigzag position, [1] deq, [2] scale, [3] rcp (float bits).
 constexpr int kQTabDwords = 4 * 64;
-template <bool ENC>
+template <bool ENC, bool FLT = false>
 __device__ __forceinline__ void fill_qtable(int *tab, const QTab *qt, int lane)
 {
     tab[lane] = kInvZigzag[lane];
-    tab[64 + lane] = qt->deq[lane];
+    tab[64 + lane] = FLT ? __float_as_int((float)qt->deq[lane]) : qt->deq[lane];   // float form: deq < 2^24 (checked on the host)
     if (ENC) {
         tab[128 + lane] = kScale[lane];
         tab[192 + lane] = __float_as_int(qt->rcp[lane]);
@@ -468,10 +469,171 @@ __device__ __forceinline__ void gather_half(int (&v)[2][8], const int *xw, int m
     wave_lds_sync();
 }
 
+// ------------------------------------------------------------------ the same transforms in f32 (encoders only)
+// Inside the ENCODERS every value of the forward transform, of the dequantised coefficients and of the inverse transform
+// is an integer far below 2^24: |fdct| <= 2.5 M for 8-bit pixels / residuals whatever the quantiser, and for the session's
+// quality-derived tables the inverse stays below 1.9 M even by an L1 worst-case bound over all 64 coefficients at once
+// (tests/test_float_exact.py proves both; pfv_enc_session_create re-checks the bound for the tables it is given and
+// falls back to the integer kernels otherwise).  Integers below 2^24 and their products with 1/2, 1/4, 5/4, 11/16, 19/16 --
+// exact because the operands are multiples of 16 where the integer form divides by 16 -- are exact in f32, so the float
+// butterflies below produce THE SAME numbers as fdct8 / idct8, with two gains on gfx950 where every VALU instruction of a
+// mixed stream costs ~4.2 cycles: (1) v_pk_add/mul/fma_f32 work on two values (the lane's two subblocks) per
+// instruction, (2) fma fuses the shift-and-add pairs of the integer butterfly (30 packed instructions for two 8-point
+// forward transforms instead of 2 x 48), and truncation toward zero is one v_trunc_f32 instead of a sign-bias sequence
+// (72 instead of 2 x 70 for two inverse transforms).  The decoders keep the integer form: they must wrap exactly like i32
+// on hostile coefficients.
+typedef float f2 __attribute__((vector_size(8)));   // lane's two subblocks, element s = subblock s
+__device__ __forceinline__ f2 f2s(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 f2trunc(f2 x) { return f2{__builtin_truncf(x[0]), __builtin_truncf(x[1])}; }
+__device__ __forceinline__ f2 f2floor(f2 x) { return f2{__builtin_floorf(x[0]), __builtin_floorf(x[1])}; }
+
+// src/dct.rs:176-239 in exact f32 (see fdct8)
+__device__ __forceinline__ void ffdct8(f2 (&v)[8])
+{
+    const f2 a0 = v[0] + v[7], a1 = v[1] + v[6], a2 = v[2] + v[5], a3 = v[3] + v[4];
+    const f2 a4 = v[0] - v[7], a5 = v[1] - v[6], a6 = v[2] - v[5], a7 = v[3] - v[4];
+    const f2 b0 = a0 + a3, b1 = a1 + a2, b2 = a0 - a3, b3 = a1 - a2;
+    const f2 c0 = b0 + b1, c1 = b0 - b1;
+    const f2 c2 = b2 * f2s(1.25f) + b3 * f2s(0.5f);             // b2 + b2/4 + b3/2
+    const f2 c3 = b2 * f2s(0.5f) - b3 * f2s(1.25f);             // b2/2 - b3 - b3/4
+    const f2 b4 = a4 * f2s(1.1875f) + a7 * f2s(0.25f);          // a7/4 + a4 + a4/4 - a4/16
+    const f2 b7 = a4 * f2s(0.25f) - a7 * f2s(1.1875f);          // a4/4 - a7 - a7/4 + a7/16
+    const f2 b5 = a5 + a6 * f2s(0.6875f);                       // a5 + a6 - a6/4 - a6/16
+    const f2 b6 = a6 - a5 * f2s(0.6875f);                       // a6 - a5 + a5/4 + a5/16
+    const f2 c4 = b4 + b5, c5 = b4 - b5, c6 = b6 + b7, c7 = b6 - b7;
+    v[0] = c0; v[1] = c4; v[2] = c2; v[3] = c5 - c7;
+    v[4] = c1; v[5] = c5 + c7; v[6] = c3; v[7] = c6;
+}
+// src/dct.rs:241-293 in exact f32 (see idct8): x / 2^k of the reference = truncation toward zero = v_trunc_f32 of the exact quotient
+__device__ __forceinline__ void fidct8(f2 (&v)[8])
+{
+    const f2 c0 = v[0], d4 = v[1], c2 = v[2], d6 = v[3], c1 = v[4], d5 = v[5], c3 = v[6], d7 = v[7];
+    const f2 c5 = d5 + d6, c7 = d5 - d6;
+    const f2 b4 = d4 + c5, b5 = d4 - c5, b6 = d7 + c7, b7 = d7 - c7;
+    const f2 b0 = c0 + c1, b1 = c0 - c1;
+    const f2 half = f2s(0.5f), quarter = f2s(0.25f);
+    const f2 c2h = f2trunc(c2 * half), c2q = f2trunc(c2h * half), c3h = f2trunc(c3 * half), c3q = f2trunc(c3h * half);
+    const f2 b4q = f2trunc(b4 * quarter), b4s = f2trunc(b4q * quarter), b5q = f2trunc(b5 * quarter), b5s = f2trunc(b5q * quarter);
+    const f2 b6q = f2trunc(b6 * quarter), b6s = f2trunc(b6q * quarter), b7q = f2trunc(b7 * quarter), b7s = f2trunc(b7q * quarter);
+    const f2 b2 = c2 + c2q + c3h, b3 = c2h - c3 - c3q;
+    const f2 a4 = b7q + b4 + b4q - b4s;
+    const f2 a7 = b4q - b7 - b7q + b7s;
+    const f2 a5 = b5 - b6 + b6q + b6s;
+    const f2 a6 = b6 + b5 - b5q - b5s;
+    const f2 a0 = b0 + b2, a1 = b1 + b3, a2 = b1 - b3, a3 = b0 - b2;
+    v[0] = a0 + a4; v[1] = a1 + a5; v[2] = a2 + a6; v[3] = a3 + a7;
+    v[4] = a3 - a7; v[5] = a2 - a6; v[6] = a1 - a5; v[7] = a0 - a4;
+}
+// The LDS transposes of the float form.  A lane's values are (subblock 0, subblock 1) pairs in aligned register pairs, so the
+// exchange region of macroblock m is laid out M[row][col][s] (16 dwords per row, 128 per macroblock, as before) and moves
+// pairs: row layout <-> 4 x 16-byte chunks {col 2j, col 2j+1} x {s0, s1}, column layout <-> 8 x 8-byte pairs -- half the LDS
+// read instructions of the integer form and no register shuffling.  Conflict-free without padding by two XOR swizzles:
+//   * row `row` of macroblock m sits at row position p = row ^ (m & 3): the 4 macroblocks of a 32-lane group (regions 128
+//     dwords = 0 banks apart) touch 4 different rows in a column access;
+//   * chunk j of the row at position p sits at chunk (j ^ ((p >> 1) & 3)): the 8 lanes of a 16-byte row access (rows 64 bytes
+//     apart) land in 8 different 16-byte bank groups.
+__device__ __forceinline__ int f_chunk(int p, int j) { return j ^ ((p >> 1) & 3); }
+// row layout (lane i holds row i: x[k] = {M0[i][k], M1[i][k]})  ->  column layout (lane i holds column i: x[r] = {M0[r][i], M1[r][i]})
+__device__ __forceinline__ void f_rows_to_cols(f2 (&x)[8], int *mb, int i, int mx)
+{
+    {
+        const int p = i ^ mx;
+        float4 *row = reinterpret_cast<float4 *>(mb + p * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) row[f_chunk(p, j)] = make_float4(x[2 * j][0], x[2 * j][1], x[2 * j + 1][0], x[2 * j + 1][1]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int p = r ^ mx;
+        x[r] = *reinterpret_cast<const f2 *>(mb + p * 16 + f_chunk(p, i >> 1) * 4 + (i & 1) * 2);
+    }
+    wave_lds_sync();
+}
+// column layout  ->  row layout
+__device__ __forceinline__ void f_cols_to_rows(f2 (&x)[8], int *mb, int i, int mx)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int p = r ^ mx;
+        *reinterpret_cast<f2 *>(mb + p * 16 + f_chunk(p, i >> 1) * 4 + (i & 1) * 2) = x[r];
+    }
+    wave_lds_sync();
+    {
+        const int p = i ^ mx;
+        const float4 *row = reinterpret_cast<const float4 *>(mb + p * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float4 c = row[f_chunk(p, j)];
+            x[2 * j] = f2{c.x, c.y};
+            x[2 * j + 1] = f2{c.z, c.w};
+        }
+    }
+    wave_lds_sync();
+}
+// Forward, float form: x = row-layout samples in 24.8 fixed point AS FLOATS ((px - 128) * 256 or trunc(d / 2) * 256); leaves the
+// quantised coefficients (column layout, as floats) in x and scatters them in zigzag order into the coefficient stage.
+// The quantiser itself is the integer one of forward_half (exact division by reciprocal).
+__device__ __forceinline__ void forward_half_f(f2 (&x)[8], int *xw, int m, int i, const LaneQ &lq)
+{
+    int *mb = xw + m * kMBPitch;
+    ffdct8(x);   // dct_transform_rows (both subblocks)
+    f_rows_to_cols(x, mb, i, m & 3);
+    ffdct8(x);   // dct_transform_columns
+    int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 128;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int scale = lq.scale(k), zz = lq.zz(k);
+        const float rcp = lq.rcp(k);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int n = wmul24((int)x[k][s], scale) >> 16;          // the transform output is an exact integer
+            const float q = __builtin_truncf((float)n * rcp);         // n / q, truncating (QTab::rcp)
+            x[k][s] = q;
+            stage[s * 64 + zz] = (int16_t)(int)q;
+        }
+    }
+    wave_lds_sync();
+}
+// Inverse, float form: c = quantised coefficients in column layout (floats) -> row-layout t = floor(x / 256) (floats); the
+// callers add the prediction / 128 and clamp.  lq.deqf = SCALE[z] * q[z] as float (fill_qtable<true, true>).
+__device__ __forceinline__ void inverse_half_f(f2 (&c)[8], int *xw, int m, int i, const LaneQ &lq)
+{
+    int *mb = xw + m * kMBPitch;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = c[k] * f2s(lq.deqf(k));   // |coefficient * deq| < 2^24: exact
+    fidct8(c);   // dct_inverse_transform_columns
+    f_cols_to_rows(c, mb, i, m & 3);
+    fidct8(c);   // dct_inverse_transform_rows
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = f2floor(c[k] * f2s(1.0f / 256.0f));     // v >> 8
+}
+// 16 reconstructed pixels (floats, integer-valued) -> saturated bytes: v_cvt_pk_u8_f32 clamps to 0..255 and places the byte
+__device__ __forceinline__ uint4 pack_row_f(const f2 (&px)[8])
+{
+    unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        w[k >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(px[k][0], (unsigned)(k & 3), w[k >> 2]);            // subblock 2h: pixels 0..7
+        w[2 + (k >> 2)] = __builtin_amdgcn_cvt_pk_u8_f32(px[k][1], (unsigned)(k & 3), w[2 + (k >> 2)]);   // subblock 2h+1: pixels 8..15
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// the 16 bytes of a row as floats, px[k] = {pixel k, pixel 8 + k}
+__device__ __forceinline__ void unpack_row_f(const uint4 &row, f2 (&px)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        px[k] = f2{(float)byte_of(row.x, k), (float)byte_of(row.z, k)};
+        px[k + 4] = f2{(float)byte_of(row.y, k), (float)byte_of(row.w, k)};
+    }
+}
+
 // ================================================================== I-frame encode (+ closed-loop reconstruction)
 // reference: VideoPlane::encode_plane (src/common.rs:351-386) fused with the
 // VideoPlane::decode_plane that Encoder::encode_iframe runs on its output
 // (src/enc.rs:84-97).  recon == nullptr -> encode only (plane-level operator).
+template <bool FLT>
 __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           int16_t *__restrict__ coef, uint8_t *__restrict__ recon,
                                                           const QTab *__restrict__ qtabs)
@@ -487,7 +649,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
     const int m = lane >> 3, i = lane & 7;
     int *xw = xchg[wave];
 
-    fill_qtable<true>(qtab_lds[wave], qtabs + p.qsel, lane);
+    fill_qtable<true, FLT>(qtab_lds[wave], qtabs + p.qsel, lane);
     const uint8_t *plane = src + (long)sp.stream * g.src_frame_bytes + p.src_off;
     uint4 rows[2];
     rows[0] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
@@ -500,23 +662,39 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
                          : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        int v[2][8];
-        unpack_row(rows[h], v);
+        if (FLT) {
+            f2 x[8];
+            unpack_row_f(rows[h], x);
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
+            for (int k = 0; k < 8; k++) x[k] = x[k] * f2s(256.0f) - f2s(32768.0f);   // (px - 128) << 8, src/common.rs:291
+            forward_half_f(x, xw, m, i, lq);
+            store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+            wave_lds_sync();   // the stage has been read back before the region is reused
+            if (recon) {
+                inverse_half_f(x, xw, m, i, lq);
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[s][k] = (int)((unsigned)(v[s][k] - 128) << 8);   // src/common.rs:291
-        }
-        forward_half(v, xw, m, i, lq, true);
-        store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
-        wave_lds_sync();   // the stage has been read back before the region is reused
-        if (recon) {
-            inverse_half(v, xw, m, i, lq);
+                for (int k = 0; k < 8; k++) x[k] = x[k] + f2s(128.0f);               // the pack saturates to 0..255 (src/common.rs:321)
+                if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row_f(x);
+            }
+        } else {
+            int v[2][8];
+            unpack_row(rows[h], v);
 #pragma unroll
-            for (int s = 0; s < 2; s++)
+            for (int s = 0; s < 2; s++) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[s][k] = min(max(v[s][k] + 128, 0), 255);   // src/common.rs:321
-            if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(v);
+                for (int k = 0; k < 8; k++) v[s][k] = (int)((unsigned)(v[s][k] - 128) << 8);   // src/common.rs:291
+            }
+            forward_half(v, xw, m, i, lq, true);
+            store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+            wave_lds_sync();   // the stage has been read back before the region is reused
+            if (recon) {
+                inverse_half(v, xw, m, i, lq);
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[s][k] = min(max(v[s][k] + 128, 0), 255);   // src/common.rs:321
+                if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(v);
+            }
         }
     }
 }
@@ -848,6 +1026,7 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
 
 // Phase 2: block headers, residual transform, coefficient + reconstruction stores.  xw: this wavefront's
 // exchange region (lives in the wavefront's own part of the window buffer that has just been released).
+template <bool FLT>
 __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos &tp, const SearchOut &so, const uint4 (&rows)[2], int *xw,
                                                int lane, int8_t *__restrict__ mv_out, uint8_t *__restrict__ has_out,
                                                int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const int *qtab_lds)
@@ -870,32 +1049,53 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
         const LaneQ lq{qtab_lds, i};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            int v[2][8], pp[2][8];
             // a skipped macroblock (None in the reference, zero coefficients here) takes its prediction as its source:
             // zero residual -> zero coefficients -> reconstruction = prediction, without masking 16 values per pass
             const uint4 srow = coded ? rows[h] : so.patch[h];
-            unpack_row(srow, v);
-            unpack_row(so.patch[h], pp);
+            if (FLT) {
+                f2 x[8], pp[8];
+                unpack_row_f(srow, x);
+                unpack_row_f(so.patch[h], pp);
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
+                for (int k = 0; k < 8; k++)   // calc_residuals (:118-119), delta / 2 truncating, << 8 (:304)
+                    x[k] = f2trunc((x[k] - pp[k]) * f2s(0.5f)) * f2s(256.0f);
+                forward_half_f(x, xw, m, i, lq);
+                store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+                wave_lds_sync();
+                if (recon) {
+                    inverse_half_f(x, xw, m, i, lq);
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    int d = v[s][k] - pp[s][k];                       // calc_residuals (:118-119); |d| <= 255
-                    v[s][k] = (int)((unsigned)tdiv2(d) << 8);         // (:304)
+                    for (int k = 0; k < 8; k++) {   // apply_residuals (:98-104): prev + 2 * min(t, 127), saturated by the pack
+                        const f2 t = f2{__builtin_fminf(x[k][0], 127.0f), __builtin_fminf(x[k][1], 127.0f)};
+                        pp[k] = pp[k] + t * f2s(2.0f);
+                    }
+                    if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row_f(pp);
                 }
-            }
-            forward_half(v, xw, m, i, lq, true);
-            store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
-            wave_lds_sync();
-            if (recon) {
-                inverse_half(v, xw, m, i, lq);
+            } else {
+                int v[2][8], pp[2][8];
+                unpack_row(srow, v);
+                unpack_row(so.patch[h], pp);
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
-                        pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
+                    for (int k = 0; k < 8; k++) {
+                        int d = v[s][k] - pp[s][k];                       // calc_residuals (:118-119); |d| <= 255
+                        v[s][k] = (int)((unsigned)tdiv2(d) << 8);         // (:304)
+                    }
                 }
-                if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
+                forward_half(v, xw, m, i, lq, true);
+                store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+                wave_lds_sync();
+                if (recon) {
+                    inverse_half(v, xw, m, i, lq);
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
+                            pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
+                    }
+                    if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
+                }
             }
         }
     } else {
@@ -920,6 +1120,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
 //     transform + reconstruct + store; the exchange region lives in the wavefront's own window slice
 // LDS per workgroup: 17 KiB window (+ 16 bytes in front of it: the 1-pixel level reads one dword to the left of the
 // leftmost candidate of the first window row) + 9 KiB reduction regions + 1 KiB quantiser tables.
+template <bool FLT>
 __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
@@ -936,7 +1137,7 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const TilePos cur = locate_tile(g, vt, wave);
     const PlaneGeom &p = g.p[cur.sp.plane];
-    if (wave == 0) fill_qtable<true>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
+    if (wave == 0) fill_qtable<true, FLT>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
 
     issue_window(p, ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off, cur, win, wave, lane);
     uint4 rows[2];
@@ -953,7 +1154,7 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, so);
     __syncthreads();   // window released by every wavefront
     if (cur.wave_valid)
-        penc_transform(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
+        penc_transform<FLT>(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
                        recon, qtab_lds);
 }
 

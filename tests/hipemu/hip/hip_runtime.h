@@ -37,6 +37,8 @@ struct dim3 {
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct int4 { int x, y, z, w; };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
@@ -119,6 +121,14 @@ static inline void hipemu_global_load_lds(const void *g, void *l, unsigned size,
 #define __builtin_amdgcn_global_load_lds hipemu_global_load_lds
 static inline int hipemu_ds_bpermute(int byte_addr, int v) { return hipemu::wave_exchange(v, (byte_addr >> 2) & 63); }
 #define __builtin_amdgcn_ds_bpermute hipemu_ds_bpermute
+// v_cvt_pk_u8_f32: byte `idx` of `old` replaced by the float converted to u8 (round to nearest even, saturated to 0..255)
+static inline unsigned hipemu_cvt_pk_u8_f32(float v, unsigned idx, unsigned old)
+{
+    float r = __builtin_rintf(v);
+    unsigned b = !(r > 0.0f) ? 0u : (r >= 255.0f ? 255u : (unsigned)r);
+    return (old & ~(0xffu << (8 * (idx & 3)))) | (b << (8 * (idx & 3)));
+}
+#define __builtin_amdgcn_cvt_pk_u8_f32 hipemu_cvt_pk_u8_f32
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
