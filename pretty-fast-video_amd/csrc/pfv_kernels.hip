@@ -784,6 +784,36 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
     // span origin (bytes from the window row start): dword aligned
     const int col = kAligned ? (wcol0 + st.cx - S) : (wcol0 + (st.cx & ~3) - 4);
     int part[3][3];
+    if (S == 8) {
+        // Step 8 (always the first level): the candidate rows are 8 apart, so the bottom row of candidate row my is the top row of
+        // my + 1 -- four distinct reference rows per lane instead of six; each is read once, its three window sums of squares are
+        // computed once (8 v_dot4 + 1 add) and serve both candidate rows that contain it.
+        unsigned ab[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, bb[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint8_t *rp = win + (wrow0 + st.cy + (j - 1) * 8) * kWinStride + col;   // col = 16m + 8 (mod 16 == 8): 8-, 16-, 8-byte pieces
+            const uint2 p0 = *reinterpret_cast<const uint2 *>(rp), p2 = *reinterpret_cast<const uint2 *>(rp + 24);
+            const uint4 p1 = *reinterpret_cast<const uint4 *>(rp + 8);
+            const unsigned d[8] = {p0.x, p0.y, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y};
+            const unsigned q23 = sq2(d[2], d[3], 0), q45 = sq2(d[4], d[5], 0);
+            const unsigned rsq[3] = {sq2(d[0], d[1], q23), q23 + q45, sq2(d[6], d[7], q45)};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {   // candidates at dwords 0, 2, 4
+                if (j <= 2) {
+                    ab[j][c] = dot_ab(top, d[2 * c], d[2 * c + 1], d[2 * c + 2], d[2 * c + 3], ab[j][c]);
+                    bb[j][c] += rsq[c];
+                }
+                if (j >= 1) {
+                    ab[j - 1][c] = dot_ab(bot, d[2 * c], d[2 * c + 1], d[2 * c + 2], d[2 * c + 3], ab[j - 1][c]);
+                    bb[j - 1][c] += rsq[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int my = 0; my < 3; my++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) part[my][c] = (int)bb[my][c] + __mul24((int)ab[my][c], -2);
+    } else
 #pragma unroll
     for (int my = -1; my <= 1; my++) {
 #ifdef PFV_ABL_LDSLINEAR   // ablation experiment only (results invalid): lane-linear addresses, 16 bytes apart -> (almost) no bank conflicts
@@ -793,28 +823,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
 #endif
         const bool centre_known = !FIRST && my == 0;   // (0,0) is not evaluated again (:176)
         unsigned ab[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
-        if (S == 8) {   // col = 16m + 8 (mod 16 == 8): 8-byte, 16-byte, 8-byte pieces; candidates at dwords 0, 2, 4
-            uint2 t0 = *reinterpret_cast<const uint2 *>(rp), b0 = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride);
-            uint4 t1 = *reinterpret_cast<const uint4 *>(rp + 8), b1 = *reinterpret_cast<const uint4 *>(rp + 8 * kWinStride + 8);
-            uint2 t2 = *reinterpret_cast<const uint2 *>(rp + 24), b2 = *reinterpret_cast<const uint2 *>(rp + 8 * kWinStride + 24);
-            const unsigned dT[8] = {t0.x, t0.y, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y};
-            const unsigned dB[8] = {b0.x, b0.y, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                if (centre_known && c == 1) continue;
-                ab[c] = dot_ab(bot, dB[2 * c], dB[2 * c + 1], dB[2 * c + 2], dB[2 * c + 3],
-                               dot_ab(top, dT[2 * c], dT[2 * c + 1], dT[2 * c + 2], dT[2 * c + 3], 0));
-            }
-            if (centre_known) {   // windows 0..3 and 4..7: disjoint
-                bb[0] = sq4(dB[0], dB[1], dB[2], dB[3], sq4(dT[0], dT[1], dT[2], dT[3], 0));
-                bb[2] = sq4(dB[4], dB[5], dB[6], dB[7], sq4(dT[4], dT[5], dT[6], dT[7], 0));
-            } else {
-                const unsigned q23 = sq2(dB[2], dB[3], sq2(dT[2], dT[3], 0)), q45 = sq2(dB[4], dB[5], sq2(dT[4], dT[5], 0));
-                bb[0] = sq2(dB[0], dB[1], sq2(dT[0], dT[1], q23));
-                bb[1] = q23 + q45;
-                bb[2] = sq2(dB[6], dB[7], sq2(dT[6], dT[7], q45));
-            }
-        } else if (S == 4) {   // dword, 16-byte, dword; candidates at dwords 0, 1, 2 of a 6-dword span
+        if (S == 4) {   // dword, 16-byte, dword; candidates at dwords 0, 1, 2 of a 6-dword span
             const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);
             uint4 t1, b1;     // col + 4 is a multiple of 8 only: two 8-byte reads each (no 16-byte access at an 8-byte aligned address)
             {
@@ -840,6 +849,24 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
                 bb[0] = __builtin_amdgcn_udot4(dB[0], dB[0], __builtin_amdgcn_udot4(dT[0], dT[0], y, false), false);
                 bb[1] = y + z;
                 bb[2] = __builtin_amdgcn_udot4(dB[5], dB[5], __builtin_amdgcn_udot4(dT[5], dT[5], q23 + z, false), false);
+            }
+        } else if (S == 2) {   // steps 8 and 4 came first: st.cx is a multiple of 4, the candidates sit 2 bytes before, on and 2 bytes after a dword boundary
+            const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);
+            unsigned rt[6], rb[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { rt[k] = t[k]; rb[k] = b[k]; }      // bytes cx - 4 .. cx + 19
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (centre_known && c == 1) continue;
+                unsigned eT[4], eB[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int o = k + (c >> 1);
+                    eT[k] = c == 1 ? rt[k + 1] : __builtin_amdgcn_alignbyte(rt[o + 1], rt[o], 2);
+                    eB[k] = c == 1 ? rb[k + 1] : __builtin_amdgcn_alignbyte(rb[o + 1], rb[o], 2);
+                }
+                ab[c] = dot_ab(bot, eB[0], eB[1], eB[2], eB[3], dot_ab(top, eT[0], eT[1], eT[2], eT[3], 0));
+                bb[c] = sq4(eB[0], eB[1], eB[2], eB[3], sq4(eT[0], eT[1], eT[2], eT[3], 0));
             }
         } else {
             const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);

@@ -23,7 +23,8 @@ ks = {}
 try:
     for r in csv.DictReader(open(c)):
         if "pfv::" in r["Name"]:
-            ks[r["Name"].split("(")[0].replace("pfv::k_", "")] = round(float(r["AverageNs"]) / 1000, 1)
+            import re
+            ks[re.search(r"pfv::k_(\w+)", r["Name"]).group(1)] = round(float(r["AverageNs"]) / 1000, 1)
 except Exception as e:
     ks = {"err": str(e)}
 print(f"{name:14s} {v:8.1f} M MB/s  {ks}")

@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """Per-kernel mean of each PMC counter from a rocprofv3 counter_collection.csv (pfv:: kernels only)."""
 import csv, collections, sys
+
+def kname(full):
+    """'void pfv::k_enc_pframe<true>(pfv::FrameGeom, ...)' -> 'k_enc_pframe' (template instances of one kernel are pooled)"""
+    import re
+    m = re.search(r"pfv::(k_\w+)", full)
+    return m.group(1) if m else full
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(sys.argv[1]) as f:
     for row in csv.DictReader(f):
         k = row.get("Kernel_Name", "")
         if "pfv::" not in k:
             continue
-        k = k.split("(")[0].replace("pfv::", "")
+        k = kname(k)
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     for c in sorted(acc[k]):

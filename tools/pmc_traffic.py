@@ -6,13 +6,20 @@ FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports exactly half o
 read stream (MI355X_MICROARCH.md, section HBM): it is doubled here; WRITE_SIZE is taken as is."""
 import collections, csv, json, sys
 
+def kname(full):
+    """'void pfv::k_enc_pframe<true>(pfv::FrameGeom, ...)' -> 'k_enc_pframe' (template instances of one kernel are pooled)"""
+    import re
+    m = re.search(r"pfv::(k_\w+)", full)
+    return m.group(1) if m else full
+
+
 def means(path, counter):
     acc = collections.defaultdict(list)
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row.get("Kernel_Name", "")
             if "pfv::" in k and row["Counter_Name"] == counter:
-                acc[k.split("(")[0].replace("pfv::", "")].append(float(row["Counter_Value"]))
+                acc[kname(k)].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")

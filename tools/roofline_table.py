@@ -8,6 +8,13 @@ import os
 import re
 import sys
 
+def kname(full):
+    """'void pfv::k_enc_pframe<true>(pfv::FrameGeom, ...)' -> 'k_enc_pframe' (template instances of one kernel are pooled)"""
+    import re
+    m = re.search(r"pfv::(k_\w+)", full)
+    return m.group(1) if m else full
+
+
 d = sys.argv[1]
 bench = json.load(open(os.path.join(d, "bench.json")))
 launch_mbs = bench["roofline"]["macroblocks_per_launch"]
@@ -15,7 +22,7 @@ algo = {"k_enc_iframe": 1024, "k_enc_pframe": 1284, "k_dec_iframe": 1024, "k_dec
 stats = {}
 for r in csv.DictReader(open(os.path.join(d, "prof", "prof_kernel_stats.csv"))):
     if "pfv::" in r["Name"]:
-        stats[r["Name"].split("(")[0].replace("pfv::", "")] = float(r["AverageNs"]) / 1e3
+        stats[kname(r["Name"])] = float(r["AverageNs"]) / 1e3
 # with the entropy stage on a second stream in half of the bench's extra passes, k_ent_* durations from rocprof include
 # time-slicing; use their minimum-overlap figures from the same-stream pass when present
 traffic = json.load(open(os.path.join(d, "pmc_traffic.json")))["kernels"]
