@@ -170,10 +170,15 @@ class Timer:
             self.torch = torch
             self.stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
 
+    def reserve(self, n):
+        """events created ahead of the timed region (creating one costs far more host time than recording it)"""
+        if not EMU:
+            self.pool = [self.torch.cuda.Event(enable_timing=True) for _ in range(n)]
+
     def stamp(self):
         if EMU:
             return time.perf_counter()
-        e = self.torch.cuda.Event(enable_timing=True)
+        e = self.pool.pop() if getattr(self, "pool", None) else self.torch.cuda.Event(enable_timing=True)
         e.record(self.stream)
         return e
 
@@ -602,6 +607,7 @@ def main():
 
     for _ in range(args.warmup):
         ss.step()
+    timer.reserve(args.steps * 4 * min(NF, 2 * GOP) + 64)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

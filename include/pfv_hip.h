@@ -164,6 +164,9 @@ PFV_API size_t pfv_frame_bytes(int width, int height);
 PFV_API size_t pfv_padded_frame_bytes(int width, int height);
 PFV_API int pfv_total_blocks(int width, int height);
 
+/* The encode kernels run the transforms of the closed loop in f32 where that is provably the same arithmetic (every
+ * intermediate an integer below 2^24 for the session's tables -- checked here at creation; always true for quality 0..10) and
+ * in i32 otherwise; the environment variable PFV_ENC_INT_TRANSFORM=1 forces the integer kernels (diagnostics).  Same bytes. */
 PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int quality, int n_streams,
                                    pfv_enc_session **out);
 PFV_API void pfv_enc_session_destroy(pfv_enc_session *s);
