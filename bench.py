@@ -159,32 +159,47 @@ def cpu_baseline(width, height, quality, frames_one_stream, n_mb, budget_s=12.0)
 
 
 class Timer:
-    """HIP events on the kernels' own stream (GPU) or wall-clock stamps (CPU emulator runs of the control flow)."""
+    """HIP events on the kernels' own stream (pfv_event_*: hipEventRecord on the context's stream) or wall-clock stamps (CPU
+    emulator runs of the control flow)."""
+
+    class _Ev:
+        __slots__ = ("h",)
 
     def __init__(self, ctx, dev):
-        self.ctx = ctx
-        if EMU:
-            self.stream = None
-        else:
-            import torch
-            self.torch = torch
-            self.stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+        import ctypes
+        self.ctx, self.ct = ctx, ctypes
+        self.pool, self.all = [], []
 
     def reserve(self, n):
-        """events created ahead of the timed region (creating one costs far more host time than recording it)"""
-        if not EMU:
-            self.pool = [self.torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        """events created ahead of the timed region"""
+        if EMU:
+            return
+        for _ in range(n):
+            h = self.ct.c_void_p()
+            self.ctx.check(self.ctx._lib.pfv_event_create(self.ctx.handle, self.ct.byref(h)))
+            self.pool.append(h)
+            self.all.append(h)
 
     def stamp(self):
         if EMU:
             return time.perf_counter()
-        e = self.pool.pop() if getattr(self, "pool", None) else self.torch.cuda.Event(enable_timing=True)
-        e.record(self.stream)
-        return e
+        if not self.pool:
+            self.reserve(64)
+        h = self.pool.pop()
+        self.ctx._lib.pfv_event_record(h)
+        return h
 
-    @staticmethod
-    def ms(a, b):
-        return (b - a) * 1e3 if EMU else a.elapsed_time(b)
+    def ms(self, a, b):
+        if EMU:
+            return (b - a) * 1e3
+        out = self.ct.c_float()
+        self.ctx.check(self.ctx._lib.pfv_event_elapsed_ms(a, b, self.ct.byref(out)))
+        return float(out.value)
+
+    def close(self):
+        for h in self.all:
+            self.ctx._lib.pfv_event_destroy(h)
+        self.pool, self.all = [], []
 
 
 class StreamSet:
@@ -312,7 +327,7 @@ def entropy_side(ss, timer, args):
         enc.entropy_join()          # the kernels' stream waits for the entropy stream before the closing event
         e1 = timer.stamp()
         ctx.sync()
-        return Timer.ms(e0, e1) / reps, enc.payload_sizes()
+        return timer.ms(e0, e1) / reps, enc.payload_sizes()
 
     serial_ms, sizes = measure(False)
     two_ms = None
@@ -532,24 +547,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
-    import torch
-    import torch.distributed as dist
     import __graft_entry__ as graft
+    # torch only where it is needed -- N > 1, for torch.distributed.  Its wheel bundles a second HIP / HSA runtime; with both
+    # runtimes in one process every launch of a small kernel costs about twice as much host time (measured: a 4K single-stream
+    # pass of 600 launches takes 14.2 ms without `import torch`, 25.7 ms with it), which would be charged to the kernels of
+    # the single-stream workloads.  At N = 1 the timed region is bracketed by hipDeviceSynchronize through the C ABI instead.
+    torch = dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
 
     if EMU:
         import conftest                               # tests/conftest.py: g++ build of the kernel sources on the fiber emulator
         os.environ["PFV_HIP_LIB"] = conftest.build_emulator()
         dev, backend, share, local_rank = None, "gloo", False, 0
-    else:
+    elif world > 1:
         n_dev = torch.cuda.device_count()
         # fewer devices than ranks (developer dry run of the N > 1 control flow on a one-GPU box): every rank on device 0,
         # control plane on gloo (RCCL refuses two ranks on one device)
-        share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1" or (world > 1 and n_dev < world)
+        share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1" or n_dev < world
         if share:
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         backend = "gloo" if share else "nccl"
+        graft.build_hip()
+    else:
+        dev, backend, share = None, None, False
         graft.build_hip()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -585,8 +609,6 @@ def main():
     timer = Timer(ctx, dev)
     ss = StreamSet(pkg, ctx, W, H, Q, [int(r[1]) for r in mine], NF)      # synthetic input generated in HBM: [NF][S][frame_bytes]
     n_mb = ss.n_mb
-    if not EMU:
-        torch.cuda.synchronize()
 
     ev = {k: [] for k in BYTES_PER_MB}
 
@@ -601,7 +623,9 @@ def main():
     def barrier():
         ctx.sync()
         if not EMU:
-            torch.cuda.synchronize()
+            ctx.device_sync()                         # hipDeviceSynchronize (what torch.cuda.synchronize() does)
+            if torch is not None:
+                torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
@@ -617,7 +641,7 @@ def main():
     if not args.no_verify:
         ss.verify()                                   # decoder output == encoder reconstruction, no bad motion vector
     coded_frac = ss.coded_fraction()
-    kern_ms = {k: float(np.mean([Timer.ms(a, b) for a, b in v])) for k, v in ev.items() if v}
+    kern_ms = {k: float(np.mean([timer.ms(a, b) for a, b in v])) for k, v in ev.items() if v}
     pe_ms = kern_ms.get("k_enc_pframe", float("nan"))
 
     ent = None if args.no_entropy else entropy_side(ss, timer, args)
@@ -691,6 +715,7 @@ def main():
         print(json.dumps(res), flush=True)
 
     ss.close()
+    timer.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -61,11 +61,21 @@ typedef struct pfv_ctx pfv_ctx;
 PFV_API int pfv_ctx_create(int device, pfv_ctx **out);
 PFV_API void pfv_ctx_destroy(pfv_ctx *ctx);
 PFV_API int pfv_ctx_sync(pfv_ctx *ctx);
+/* hipDeviceSynchronize on the context's device (all streams) */
+PFV_API int pfv_device_sync(pfv_ctx *ctx);
 /* hipStream_t of the context (for callers that enqueue their own work / HIP events) */
 PFV_API void *pfv_ctx_stream(pfv_ctx *ctx);
 /* last error text of this context (or of the calling thread when ctx == NULL) */
 PFV_API const char *pfv_last_error(pfv_ctx *ctx);
 PFV_API const char *pfv_version(void);
+
+/* Timing events on the context's stream (HIP events): record costs a microsecond or two, so every launch of a pass can be
+ * bracketed without disturbing it; pfv_event_elapsed_ms waits for the later event. */
+typedef struct pfv_event pfv_event;
+PFV_API int pfv_event_create(pfv_ctx *ctx, pfv_event **out);
+PFV_API int pfv_event_record(pfv_event *e);
+PFV_API int pfv_event_elapsed_ms(pfv_event *start, pfv_event *stop, float *ms);
+PFV_API void pfv_event_destroy(pfv_event *e);
 
 /* HIP graphs over the `*_dev` entry points.  The reference's caller is one Encoder per stream, one call per frame
  * (src/enc.rs:125-173); for a single stream the launches, not the kernels, are the cost.  Every `*_dev` call made between

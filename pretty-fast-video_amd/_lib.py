@@ -38,9 +38,14 @@ SIGNATURES = [
     ("pfv_ctx_create", c_int, [c_int, POINTER(_P)]),
     ("pfv_ctx_destroy", None, [_P]),
     ("pfv_ctx_sync", c_int, [_P]),
+    ("pfv_device_sync", c_int, [_P]),
     ("pfv_ctx_stream", _P, [_P]),
     ("pfv_last_error", c_char_p, [_P]),
     ("pfv_version", c_char_p, []),
+    ("pfv_event_create", c_int, [_P, POINTER(_P)]),
+    ("pfv_event_record", c_int, [_P]),
+    ("pfv_event_elapsed_ms", c_int, [_P, _P, POINTER(c_float)]),
+    ("pfv_event_destroy", None, [_P]),
     ("pfv_graph_begin", c_int, [_P]),
     ("pfv_graph_end", c_int, [_P, POINTER(_P)]),
     ("pfv_graph_launch", c_int, [_P]),

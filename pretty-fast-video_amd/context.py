@@ -57,6 +57,10 @@ class Context:
     def sync(self):
         self.check(self._lib.pfv_ctx_sync(self.handle))
 
+    def device_sync(self):
+        """hipDeviceSynchronize: every stream of the device"""
+        self.check(self._lib.pfv_device_sync(self.handle))
+
     @property
     def stream(self) -> int:
         return int(self._lib.pfv_ctx_stream(self.handle) or 0)

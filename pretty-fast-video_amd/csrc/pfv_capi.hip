@@ -147,6 +147,54 @@ PFV_API int pfv_ctx_sync(pfv_ctx *ctx)
     return PFV_OK;
 }
 PFV_API void *pfv_ctx_stream(pfv_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+// every stream of the context's device (hipDeviceSynchronize), for callers that bracket a timed region
+PFV_API int pfv_device_sync(pfv_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return PFV_OK;
+}
+
+// ------------------------------------------------------------------ timing events on the context's stream
+// For callers that time the kernels where they run (bench.py's roofline figure): hipEventRecord on the context's own stream
+// costs a microsecond or two, a framework's event object on a foreign stream far more.
+struct pfv_event {
+    pfv_ctx *ctx = nullptr;
+    hipEvent_t ev = nullptr;
+};
+PFV_API int pfv_event_create(pfv_ctx *ctx, pfv_event **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_event_create: bad argument");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev = nullptr;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDefault));
+    pfv_event *e = new pfv_event();
+    e->ctx = ctx; e->ev = ev;
+    *out = e;
+    return PFV_OK;
+}
+PFV_API int pfv_event_record(pfv_event *e)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null event");
+    HIP_TRY(e->ctx, hipEventRecord(e->ev, e->ctx->stream));
+    return PFV_OK;
+}
+// milliseconds between two recorded events (waits for the later one)
+PFV_API int pfv_event_elapsed_ms(pfv_event *start, pfv_event *stop, float *ms)
+{
+    if (!start || !stop || !ms) return fail(start ? start->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_event_elapsed_ms: bad argument");
+    HIP_TRY(stop->ctx, hipEventSynchronize(stop->ev));
+    HIP_TRY(stop->ctx, hipEventElapsedTime(ms, start->ev, stop->ev));
+    return PFV_OK;
+}
+PFV_API void pfv_event_destroy(pfv_event *e)
+{
+    if (!e) return;
+    (void)hipEventDestroy(e->ev);
+    delete e;
+}
 
 // ------------------------------------------------------------------ HIP graphs over the device-pointer entry points
 // One Encoder = one stream is the reference's calling pattern (src/enc.rs:125-173): 30 small launches per GOP, each of

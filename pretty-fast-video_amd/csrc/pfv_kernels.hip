@@ -812,7 +812,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
 #pragma unroll
         for (int my = 0; my < 3; my++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) part[my][c] = (int)bb[my][c] + __mul24((int)ab[my][c], -2);
+            for (int c = 0; c < 3; c++) part[my][c] = (int)(bb[my][c] - (ab[my][c] << 1));
     } else
 #pragma unroll
     for (int my = -1; my <= 1; my++) {
@@ -893,7 +893,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) part[my + 1][c] = (int)bb[c] + __mul24((int)ab[c], -2);   // sum ab < 2^22
+        for (int c = 0; c < 3; c++) part[my + 1][c] = (int)(bb[c] - (ab[c] << 1));
     }
     // transposed reduction: lane c of the macroblock collects the 8 row-pair partials of candidate c
     int ord = 0;

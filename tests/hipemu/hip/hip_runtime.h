@@ -149,8 +149,11 @@ static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (void *)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 typedef void *hipEvent_t;
-enum { hipEventDisableTiming = 2 };
+enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (void *)1; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
