@@ -553,7 +553,12 @@ def main():
     # pass of 600 launches takes 14.2 ms without `import torch`, 25.7 ms with it), which would be charged to the kernels of
     # the single-stream workloads.  At N = 1 the timed region is bracketed by hipDeviceSynchronize through the C ABI instead.
     torch = dist = None
+    stdout_fd = None
     if world > 1:
+        # the contract is ONE line on stdout: libraries that chat on fd 1 (gloo prints its rendezvous there) go to stderr
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
 
@@ -712,7 +717,12 @@ def main():
                 res["pframe_encode"]["vs_cpu_baseline"] = res["pframe_encode"]["value"] / res["cpu_baseline"]["pframe_encode_value"]
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None                # rank 0 at N = 1 only
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
         print(json.dumps(res), flush=True)
+        if stdout_fd is not None:
+            os.dup2(2, 1)
 
     ss.close()
     timer.close()
