@@ -780,9 +780,9 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
                                              int a2, int mbx, int mby, int pw, int ph, SearchState &st, const SearchLane &sl)
 {
     constexpr bool kAligned = (S >= 4);            // displacement is a multiple of 4 pixels: no byte shifts
-    const int sh = st.cx & 3;                      // only used when !kAligned
+    const int sh = (st.cx - 1) & 3;                // only used at step 1: phase of the leftmost candidate
     // span origin (bytes from the window row start): dword aligned
-    const int col = kAligned ? (wcol0 + st.cx - S) : (wcol0 + (st.cx & ~3) - 4);
+    const int col = kAligned ? (wcol0 + st.cx - S) : (S == 2 ? wcol0 + st.cx - 4 : wcol0 + ((st.cx - 1) & ~3));
     int part[3][3];
     if (S == 8) {
         // Step 8 (always the first level): the candidate rows are 8 apart, so the bottom row of candidate row my is the top row of
@@ -870,23 +870,25 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
             }
         } else {
             const unsigned *t = reinterpret_cast<const unsigned *>(rp), *b = reinterpret_cast<const unsigned *>(rp + 8 * kWinStride);
-            unsigned rt[7], rb[7], dT[6], dB[6];
+            static_assert(S == 1 || S == 2 || S >= 4, "the byte-granular path is the 1-pixel level");
+            // step 1: candidates at bytes cx - 1, cx, cx + 1.  Rebase once to the leftmost one (lane-variable shift), then
+            // compile-time shifts of 0, 1, 2 bytes
+            unsigned rt[6], rb[6], dT[5], dB[5];
 #pragma unroll
-            for (int k = 0; k < 7; k++) { rt[k] = t[k]; rb[k] = b[k]; }
+            for (int k = 0; k < 6; k++) { rt[k] = t[k]; rb[k] = b[k]; }
 #pragma unroll
-            for (int k = 0; k < 6; k++) {   // rebase: e[k] = bytes starting at (cx - 4) + 4k
+            for (int k = 0; k < 5; k++) {   // e[k] = bytes starting at (cx - 1) + 4k
                 dT[k] = __builtin_amdgcn_alignbyte(rt[k + 1], rt[k], sh);
                 dB[k] = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
             }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 if (centre_known && c == 1) continue;
-                const int ob = 4 + (c - 1) * S, o = ob >> 2, bs = ob & 3;   // compile-time byte offset from the rebased origin
                 unsigned eT[4], eB[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    eT[k] = bs ? __builtin_amdgcn_alignbyte(dT[o + k + 1], dT[o + k], bs) : dT[o + k];
-                    eB[k] = bs ? __builtin_amdgcn_alignbyte(dB[o + k + 1], dB[o + k], bs) : dB[o + k];
+                    eT[k] = c ? __builtin_amdgcn_alignbyte(dT[k + 1], dT[k], c) : dT[k];
+                    eB[k] = c ? __builtin_amdgcn_alignbyte(dB[k + 1], dB[k], c) : dB[k];
                 }
                 ab[c] = dot_ab(bot, eB[0], eB[1], eB[2], eB[3], dot_ab(top, eT[0], eT[1], eT[2], eT[3], 0));
                 bb[c] = sq4(eB[0], eB[1], eB[2], eB[3], sq4(eT[0], eT[1], eT[2], eT[3], 0));
@@ -922,12 +924,9 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
     const unsigned best = min(mb_min(key), centre);
     const int bo = (int)(best & 15u);
     st.err = (int)(best >> 4);
-    if (bo) {
-        int b9 = bo - 1;
-        b9 = b9 < 4 ? b9 : b9 + 1;
-        st.cy += (b9 / 3 - 1) * S;
-        st.cx += (b9 - (b9 / 3) * 3 - 1) * S;
-    }
+    // winner -> step: two-bit fields indexed by the visiting order (0 = the centre stays): my + 1 and mx + 1
+    st.cy += ((int)((0x2A501u >> (2 * bo)) & 3u) - 1) * S;
+    st.cx += ((int)((0x24891u >> (2 * bo)) & 3u) - 1) * S;
 }
 
 // Geometry of one p-frame tile (128 x 64 px = 4 vertically stacked strips) as seen by one wavefront.
