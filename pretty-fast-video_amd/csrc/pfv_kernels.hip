@@ -742,14 +742,17 @@ __device__ __forceinline__ unsigned sq4(unsigned b0, unsigned b1, unsigned b2, u
 constexpr int kRedPitch = 72;   // dwords per macroblock: 64 used; 72 = 8 (mod 32) spreads the 4 macroblocks of a 32-lane group over the banks
 constexpr int kRedDwords = kStripMB * kRedPitch;
 struct SearchLane {
+    int neg2;           // -2, handed in as a kernel argument: with an opaque multiplier  bb - 2 ab  stays ONE v_mad_i32_i24 (a literal -2 is
+                        // expanded to a shift and a subtract, 33 more instructions per search)
     int ord;            // visiting order 1..8 of this lane's candidate: my outer, mx inner, centre skipped (src/common.rs:168-179)
     int dy, dx;         // its position in the 3 x 3 pattern (-1, 0, 1)
     int *wr;            // &red[m][0][i]: the lane's partial for candidate c goes to wr[c * 8]
     const int4 *rd;     // &red[m][i][0]: the 8 lanes' partials of this lane's candidate
 };
-__device__ __forceinline__ SearchLane make_search_lane(int *red, int m, int i)
+__device__ __forceinline__ SearchLane make_search_lane(int *red, int m, int i, int neg2)
 {
     SearchLane sl;
+    sl.neg2 = neg2;
     sl.ord = i + 1;
     const int b9 = i < 4 ? i : i + 1;           // index in the full 3 x 3 pattern
     sl.dy = b9 / 3 - 1;
@@ -812,7 +815,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
 #pragma unroll
         for (int my = 0; my < 3; my++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) part[my][c] = (int)(bb[my][c] - (ab[my][c] << 1));
+            for (int c = 0; c < 3; c++) part[my][c] = __mul24((int)ab[my][c], sl.neg2) + (int)bb[my][c];
     } else
 #pragma unroll
     for (int my = -1; my <= 1; my++) {
@@ -895,7 +898,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) part[my + 1][c] = (int)(bb[c] - (ab[c] << 1));
+        for (int c = 0; c < 3; c++) part[my + 1][c] = __mul24((int)ab[c], sl.neg2) + (int)bb[c];   // sum ab < 2^22
     }
     // transposed reduction: lane c of the macroblock collects the 8 row-pair partials of candidate c
     int ord = 0;
@@ -987,7 +990,7 @@ struct SearchOut {
 // Phase 1 of a tile for one wavefront: motion search, skip decision, fetch of the chosen patch rows.
 // Reads the window; issues no global memory operation.
 __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &tp, const uint8_t *win, int *red, const uint4 (&rows)[2], int lane,
-                                            float min_err, SearchOut &so)
+                                            float min_err, int neg2, SearchOut &so)
 {
     const StripPos &sp = tp.sp;
     const PlaneGeom &p = g.p[sp.plane];
@@ -1011,7 +1014,7 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
     // 4-step search (reference src/common.rs:154-204, steps 8, 4, 2, 1)
     SearchState st;
     st.cx = 0; st.cy = 0; st.err = 0;
-    const SearchLane sl = make_search_lane(red, m, i);
+    const SearchLane sl = make_search_lane(red, m, i, neg2);
     // strips at least 15 px inside the plane on every side (84 % of a 1080p luma plane) skip the bounds tests
     const bool interior = sp.x0 >= 16 && sp.x0 + kStripMB * 16 + 16 <= p.pw && sp.y0 >= 16 && sp.y0 + 32 <= p.ph;   // wave-uniform
     if (interior) {
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs,
-                                                          float min_err)
+                                                          float min_err, int neg2)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win_lds[16 + kWinAlloc];
     __shared__ __attribute__((aligned(16))) int red_lds[kStripsPerWG][kRedDwords];
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     SearchOut so;
     so.cx = so.cy = 0; so.coded = false;
     so.patch[0] = so.patch[1] = make_uint4(0, 0, 0, 0);
-    if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, so);
+    if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, neg2, so);
     __syncthreads();   // window released by every wavefront
     if (cur.wave_valid)
         penc_transform<FLT>(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
