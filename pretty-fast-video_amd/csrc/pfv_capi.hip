@@ -983,8 +983,6 @@ PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap)
     };
     const size_t n_groups = (n_sb + kEntThreads - 1) / kEntThreads;
     hipError_t e = grab((void **)&s->ent.syms, S * n_groups * kEntGroupSyms * 4);
-    if (e == hipSuccess) e = grab((void **)&s->ent.counts, S * n_sb * 16);
-    if (e == hipSuccess) e = grab((void **)&s->ent.lanew, S * n_sb * 4);
     if (e == hipSuccess) e = grab((void **)&s->ent.groups, S * n_groups * sizeof(EntGroup));
     if (e == hipSuccess) e = grab((void **)&s->ent.hist, S * 16 * 4);
     if (e == hipSuccess) e = grab((void **)&s->ent.codes, S * sizeof(EntCodes));
@@ -1015,6 +1013,7 @@ static int ent_pack(pfv_enc_session *s, bool pframe, const int8_t *mv_dev, const
     f.n_groups = (f.total_blocks * 4 + kEntThreads - 1) / kEntThreads;
     f.pframe = pframe ? 1 : 0;
     f.cap_bytes = s->ent_cap;
+    f.ones16 = 0x00010001u;
     f.qidx[0] = pframe ? 2 : 0;                    // intra_l, intra_c, intra_c / inter_l, inter_c, inter_c
     f.qidx[1] = f.qidx[2] = pframe ? 3 : 1;        // (enc.rs:296-298, :409-411)
     EntBufs b = s->ent;
@@ -1141,6 +1140,7 @@ PFV_API int pfv_enc_payloads_fetch(pfv_enc_session *s, uint8_t *out, size_t cap,
     EntFrame f{};
     f.n_streams = S;
     f.cap_bytes = s->ent_cap;
+    f.ones16 = 0x00010001u;
     hipLaunchKernelGGL(k_ent_gather, dim3(32, (unsigned)S), dim3(kEntThreads), 0, st, f, s->ent, s->ent_offsets_dev, s->ent_packed);
     if ((rc = launch_check(ctx, "k_ent_gather"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, s->ent_packed, total, hipMemcpyDeviceToHost, st));
@@ -2483,3 +2483,13 @@ PFV_API int pfv_decoder_advance_delta(pfv_decoder *d, double delta, pfv_video_cb
 }
 
 }  // extern "C"
+
+#ifdef PFV_ENT_PROFILE   // experiment builds only (tools/ent_profile.py): the timestamp rows of kernel `kern` (0 scan, 1 pack)
+extern "C" __attribute__((visibility("default"))) int pfv_debug_ent_profile(int kern, unsigned long long *out, int n_groups)
+{
+    hipDeviceSynchronize();
+    const size_t row = sizeof(unsigned long long) * 16;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pfv::ent_prof), row * (size_t)n_groups, row * pfv::kEntProfGroups * (size_t)kern) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -7,20 +7,22 @@
 // the same byte stream is produced here, from the coefficient / header buffers the encode kernels left in HBM:
 //
 //   k_ent_scan   workgroup = 256 consecutive subblocks of one stream (64 macroblocks), lane = one 8x8 subblock.  The
-//                group's 32 KiB of coefficients come in with coalesced 16-byte loads and are staged in LDS (rows padded
-//                to 136 B); each lane builds its non-zero bitmap and walks the set bits: one 32-bit word per run symbol
-//                (fillers, num_zeroes, coeff_size, value bits) appended to the group's symbol list -- the lanes' runs
-//                are contiguous in it --, symbol counts (16 x 8-bit), sum of coefficient sizes.  Per lane -> HBM
-//                (counts, packed size sum / list position); per workgroup -> HBM (counts, size sum, block-header
-//                bits); per stream -> the frame histogram (atomics).
+//                group's 32 KiB of coefficients come in with coalesced 16-byte loads -- p-frames: only the macroblocks
+//                that have any -- and are staged in LDS (rows padded to 136 B); each lane builds its non-zero bitmap
+//                (v_pk_min_u16 + v_dot2_u32_u16 per coefficient pair) and walks the set bits: one 32-bit word per run
+//                symbol (fillers, num_zeroes, coeff_size, value bits) appended to the group's symbol list -- the
+//                lanes' runs are contiguous in it --, symbol counts in 16 byte-wide LDS counters, sum of coefficient
+//                sizes.  Per workgroup -> HBM (symbol list and its length, counts, size sum, block-header bits); per
+//                stream -> the frame histogram (atomics).
 //   k_ent_codes  one workgroup per stream.  Wavefront 0 builds the reference's Huffman tree lane-parallel (stable
 //                rank sort, ballot-positioned merges, codes by walking the parent chain), all lanes fill the 256
 //                pre-joined (num_zeroes, coeff_size) code pairs; then bits per workgroup-of-scan = counts . code lengths
 //                + sizes, exclusive prefix over the workgroups -> base bit offsets and the payload size.
 //   k_ent_init   zeroes exactly the words the payload will occupy and writes the 19 header bytes.
-//   k_ent_pack   same tiling as k_ent_scan: bits per lane from its counts, workgroup exclusive scan + the workgroup's
-//                base = the lane's bit offset; the lane reads its symbol words back (never the coefficients), looks the
-//                code pairs up and ORs its bits into an LDS window that leaves with coalesced stores.
+//   k_ent_pack   one workgroup per group of k_ent_scan, lane = one SYMBOL of the group's list, 256 at a time (never the
+//                coefficients): code pair and bit length from LDS tables, workgroup prefix sum of the lengths on top
+//                of the group's base = the symbol's bit offset, bits ORed into an LDS window that leaves with
+//                coalesced stores.
 //
 // Run order inside a macroblock is the coefficient buffer's own (zigzag within a subblock, subblocks 0..3), runs cross
 // subblock boundaries and end at the macroblock (enc.rs:246-255), so lane (mb, sb) needs only the bitmaps of the
@@ -54,6 +56,7 @@ struct EntGroup {
     uint32_t hdr_bits;         // block-header bits of its macroblocks (p-frames)
     uint32_t sym_base;         // written by k_ent_codes: bit offset of the group's first symbol ...
     uint32_t hdr_base;         // ... and of its first block header
+    uint32_t n_syms;           // words in the group's symbol list
 };
 
 struct EntFrame {
@@ -64,6 +67,8 @@ struct EntFrame {
     uint32_t cap_bytes;        // payload capacity per stream (multiple of 4)
     uint8_t qidx[3];
     uint8_t pad;
+    uint32_t ones16;           // 0x00010001, from the host: a literal would let the compiler rewrite min(x, 1) per 16-bit half
+                               // into compare + select + repack (6 instructions where v_pk_min_u16 is 1)
 };
 
 struct EntBufs {
@@ -71,14 +76,22 @@ struct EntBufs {
     const int8_t *mv;          // [S][total_blocks][2]   (p-frames)
     const uint8_t *has;        // [S][total_blocks]      (p-frames)
     uint32_t *syms;            // [S][n_groups][kEntGroupSyms] run symbols: fillers << 24 | value bits << 8 | coeff_size << 4 | num_zeroes
-    uint4 *counts;             // [S][total_blocks*4] 16 x 8-bit symbol counts
-    uint32_t *lanew;           // [S][total_blocks*4] size sum (10 bits) | symbols << 10 (7 bits) | position in the group's list << 17
     EntGroup *groups;          // [S][n_groups]
     int32_t *hist;             // [S][16]
     EntCodes *codes;           // [S]
     uint32_t *sizes;           // [S] payload bytes or kEntErr*
     uint8_t *payload;          // [S][cap_bytes]
 };
+
+#ifdef PFV_ENT_PROFILE   // experiment builds only: clock64 of lane 0 at the marks, one row of 16 per workgroup (tools/ent_profile.py)
+constexpr int kEntProfGroups = 1 << 15;
+__device__ unsigned long long ent_prof[2][kEntProfGroups][16];
+#define ENT_MARK(kern, i) do { if (threadIdx.x == 0 && prof_row_ < kEntProfGroups) ent_prof[kern][prof_row_][i] = clock64(); } while (0)
+#define ENT_MARK0() const unsigned prof_row_ = blockIdx.y * gridDim.x + blockIdx.x
+#else
+#define ENT_MARK(kern, i) do {} while (0)
+#define ENT_MARK0() do {} while (0)
+#endif
 
 __device__ __forceinline__ void ent_wave_lds_sync()
 {
@@ -127,30 +140,36 @@ __device__ __forceinline__ void ent_split_run(unsigned run, unsigned &fillers, u
     rest = run - 15u * fillers;
 }
 
-// The workgroup's 256 subblocks (32 KiB, contiguous in the coefficient buffer) -> LDS rows, coalesced: thread t moves
-// the 16-byte pieces t, t + 256, ...; piece p belongs to subblock p / 8.
-__device__ __forceinline__ void ent_stage_rows(uint64_t *rows, const int16_t *group_base, int n_live_sb)
+// The workgroup's 256 subblocks (32 KiB, contiguous in the coefficient buffer) -> LDS rows, coalesced: a half-wavefront
+// moves one macroblock (512 B = 32 pieces of 16 bytes) per step, thread t the pieces of macroblocks 8 * (t / 32) + k,
+// k = 0..7.  `has` (p-frames; nullptr for i-frames) points at the group's first macroblock flag: a macroblock without
+// coefficients is never looked at by its lanes (`coded` in k_ent_scan), so its 512 bytes stay in HBM -- a third of a
+// typical p-frame -- and its LDS rows stay unwritten.
+__device__ __forceinline__ void ent_stage_rows(uint64_t *rows, const int16_t *group_base, int n_live_sb, const uint8_t *has)
 {
     const uint4 *src = (const uint4 *)group_base;
-    if (n_live_sb == kEntThreads) {   // every group but a stream's last: all eight loads in flight before the first LDS write
-        uint4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = src[k * kEntThreads + (int)threadIdx.x];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int piece = k * kEntThreads + (int)threadIdx.x, sbl = piece >> 3, part = piece & 7;
-            rows[sbl * kEntRow64 + 2 * part] = (uint64_t)v[k].x | ((uint64_t)v[k].y << 32);
-            rows[sbl * kEntRow64 + 2 * part + 1] = (uint64_t)v[k].z | ((uint64_t)v[k].w << 32);
+    const int half = (int)(threadIdx.x >> 5), j = (int)(threadIdx.x & 31u);
+    const int n_live_mb = n_live_sb >> 2;
+    uint64_t flags = ~0ull;   // byte k: macroblock 8 * half + k has coefficients
+    if (has) {
+        if (n_live_sb == kEntThreads) {
+            __builtin_memcpy(&flags, has + 8 * half, 8);
+        } else {
+            flags = 0;
+            for (int k = 0; k < 8; k++)
+                if (8 * half + k < n_live_mb) flags |= (uint64_t)has[8 * half + k] << (8 * k);
         }
-        return;
     }
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)   // all loads in flight before the first LDS write
+        if (8 * half + k < n_live_mb && ((flags >> (8 * k)) & 0xffu)) v[k] = src[32 * (8 * half + k) + j];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int piece = k * kEntThreads + (int)threadIdx.x, sbl = piece >> 3, part = piece & 7;
-        if (sbl < n_live_sb) {
-            const uint4 v = src[piece];
-            rows[sbl * kEntRow64 + 2 * part] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-            rows[sbl * kEntRow64 + 2 * part + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        if (8 * half + k < n_live_mb && ((flags >> (8 * k)) & 0xffu)) {
+            const int piece = 32 * (8 * half + k) + j, sbl = piece >> 3, part = piece & 7;
+            rows[sbl * kEntRow64 + 2 * part] = (uint64_t)v[k].x | ((uint64_t)v[k].y << 32);
+            rows[sbl * kEntRow64 + 2 * part + 1] = (uint64_t)v[k].z | ((uint64_t)v[k].w << 32);
         }
     }
 }
@@ -167,11 +186,23 @@ __device__ __forceinline__ uint32_t ent_pk_min_u16(uint32_t a, uint32_t b)
     __builtin_memcpy(&r, &m, 4);
     return r;
 }
-// bit 0 / bit 1: the low / high 16-bit half of d is non-zero
-__device__ __forceinline__ uint32_t ent_nz2(uint32_t d)
+// v_dot2_u32_u16: acc + a.lo * b.lo + a.hi * b.hi
+__device__ __forceinline__ uint32_t ent_udot2(uint32_t a, uint32_t b, uint32_t acc)
 {
-    const uint32_t m = ent_pk_min_u16(d, 0x00010001u);   // 0 or 1 in each half
-    return (m | (m >> 15)) & 3u;
+    ent_us2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_udot2(x, y, acc, false);
+}
+// Non-zero bitmap of 16 coefficients (8 dwords, two 16-bit values each) in the low 16 bits: v_pk_min_u16 against
+// ones16 = (1, 1) turns each half into 0 / 1, v_dot2_u32_u16 drops the pair onto bits 2j, 2j + 1 of the accumulator
+// -- two instructions per dword.
+__device__ __forceinline__ uint32_t ent_nz16(const uint32_t (&d)[8], uint32_t ones16)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc = ent_udot2(ent_pk_min_u16(d[j], ones16), (1u << (2 * j)) | (1u << (2 * j + 17)), acc);
+    return acc;
 }
 
 // sum over each 16-lane row, valid in every lane of the row (DPP butterflies)
@@ -197,22 +228,34 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     const bool live = sbi < n_sb;
     const int mb = sbi >> 2, sb = sbi & 3;
     if (threadIdx.x < 10) blk[threadIdx.x] = 0;
-    ent_stage_rows(rows, b.coef + ((size_t)stream * f.total_blocks * 4 + sb0) * 64, min(kEntThreads, n_sb - sb0));
-    __syncthreads();
-
-    const size_t sbase = (size_t)stream * n_sb;
+    ENT_MARK0();
+    ENT_MARK(0, 0);
     const size_t bi = (size_t)stream * f.total_blocks + (live ? mb : 0);
-    const bool coded = live && (!f.pframe || b.has[bi] != 0);
+    const bool coded = live && (!f.pframe || b.has[bi] != 0);   // in flight together with the coefficients, and so are the
+    int mvx = 0, mvy = 0;                                       // motion vector components for the block-header bits
+    if (f.pframe && live && sb == 0) { mvx = b.mv[2 * bi]; mvy = b.mv[2 * bi + 1]; }
+    ent_stage_rows(rows, b.coef + ((size_t)stream * f.total_blocks * 4 + sb0) * 64, min(kEntThreads, n_sb - sb0),
+                   f.pframe ? b.has + (size_t)stream * f.total_blocks + (sb0 >> 2) : nullptr);
+    ENT_MARK(0, 1);
+    __syncthreads();
+    ENT_MARK(0, 2);
+
     const uint64_t *row = rows + threadIdx.x * kEntRow64;
     uint64_t mask = 0;
     if (coded) {
-        uint32_t lo = 0, hi = 0;
+        uint32_t q[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint64_t x = row[k], y = row[8 + k];
-            lo |= (ent_nz2((uint32_t)x) | (ent_nz2((uint32_t)(x >> 32)) << 2)) << (4 * k);
-            hi |= (ent_nz2((uint32_t)y) | (ent_nz2((uint32_t)(y >> 32)) << 2)) << (4 * k);
+        for (int fld = 0; fld < 4; fld++) {   // coefficients 16 * fld .. 16 * fld + 15
+            uint32_t d[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t x = row[4 * fld + k];
+                d[2 * k] = (uint32_t)x;
+                d[2 * k + 1] = (uint32_t)(x >> 32);
+            }
+            q[fld] = ent_nz16(d, f.ones16);
         }
+        const uint32_t lo = q[0] | (q[1] << 16), hi = q[2] | (q[3] << 16);
         mask = (uint64_t)lo | ((uint64_t)hi << 32);
     }
     int last = ent_prev_last(mask, sb);   // every lane of the wavefront takes part in the exchange
@@ -226,7 +269,9 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     if ((threadIdx.x & 63u) == 63u) wave_syms[threadIdx.x >> 6] = incl;
     // symbol counts: 16 byte-wide counters per lane in LDS (ds_add without return: nothing to wait for in the loop)
     cnt4[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    ENT_MARK(0, 3);
     __syncthreads();
+    ENT_MARK(0, 4);
     uint32_t sym_off = incl - n_sym;
     for (unsigned w = 0; w < (threadIdx.x >> 6); w++) sym_off += wave_syms[w];
     uint32_t *out = b.syms + ((size_t)stream * f.n_groups + blockIdx.x) * kEntGroupSyms + sym_off;
@@ -234,7 +279,7 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     uint32_t *my_cnt = (uint32_t *)&cnt4[threadIdx.x];
     auto count = [&](unsigned bin, unsigned n) { atomicAdd(&my_cnt[bin >> 2], n << (8u * (bin & 3u))); };
     const int16_t *c = (const int16_t *)row;
-    uint32_t sumsize = 0, oversize = 0;
+    uint32_t sumsize = 0, maxsize = 0;
     if (mask) {
         uint64_t mm = mask;
         int bit = __builtin_ctzll(mm);
@@ -253,7 +298,7 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
             }
             const unsigned mag = (unsigned)(v < 0 ? -v : v);
             const unsigned size = 33u - (unsigned)__builtin_clz(mag);   // bit length + 1 (rle.rs:23-24)
-            oversize |= size > 15u;
+            maxsize = max(maxsize, size);
             count(run, 1u);
             count(size & 15u, 1u);
             sumsize += size;
@@ -272,15 +317,12 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
         count(rest, 1u);
         *out++ = (fillers << 24) | rest;
     }
+    ENT_MARK(0, 5);
     uint32_t hdr_bits = 0;
     if (f.pframe && live && sb == 0)      // has_mvec, has_coeff, then two 7-bit components (enc.rs:414-451)
-        hdr_bits = (b.mv[2 * bi] != 0 || b.mv[2 * bi + 1] != 0) ? 16u : 2u;
+        hdr_bits = (mvx != 0 || mvy != 0) ? 16u : 2u;
     ent_wave_lds_sync();
     const uint4 c4 = cnt4[threadIdx.x];
-    if (live) {
-        b.counts[sbase + sbi] = c4;
-        b.lanew[sbase + sbi] = (sumsize & 1023u) | (n_sym << 10) | (sym_off << 17);
-    }
 
     // workgroup totals: counts widened to 16-bit fields (two symbols per word; at most 256 * 164 per field)
     const uint32_t w8[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -299,18 +341,22 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
         atomicAdd(&blk[8], ws);
         if (wh) atomicAdd(&blk[9], wh);
     }
-    if (__any(oversize != 0) && (threadIdx.x & 63u) == 0) atomicOr(&b.codes[stream].oversize, 1u);
+    if (__any(maxsize > 15u) && (threadIdx.x & 63u) == 0) atomicOr(&b.codes[stream].oversize, 1u);
+    ENT_MARK(0, 6);
     __syncthreads();
+    ENT_MARK(0, 7);
     EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
     if (threadIdx.x < 8) g->counts[threadIdx.x] = blk[threadIdx.x];
     if (threadIdx.x == 8) g->sumsize = blk[8];
     if (threadIdx.x == 9) g->hdr_bits = blk[9];
+    if (threadIdx.x == 10) g->n_syms = wave_syms[0] + wave_syms[1] + wave_syms[2] + wave_syms[3];
     if (threadIdx.x >= 16 && threadIdx.x < 32) {
         const unsigned sym = threadIdx.x - 16u;
         const uint32_t w = blk[sym >> 1];
         const uint32_t n = (sym & 1u) ? (w >> 16) : (w & 0xffffu);
         if (n) atomicAdd(&b.hist[stream * 16 + (int)sym], (int32_t)n);
     }
+    ENT_MARK(0, 8);
 }
 
 // ---------------------------------------------------------------------------------------------------- k_ent_codes
@@ -474,160 +520,208 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_init(EntFrame f, EntBufs b)
 }
 
 // ---------------------------------------------------------------------------------------------------- k_ent_pack
-// The 256 lanes of a workgroup own one contiguous bit range of the symbol section (and, for p-frames, one of the
-// header section).  Lanes OR their words into an LDS window anchored at the workgroup's first word; after a barrier
-// the window goes out with coalesced dword stores, only its first and last word -- shared with the neighbouring
-// workgroups -- as atomicOr onto the zeroed payload.  A workgroup whose symbols outgrow the window (kEntWinWords * 32
-// bits, ~6x the typical load at quality 5) sends the lanes past it straight to memory, one atomicOr for each lane's
-// first and last word; `cutoff` marks where the window's part ends.
-constexpr int kEntWinWords = 2048;
+// A workgroup owns one contiguous bit range of the symbol section (and, for p-frames, one of the header section).  Its
+// lanes OR their bits into an LDS window anchored at the range's first word; the window leaves with coalesced dword
+// stores, only its first and last word -- shared with the neighbouring workgroups -- as atomicOr onto the zeroed
+// payload.  The window holds kEntWinWords * 32 bits (~6x the typical group at quality 5); a denser group sends the
+// finished words out whenever the next 256 symbols would not fit and re-anchors the window at the running offset.
+#ifndef PFV_ENT_WIN_WORDS
+#define PFV_ENT_WIN_WORDS 2048   // tests build a 64-word variant so that small frames reach the re-anchoring and memory paths
+#endif
+constexpr int kEntWinWords = PFV_ENT_WIN_WORDS;
 constexpr int kEntHdrWords = 64 * 16 / 32 + 2;   // 64 macroblocks x 16 header bits, plus unaligned ends
 
-// LSB-first bit writer of one lane.  kWindow: words are ORed into the workgroup's LDS window (ds_or_b32, nothing
-// returned, no branches); otherwise straight to memory, where the first and the last word a lane touches may be shared
-// with its neighbours (atomicOr onto the zeroed payload) and the words in between are its own (plain stores).
-template <bool kWindow>
-struct LaneBits {
-    uint32_t *w;
-    uint64_t acc = 0;
-    unsigned fill;
-    bool first = true;
-    __device__ __forceinline__ LaneBits(uint32_t *window, uint32_t *words, uint32_t word0, uint32_t bit_off)
-        : w(kWindow ? window + ((bit_off >> 5) - word0) : words + (bit_off >> 5)), fill(bit_off & 31u) {}
-    __device__ __forceinline__ void word_out(uint32_t x, bool last)
+// Bits at bit `off` of an LDS window (ds_or_b32, nothing returned): no carried accumulator and no branches -- ORing
+// zero bits is harmless, so every call touches all the words the longest case can reach.  ent_or_bits: bits < 2^45
+// (a code pair of at most 30 bits + 15 value bits) -> three words; ent_or_bits32: bits < 2^32 -> two words.
+__device__ __forceinline__ void ent_or_bits32(uint32_t *win, uint32_t off, uint32_t bits)
+{
+    const uint32_t sh = off & 31u;
+    uint32_t *w = win + (off >> 5);
+    const uint64_t x = (uint64_t)bits << sh;
+    atomicOr(w, (uint32_t)x);
+    atomicOr(w + 1, (uint32_t)(x >> 32));
+}
+__device__ __forceinline__ void ent_or_bits(uint32_t *win, uint32_t off, uint64_t bits)
+{
+    const uint32_t sh = off & 31u;
+    uint32_t *w = win + (off >> 5);
+    const uint64_t x = bits << sh;
+    atomicOr(w, (uint32_t)x);
+    atomicOr(w + 1, (uint32_t)(x >> 32));
+    atomicOr(w + 2, ((uint32_t)(bits >> 32) >> 1) >> (31u - sh));   // bits >> (64 - sh), 0 for sh == 0
+}
+
+// The same onto the zeroed payload in memory (a symbol that does not fit the window even after re-anchoring): every word
+// may be shared with a neighbour, so every non-zero word is an atomicOr.
+__device__ __forceinline__ void ent_or_bits_mem(uint32_t *words, uint32_t off, uint64_t bits)
+{
+    const uint32_t sh = off & 31u;
+    uint32_t *w = words + (off >> 5);
+    const uint64_t x = bits << sh;
+    const uint32_t x2 = ((uint32_t)(bits >> 32) >> 1) >> (31u - sh);
+    if ((uint32_t)x) atomicOr(w, (uint32_t)x);
+    if ((uint32_t)(x >> 32)) atomicOr(w + 1, (uint32_t)(x >> 32));
+    if (x2) atomicOr(w + 2, x2);
+}
+
+// inclusive prefix sum over the wavefront, DPP form (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31):
+// six v_add with a DPP operand instead of six ds_bpermute + compare + add
+__device__ __forceinline__ uint32_t ent_wave_scan_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------- k_ent_pack
+// One workgroup per group of k_ent_scan; the group's symbol list is walked 256 symbols at a time, lane = one symbol
+// (not one subblock: the lanes of a subblock-per-lane walk wait for the fullest subblock of the wavefront, 9-10 symbols
+// against a mean of 2-3 in a typical p-frame).  Per step: the symbol's code pair and bit length from the LDS tables,
+// workgroup prefix sum of the lengths (DPP scan + the four wavefront totals) on top of the running offset, then the bits
+// are ORed into the LDS window (enc.rs:307-316, :459-466: fillers, code pair, value bits).  A step that would run past
+// the window first sends the finished words out and re-anchors the window at the running offset.
+struct EntWindow {
+    uint32_t *win;        // LDS, kEntWinWords + 2 words
+    uint32_t *words;      // the stream's payload
+    uint32_t word0;       // payload word of win[0]
+    // Words [0, end_bit / 32) go out, the first as atomicOr (shared with the previous group or carried over from the
+    // previous anchor), the others as plain stores; the partial last word follows as atomicOr when `close`, else it is
+    // returned to be carried into the next anchor.  Workgroup-uniform arguments; the caller has a barrier on either side.
+    __device__ __forceinline__ uint32_t flush(uint32_t end_bit, bool close) const
     {
-        if (kWindow) atomicOr(w, x);
-        else if (first || last) atomicOr(w, x);
-        else *w = x;
-        w++;
-        first = false;
-    }
-    __device__ __forceinline__ void put(uint32_t bits, unsigned len)   // len <= 32, bits < 2^len
-    {
-        acc |= (uint64_t)bits << fill;
-        fill += len;
-        if (fill >= 32u) {
-            word_out((uint32_t)acc, false);
-            acc >>= 32;
-            fill -= 32u;
+        const uint32_t n_full = end_bit >> 5;
+        for (uint32_t i = threadIdx.x; i < n_full; i += kEntThreads) {
+            const uint32_t x = win[i];
+            if (i == 0) { if (x) atomicOr(&words[word0], x); }
+            else words[word0 + i] = x;
         }
-    }
-    __device__ __forceinline__ void finish()
-    {
-        if (fill && (uint32_t)acc) word_out((uint32_t)acc, true);
+        if (!(end_bit & 31u)) return 0;
+        const uint32_t x = win[n_full];
+        if (close) {
+            if (threadIdx.x == 0 && x) atomicOr(&words[word0 + n_full], x);
+            return 0;
+        }
+        return x;
     }
 };
 
-// One lane's run symbols -> bits (enc.rs:307-316, :459-466): fillers, the pre-joined code pair, the value bits.
-template <bool kWindow>
-__device__ __forceinline__ void ent_emit_symbols(LaneBits<kWindow> &bw, const uint32_t *sym, uint32_t n_sym, uint32_t w_next,
-                                                 const uint32_t *pair_bits, const uint8_t *pair_len)
-{
-    const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
-    for (uint32_t k = 0; k < n_sym; k++) {
-        const uint32_t w = w_next;
-        if (k + 1 < n_sym) w_next = sym[k + 1];   // next symbol on its way while this one is written
-        for (uint32_t fl = w >> 24; fl; fl--) bw.put(filler_bits, filler_len);
-        const uint32_t p = w & 255u, size = (w >> 4) & 15u;
-        const uint32_t pb = pair_bits[p], pl = pair_len[p], vb = (w >> 8) & 0x7fffu;
-        if (pl + size <= 32u) bw.put(pb | (vb << pl), pl + size);
-        else { bw.put(pb, pl); bw.put(vb, size); }
-    }
-    bw.finish();
-}
-
-__device__ __forceinline__ void ent_flush_window(const uint32_t *win, uint32_t *words, uint32_t word0, uint32_t end_bit)
-{
-    if (end_bit <= (word0 << 5)) return;
-    const uint32_t n = (end_bit - (word0 << 5) + 31u) >> 5;
-    for (uint32_t i = threadIdx.x; i < n; i += kEntThreads) {
-        const uint32_t x = win[i];
-        if (i == 0 || i == n - 1) {
-            if (x) atomicOr(&words[word0 + i], x);
-        } else {
-            words[word0 + i] = x;
-        }
-    }
-}
-
 __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
 {
-    __shared__ uint32_t win[kEntWinWords];
-    __shared__ uint32_t hwin[kEntHdrWords];
+    __shared__ uint32_t win[kEntWinWords + 2];   // + the two words ent_or_bits may touch past a symbol's last bit
+    __shared__ uint32_t hwin[kEntHdrWords + 1];
     __shared__ uint32_t pair_bits[256];
     __shared__ uint8_t pair_len[256];
     __shared__ uint32_t wave_tot[2][kEntThreads / 64];
-    __shared__ uint32_t cutoff;
-    const int stream = (int)blockIdx.y, n_sb = f.total_blocks * 4;
-    if (b.sizes[stream] >= kEntErrCapacity) return;   // uniform over the workgroup
-    const EntCodes *codes = b.codes + stream;
-    pair_bits[threadIdx.x] = codes->pair_bits[threadIdx.x];
-    pair_len[threadIdx.x] = codes->pair_len[threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < kEntWinWords / kEntThreads; k++) win[k * kEntThreads + (int)threadIdx.x] = 0;
-    if (threadIdx.x < kEntHdrWords) hwin[threadIdx.x] = 0;
-    if (threadIdx.x == 0) cutoff = 0xffffffffu;
-    const uint32_t *len4 = (const uint32_t *)codes->len;   // 16 code lengths, four to a word
-    const uint32_t l0 = len4[0], l1 = len4[1], l2 = len4[2], l3 = len4[3];
-    const int sbi = (int)blockIdx.x * kEntThreads + (int)threadIdx.x;
-    const bool live = sbi < n_sb;
-    const int mb = sbi >> 2, sb = sbi & 3;
-    const size_t sbase = (size_t)stream * n_sb;
-    const size_t bi = (size_t)stream * f.total_blocks + (live ? mb : 0);
-    // this lane's symbol bits (counts . code lengths + sizes) and block-header bits, then their place in the workgroup
-    uint32_t my_bits = 0, my_hdr = 0, lanew = 0;
-    int mvx = 0, mvy = 0;
-    if (live) {
-        const uint4 c4 = b.counts[sbase + sbi];
-        lanew = b.lanew[sbase + sbi];
-        my_bits = lanew & 1023u;
-        my_bits = __builtin_amdgcn_udot4(c4.x, l0, my_bits, false);
-        my_bits = __builtin_amdgcn_udot4(c4.y, l1, my_bits, false);
-        my_bits = __builtin_amdgcn_udot4(c4.z, l2, my_bits, false);
-        my_bits = __builtin_amdgcn_udot4(c4.w, l3, my_bits, false);
-        if (f.pframe && sb == 0) {
-            mvx = b.mv[2 * bi];
-            mvy = b.mv[2 * bi + 1];
-            my_hdr = (mvx != 0 || mvy != 0) ? 16u : 2u;
-        }
-    }
-    const uint32_t n_sym = (lanew >> 10) & 127u;
-    const uint32_t *sym = b.syms + ((size_t)stream * f.n_groups + blockIdx.x) * kEntGroupSyms + (lanew >> 17);
-    uint32_t w_next = n_sym ? sym[0] : 0;   // in flight across the offset computation
-    const uint32_t si = ent_wave_scan(my_bits), hi = ent_wave_scan(my_hdr);
-    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    if (lane == 63) { wave_tot[0][wave] = si; wave_tot[1][wave] = hi; }
-    __syncthreads();
+    __shared__ uint32_t cut;                     // window-relative bit where the symbols that went to memory start
+    __shared__ uint32_t hdr_total;
+    constexpr uint32_t kWinBits = (uint32_t)kEntWinWords * 32u, kNoCut = 0xffffffffu;
+    const int stream = (int)blockIdx.y;
+    ENT_MARK0();
+    ENT_MARK(1, 0);
+    // every global read of the kernel's head is issued here, before anything waits
+    const uint32_t stream_bytes = b.sizes[stream];
     const EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
-    const uint32_t sym_base = g->sym_base, hdr_base = g->hdr_base;
-    uint32_t sym_off = sym_base + si - my_bits, hdr_off = hdr_base + hi - my_hdr, sym_all = 0, hdr_all = 0;
-    for (int w = 0; w < kEntThreads / 64; w++) {
-        if (w < wave) { sym_off += wave_tot[0][w]; hdr_off += wave_tot[1][w]; }
-        sym_all += wave_tot[0][w];
-        hdr_all += wave_tot[1][w];
+    const uint32_t sym_base = g->sym_base, hdr_base = g->hdr_base, n_list = g->n_syms;
+    const uint32_t *gsyms = b.syms + ((size_t)stream * f.n_groups + blockIdx.x) * kEntGroupSyms;
+    uint32_t w_next = gsyms[threadIdx.x];        // the list's first 256 words exist whatever n_list is
+    const EntCodes *codes = b.codes + stream;
+    const uint32_t my_pair_bits = codes->pair_bits[threadIdx.x];
+    const uint8_t my_pair_len = codes->pair_len[threadIdx.x];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    // block headers (p-frames, enc.rs:414-451): the group's 64 macroblocks on wavefront 0
+    const int mbi = (int)blockIdx.x * (kEntThreads / 4) + lane;
+    uint32_t my_hdr = 0, hdr_bits = 0;
+    if (f.pframe && wave == 0 && mbi < f.total_blocks) {
+        const size_t bi = (size_t)stream * f.total_blocks + mbi;
+        const int mvx = b.mv[2 * bi], mvy = b.mv[2 * bi + 1];
+        const bool has_coef = b.has[bi] != 0;
+        my_hdr = (mvx != 0 || mvy != 0) ? 16u : 2u;
+        hdr_bits = (my_hdr == 16u ? 1u : 0u) | (has_coef ? 2u : 0u);
+        if (my_hdr == 16u) hdr_bits |= ((uint32_t)mvx & 0x7fu) << 2 | ((uint32_t)mvy & 0x7fu) << 9;
     }
-    const uint32_t word0 = sym_base >> 5, hword0 = hdr_base >> 5;
-    const bool in_window = sym_off + my_bits - (word0 << 5) <= (uint32_t)kEntWinWords * 32u;
-    if (!in_window && my_bits) atomicMin(&cutoff, sym_off);
+    if (stream_bytes >= kEntErrCapacity) return;   // uniform over the workgroup
 
-    uint32_t *words = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
-    if (my_hdr) {   // block header (enc.rs:414-451)
-        uint32_t bits = (my_hdr == 16u ? 1u : 0u) | (b.has[bi] ? 2u : 0u);
-        if (my_hdr == 16u) bits |= ((uint32_t)mvx & 0x7fu) << 2 | ((uint32_t)mvy & 0x7fu) << 9;
-        LaneBits<true> hw(hwin, words, hword0, hdr_off);
-        hw.put(bits, my_hdr);
-        hw.finish();
-    }
-    if (n_sym && in_window) {
-        LaneBits<true> bw(win, words, word0, sym_off);
-        ent_emit_symbols(bw, sym, n_sym, w_next, pair_bits, pair_len);
-    } else if (n_sym) {   // dense content: past the window, straight to memory
-        LaneBits<false> bw(win, words, word0, sym_off);
-        ent_emit_symbols(bw, sym, n_sym, w_next, pair_bits, pair_len);
-    }
+    pair_bits[threadIdx.x] = my_pair_bits;
+    pair_len[threadIdx.x] = my_pair_len;
+    for (int i = (int)threadIdx.x; i < kEntWinWords + 2; i += kEntThreads) win[i] = 0;
+    if (threadIdx.x <= kEntHdrWords) hwin[threadIdx.x] = 0;
+    if (threadIdx.x == 0) cut = kNoCut;
+    ENT_MARK(1, 1);
     __syncthreads();
-    ent_flush_window(win, words, word0, min(cutoff, sym_base + sym_all));
-    ent_flush_window(hwin, words, hword0, hdr_base + hdr_all);
+    ENT_MARK(1, 2);
+    uint32_t *words = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
+    const uint32_t hword0 = hdr_base >> 5;
+    if (f.pframe && wave == 0) {
+        const uint32_t hi = ent_wave_scan_dpp(my_hdr);
+        if (my_hdr) ent_or_bits32(hwin, (hdr_base & 31u) + hi - my_hdr, hdr_bits);
+        if (lane == 63) hdr_total = hi;
+    }
+
+    const uint32_t filler_bits = pair_bits[15], filler_len = pair_len[15];   // (15, size 0)
+    EntWindow wnd{win, words, sym_base >> 5};
+    uint32_t running = sym_base & 31u;           // window-relative bit of the next symbol (workgroup-uniform)
+    int parity = 0;
+    for (uint32_t base = 0; base < n_list; base += kEntThreads, parity ^= 1) {
+        const uint32_t j = base + threadIdx.x;
+        const bool active = j < n_list;
+        const uint32_t w = active ? w_next : 0u;
+        if (j + kEntThreads < n_list) w_next = gsyms[j + kEntThreads];   // the next step's word on its way
+        const uint32_t fillers = w >> 24, p = w & 255u, size = (w >> 4) & 15u;
+        const uint32_t pb = pair_bits[p], pl = pair_len[p], vb = (w >> 8) & 0x7fffu;
+        const uint32_t len = active ? fillers * filler_len + pl + size : 0u;
+        const uint32_t incl = ent_wave_scan_dpp(len);
+        if (lane == 63) wave_tot[parity][wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < kEntThreads / 64; k++) {
+            const uint32_t t = wave_tot[parity][k];
+            if (k < wave) before += t;
+            total += t;
+        }
+        if (running + total > kWinBits) {        // uniform: send the finished words out, anchor the window at `running`
+            const uint32_t stop = min(running, cut);
+            const uint32_t carry = wnd.flush(stop, stop != running);
+            __syncthreads();
+            for (int i = (int)threadIdx.x; i < kEntWinWords + 2; i += kEntThreads) win[i] = i ? 0u : carry;
+            if (threadIdx.x == 0) cut = kNoCut;
+            wnd.word0 += running >> 5;
+            running &= 31u;
+            __syncthreads();
+        }
+        uint32_t off = running + before + incl - len;
+        if (active) {
+            const uint64_t code = (uint64_t)pb | ((uint64_t)vb << pl);
+            if (off + len <= kWinBits) {
+                for (uint32_t fl = fillers; fl; fl--) {
+                    ent_or_bits32(win, off, filler_bits);
+                    off += filler_len;
+                }
+                ent_or_bits(win, off, code);
+            } else {                             // a single step larger than the window: its tail goes straight to memory
+                atomicMin(&cut, off);
+                uint32_t abs_off = (wnd.word0 << 5) + off;
+                for (uint32_t fl = fillers; fl; fl--) {
+                    ent_or_bits_mem(words, abs_off, filler_bits);
+                    abs_off += filler_len;
+                }
+                ent_or_bits_mem(words, abs_off, code);
+            }
+        }
+        running += total;
+    }
+    ENT_MARK(1, 5);
+    __syncthreads();
+    ENT_MARK(1, 6);
+    wnd.flush(min(running, cut), true);
+    const EntWindow hw{hwin, words, hword0};
+    if (f.pframe) hw.flush((hdr_base & 31u) + hdr_total, true);
+    ENT_MARK(1, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------- k_ent_gather

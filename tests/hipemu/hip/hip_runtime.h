@@ -99,21 +99,41 @@ static inline unsigned hipemu_udot4(unsigned a, unsigned b, unsigned c, bool)
     return c;
 }
 #define __builtin_amdgcn_udot4 hipemu_udot4
+template <class V>
+static inline unsigned hipemu_udot2(V a, V b, unsigned c, bool)
+{
+    unsigned short x[2], y[2];
+    static_assert(sizeof(V) == 4, "two 16-bit values");
+    __builtin_memcpy(x, &a, 4);
+    __builtin_memcpy(y, &b, 4);
+    return c + (unsigned)x[0] * y[0] + (unsigned)x[1] * y[1];
+}
+#define __builtin_amdgcn_udot2 hipemu_udot2
 static inline unsigned hipemu_alignbyte(unsigned hi, unsigned lo, unsigned sh)
 {
     uint64_t v = ((uint64_t)hi << 32) | lo;
     return (unsigned)(v >> (8 * (sh & 3)));
 }
 #define __builtin_amdgcn_alignbyte hipemu_alignbyte
-static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool)
+static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int, bool bound_ctrl)
 {
-    (void)old;
-    int lane = (int)(threadIdx.x & 63), from;
+    int lane = (int)(threadIdx.x & 63), from = lane;
+    bool valid = true;   // an invalid source lane leaves `old` in the destination (bound_ctrl: 0 instead)
     if (ctrl >= 0 && ctrl <= 0xff) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);   // quad_perm
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) {                                              // row_shr:n
+        const int n = ctrl & 15;
+        valid = (lane & 15) >= n;
+        from = valid ? lane - n : lane;
+    }
     else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));                       // row_mirror
     else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));                          // row_half_mirror
+    else if (ctrl == 0x142) { valid = lane >= 16; from = valid ? ((lane & ~15) - 1) : lane; }   // row_bcast:15
+    else if (ctrl == 0x143) { valid = lane >= 32; from = valid ? 31 : lane; }                   // row_bcast:31
     else abort();
-    return hipemu::wave_exchange(src, from);
+    const int got = hipemu::wave_exchange(src, from);
+    if (!((row_mask >> (lane >> 4)) & 1)) return old;
+    if (!valid) return bound_ctrl ? 0 : old;
+    return got;
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
 // global_load_lds: per-lane copy global -> LDS (the emulator has no lane-linear restriction; the kernels keep to it)

@@ -3,6 +3,8 @@ unmodified with g++ against tests/hipemu (every GPU thread a fiber, wavefront = 
 through the same C ABI and the same parity checks as the real-GPU tests, at tiny sizes.
 This is not the parity gate (that is tests/test_gpu_parity.py on a real MI355X); it keeps
 indexing / cross-lane / LDS-layout regressions from reaching the GPU box."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,6 +88,18 @@ def test_emu_device_entropy(pkg, emu_ctx, oracle):
     """k_ent_* (RLE + Huffman + bit packing on the device) vs the oracle's packet serialisers, byte for byte"""
     assert pc.check_device_entropy(pkg, emu_ctx, oracle, 48, 32, n_streams=2, seed=3) == 20
     assert pc.check_device_entropy(pkg, emu_ctx, oracle, 34, 18, n_streams=1, seed=4, kinds=("typical", "edges")) == 4
+
+
+def test_emu_device_entropy_small_window():
+    """the same check on a build whose k_ent_pack window holds 64 words instead of 2048: at these frame sizes the dense
+    and typical cases then re-anchor the window several times per group and single steps overflow it (memory path)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PFV_EMU_DEFS="-DPFV_ENT_WIN_WORDS=64")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
+                        os.path.abspath(__file__) + "::test_emu_device_entropy"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout
 
 
 def test_emu_sparse_decode(pkg, emu_ctx):
