@@ -108,28 +108,34 @@ __device__ __forceinline__ uint32_t ent_wave_sum(uint32_t v)
     for (int m = 1; m < 64; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
     return v;
 }
-// inclusive prefix sum over the wavefront
+// inclusive prefix sum over the wavefront, DPP form (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31):
+// six v_add with a DPP operand instead of six ds_bpermute + compare + add
 __device__ __forceinline__ uint32_t ent_wave_scan(uint32_t v)
 {
-    const int lane = (int)(threadIdx.x & 63u);
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = ent_shfl(v, lane >= d ? lane - d : lane);
-        if (lane >= d) v += up;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
 // Position of the last non-zero coefficient before subblock `sb` in macroblock order (-1: none), from the quad's bitmaps.
+template <int J>
+__device__ __forceinline__ uint64_t ent_quad_bcast(uint64_t v)   // lane J of the quad, DPP quad_perm [J, J, J, J]
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, J * 0x55, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), J * 0x55, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ int ent_prev_last(uint64_t mine, int sb)
 {
-    const int lane = (int)(threadIdx.x & 63u), q0 = lane & ~3;
+    const uint64_t m0 = ent_quad_bcast<0>(mine), m1 = ent_quad_bcast<1>(mine), m2 = ent_quad_bcast<2>(mine);
     int last = -1;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const uint32_t lo = ent_shfl((uint32_t)mine, q0 + j), hi = ent_shfl((uint32_t)(mine >> 32), q0 + j);
-        const uint64_t m = ((uint64_t)hi << 32) | lo;
-        if (j < sb && m) last = 64 * j + 63 - __builtin_clzll(m);
-    }
+    if (0 < sb && m0) last = 63 - __builtin_clzll(m0);
+    if (1 < sb && m1) last = 64 + 63 - __builtin_clzll(m1);
+    if (2 < sb && m2) last = 128 + 63 - __builtin_clzll(m2);
     return last;
 }
 
@@ -273,7 +279,8 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     __syncthreads();
     ENT_MARK(0, 4);
     uint32_t sym_off = incl - n_sym;
-    for (unsigned w = 0; w < (threadIdx.x >> 6); w++) sym_off += wave_syms[w];
+#pragma unroll
+    for (unsigned w = 0; w + 1 < kEntThreads / 64; w++) sym_off += w < (threadIdx.x >> 6) ? wave_syms[w] : 0u;
     uint32_t *out = b.syms + ((size_t)stream * f.n_groups + blockIdx.x) * kEntGroupSyms + sym_off;
 
     uint32_t *my_cnt = (uint32_t *)&cnt4[threadIdx.x];
@@ -565,19 +572,6 @@ __device__ __forceinline__ void ent_or_bits_mem(uint32_t *words, uint32_t off, u
     if (x2) atomicOr(w + 2, x2);
 }
 
-// inclusive prefix sum over the wavefront, DPP form (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31):
-// six v_add with a DPP operand instead of six ds_bpermute + compare + add
-__device__ __forceinline__ uint32_t ent_wave_scan_dpp(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------------------- k_ent_pack
 // One workgroup per group of k_ent_scan; the group's symbol list is walked 256 symbols at a time, lane = one symbol
 // (not one subblock: the lanes of a subblock-per-lane walk wait for the fullest subblock of the wavefront, 9-10 symbols
@@ -657,7 +651,7 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
     uint32_t *words = (uint32_t *)(b.payload + (size_t)stream * f.cap_bytes);
     const uint32_t hword0 = hdr_base >> 5;
     if (f.pframe && wave == 0) {
-        const uint32_t hi = ent_wave_scan_dpp(my_hdr);
+        const uint32_t hi = ent_wave_scan(my_hdr);
         if (my_hdr) ent_or_bits32(hwin, (hdr_base & 31u) + hi - my_hdr, hdr_bits);
         if (lane == 63) hdr_total = hi;
     }
@@ -674,7 +668,7 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_pack(EntFrame f, EntBufs b)
         const uint32_t fillers = w >> 24, p = w & 255u, size = (w >> 4) & 15u;
         const uint32_t pb = pair_bits[p], pl = pair_len[p], vb = (w >> 8) & 0x7fffu;
         const uint32_t len = active ? fillers * filler_len + pl + size : 0u;
-        const uint32_t incl = ent_wave_scan_dpp(len);
+        const uint32_t incl = ent_wave_scan(len);
         if (lane == 63) wave_tot[parity][wave] = incl;
         __syncthreads();
         uint32_t before = 0, total = 0;

@@ -19,7 +19,8 @@ n_groups = S * ((ss.n_mb * 4 + 255) // 256)
 assert n_groups <= 1 << 15
 rows = np.zeros((n_groups, 16), np.uint64)
 SCAN = ["issue loads, stage->LDS", "barrier", "bitmap+prefix", "barrier", "symbol walk", "tail sums", "barrier", "group outputs"]
-PACK = ["loads -> LDS init", "rest of list", "bits+scans", "barrier", "emit", "barrier", "flush"]
+PACK = ["loads -> LDS init", "barrier", "headers + symbol steps", "barrier", "flush"]
+PACK_MARKS = [0, 1, 2, 5, 6, 7]
 acc = {}
 for t in range(ss.n_frames):
     f = ss.frame_ptr(t)
@@ -31,8 +32,9 @@ for t in range(ss.n_frames):
     kind = "i-frame" if t == 0 else ("p-frame after the scene jump" if t == 8 else "p-frames")
     for k, names in ((0, SCAN), (1, PACK)):
         assert lib.pfv_debug_ent_profile(k, rows.ctypes.data_as(ctypes.c_void_p), n_groups) == 0
-        d = np.diff(rows[:, :len(names) + 1].astype(np.int64), axis=1)
-        span = int(rows[:, len(names)].max() - rows[:, 0].min())
+        marks = PACK_MARKS if k == 1 else list(range(len(names) + 1))
+        d = np.diff(rows[:, marks].astype(np.int64), axis=1)
+        span = int(rows[:, marks[-1]].max() - rows[:, 0].min())
         a = acc.setdefault((kind, k), [0, np.zeros(len(names)), 0, 0])
         a[0] += 1; a[1] += d.mean(0); a[2] += span; a[3] += d.sum(1).mean()
 for (kind, k), (n, d, span, life) in acc.items():
