@@ -2493,3 +2493,11 @@ extern "C" __attribute__((visibility("default"))) int pfv_debug_ent_profile(int 
     return 0;
 }
 #endif
+
+#ifdef PFV_KPROF   // experiment builds only (tools/kprof.py): the timestamp rows of the last k_enc_pframe launch
+extern "C" __attribute__((visibility("default"))) int pfv_debug_kprof(unsigned long long *out, int n_rows)
+{
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pfv::pfv_kprof), sizeof(unsigned long long) * 16 * (size_t)n_rows) == hipSuccess ? 0 : -1;
+}
+#endif

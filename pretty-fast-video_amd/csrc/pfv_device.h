@@ -6,8 +6,11 @@
 namespace pfv {
 
 constexpr int kStripMB = 8;     // macroblocks per wavefront: a 128 x 16 pixel strip, 8 lanes per macroblock
-constexpr int kStripsPerWG = 4; // wavefronts (= strips) per workgroup
-constexpr int kThreads = 256;
+#ifndef PFV_STRIPS_PER_WG
+#define PFV_STRIPS_PER_WG 4     // tuning constant (measured: 2 and 4 within 1 % of each other)
+#endif
+constexpr int kStripsPerWG = PFV_STRIPS_PER_WG; // wavefronts (= strips) per workgroup
+constexpr int kThreads = 64 * kStripsPerWG;
 
 // Per-plane quantiser constants, prepared on the host from one reference q-table
 // (int32_t[64], raster order, entries in [1,65535]).

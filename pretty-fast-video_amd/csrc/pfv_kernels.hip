@@ -60,7 +60,7 @@ constexpr int kWinChunksPerRow = kWinStride / 16;                               
 constexpr int kWinIssues = (kWinRows * kWinChunksPerRow + 63) / 64;                  // 17 wave-wide 1 KiB LDS-DMA loads per window
 constexpr int kWinAlloc = kWinIssues * 1024;                                         // 17 KiB per window buffer
 // wavefront w issues (and later owns as its exchange region) the contiguous loads [first(w), first(w+1)): 5,4,4,4
-__device__ __forceinline__ constexpr int win_first_issue(int w) { return w == 0 ? 0 : 1 + 4 * w; }
+__device__ __forceinline__ constexpr int win_first_issue(int w) { return (w * kWinIssues + kStripsPerWG - 1) / kStripsPerWG; }
 static_assert(win_first_issue(kStripsPerWG) == kWinIssues, "window issue split");
 constexpr int kMBPitch = 2 * 64;                   // dwords per macroblock in the exchange region (bank spread by XOR swizzle)
 constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 1024 dwords = 4 KiB
@@ -734,6 +734,14 @@ __device__ __forceinline__ unsigned sq2(unsigned x, unsigned y, unsigned acc)
 }
 __device__ __forceinline__ unsigned sq4(unsigned b0, unsigned b1, unsigned b2, unsigned b3, unsigned acc) { return sq2(b2, b3, sq2(b0, b1, acc)); }
 
+#ifdef PFV_KPROF   // experiment builds only (tools/kprof.py): clock64 of thread 0 at the marks, one row of 16 per workgroup
+constexpr int kProfRows = 1 << 16;
+__device__ unsigned long long pfv_kprof[kProfRows][16];
+#define KMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < kProfRows) pfv_kprof[blockIdx.x][i] = clock64(); } while (0)
+#else
+#define KMARK(i) do {} while (0)
+#endif
+
 // What one lane of a macroblock needs to finalise "its" candidate of a search level: after the dot products every
 // lane holds a partial sum (its two rows) for each of the 8 neighbours; the partials are transposed through a small
 // wavefront-private LDS region (8 ds_write_b32 + 2 ds_read_b128 per lane: LDS-pipe work) so that lane c ends up with
@@ -1019,10 +1027,14 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
     const bool interior = sp.x0 >= 16 && sp.x0 + kStripMB * 16 + 16 <= p.pw && sp.y0 >= 16 && sp.y0 + 32 <= p.ph;   // wave-uniform
     if (interior) {
         search_level<8, true, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        KMARK(3);
 #ifndef PFV_ABL_SEARCH1   // ablation experiment only (results invalid): first search level alone
         search_level<4, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        KMARK(4);
         search_level<2, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        KMARK(5);
         search_level<1, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        KMARK(6);
 #endif
     } else {
         search_level<8, true, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
@@ -1091,6 +1103,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                 forward_half_f(x, xw, m, i, lq);
                 store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
                 wave_lds_sync();
+                if (h == 0) KMARK(9);
                 if (recon) {
                     inverse_half_f(x, xw, m, i, lq);
 #pragma unroll
@@ -1100,6 +1113,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                     }
                     if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row_f(pp);
                 }
+                if (h == 0) KMARK(10);
             } else {
                 int v[2][8], pp[2][8];
                 unpack_row(srow, v);
@@ -1168,6 +1182,13 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     const PlaneGeom &p = g.p[cur.sp.plane];
     if (wave == 0) fill_qtable<true, FLT>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
 
+    KMARK(0);
+#ifdef PFV_KPROF
+    if (threadIdx.x == 0 && blockIdx.x < kProfRows) {   // where the workgroup runs: HW_ID (cu / sh / se ids) and XCC_ID
+        pfv_kprof[blockIdx.x][12] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        pfv_kprof[blockIdx.x][13] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+    }
+#endif
     issue_window(p, ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off, cur, win, wave, lane);
     uint4 rows[2];
     rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
@@ -1176,15 +1197,20 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
         rows[0] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i);
         rows[1] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i + 8);
     }
+    KMARK(1);
     __syncthreads();   // window complete (vmcnt drained at the barrier)
+    KMARK(2);
     SearchOut so;
     so.cx = so.cy = 0; so.coded = false;
     so.patch[0] = so.patch[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, neg2, so);
+    KMARK(7);
     __syncthreads();   // window released by every wavefront
+    KMARK(8);
     if (cur.wave_valid)
         penc_transform<FLT>(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
                        recon, qtab_lds);
+    KMARK(11);
 }
 
 // ================================================================== I-frame decode
