@@ -20,7 +20,7 @@ def build_emulator() -> str:
     """g++ build of the UNMODIFIED csrc/ sources against tests/hipemu (CPU fiber emulator)."""
     csrc = os.path.join(ROOT, "pretty-fast-video_amd", "csrc")
     emu = os.path.join(ROOT, "tests", "hipemu")
-    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(emu, "hipemu.cpp"),
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if os.path.isfile(os.path.join(csrc, f))] + [os.path.join(emu, "hipemu.cpp"),
                                                                 os.path.join(emu, "hip", "hip_runtime.h"),
                                                                 os.path.join(ROOT, "include", "pfv_hip.h")]
     defs = os.environ.get("PFV_EMU_DEFS", "").split()      # developer switch: e.g. -DPFV_PENC_PERSISTENT
