@@ -1028,29 +1028,21 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
     if (interior) {
         search_level<8, true, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(3);
-#ifndef PFV_ABL_SEARCH1   // ablation experiment only (results invalid): first search level alone
         search_level<4, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(4);
         search_level<2, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(5);
         search_level<1, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(6);
-#endif
     } else {
         search_level<8, true, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
-#ifndef PFV_ABL_SEARCH1
         search_level<4, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         search_level<2, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         search_level<1, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
-#endif
     }
 
     // skip decision (src/common.rs:209, :221): best_err <= px_err^2 * 256, compared in f32
-#ifdef PFV_ABL_NOXFORM   // ablation experiment only (results invalid): never code
-    so.coded = mb_valid && !((float)st.err <= 1e30f);
-#else
     so.coded = mb_valid && !((float)st.err <= min_err);
-#endif
     so.cx = st.cx; so.cy = st.cy;
 
     // the lane's two rows of the chosen patch (get_block of the reconstruction, :261)
