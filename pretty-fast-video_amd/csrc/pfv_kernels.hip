@@ -585,19 +585,22 @@ __device__ __forceinline__ void forward_half_f(f2 (&x)[8], int *xw, int m, int i
     for (int k = 0; k < 8; k++) {
         const int scale = lq.scale(k), zz = lq.zz(k);
         const float rcp = lq.rcp(k);
+        f2 n;
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int n = wmul24((int)x[k][s], scale) >> 16;          // the transform output is an exact integer
-            const float q = __builtin_truncf((float)n * rcp);         // n / q, truncating (QTab::rcp)
-            x[k][s] = q;
-            stage[s * 64 + zz] = (int16_t)(int)q;
-        }
+        for (int s = 0; s < 2; s++) n[s] = (float)(wmul24((int)x[k][s], scale) >> 16);   // the transform output is an exact integer
+        x[k] = f2trunc(n * f2s(rcp));                                   // n / q, truncating (QTab::rcp); one v_pk_mul_f32 for the pair
+        // the 16-bit store takes the low half of the register: |q| < 2^15, so q + 1.5 * 2^23 carries q's two's complement in
+        // its low mantissa bits -- one packed add for the pair instead of two float -> int conversions
+        const f2 biased = x[k] + f2s(12582912.0f);
+#pragma unroll
+        for (int s = 0; s < 2; s++) stage[s * 64 + zz] = (int16_t)__float_as_int(biased[s]);
     }
     wave_lds_sync();
 }
 // Inverse, float form: c = quantised coefficients in column layout (floats) -> row-layout t = floor(x / 256) (floats); the
 // callers add the prediction / 128 and clamp.  lq.deqf = SCALE[z] * q[z] as float (fill_qtable<true, true>).
-__device__ __forceinline__ void inverse_half_f(f2 (&c)[8], int *xw, int m, int i, const LaneQ &lq)
+// bias: added to the result (an integer; the i-frame path's + 128 rides in the final fma)
+__device__ __forceinline__ void inverse_half_f(f2 (&c)[8], int *xw, int m, int i, const LaneQ &lq, float bias = 0.0f)
 {
     int *mb = xw + m * kMBPitch;
 #pragma unroll
@@ -606,7 +609,7 @@ __device__ __forceinline__ void inverse_half_f(f2 (&c)[8], int *xw, int m, int i
     f_cols_to_rows(c, mb, i, m & 3);
     fidct8(c);   // dct_inverse_transform_rows
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = f2floor(c[k] * f2s(1.0f / 256.0f));     // v >> 8
+    for (int k = 0; k < 8; k++) c[k] = f2floor(c[k] * f2s(1.0f / 256.0f) + f2s(bias));     // (v >> 8) + bias: |v| < 2^24, exact
 }
 // 16 reconstructed pixels (floats, integer-valued) -> saturated bytes: v_cvt_pk_u8_f32 clamps to 0..255 and places the byte
 __device__ __forceinline__ uint4 pack_row_f(const f2 (&px)[8])
@@ -671,9 +674,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
             store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
             wave_lds_sync();   // the stage has been read back before the region is reused
             if (recon) {
-                inverse_half_f(x, xw, m, i, lq);
-#pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = x[k] + f2s(128.0f);               // the pack saturates to 0..255 (src/common.rs:321)
+                inverse_half_f(x, xw, m, i, lq, 128.0f);                              // + 128; the pack saturates to 0..255 (src/common.rs:321)
                 if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row_f(x);
             }
         } else {
