@@ -226,14 +226,13 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
 {
     __shared__ uint64_t rows[kEntThreads * kEntRow64];
     __shared__ uint4 cnt4[kEntThreads];
-    __shared__ uint32_t blk[10];
+    __shared__ uint32_t part[kEntThreads / 16][10];   // per 16-lane row: 8 count words, size sum, header bits
     __shared__ uint32_t wave_syms[kEntThreads / 64];
     const int stream = (int)blockIdx.y, n_sb = f.total_blocks * 4;
     const int sb0 = (int)blockIdx.x * kEntThreads;
     const int sbi = sb0 + (int)threadIdx.x;
     const bool live = sbi < n_sb;
     const int mb = sbi >> 2, sb = sbi & 3;
-    if (threadIdx.x < 10) blk[threadIdx.x] = 0;
     ENT_MARK0();
     ENT_MARK(0, 0);
     const size_t bi = (size_t)stream * f.total_blocks + (live ? mb : 0);
@@ -331,37 +330,39 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_scan(EntFrame f, EntBufs b)
     ent_wave_lds_sync();
     const uint4 c4 = cnt4[threadIdx.x];
 
-    // workgroup totals: counts widened to 16-bit fields (two symbols per word; at most 256 * 164 per field)
+    // workgroup totals: counts widened to 16-bit fields (two symbols per word; at most 256 * 164 per field), summed over each
+    // 16-lane row with DPP; the 16 row totals go to LDS with plain stores and are added up after the barrier (LDS atomics on
+    // one address from four lanes of a wavefront are turned into a scalar loop over the lanes by the compiler -- ten of
+    // those cost more than the sums themselves)
     const uint32_t w8[4] = {c4.x, c4.y, c4.z, c4.w};
     const bool lead = (threadIdx.x & 15u) == 0;
+    uint32_t *my_part = part[threadIdx.x >> 4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t a = ent_row_sum((w8[j] & 0xffu) | ((w8[j] & 0xff00u) << 8));
         const uint32_t c2 = ent_row_sum(((w8[j] >> 16) & 0xffu) | ((w8[j] >> 24) << 16));
-        if (lead) {
-            if (a) atomicAdd(&blk[2 * j], a);
-            if (c2) atomicAdd(&blk[2 * j + 1], c2);
-        }
+        if (lead) { my_part[2 * j] = a; my_part[2 * j + 1] = c2; }
     }
     const uint32_t ws = ent_row_sum(sumsize), wh = ent_row_sum(hdr_bits);
-    if (lead) {
-        atomicAdd(&blk[8], ws);
-        if (wh) atomicAdd(&blk[9], wh);
-    }
+    if (lead) { my_part[8] = ws; my_part[9] = wh; }
     if (__any(maxsize > 15u) && (threadIdx.x & 63u) == 0) atomicOr(&b.codes[stream].oversize, 1u);
     ENT_MARK(0, 6);
     __syncthreads();
     ENT_MARK(0, 7);
-    EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
-    if (threadIdx.x < 8) g->counts[threadIdx.x] = blk[threadIdx.x];
-    if (threadIdx.x == 8) g->sumsize = blk[8];
-    if (threadIdx.x == 9) g->hdr_bits = blk[9];
-    if (threadIdx.x == 10) g->n_syms = wave_syms[0] + wave_syms[1] + wave_syms[2] + wave_syms[3];
-    if (threadIdx.x >= 16 && threadIdx.x < 32) {
-        const unsigned sym = threadIdx.x - 16u;
-        const uint32_t w = blk[sym >> 1];
-        const uint32_t n = (sym & 1u) ? (w >> 16) : (w & 0xffffu);
-        if (n) atomicAdd(&b.hist[stream * 16 + (int)sym], (int32_t)n);
+    if (threadIdx.x < 32) {   // threads 0..9: total k = thread; threads 16..31: symbol (thread - 16) of the frame histogram
+        const unsigned sym = threadIdx.x - 16u, k = threadIdx.x < 16 ? min(threadIdx.x, 9u) : sym >> 1;
+        uint32_t total = 0;
+#pragma unroll
+        for (int r = 0; r < kEntThreads / 16; r++) total += part[r][k];
+        EntGroup *g = b.groups + (size_t)stream * f.n_groups + blockIdx.x;
+        if (threadIdx.x < 8) g->counts[threadIdx.x] = total;
+        if (threadIdx.x == 8) g->sumsize = total;
+        if (threadIdx.x == 9) g->hdr_bits = total;
+        if (threadIdx.x == 10) g->n_syms = wave_syms[0] + wave_syms[1] + wave_syms[2] + wave_syms[3];
+        if (threadIdx.x >= 16) {
+            const uint32_t n = (sym & 1u) ? (total >> 16) : (total & 0xffffu);
+            if (n) atomicAdd(&b.hist[stream * 16 + (int)sym], (int32_t)n);
+        }
     }
     ENT_MARK(0, 8);
 }
