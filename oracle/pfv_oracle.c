@@ -583,6 +583,35 @@ PFVO_API void pfvo_blit(uint8_t *dst, int dstw, const uint8_t *src, int srcw, in
         memcpy(dst + (size_t)(row + dy) * dstw + dx, src + (size_t)(row + sy) * srcw + sx, (size_t)sw);
 }
 
+/* src/common.rs:523-536  VideoPlane::reduce: a (width / 2) x (height / 2) plane (integer division) holding the
+ * pixel at (2 ix, 2 iy) of every 2 x 2 cell -- point sampling, no averaging. */
+PFVO_API void pfvo_reduce(const uint8_t *src, int srcw, int srch, uint8_t *dst)
+{
+    int nw = srcw / 2, nh = srch / 2;
+    for (int iy = 0; iy < nh; iy++)
+        for (int ix = 0; ix < nw; ix++) {
+            int sx = ix * 2, sy = iy * 2;
+            dst[ix + (size_t)iy * nw] = src[sx + (size_t)sy * srcw];
+        }
+}
+
+/* src/common.rs:538-556  VideoPlane::double: a (2 width) x (2 height) plane, every source pixel written to the four
+ * positions d_idx, d_idx + 1, d_idx + new_width, d_idx + new_width + 1. */
+PFVO_API void pfvo_double(const uint8_t *src, int srcw, int srch, uint8_t *dst)
+{
+    int nw = srcw * 2;
+    for (int iy = 0; iy < srch; iy++)
+        for (int ix = 0; ix < srcw; ix++) {
+            int dx = ix * 2, dy = iy * 2;
+            size_t d_idx = (size_t)dx + (size_t)dy * nw;
+            uint8_t px = src[ix + (size_t)iy * srcw];
+            dst[d_idx] = px;
+            dst[d_idx + 1] = px;
+            dst[d_idx + nw] = px;
+            dst[d_idx + nw + 1] = px;
+        }
+}
+
 /* ---------------------------------------------------------------- session level */
 /* src/enc.rs:40-51  q-table derivation: max(1.0, base as f32 * qscale [* 0.5]) as i32 */
 PFVO_API void pfvo_qtables(int quality, int32_t intra_l[64], int32_t intra_c[64], int32_t inter_l[64],

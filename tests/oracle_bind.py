@@ -44,7 +44,34 @@ class Oracle:
         L.pfvo_encode_iframe.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.pfvo_encode_pframe.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.pfvo_blit.argtypes = [c_void_p, c_int, c_void_p, c_int] + [c_int] * 6
+        L.pfvo_blit.restype = None
+        L.pfvo_reduce.argtypes = L.pfvo_double.argtypes = [c_void_p, c_int, c_int, c_void_p]
+        L.pfvo_reduce.restype = L.pfvo_double.restype = None
         self.L = L
+
+    # ---- plane container ops (src/plane.rs:20-29, src/common.rs:523-556)
+    def blit(self, dst, src, dx, dy, sx, sy, sw, sh):
+        """VideoPlane::blit on 2-D u8 arrays; returns the new destination (dst is not modified)"""
+        d = np.ascontiguousarray(dst, dtype=np.uint8).copy()
+        s = np.ascontiguousarray(src, dtype=np.uint8)
+        assert 0 <= dx and dx + sw <= d.shape[1] and 0 <= dy and dy + sh <= d.shape[0]
+        assert 0 <= sx and sx + sw <= s.shape[1] and 0 <= sy and sy + sh <= s.shape[0]
+        self.L.pfvo_blit(_p(d), d.shape[1], _p(s), s.shape[1], dx, dy, sx, sy, sw, sh)
+        return d
+
+    def reduce(self, src):
+        s = np.ascontiguousarray(src, dtype=np.uint8)
+        h, w = s.shape
+        out = np.zeros((h // 2, w // 2), dtype=np.uint8)
+        self.L.pfvo_reduce(_p(s), w, h, _p(out))
+        return out
+
+    def double(self, src):
+        s = np.ascontiguousarray(src, dtype=np.uint8)
+        h, w = s.shape
+        out = np.zeros((h * 2, w * 2), dtype=np.uint8)
+        self.L.pfvo_double(_p(s), w, h, _p(out))
+        return out
 
     # ---- 1-D / subblock
     def fdct8(self, v):

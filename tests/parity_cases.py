@@ -119,6 +119,70 @@ def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames,
     return stats
 
 
+def check_session_batched_dev(pkg, ctx, oracle, width, height, quality, seeds, n_frames=2, gop=15, threads=1):
+    """The BENCHED shape (bench.py StreamSet.step): len(seeds) streams in ONE launch per frame operation through the
+    device-pointer entry points, frames generated on the device, retframe crop fused into the decode kernels -- and then
+    every byte of every stream (coefficients, motion vectors, skip flags, encoder reconstruction, decoder framebuffer,
+    cropped retframe) against the oracle, stream by stream.  With 96 x 1080p the stream offsets reach 601 MB into the
+    coefficient buffer."""
+    S = len(seeds)
+    enc = pkg.EncoderSession(ctx, width, height, quality, S)
+    dec = pkg.DecoderSession(ctx, width, height, np.stack(pkg.qtables_from_quality(quality)[:4]), S)
+    nb, fb, pfb = enc.total_blocks, enc.frame_bytes, enc.padded_frame_bytes
+    d_frames = ctx.alloc(S * fb)
+    d_coef, d_mv, d_has = ctx.alloc(S * nb * 512), ctx.alloc(S * nb * 2), ctx.alloc(S * nb)
+    d_out = ctx.alloc(S * fb)
+    dec.set_output_dev(d_out)
+    oencs = [oracle.encoder(width, height, quality, threads) for _ in range(S)]
+    frames = np.empty((S, fb), np.uint8)
+    coef = np.empty((S, nb, 256), np.int16)
+    mv, has = np.empty((S, nb, 2), np.int8), np.empty((S, nb), np.uint8)
+    out = np.empty((S, fb), np.uint8)
+    stats = {"coded": 0, "mbs": 0, "streams": S}
+    for t in range(n_frames):
+        ctx.synth_frames_dev(width, height, seeds, t, d_frames)
+        if t % gop == 0:
+            enc.encode_iframe_dev(d_frames, d_coef)
+            dec.decode_iframe_dev(d_coef)
+        else:
+            enc.encode_pframe_dev(d_frames, d_mv, d_has, d_coef)
+            dec.decode_pframe_dev(d_mv, d_has, d_coef)
+        dec.check()
+        ctx.download(frames, d_frames)
+        ctx.download(coef, d_coef)
+        ctx.download(out, d_out)
+        if t % gop:
+            ctx.download(mv, d_mv)
+            ctx.download(has, d_has)
+            stats["coded"] += int(has.sum())
+            stats["mbs"] += has.size
+        recon, fbuf = enc.prev_frame(), dec.framebuffer()
+        for s in (0, S - 1):          # the device generator against synth.py for the first and the last stream
+            assert np.array_equal(frames[s], pkg.SyntheticStream(width, height, seed=int(seeds[s])).frame(t)), f"frame {t} stream {s}: generator"
+        for s in range(S):
+            if t % gop == 0:
+                ocoef = oencs[s].encode_iframe(frames[s])
+            else:
+                omv, ohas, ocoef = oencs[s].encode_pframe(frames[s])
+                assert np.array_equal(mv[s], omv), f"frame {t} stream {s}: motion vectors differ"
+                assert np.array_equal(has[s], ohas), f"frame {t} stream {s}: skip flags differ"
+            assert np.array_equal(coef[s], ocoef), f"frame {t} stream {s}: coefficients differ"
+            oprev = oencs[s].prev_frame()
+            assert np.array_equal(recon[s], oprev), f"frame {t} stream {s}: encoder reconstruction differs"
+            assert np.array_equal(fbuf[s], oprev), f"frame {t} stream {s}: decoder framebuffer differs"
+            f = pkg.VideoFrame.from_packed(width, height, oprev, padded=True)
+            crop = np.concatenate([f.plane_y.image()[:height, :width].reshape(-1),
+                                   f.plane_u.image()[:height // 2, :width // 2].reshape(-1),
+                                   f.plane_v.image()[:height // 2, :width // 2].reshape(-1)])
+            assert np.array_equal(out[s], crop), f"frame {t} stream {s}: fused retframe differs"
+    dec.set_output_dev(None)
+    for p in (d_frames, d_coef, d_mv, d_has, d_out):
+        ctx.free(p)
+    enc.close()
+    dec.close()
+    return stats
+
+
 def check_golden(pkg, ctx, oracle):
     """the HIP path against the committed known-answer vectors (tests/golden/hotpath_vectors.npz)"""
     import os
@@ -183,30 +247,97 @@ def check_trap_vectors(pkg, ctx, oracle):
     assert np.array_equal(rec, want)
 
 
-def check_colour_utils(pkg, ctx):
-    """VideoPlane::reduce / double on the device vs the host container ops (src/common.rs:523-556)"""
+def check_colour_utils(pkg, ctx, oracle):
+    """pfv_reduce_dev / pfv_double_dev against the ORACLE's VideoPlane::reduce / double (src/common.rs:523-556,
+    oracle/pfv_oracle.c pfvo_reduce / pfvo_double); the package's own numpy mirror is checked against the oracle too"""
     import ctypes
     rng = np.random.default_rng(8)
-    for (w, h) in [(37, 21), (64, 48), (2, 2), (1, 1)]:
-        src = pkg.VideoPlane.from_slice(w, h, rng.integers(0, 256, w * h, dtype=np.uint8))
+    for (w, h) in [(37, 21), (64, 48), (2, 2), (1, 1), (3, 1), (1, 3), (640, 360), (1921, 1081), (5, 4096)]:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        src = pkg.VideoPlane.from_slice(w, h, img)
         d_src = ctx.alloc(max(w * h, 1))
         ctx.upload(d_src, src.pixels)
-        red = src.reduce()
-        if red.pixels.size:
-            d_red = ctx.alloc(red.pixels.size)
+        want = oracle.reduce(img)
+        assert np.array_equal(src.reduce().image(), want), ("host mirror reduce", w, h)
+        if want.size:
+            d_red = ctx.alloc(want.size + 16)
+            guard = np.full(want.size + 16, 0xA5, np.uint8)
+            ctx.upload(d_red, guard)
             ctx.check(ctx._lib.pfv_reduce_dev(ctx.handle, ctypes.c_void_p(d_red), ctypes.c_void_p(d_src), w, h))
-            out = np.empty(red.pixels.size, np.uint8)
+            out = np.empty(want.size + 16, np.uint8)
             ctx.download(out, d_red)
-            assert np.array_equal(out, red.pixels), ("reduce", w, h)
+            assert np.array_equal(out[:want.size], want.reshape(-1)), ("reduce", w, h)
+            assert (out[want.size:] == 0xA5).all(), ("reduce wrote past its plane", w, h)
             ctx.free(d_red)
-        dbl = src.double()
-        d_dbl = ctx.alloc(dbl.pixels.size)
+        want = oracle.double(img)
+        assert np.array_equal(src.double().image(), want), ("host mirror double", w, h)
+        d_dbl = ctx.alloc(want.size + 16)
+        guard = np.full(want.size + 16, 0x5A, np.uint8)
+        ctx.upload(d_dbl, guard)
         ctx.check(ctx._lib.pfv_double_dev(ctx.handle, ctypes.c_void_p(d_dbl), ctypes.c_void_p(d_src), w, h))
-        out = np.empty(dbl.pixels.size, np.uint8)
+        out = np.empty(want.size + 16, np.uint8)
         ctx.download(out, d_dbl)
-        assert np.array_equal(out, dbl.pixels), ("double", w, h)
+        assert np.array_equal(out[:want.size], want.reshape(-1)), ("double", w, h)
+        assert (out[want.size:] == 0x5A).all(), ("double wrote past its plane", w, h)
         ctx.free(d_dbl)
         ctx.free(d_src)
+
+
+def check_blit_dev(pkg, ctx, oracle, n_random=64, seed=5):
+    """pfv_blit_dev against the ORACLE's VideoPlane::blit (src/plane.rs:20-29, pfvo_blit): random rectangles between
+    planes of unrelated widths plus the corner cases -- one pixel, one row, one column, the full plane, rectangles that
+    touch every edge of source and destination, unaligned origins and widths.  Everything outside the rectangle must
+    keep its old value.  The package's numpy mirror (VideoPlane.blit) is held to the same oracle."""
+    import ctypes
+    rng = np.random.default_rng(seed)
+    geoms = [((100, 40), (64, 64)), ((1920, 1080), (1920, 1088)), ((17, 33), (33, 17)), ((1, 1), (1, 1)), ((255, 3), (300, 7))]
+    n_checked = 0
+    for (sw_, sh_), (dw_, dh_) in geoms:
+        simg = rng.integers(0, 256, (sh_, sw_), dtype=np.uint8)
+        dimg = rng.integers(0, 256, (dh_, dw_), dtype=np.uint8)
+        d_src, d_dst = ctx.alloc(simg.size), ctx.alloc(dimg.size)
+        ctx.upload(d_src, simg)
+        mw, mh = min(sw_, dw_), min(sh_, dh_)
+        rects = [(0, 0, 0, 0, 1, 1),                                   # one pixel, origin
+                 (dw_ - 1, dh_ - 1, sw_ - 1, sh_ - 1, 1, 1),           # one pixel, last corner of both
+                 (0, 0, 0, 0, mw, mh),                                 # the largest common rectangle, top left
+                 (dw_ - mw, dh_ - mh, sw_ - mw, sh_ - mh, mw, mh),     # ... bottom right: touches right / bottom edges
+                 (0, dh_ - 1, 0, 0, mw, 1),                            # one row into the last row
+                 (dw_ - 1, 0, 0, 0, 1, mh),                            # one column into the last column
+                 (0, 0, sw_ - 1, 0, 1, mh)]                            # last source column
+        if sw_ == dw_ and sh_ <= dh_:
+            rects.append((0, 0, 0, 0, sw_, sh_))                       # full-plane copy (the pad blit of common.rs:356)
+        for _ in range(n_random if mw > 1 else 2):
+            w = int(rng.integers(1, mw + 1)); h = int(rng.integers(1, mh + 1))
+            rects.append((int(rng.integers(0, dw_ - w + 1)), int(rng.integers(0, dh_ - h + 1)),
+                          int(rng.integers(0, sw_ - w + 1)), int(rng.integers(0, sh_ - h + 1)), w, h))
+        for (dx, dy, sx, sy, w, h) in rects:
+            ctx.upload(d_dst, dimg)
+            ctx.check(ctx._lib.pfv_blit_dev(ctx.handle, ctypes.c_void_p(d_dst), dw_, dh_, ctypes.c_void_p(d_src), sw_, sh_,
+                                            dx, dy, sx, sy, w, h))
+            out = np.empty(dimg.shape, np.uint8)
+            ctx.download(out, d_dst)
+            want = oracle.blit(dimg, simg, dx, dy, sx, sy, w, h)
+            assert np.array_equal(out, want), ("pfv_blit_dev", (sw_, sh_), (dw_, dh_), (dx, dy, sx, sy, w, h))
+            n_checked += 1
+        # the host mirror, a few rectangles per geometry
+        for (dx, dy, sx, sy, w, h) in rects[:12]:
+            dst = pkg.VideoPlane.from_slice(dw_, dh_, dimg)
+            dst.blit(pkg.VideoPlane.from_slice(sw_, sh_, simg), dx, dy, sx, sy, w, h)
+            assert np.array_equal(dst.image(), oracle.blit(dimg, simg, dx, dy, sx, sy, w, h)), "host mirror blit"
+        # empty rectangles are legal no-ops (0..0 loops in the reference); rectangles outside either plane are errors
+        ctx.upload(d_dst, dimg)
+        ctx.check(ctx._lib.pfv_blit_dev(ctx.handle, ctypes.c_void_p(d_dst), dw_, dh_, ctypes.c_void_p(d_src), sw_, sh_, 0, 0, 0, 0, 0, 1))
+        ctx.check(ctx._lib.pfv_blit_dev(ctx.handle, ctypes.c_void_p(d_dst), dw_, dh_, ctypes.c_void_p(d_src), sw_, sh_, 0, 0, 0, 0, 1, 0))
+        out = np.empty(dimg.shape, np.uint8)
+        ctx.download(out, d_dst)
+        assert np.array_equal(out, dimg)
+        for bad in ((dw_, 0, 0, 0, 1, 1), (0, dh_, 0, 0, 1, 1), (0, 0, sw_, 0, 1, 1), (0, 0, 0, sh_, 1, 1), (0, 0, 0, 0, mw + max(sw_, dw_), 1),
+                    (-1, 0, 0, 0, 1, 1), (0, 0, 0, -1, 1, 1)):
+            rc = ctx._lib.pfv_blit_dev(ctx.handle, ctypes.c_void_p(d_dst), dw_, dh_, ctypes.c_void_p(d_src), sw_, sh_, *bad)
+            assert rc == pkg._lib.PFV_ERR_BAD_ARG, bad
+        ctx.free(d_src); ctx.free(d_dst)
+    return n_checked
 
 
 def check_misaligned_device_frames(pkg, ctx, oracle):

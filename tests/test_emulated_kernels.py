@@ -35,6 +35,12 @@ def test_emu_session_two_streams(pkg, emu_ctx, oracle):
     assert 0 < stats["coded"] < stats["mbs"]
 
 
+def test_emu_session_batched_dev(pkg, emu_ctx, oracle):
+    """the benched call pattern (device-pointer entry points, device generator, fused crop) at toy size"""
+    stats = pc.check_session_batched_dev(pkg, emu_ctx, oracle, 64, 48, 5, [pkg.synth.SEED + 17 * k for k in range(3)], n_frames=3)
+    assert stats["mbs"] == 2 * 3 * 20 and 0 < stats["coded"]
+
+
 def test_emu_bad_motion_vector(pkg, emu_ctx, oracle):
     q = oracle.qtables(5)[2]
     ref = pkg.VideoPlane(32, 32)
@@ -64,8 +70,12 @@ def test_emu_encoder_keeps_nothing(pkg, emu_ctx):
     sc.check_encoder_keeps_nothing(pkg, emu_ctx)
 
 
-def test_emu_colour_utils(pkg, emu_ctx):
-    pc.check_colour_utils(pkg, emu_ctx)
+def test_emu_colour_utils(pkg, emu_ctx, oracle):
+    pc.check_colour_utils(pkg, emu_ctx, oracle)
+
+
+def test_emu_blit_dev(pkg, emu_ctx, oracle):
+    assert pc.check_blit_dev(pkg, emu_ctx, oracle, n_random=12) >= 50
 
 
 def test_emu_misaligned_device_frames(pkg, emu_ctx, oracle):

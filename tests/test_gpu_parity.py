@@ -161,6 +161,21 @@ def test_session_1080p_iframe_and_pframe(pkg, gpu_ctx, oracle):
     assert 0 < stats["coded"] < stats["mbs"]
 
 
+def test_benched_shape_96_streams_1080p_vs_oracle(pkg, gpu_ctx, oracle):
+    """The shape bench.py times -- 96 distinct 1080p streams (its own seed table) per launch, device-pointer entry points,
+    fused retframe crop, quality 5 -- one i-frame and one p-frame step, every byte of all 96 streams against the oracle
+    (2 x 1 175 040 macroblocks; 601 MB of coefficients per step)."""
+    from importlib import import_module
+    shard = import_module("pretty_fast_video_amd.shard")
+    table = shard.assign_streams(n_streams_total=96, world=1, base_seed=pkg.synth.SEED)
+    seeds = [int(r[1]) for r in shard.streams_of_rank(table, 0)]
+    assert len(seeds) == 96 and len(set(seeds)) == 96
+    threads = min(32, len(os.sched_getaffinity(0)))
+    stats = pc.check_session_batched_dev(pkg, gpu_ctx, oracle, 1920, 1080, 5, seeds, n_frames=2, threads=threads)
+    oracle.L.pfvo_pool_shutdown()
+    assert stats["mbs"] == 96 * 12240 and 0 < stats["coded"] < stats["mbs"]
+
+
 def test_session_4k_roundtrip_property(pkg, gpu_ctx):
     """BASELINE config #4 geometry (3840x2160, 48 720 MB/frame): size-independent property --
     the decoder's framebuffer equals the encoder's closed-loop reconstruction for every frame
@@ -189,25 +204,9 @@ def test_session_4k_roundtrip_property(pkg, gpu_ctx):
     dec.close()
 
 
-def test_blit_dev(pkg, gpu_ctx):
-    """VideoPlane::blit (src/plane.rs:20-29) on device planes vs the host container op"""
-    rng = np.random.default_rng(5)
-    src = pkg.VideoPlane.from_slice(100, 40, rng.integers(0, 256, 4000, dtype=np.uint8))
-    dst = pkg.VideoPlane.from_slice(64, 64, rng.integers(0, 256, 4096, dtype=np.uint8))
-    d_src, d_dst = gpu_ctx.alloc(4000), gpu_ctx.alloc(4096)
-    gpu_ctx.upload(d_src, src.pixels)
-    gpu_ctx.upload(d_dst, dst.pixels)
-    lib = gpu_ctx._lib
-    gpu_ctx.check(lib.pfv_blit_dev(gpu_ctx.handle, ctypes.c_void_p(d_dst), 64, 64, ctypes.c_void_p(d_src), 100, 40, 3, 5, 7,
-                                   9, 33, 21))
-    out = np.empty(4096, np.uint8)
-    gpu_ctx.download(out, d_dst)
-    dst.blit(src, 3, 5, 7, 9, 33, 21)
-    assert np.array_equal(out, dst.pixels)
-    rc = lib.pfv_blit_dev(gpu_ctx.handle, ctypes.c_void_p(d_dst), 64, 64, ctypes.c_void_p(d_src), 100, 40, 60, 0, 0, 0, 8, 8)
-    assert rc == pkg._lib.PFV_ERR_BAD_ARG
-    gpu_ctx.free(d_src)
-    gpu_ctx.free(d_dst)
+def test_blit_dev(pkg, gpu_ctx, oracle):
+    """VideoPlane::blit (src/plane.rs:20-29) on device planes vs the oracle's pfvo_blit: random + corner rectangles"""
+    assert pc.check_blit_dev(pkg, gpu_ctx, oracle) >= 200
 
 
 def test_stream_encoder_decoder_vs_oracle(pkg, gpu_ctx, oracle):
@@ -299,8 +298,8 @@ def test_sparse_decode(pkg, gpu_ctx):
     pc.check_sparse_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12)
 
 
-def test_colour_utils(pkg, gpu_ctx):
-    pc.check_colour_utils(pkg, gpu_ctx)
+def test_colour_utils(pkg, gpu_ctx, oracle):
+    pc.check_colour_utils(pkg, gpu_ctx, oracle)
 
 
 def test_misaligned_device_frames(pkg, gpu_ctx, oracle):
