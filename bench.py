@@ -678,7 +678,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "i32",
+            "dtype": "i32 (encoder transforms evaluated in exact f32; decoders i32)",
             "data": f"synthetic, generated on the device ({S} distinct integer-hash texture streams per GPU, seed per stream; quality {Q})",
             "rccl_ranks": world if backend == "nccl" and world > 1 else 0,
             "control_plane": {"backend": backend if world > 1 else None, "shared_gpu": bool(share), "emulated": EMU,

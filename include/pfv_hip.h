@@ -69,6 +69,19 @@ PFV_API void *pfv_ctx_stream(pfv_ctx *ctx);
 PFV_API const char *pfv_last_error(pfv_ctx *ctx);
 PFV_API const char *pfv_version(void);
 
+/* Context options (diagnostics / test parametrisation; the defaults are what production wants).  An option applies to the
+ * plane-level operators called on the context and to sessions CREATED afterwards (a session keeps the values it was created
+ * with).  Results are the same bytes under every value.
+ *   PFV_OPT_ENC_TRANSFORM  how the encode kernels evaluate the transforms of the closed loop (src/dct.rs:176-293):
+ *       PFV_ENC_TRANSFORM_AUTO (default)  in f32 where that is provably the same arithmetic -- every intermediate an integer
+ *                                          below 2^24 for the session's tables, checked at session creation; always true for
+ *                                          quality 0..10 -- and in i32 otherwise
+ *       PFV_ENC_TRANSFORM_INT             always the i32 kernels */
+typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1 } pfv_option;
+enum { PFV_ENC_TRANSFORM_AUTO = 0, PFV_ENC_TRANSFORM_INT = 1 };
+PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value);
+PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value);
+
 /* Timing events on the context's stream (HIP events): record costs a microsecond or two, so every launch of a pass can be
  * bracketed without disturbing it; pfv_event_elapsed_ms waits for the later event. */
 typedef struct pfv_event pfv_event;
@@ -176,7 +189,8 @@ PFV_API int pfv_total_blocks(int width, int height);
 
 /* The encode kernels run the transforms of the closed loop in f32 where that is provably the same arithmetic (every
  * intermediate an integer below 2^24 for the session's tables -- checked here at creation; always true for quality 0..10) and
- * in i32 otherwise; the environment variable PFV_ENC_INT_TRANSFORM=1 forces the integer kernels (diagnostics).  Same bytes. */
+ * in i32 otherwise; pfv_ctx_set_option(ctx, PFV_OPT_ENC_TRANSFORM, PFV_ENC_TRANSFORM_INT) before the call forces the integer
+ * kernels (diagnostics).  Same bytes. */
 PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int quality, int n_streams,
                                    pfv_enc_session **out);
 PFV_API void pfv_enc_session_destroy(pfv_enc_session *s);

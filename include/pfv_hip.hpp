@@ -146,6 +146,7 @@ class Encoder {
         size_t len = 0;
         ctx_.check(pfv_encoder_drain(h_, &data, &len));   // hands the pending bytes over; the library keeps nothing
         if (len) out_.write(reinterpret_cast<const char *>(data), (std::streamsize)len);
+        if (!out_) throw Error(PFV_ERR_IO, "Encoder: the writer failed (the reference propagates io::Error, src/enc.rs:190-235)");
     }
     Context &ctx_;
     std::ostream &out_;
@@ -235,20 +236,36 @@ class BatchEncoder {
     size_t frame_bytes() const { return frame_bytes_; }
     // page-locked [n][frame_bytes] array to fill for the next encode call (packed Y|U|V per stream)
     uint8_t *frames() { return pfv_batch_encoder_frames(h_); }
-    void encode_iframes() { ctx_.check(pfv_batch_encoder_encode(h_, 0, nullptr)); }
-    void encode_pframes() { ctx_.check(pfv_batch_encoder_encode(h_, 1, nullptr)); }
+    void encode_iframes() { done(pfv_batch_encoder_encode(h_, 0, nullptr)); }
+    void encode_pframes() { done(pfv_batch_encoder_encode(h_, 1, nullptr)); }
     void finish()
     {
-        ctx_.check(pfv_batch_encoder_finish(h_));
+        const int rc = pfv_batch_encoder_finish(h_);
         finished_ = true;
+        done(rc);
     }
 
   private:
+    // A writer that fails (disk full, closed pipe) must not go unnoticed: the reference propagates every write error (`?`,
+    // src/enc.rs:190-235).  Nothing may unwind through the C callback, so the failure is remembered, all further writes are
+    // dropped (no writer receives bytes behind a hole) and the call that triggered it throws.
     static void on_write(void *user, int stream, const uint8_t *data, size_t len)
     {
         auto *self = static_cast<BatchEncoder *>(user);
-        self->writers_[(size_t)stream]->write(reinterpret_cast<const char *>(data), (std::streamsize)len);
+        if (self->failed_stream_ >= 0) return;
+        std::ostream *w = self->writers_[(size_t)stream];
+        w->write(reinterpret_cast<const char *>(data), (std::streamsize)len);
+        if (!*w) self->failed_stream_ = stream;
     }
+    void done(int rc)
+    {
+        if (failed_stream_ >= 0) {
+            finished_ = true;
+            throw Error(PFV_ERR_IO, "BatchEncoder: writer " + std::to_string(failed_stream_) + " failed; its stream is truncated");
+        }
+        ctx_.check(rc);
+    }
+    int failed_stream_ = -1;
     Context &ctx_;
     std::vector<std::ostream *> writers_;
     size_t frame_bytes_ = 0;

@@ -25,6 +25,10 @@ PFV_ERR_VERSION = -7
 PFV_ERR_IO = -8
 PFV_ERR_STATE = -9
 
+# pfv_ctx_set_option
+PFV_OPT_ENC_TRANSFORM = 1
+PFV_ENC_TRANSFORM_AUTO, PFV_ENC_TRANSFORM_INT = 0, 1
+
 
 class PfvError(RuntimeError):
     def __init__(self, code: int, msg: str):
@@ -42,6 +46,8 @@ SIGNATURES = [
     ("pfv_ctx_stream", _P, [_P]),
     ("pfv_last_error", c_char_p, [_P]),
     ("pfv_version", c_char_p, []),
+    ("pfv_ctx_set_option", c_int, [_P, c_int, c_int]),
+    ("pfv_ctx_get_option", c_int, [_P, c_int, POINTER(c_int)]),
     ("pfv_event_create", c_int, [_P, POINTER(_P)]),
     ("pfv_event_record", c_int, [_P]),
     ("pfv_event_elapsed_ms", c_int, [_P, _P, POINTER(c_float)]),

@@ -57,6 +57,15 @@ class Context:
     def sync(self):
         self.check(self._lib.pfv_ctx_sync(self.handle))
 
+    def set_option(self, option: int, value: int):
+        """pfv_ctx_set_option: applies to plane-level operators on this context and to sessions created afterwards"""
+        self.check(self._lib.pfv_ctx_set_option(self.handle, int(option), int(value)))
+
+    def get_option(self, option: int) -> int:
+        v = ctypes.c_int()
+        self.check(self._lib.pfv_ctx_get_option(self.handle, int(option), ctypes.byref(v)))
+        return int(v.value)
+
     def device_sync(self):
         """hipDeviceSynchronize: every stream of the device"""
         self.check(self._lib.pfv_device_sync(self.handle))

@@ -7,6 +7,7 @@
 #include "pfv_entropy_kernels.hip"
 #include "pfv_synth_kernels.hip"
 #include "pfv_host.hip"
+#include "pfv_selfcheck.hip"
 
 #include <math.h>
 #include <stdio.h>
@@ -59,6 +60,7 @@ struct pfv_ctx {
     int *flag_dev = nullptr;
     int n_cus = 256;             // compute units of the device (persistent-kernel grid sizing)
     bool capturing = false;      // a pfv_graph_begin is open on the stream
+    int opt_enc_transform = PFV_ENC_TRANSFORM_AUTO;   // pfv_ctx_set_option(PFV_OPT_ENC_TRANSFORM)
 };
 
 static thread_local std::string g_tls_err;
@@ -93,6 +95,27 @@ PFV_API const char *pfv_version(void) { return "pfv-hip 0.2 (gfx950; pfv-rs 0.2.
 PFV_API int pfv_pad16(int x) { return pad16(x); }
 
 PFV_API const char *pfv_last_error(pfv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+
+PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value)
+{
+    if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
+    switch (option) {
+    case PFV_OPT_ENC_TRANSFORM:
+        if (value != PFV_ENC_TRANSFORM_AUTO && value != PFV_ENC_TRANSFORM_INT) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENC_TRANSFORM: unknown value");
+        ctx->opt_enc_transform = value;
+        return PFV_OK;
+    default:
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_set_option: unknown option");
+    }
+}
+PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value)
+{
+    if (!ctx || !value) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_get_option: bad argument");
+    switch (option) {
+    case PFV_OPT_ENC_TRANSFORM: *value = ctx->opt_enc_transform; return PFV_OK;
+    default: return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_get_option: unknown option");
+    }
+}
 
 PFV_API int pfv_ctx_create(int device, pfv_ctx **out)
 {
@@ -271,15 +294,20 @@ PFV_API int pfv_qtables_from_quality(int quality, int32_t intra_l[64], int32_t i
 // ------------------------------------------------------------------ internal helpers
 // decode_only: tables read from a stream header may hold 0 (the reference's decode only multiplies, src/dct.rs:75-86);
 // an encoder table must be >= 1 (it divides, src/dct.rs:95).
+// QTab::rcp: fl(fl(1 / q) * (1 + 2^-21)), each step rounded to f32 (volatile: no excess precision, no contraction)
+static float biased_rcp(int q)
+{
+    volatile float r = q ? 1.0f / (float)q : 0.0f;
+    r = r * 1.000000476837158203125f;
+    return r;
+}
 static int make_qtab(pfv_ctx *ctx, const int32_t q[64], QTab *out, bool decode_only = false)
 {
     if (!q) return fail(ctx, PFV_ERR_BAD_ARG, "q-table is null");
     for (int i = 0; i < 64; i++)
         if (q[i] < (decode_only ? 0 : 1) || q[i] > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "q-table entry outside [1,65535]");
     for (int i = 0; i < 64; i++) {
-        volatile float r = q[i] ? 1.0f / (float)q[i] : 0.0f;
-        r = r * 1.000000476837158203125f;   // 1 + 2^-21: see QTab::rcp
-        out->rcp[i] = r;
+        out->rcp[i] = biased_rcp(q[i]);
         int z = H_INV_ZIGZAG[i];
         out->deq[i] = (int32_t)((uint32_t)H_SCALE[z] * (uint32_t)q[z]);
     }
@@ -421,8 +449,12 @@ PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, cons
     if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     // encode only: the forward transform is exact in f32 for any table
-    hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
-                                                                   ctx->qtab_dev);
+    if (ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT)
+        hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
+                                                                       ctx->qtab_dev);
+    else
+        hipLaunchKernelGGL(k_enc_iframe<false>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
+                                                                        ctx->qtab_dev);
     if ((rc = launch_check(ctx, "k_enc_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -451,9 +483,14 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
     float min_err = px_err * px_err * 256.0f;   // src/common.rs:209
-    hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
-                                                                   (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
-                                                                   nullptr, ctx->qtab_dev, min_err, -2);
+    if (ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT)
+        hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
+                                                                       (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
+                                                                       nullptr, ctx->qtab_dev, min_err, -2);
+    else
+        hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
+                                                                        (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
+                                                                        nullptr, ctx->qtab_dev, min_err, -2);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mv_out, d_mv, n * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -694,28 +731,51 @@ static int init_padded(pfv_ctx *ctx, const FrameGeom &g, uint8_t *buf)
 // floor(floor(M * SCALE / 65536) / q), decode multiplies it by SCALE[z] * q[z] at its zigzag position z (src/dct.rs:78-82), and an L1
 // bound pushes all 64 such maxima through |idct| columns and rows at once (with slack for the truncations).  Quality-derived
 // tables give 1.9 M; a table for which the bound reaches 2^23 keeps the integer kernels.
+// |d out / d in| of the two 1-D transforms (the integer butterflies on scaled unit vectors) and the signs of those derivatives;
+// built once, thread-safely (function-local static), sessions may be created from several threads
+struct XformNorms {
+    double F1[8];            // L1 norm of each forward output
+    double Iabs[8][8];       // |inverse|
+    signed char fsign[64];   // [u * 8 + k]: sign of d fdct(out u) / d (in k)
+    signed char isign[64];
+};
+static const XformNorms &xform_norms()
+{
+    static const XformNorms t = [] {
+        XformNorms n{};
+        for (int k = 0; k < 8; k++) {
+            int f[8] = {0, 0, 0, 0, 0, 0, 0, 0}, i8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            f[k] = i8[k] = 1 << 20;
+            fdct8(f);
+            idct8(i8);
+            for (int u = 0; u < 8; u++) {
+                n.F1[u] += fabs((double)f[u]) / (1 << 20);
+                n.Iabs[u][k] = fabs((double)i8[u]) / (1 << 20);
+                n.fsign[u * 8 + k] = (signed char)(f[u] < 0 ? -1 : 1);
+                n.isign[u * 8 + k] = (signed char)(i8[u] < 0 ? -1 : 1);
+            }
+        }
+        return n;
+    }();
+    return t;
+}
+// largest coefficient magnitude the encoder can produce at raster position i for inputs of the given amplitude (24.8 fixed point)
+static double enc_max_coef(const int32_t q[64], double amplitude, int i)
+{
+    const XformNorms &n = xform_norms();
+    const double M = amplitude * n.F1[i >> 3] * n.F1[i & 7];
+    return floor(floor(M * H_SCALE[i] / 65536.0) / (double)q[i]);
+}
 static bool enc_float_exact(const int32_t q[64], double amplitude)
 {
-    static double F1[8], Iabs[8][8];
-    static bool init = false;
-    if (!init) {
-        for (int k = 0; k < 8; k++) {
-            int e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            e[k] = 1 << 20;
-            int f[8], t[8];
-            memcpy(f, e, sizeof e); memcpy(t, e, sizeof e);
-            int (&fr)[8] = f; int (&tr)[8] = t;
-            fdct8(fr);
-            idct8(tr);
-            for (int u = 0; u < 8; u++) { if (k == 0) F1[u] = 0; F1[u] += fabs((double)f[u]) / (1 << 20); Iabs[u][k] = fabs((double)t[u]) / (1 << 20); }
-        }
-        init = true;
-    }
+    const XformNorms &nm = xform_norms();
     double D[8][8], worst = 0;
     for (int i = 0; i < 64; i++) {
         const int u = i >> 3, v = i & 7, z = H_INV_ZIGZAG[i];
-        const double M = amplitude * F1[u] * F1[v];
-        const double n = floor(M * H_SCALE[i] / 65536.0), c = floor(n / (double)q[i]);
+        const double M = amplitude * nm.F1[u] * nm.F1[v];
+        // decode puts encode's coefficient of raster i back at raster i (slot z = INV_ZIGZAG[i] is where encode stored it) but
+        // multiplies it by the table entries at index z (src/dct.rs:78-82)
+        const double c = enc_max_coef(q, amplitude, i);
         D[u][v] = c * (double)H_SCALE[z] * (double)q[z];
         worst = std::max(worst, std::max(M, D[u][v]));
     }
@@ -723,14 +783,14 @@ static bool enc_float_exact(const int32_t q[64], double amplitude)
     for (int u = 0; u < 8; u++)
         for (int v = 0; v < 8; v++) {
             double a = 16;
-            for (int k = 0; k < 8; k++) a += Iabs[u][k] * D[k][v];     // columns first (src/common.rs:315)
+            for (int k = 0; k < 8; k++) a += nm.Iabs[u][k] * D[k][v];     // columns first (src/common.rs:315)
             col[u][v] = a;
             worst = std::max(worst, a);
         }
     for (int u = 0; u < 8; u++)
         for (int v = 0; v < 8; v++) {
             double a = 16;
-            for (int k = 0; k < 8; k++) a += col[u][k] * Iabs[v][k];   // then rows
+            for (int k = 0; k < 8; k++) a += col[u][k] * nm.Iabs[v][k];   // then rows
             worst = std::max(worst, a);
         }
     return worst < 8388608.0;   // 2^23: a factor 2 below what f32 holds exactly
@@ -808,7 +868,7 @@ PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int qual
         int rc = make_qtab(ctx, q[i], &tabs[i]);
         if (rc) { delete s; return rc; }
     }
-    s->flt = getenv("PFV_ENC_INT_TRANSFORM") == nullptr && enc_float_exact(q[0], 128.0 * 256.0) && enc_float_exact(q[1], 128.0 * 256.0) &&
+    s->flt = ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT && enc_float_exact(q[0], 128.0 * 256.0) && enc_float_exact(q[1], 128.0 * 256.0) &&
              enc_float_exact(q[2], 127.0 * 256.0) && enc_float_exact(q[3], 127.0 * 256.0);
     size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
     hipError_t e = hipMalloc((void **)&s->qtab_dev, sizeof tabs);
@@ -1858,6 +1918,13 @@ PFV_API int pfv_batch_encoder_encode(pfv_batch_encoder *b, int pframe, const uin
     const uint8_t *src = frames ? frames : b->in_host[slot];
     // in_dev[slot] was last read by the kernels of step t-2, which the collect of step t-1's call has waited for
     HIP_TRY(ctx, hipMemcpyAsync(b->in_dev[slot], src, (size_t)b->n * b->frame_bytes, hipMemcpyHostToDevice, b->copy_stream));
+    // From here on the copy engine may be reading the CALLER's buffer: whatever way this call ends, it returns only once
+    // that read is over ("free again when the call returns", pfv_hip.h).
+    struct UploadGuard {
+        hipStream_t s;
+        bool armed;
+        ~UploadGuard() { if (armed) (void)hipStreamSynchronize(s); }
+    } guard{b->copy_stream, frames != nullptr};
     HIP_TRY(ctx, hipEventRecord(b->ev_up[slot], b->copy_stream));
     int rc = be_collect(b);            // step t-1 -> writers, while the upload of step t is on the wire
     if (rc) return rc;
@@ -1867,7 +1934,10 @@ PFV_API int pfv_batch_encoder_encode(pfv_batch_encoder *b, int pframe, const uin
     b->poisoned = true;                // until this step's packets have been written
     rc = pframe ? pfv_enc_pack_pframe_dev(b->hot, b->mv, b->has, b->coef) : pfv_enc_pack_iframe_dev(b->hot, b->coef);
     if (rc) return rc;
-    if (frames) HIP_TRY(ctx, hipStreamSynchronize(b->copy_stream));   // the caller's buffer is free again when this returns
+    if (frames) {
+        guard.armed = false;
+        HIP_TRY(ctx, hipStreamSynchronize(b->copy_stream));   // the caller's buffer is free again when this returns
+    }
     b->pending = pframe ? 2 : 1;
     b->poisoned = false;
     b->step++;
@@ -2058,6 +2128,9 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
     }
     std::vector<int32_t> q((size_t)std::max(nq, 1) * 64, 1);
     for (int i = 0; i < nq * 64; i++) q[(size_t)i] = u16(20 + 2 * (size_t)i);
+    // the coefficient lists address [stream][macroblock][256] with 32-bit flat indices (SparseSink, k_scatter_coef_seg)
+    if (w > 0 && h > 0 && !(w & 1) && !(h & 1) && (uint64_t)n_streams * (uint64_t)pfv_total_blocks(w, h) * 256u > 0xffffffffull)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_batch_decoder_create: n_streams x macroblocks x 256 exceeds the 32-bit coefficient index; use several batch decoders");
     pfv_dec_session *hot = nullptr;
     int rc = pfv_dec_session_create(ctx, w, h, q.data(), nq, n_streams, &hot);
     if (rc) return rc;
@@ -2111,6 +2184,10 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
         bd_scan_and_start(b, &b->set[slot ^ 1]);
         return 2;
     }
+    // From here on the step counter has advanced: an error exit that left the decoder usable would make the next call join a
+    // slot whose contents are two steps old and decode it again as if it were new.  Every failure below ends the decoder
+    // (b->eof), as the parse errors above do.
+    const int rc_step = [&]() -> int {
     const size_t S = (size_t)b->n, tb = b->total_blocks;
     bool dense = false;
     for (size_t k = 0; k < S; k++) {
@@ -2159,6 +2236,9 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
     if ((rc = pfv_dec_check(hot))) return rc;      // synchronises; bad-motion-vector flag (src/common.rs:258-259)
     *frames_out = b->frames[slot].data();
     return 1;
+    }();
+    if (rc_step < 0) b->eof = true;
+    return rc_step;
 }
 
 // payload serialisers alone (for tests: product vs oracle on identical coefficient input)
@@ -2483,6 +2563,106 @@ PFV_API int pfv_decoder_advance_delta(pfv_decoder *d, double delta, pfv_video_cb
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ device self-check of the encoders' f32 arithmetic (csrc/pfv_selfcheck.h)
+int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *checked, uint64_t *mismatches, int64_t first_bad[4])
+{
+    if (!ctx || !checked || !mismatches) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_selfcheck_float_path: bad argument");
+    if (part < 0 || part > 4) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_selfcheck_float_path: part must be 0..4");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *checked = *mismatches = 0;
+    ChkDev *res = nullptr;
+    unsigned long long *n_cmp = nullptr;
+    void *aux = nullptr, *aux2 = nullptr;
+    auto cleanup = [&]() {
+        if (res) (void)hipFree(res);
+        if (n_cmp) (void)hipFree(n_cmp);
+        if (aux) (void)hipFree(aux);
+        if (aux2) (void)hipFree(aux2);
+    };
+#define CHK_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess) { cleanup(); return hip_fail(ctx, e__, #expr); }         \
+    } while (0)
+    CHK_TRY(hipMalloc((void **)&res, sizeof(ChkDev)));
+    CHK_TRY(hipMemset(res, 0, sizeof(ChkDev)));
+    CHK_TRY(hipMalloc((void **)&n_cmp, sizeof(unsigned long long)));
+    CHK_TRY(hipMemset(n_cmp, 0, sizeof(unsigned long long)));
+    // parts 1, 2: 2^15 workgroups x 256 threads = the 2^23 values of |m|; a non-zero arg limits the workgroups (emulator runs)
+    const unsigned m_blocks = (arg && arg < (1u << 15)) ? (unsigned)arg : (1u << 15);
+    if (part == 0) {
+        std::vector<float> rcp(65536);
+        for (int q = 0; q < 65536; q++) rcp[q] = biased_rcp(q);
+        CHK_TRY(hipMalloc(&aux, rcp.size() * sizeof(float)));
+        CHK_TRY(hipMemcpy(aux, rcp.data(), rcp.size() * sizeof(float), hipMemcpyHostToDevice));
+        const unsigned nq = arg ? (unsigned)std::min<uint64_t>(arg, 65535) : 65535u;      // arg: only the first `arg` values of q (emulator runs)
+        hipLaunchKernelGGL(k_chk_quant_div, dim3(nq), dim3(256), 0, ctx->stream, (const float *)aux, res);
+        *checked = (uint64_t)nq * 2 * 8193;
+    } else if (part == 1) {
+        hipLaunchKernelGGL(k_chk_quant_scale, dim3(m_blocks), dim3(256), 0, ctx->stream, res);
+        *checked = (uint64_t)m_blocks * 256 * 2 * 10;
+    } else if (part == 2) {
+        // quantiser values spread over [1, 65535]: the small ones every quality table uses, powers of two and their neighbours, the u16 limit
+        static const int kQs[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20, 27, 40, 64, 83, 127, 128, 129, 1000, 4097, 32768, 65535};
+        const int nq = (int)(sizeof kQs / sizeof kQs[0]);
+        std::vector<float> rc(nq);
+        for (int j = 0; j < nq; j++) rc[j] = biased_rcp(kQs[j]);
+        CHK_TRY(hipMalloc(&aux, sizeof kQs));
+        CHK_TRY(hipMemcpy(aux, kQs, sizeof kQs, hipMemcpyHostToDevice));
+        CHK_TRY(hipMalloc(&aux2, nq * sizeof(float)));
+        CHK_TRY(hipMemcpy(aux2, rc.data(), nq * sizeof(float), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_chk_quant_pair, dim3(m_blocks), dim3(256), 0, ctx->stream, (const int *)aux, (const float *)aux2, nq, res);
+        *checked = (uint64_t)m_blocks * 256 * 2 * 10 * nq;
+    } else {
+        // the four tables of every quality 0..10 (src/enc.rs:40-51), as the encoder sessions build them
+        std::vector<ChkTab> tabs(44);
+        for (int quality = 0; quality < 11; quality++) {
+            int32_t q[4][64];
+            float px_err;
+            pfv_qtables_from_quality(quality, q[0], q[1], q[2], q[3], &px_err);
+            for (int k = 0; k < 4; k++) {
+                ChkTab &T = tabs[quality * 4 + k];
+                int rc = make_qtab(ctx, q[k], &T.qt);
+                if (rc) { cleanup(); return rc; }
+                for (int i = 0; i < 64; i++) {
+                    T.q[i] = q[k][i];
+                    T.cmax[i] = (int)enc_max_coef(q[k], (k < 2 ? 128.0 : 127.0) * 256.0, i);
+                }
+                if (!enc_float_exact(q[k], (k < 2 ? 128.0 : 127.0) * 256.0)) { cleanup(); return fail(ctx, PFV_ERR_STATE, "a quality table fails enc_float_exact"); }
+            }
+        }
+        CHK_TRY(hipMalloc(&aux, tabs.size() * sizeof(ChkTab)));
+        CHK_TRY(hipMemcpy(aux, tabs.data(), tabs.size() * sizeof(ChkTab), hipMemcpyHostToDevice));
+        if (part == 3) {
+            const unsigned n_pairs = (unsigned)std::min<uint64_t>(arg ? (arg + 1) / 2 : (1u << 19), 1u << 26);
+            hipLaunchKernelGGL(k_chk_blocks, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, (const ChkTab *)aux, 0x50465633ull, n_pairs, res, n_cmp);
+        } else {
+            const XformNorms &nm = xform_norms();
+            CHK_TRY(hipMalloc(&aux2, 128));
+            CHK_TRY(hipMemcpy(aux2, nm.fsign, 64, hipMemcpyHostToDevice));
+            CHK_TRY(hipMemcpy((char *)aux2 + 64, nm.isign, 64, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_chk_worst_forward, dim3(4), dim3(64), 0, ctx->stream, (const ChkTab *)aux, (const signed char *)aux2, res, n_cmp);
+            hipLaunchKernelGGL(k_chk_worst_inverse, dim3(2), dim3(64), 0, ctx->stream, (const ChkTab *)aux, (const signed char *)aux2 + 64, res, n_cmp);
+        }
+    }
+    {
+        int rc = launch_check(ctx, "pfv_selfcheck_float_path");
+        if (rc) { cleanup(); return rc; }
+    }
+    CHK_TRY(hipStreamSynchronize(ctx->stream));
+    ChkDev host;
+    unsigned long long cmp = 0;
+    CHK_TRY(hipMemcpy(&host, res, sizeof host, hipMemcpyDeviceToHost));
+    CHK_TRY(hipMemcpy(&cmp, n_cmp, sizeof cmp, hipMemcpyDeviceToHost));
+#undef CHK_TRY
+    if (part >= 3) *checked = cmp;
+    *mismatches = host.mismatches;
+    if (first_bad)
+        for (int k = 0; k < 4; k++) first_bad[k] = host.first[k];
+    cleanup();
+    return PFV_OK;
+}
 
 #ifdef PFV_ENT_PROFILE   // experiment builds only (tools/ent_profile.py): the timestamp rows of kernel `kern` (0 scan, 1 pack)
 extern "C" __attribute__((visibility("default"))) int pfv_debug_ent_profile(int kern, unsigned long long *out, int n_groups)

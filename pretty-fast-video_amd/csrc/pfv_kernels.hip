@@ -74,6 +74,15 @@ __host__ __device__ __forceinline__ int wmul(int a, int b) { return (int)((unsig
 // outputs of 8-bit pixels (|m| < 2^22) times DCT_SCALE_FACTOR (<= 43), and i16 coefficients times SCALE*q (< 2^22 for
 // q <= 65535, which make_qtab enforces).
 __device__ __forceinline__ int wmul24(int a, int b) { return __mul24(a, b); }
+// High 32 bits of the 48-bit product of two signed 24-bit operands: ONE v_mul_hi_i32_i24 (the compiler matches the widened
+// product of sign-extended 24-bit values and drops the extensions, the instruction ignores bits 24..31 anyway).
+// Used as (m * (SCALE << 16)) >> 32 == (m * SCALE) >> 16 -- the arithmetic shift of src/dct.rs:92 -- for |m| < 2^23,
+// SCALE << 16 <= 43 << 16 < 2^23.
+__host__ __device__ __forceinline__ int mulhi24(int a, int b)
+{
+    const int x = (int)((unsigned)a << 8) >> 8, y = (int)((unsigned)b << 8) >> 8;
+    return (int)(((long long)x * (long long)y) >> 32);
+}
 
 // Rust `/` by 2, 4, 16 on i32 (truncation toward zero).  trunc(x / 2^k) = (x + bias) >> k with
 // bias = (2^k - 1) for negative x; truncating divisions compose (trunc(trunc(x/a)/b) = trunc(x/(ab)))
@@ -276,7 +285,7 @@ struct LaneQ {
     __device__ __forceinline__ int zz(int k) const { return tab[k * 8 + c]; }             // INV_ZIGZAG[k*8+c]
     __device__ __forceinline__ int deq(int k) const { return tab[64 + k * 8 + c]; }       // SCALE[z]*q[z], z = zz (decode)
     __device__ __forceinline__ float deqf(int k) const { return __int_as_float(tab[64 + k * 8 + c]); }   // the same as f32 bits (fill_qtable<true, true>)
-    __device__ __forceinline__ int scale(int k) const { return tab[128 + k * 8 + c]; }    // DCT_SCALE_FACTOR[k*8+c] (encode)
+    __device__ __forceinline__ int scale(int k) const { return tab[128 + k * 8 + c]; }    // DCT_SCALE_FACTOR[k*8+c] (encode); << 16 in the float encoders (fill_qtable<true, true>)
     __device__ __forceinline__ float rcp(int k) const { return __int_as_float(tab[192 + k * 8 + c]); }   // biased 1/q (encode)
 };
 // The 64-entry tables live in LDS (kQTabDwords per copy), written once per wavefront / workgroup with four
@@ -290,7 +299,7 @@ __device__ __forceinline__ void fill_qtable(int *tab, const QTab *qt, int lane)
     tab[lane] = kInvZigzag[lane];
     tab[64 + lane] = FLT ? __float_as_int((float)qt->deq[lane]) : qt->deq[lane];   // float form: deq < 2^24 (checked on the host)
     if (ENC) {
-        tab[128 + lane] = kScale[lane];
+        tab[128 + lane] = FLT ? (kScale[lane] << 16) : kScale[lane];   // float encoders: second operand of mulhi24 (quant_pair_f)
         tab[192 + lane] = __float_as_int(qt->rcp[lane]);
     }
 }
@@ -571,6 +580,32 @@ __device__ __forceinline__ void f_cols_to_rows(f2 (&x)[8], int *mb, int i, int m
     }
     wave_lds_sync();
 }
+// The float encoders' quantiser for one coefficient pair (the lane's two subblocks, same raster position), src/dct.rs:88-99,
+// in two steps that csrc/pfv_selfcheck.hip runs on the device for EVERY operand (tests/test_device_selfcheck.py):
+//   quant_scale   n = (m * SCALE) >> 16 (dct.rs:92): m = transform output, an exact integer |m| < 2^23 held in f32; scale16 =
+//                 DCT_SCALE_FACTOR[idx] << 16.  One v_mul_hi_i32_i24 between two conversions (the product needs 28 bits: not
+//                 an f32 operation).
+//   quant_div     n / q (truncating, dct.rs:95) = trunc(float(n) * rcp) with rcp = QTab::rcp[idx], the biased reciprocal: one
+//                 v_pk_mul_f32 for the pair + two v_trunc_f32.  Returns the quotients as floats (what the closed loop's dequantiser
+//                 multiplies next); `biased` = quotient + 1.5 * 2^23 carries the quotient's two's complement in its low mantissa
+//                 bits (|quotient| < 2^15), so a 16-bit store of the register's low half IS the reference's `as i16` -- one
+//                 packed add for the pair instead of two float -> int conversions.
+__device__ __forceinline__ f2 quant_scale(f2 m, int scale16)
+{
+    f2 n;
+#pragma unroll
+    for (int s = 0; s < 2; s++) n[s] = (float)mulhi24((int)m[s], scale16);
+    return n;
+}
+__device__ __forceinline__ f2 quant_div(f2 n, float rcp, f2 &biased)
+{
+    const f2 q = f2trunc(n * f2s(rcp));
+    biased = q + f2s(12582912.0f);
+    return q;
+}
+__device__ __forceinline__ f2 quant_pair_f(f2 m, int scale16, float rcp, f2 &biased) { return quant_div(quant_scale(m, scale16), rcp, biased); }
+// the 16 bits a ds_write_b16 / a global 16-bit store takes from the biased quotient
+__device__ __forceinline__ int16_t quant_low16(float biased) { return (int16_t)__float_as_int(biased); }
 // Forward, float form: x = row-layout samples in 24.8 fixed point AS FLOATS ((px - 128) * 256 or trunc(d / 2) * 256); leaves the
 // quantised coefficients (column layout, as floats) in x and scatters them in zigzag order into the coefficient stage.
 // The quantiser itself is the integer one of forward_half (exact division by reciprocal).
@@ -583,17 +618,11 @@ __device__ __forceinline__ void forward_half_f(f2 (&x)[8], int *xw, int m, int i
     int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 128;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int scale = lq.scale(k), zz = lq.zz(k);
-        const float rcp = lq.rcp(k);
-        f2 n;
+        const int zz = lq.zz(k);
+        f2 biased;
+        x[k] = quant_pair_f(x[k], lq.scale(k), lq.rcp(k), biased);
 #pragma unroll
-        for (int s = 0; s < 2; s++) n[s] = (float)(wmul24((int)x[k][s], scale) >> 16);   // the transform output is an exact integer
-        x[k] = f2trunc(n * f2s(rcp));                                   // n / q, truncating (QTab::rcp); one v_pk_mul_f32 for the pair
-        // the 16-bit store takes the low half of the register: |q| < 2^15, so q + 1.5 * 2^23 carries q's two's complement in
-        // its low mantissa bits -- one packed add for the pair instead of two float -> int conversions
-        const f2 biased = x[k] + f2s(12582912.0f);
-#pragma unroll
-        for (int s = 0; s < 2; s++) stage[s * 64 + zz] = (int16_t)__float_as_int(biased[s]);
+        for (int s = 0; s < 2; s++) stage[s * 64 + zz] = quant_low16(biased[s]);
     }
     wave_lds_sync();
 }

@@ -99,8 +99,17 @@ class BatchEncoder:
         self.finished = False
         self._np = np
 
+        self._write_error = None          # ctypes swallows exceptions raised inside a callback: keep the first one, stop
+        #                                   writing (nothing after a failed write may reach any writer out of order) and re-raise it
+        #                                   when the C call returns -- the reference propagates every write error (`?`, src/enc.rs:190-235)
+
         def on_write(_user, stream, data, length):
-            self.writers[stream].write(ctypes.string_at(data, length))
+            if self._write_error is not None:
+                return
+            try:
+                self.writers[stream].write(ctypes.string_at(data, length))
+            except BaseException as e:      # noqa: BLE001 -- re-raised by _raise_write_error
+                self._write_error = e
         self._cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t)(on_write)
         h = ctypes.c_void_p()
         ctx.check(ctx._lib.pfv_batch_encoder_create(ctx.handle, self.width, self.height, int(framerate), int(quality), self.n,
@@ -120,7 +129,15 @@ class BatchEncoder:
         if frames is not None:
             src = self._np.ascontiguousarray(frames, dtype=self._np.uint8)
             assert src.size == self.n * self.frame_bytes
-        self.ctx.check(self.ctx._lib.pfv_batch_encoder_encode(self.handle, 1 if pframe else 0, ptr(src) if src is not None else None))
+        rc = self.ctx._lib.pfv_batch_encoder_encode(self.handle, 1 if pframe else 0, ptr(src) if src is not None else None)
+        self._raise_write_error()
+        self.ctx.check(rc)
+
+    def _raise_write_error(self):
+        """a writer failed inside the callback: the stream it belongs to is truncated, nothing more is written to any writer"""
+        if self._write_error is not None:
+            self.finished = True            # close() must not try to write EOF packets behind the hole
+            raise self._write_error
 
     def encode_iframes(self, frames=None):
         self._step(False, frames)
@@ -129,11 +146,15 @@ class BatchEncoder:
         self._step(True, frames)
 
     def flush(self):
-        self.ctx.check(self.ctx._lib.pfv_batch_encoder_flush(self.handle))
+        rc = self.ctx._lib.pfv_batch_encoder_flush(self.handle)
+        self._raise_write_error()
+        self.ctx.check(rc)
 
     def finish(self):
         assert not self.finished
-        self.ctx.check(self.ctx._lib.pfv_batch_encoder_finish(self.handle))
+        rc = self.ctx._lib.pfv_batch_encoder_finish(self.handle)
+        self._raise_write_error()
+        self.ctx.check(rc)
         self.finished = True
 
     def close(self):

@@ -89,6 +89,7 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p =
 static inline unsigned atomicMin(unsigned *p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 
 // ---- gfx950 builtins used by the kernels
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

@@ -222,6 +222,39 @@ def check_batch_encoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, go
         assert bufs[s].getvalue() == oencs[s].bytes(), f"stream {s}: batch encoder bytes differ from the oracle's stream"
 
 
+def check_batch_encoder_writer_failure(pkg, ctx, w=64, h=48, n_streams=3):
+    """a writer that raises (disk full, closed pipe): the error reaches the caller of encode / flush / finish (the reference
+    propagates every write error with `?`, src/enc.rs:190-235) instead of vanishing inside the ctypes callback; after the
+    failure nothing more is written to ANY writer, so no stream has bytes behind a hole"""
+    class Failing:
+        def __init__(self, fail_after):
+            self.buf, self.calls, self.fail_after = io.BytesIO(), 0, fail_after
+
+        def write(self, b):
+            self.calls += 1
+            if self.calls > self.fail_after:
+                raise OSError(28, "No space left on device")
+            self.buf.write(b)
+
+    st = pkg.SyntheticStream(w, h)
+    for fail_after in (0, 1, 2):                      # the header write, the first packet, the second packet
+        writers = [io.BytesIO(), Failing(fail_after), io.BytesIO()][:n_streams]
+        raised = None
+        try:
+            enc = pkg.BatchEncoder(writers, w, h, 30, 5, ctx)
+            for t in range(4):
+                for s in range(n_streams):
+                    enc.frames[s] = st.frame(t)
+                (enc.encode_iframes if t == 0 else enc.encode_pframes)()
+            enc.finish()
+        except OSError as e:
+            raised = e
+        assert raised is not None and raised.errno == 28, f"writer failure after {fail_after} writes was swallowed"
+        sizes = [len(wr.getvalue()) if hasattr(wr, "getvalue") else len(wr.buf.getvalue()) for wr in writers]
+        enc.close()                                   # must not raise, must not write behind the hole
+        assert sizes == [len(wr.getvalue()) if hasattr(wr, "getvalue") else len(wr.buf.getvalue()) for wr in writers]
+
+
 def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, gop, noise=False):
     """BatchDecoder over the streams a BatchEncoder wrote: every step's frames equal the oracle decoder's, stream by stream.
     noise=True feeds white noise (dense coefficients: the decoder's sparse lists overflow and it parses the dense form)."""

@@ -149,6 +149,10 @@ def test_emu_batch_encoder(pkg, emu_ctx, oracle):
     sc.check_batch_encoder(pkg, emu_ctx, oracle, 48, 32, 5, n_streams=3, n_frames=4, gop=3)
 
 
+def test_emu_batch_encoder_writer_failure_is_reported(pkg, emu_ctx):
+    sc.check_batch_encoder_writer_failure(pkg, emu_ctx)
+
+
 def test_emu_batch_encoder_dense_content_grows_its_buffer(pkg, emu_ctx, oracle):
     """white noise at quality 10 needs more payload bytes than a raw frame: the first download reports NOMEM, the
     encoder retries with the worst-case buffer and still writes the oracle's bytes"""

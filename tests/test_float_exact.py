@@ -87,13 +87,22 @@ def test_emu_hostile_content_sessions(pkg, emu_ctx, oracle):
 
 
 def test_emu_integer_transform_fallback(pkg, emu_ctx, oracle):
-    """PFV_ENC_INT_TRANSFORM=1 (or a table that fails the bound) keeps the integer encoder kernels: same bytes"""
-    os.environ["PFV_ENC_INT_TRANSFORM"] = "1"
+    """pfv_ctx_set_option(PFV_OPT_ENC_TRANSFORM, PFV_ENC_TRANSFORM_INT) (or a table that fails the bound) keeps the integer
+    encoder kernels, in sessions and in the plane-level operators: same bytes"""
+    L = pkg._lib
+    assert emu_ctx.get_option(L.PFV_OPT_ENC_TRANSFORM) == L.PFV_ENC_TRANSFORM_AUTO
+    emu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_INT)
     try:
+        assert emu_ctx.get_option(L.PFV_OPT_ENC_TRANSFORM) == L.PFV_ENC_TRANSFORM_INT
         _check_hostile_sessions(pkg, emu_ctx, oracle, (0, 7))
         pc.check_session(pkg, emu_ctx, oracle, 64, 48, 5, n_streams=2, n_frames=3)
+        pc.check_golden(pkg, emu_ctx, oracle)
     finally:
-        del os.environ["PFV_ENC_INT_TRANSFORM"]
+        emu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_AUTO)
+    with pytest.raises(pkg.PfvError):
+        emu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, 7)
+    with pytest.raises(pkg.PfvError):
+        emu_ctx.set_option(99, 0)
 
 
 @pytest.mark.gpu
@@ -103,9 +112,12 @@ def test_gpu_hostile_content_sessions(pkg, gpu_ctx, oracle):
 
 @pytest.mark.gpu
 def test_gpu_integer_transform_fallback(pkg, gpu_ctx, oracle):
-    os.environ["PFV_ENC_INT_TRANSFORM"] = "1"
+    L = pkg._lib
+    gpu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_INT)
     try:
         _check_hostile_sessions(pkg, gpu_ctx, oracle, (0, 5, 10), w=208, h=112, n_frames=4)
         pc.check_session(pkg, gpu_ctx, oracle, 320, 240, 5, n_streams=2, n_frames=4)
+        pc.check_golden(pkg, gpu_ctx, oracle)
+        pc.check_trap_vectors(pkg, gpu_ctx, oracle)
     finally:
-        del os.environ["PFV_ENC_INT_TRANSFORM"]
+        gpu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_AUTO)

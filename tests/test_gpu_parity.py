@@ -287,6 +287,10 @@ def test_batch_encoder(pkg, gpu_ctx, oracle):
     sc.check_batch_encoder(pkg, gpu_ctx, oracle, 640, 360, 8, n_streams=2, n_frames=3, gop=15)
 
 
+def test_batch_encoder_writer_failure_is_reported(pkg, gpu_ctx):
+    sc.check_batch_encoder_writer_failure(pkg, gpu_ctx)
+
+
 def test_batch_decoder(pkg, gpu_ctx, oracle):
     sc.check_batch_decoder(pkg, gpu_ctx, oracle, 176, 144, 5, n_streams=5, n_frames=5, gop=3)
     sc.check_batch_decoder(pkg, gpu_ctx, oracle, 640, 360, 7, n_streams=2, n_frames=3, gop=15)
