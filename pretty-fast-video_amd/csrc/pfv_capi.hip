@@ -451,10 +451,10 @@ PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, cons
     // encode only: the forward transform is exact in f32 for any table
     if (ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT)
         hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
-                                                                       ctx->qtab_dev);
+                                                                       ctx->qtab_dev, kQuantMagic);
     else
         hipLaunchKernelGGL(k_enc_iframe<false>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
-                                                                        ctx->qtab_dev);
+                                                                        ctx->qtab_dev, kQuantMagic);
     if ((rc = launch_check(ctx, "k_enc_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -486,11 +486,11 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     if (ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT)
         hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
                                                                        (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
-                                                                       nullptr, ctx->qtab_dev, min_err, -2);
+                                                                       nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic);
     else
         hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
                                                                         (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
-                                                                        nullptr, ctx->qtab_dev, min_err, -2);
+                                                                        nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mv_out, d_mv, n * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -919,9 +919,9 @@ PFV_API int pfv_enc_iframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
     if (s->flt)
-        hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0);
+        hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0, kQuantMagic);
     else
-        hipLaunchKernelGGL(k_enc_iframe<false>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0);
+        hipLaunchKernelGGL(k_enc_iframe<false>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0, kQuantMagic);
     int rc = launch_check(ctx, "k_enc_iframe");
     if (rc) return rc;
     s->cur = nxt;
@@ -940,10 +940,10 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
     if (s->flt)
         hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
-            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2);
+            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic);
     else
         hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
-            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2);
+            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic);
     int rc = launch_check(ctx, "k_enc_pframe");
     if (rc) return rc;
     s->cur = nxt;
@@ -2568,7 +2568,7 @@ PFV_API int pfv_decoder_advance_delta(pfv_decoder *d, double delta, pfv_video_cb
 int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *checked, uint64_t *mismatches, int64_t first_bad[4])
 {
     if (!ctx || !checked || !mismatches) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_selfcheck_float_path: bad argument");
-    if (part < 0 || part > 4) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_selfcheck_float_path: part must be 0..4");
+    if (part < 0 || part > 6) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_selfcheck_float_path: part must be 0..6");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *checked = *mismatches = 0;
     ChkDev *res = nullptr;
@@ -2597,8 +2597,15 @@ int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *che
         CHK_TRY(hipMalloc(&aux, rcp.size() * sizeof(float)));
         CHK_TRY(hipMemcpy(aux, rcp.data(), rcp.size() * sizeof(float), hipMemcpyHostToDevice));
         const unsigned nq = arg ? (unsigned)std::min<uint64_t>(arg, 65535) : 65535u;      // arg: only the first `arg` values of q (emulator runs)
-        hipLaunchKernelGGL(k_chk_quant_div, dim3(nq), dim3(256), 0, ctx->stream, (const float *)aux, res);
+        hipLaunchKernelGGL(k_chk_quant_div, dim3(nq), dim3(256), 0, ctx->stream, (const float *)aux, kQuantMagic, res);
         *checked = (uint64_t)nq * 2 * 8193;
+    } else if (part == 5) {
+        hipLaunchKernelGGL(k_chk_residual, dim3(1), dim3(256), 0, ctx->stream, res);
+        *checked = 2 * 256 * 256;
+    } else if (part == 6) {
+        const unsigned blocks = (arg && arg < (1u << 16)) ? (unsigned)arg : (1u << 16);   // 2^16 x 256 = 2^24 values of |x|
+        hipLaunchKernelGGL(k_chk_iframe_pixel, dim3(blocks), dim3(256), 0, ctx->stream, res);
+        *checked = (uint64_t)blocks * 256 * 2;
     } else if (part == 1) {
         hipLaunchKernelGGL(k_chk_quant_scale, dim3(m_blocks), dim3(256), 0, ctx->stream, res);
         *checked = (uint64_t)m_blocks * 256 * 2 * 10;
@@ -2612,7 +2619,7 @@ int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *che
         CHK_TRY(hipMemcpy(aux, kQs, sizeof kQs, hipMemcpyHostToDevice));
         CHK_TRY(hipMalloc(&aux2, nq * sizeof(float)));
         CHK_TRY(hipMemcpy(aux2, rc.data(), nq * sizeof(float), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_chk_quant_pair, dim3(m_blocks), dim3(256), 0, ctx->stream, (const int *)aux, (const float *)aux2, nq, res);
+        hipLaunchKernelGGL(k_chk_quant_pair, dim3(m_blocks), dim3(256), 0, ctx->stream, (const int *)aux, (const float *)aux2, nq, kQuantMagic, res);
         *checked = (uint64_t)m_blocks * 256 * 2 * 10 * nq;
     } else {
         // the four tables of every quality 0..10 (src/enc.rs:40-51), as the encoder sessions build them
@@ -2636,13 +2643,13 @@ int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *che
         CHK_TRY(hipMemcpy(aux, tabs.data(), tabs.size() * sizeof(ChkTab), hipMemcpyHostToDevice));
         if (part == 3) {
             const unsigned n_pairs = (unsigned)std::min<uint64_t>(arg ? (arg + 1) / 2 : (1u << 19), 1u << 26);
-            hipLaunchKernelGGL(k_chk_blocks, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, (const ChkTab *)aux, 0x50465633ull, n_pairs, res, n_cmp);
+            hipLaunchKernelGGL(k_chk_blocks, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, (const ChkTab *)aux, 0x50465633ull, n_pairs, kQuantMagic, res, n_cmp);
         } else {
             const XformNorms &nm = xform_norms();
             CHK_TRY(hipMalloc(&aux2, 128));
             CHK_TRY(hipMemcpy(aux2, nm.fsign, 64, hipMemcpyHostToDevice));
             CHK_TRY(hipMemcpy((char *)aux2 + 64, nm.isign, 64, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_chk_worst_forward, dim3(4), dim3(64), 0, ctx->stream, (const ChkTab *)aux, (const signed char *)aux2, res, n_cmp);
+            hipLaunchKernelGGL(k_chk_worst_forward, dim3(4), dim3(64), 0, ctx->stream, (const ChkTab *)aux, (const signed char *)aux2, kQuantMagic, res, n_cmp);
             hipLaunchKernelGGL(k_chk_worst_inverse, dim3(2), dim3(64), 0, ctx->stream, (const ChkTab *)aux, (const signed char *)aux2 + 64, res, n_cmp);
         }
     }
@@ -2656,7 +2663,7 @@ int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *che
     CHK_TRY(hipMemcpy(&host, res, sizeof host, hipMemcpyDeviceToHost));
     CHK_TRY(hipMemcpy(&cmp, n_cmp, sizeof cmp, hipMemcpyDeviceToHost));
 #undef CHK_TRY
-    if (part >= 3) *checked = cmp;
+    if (part == 3 || part == 4) *checked = cmp;
     *mismatches = host.mismatches;
     if (first_bad)
         for (int k = 0; k < 4; k++) first_bad[k] = host.first[k];

@@ -279,29 +279,36 @@ __device__ __forceinline__ void cols_to_rows2(int (&v)[2][8], int *mb, int i, in
 // Per-lane quantiser constants for column c of a subblock (raster indices k*8 + c), shared by the lane's
 // four subblocks.  They are read from the LDS copy of the tables at the point of use (8 distinct addresses per
 // wave-instruction: conflict-free broadcast), which keeps them out of the long-lived register set.
+// One 16-byte entry per raster index, {rcp, scale, zigzag position, deq}: the quantiser's three constants arrive with one
+// ds_read_b128 and the float reciprocal sits in the LOW half of an aligned register pair, which is where a packed-f32
+// instruction broadcasts an operand from (the separate-table layout of round 2 cost a v_mov_b32 per pair to get it there).
 struct LaneQ {
     const int *tab;   // LDS table, see fill_qtable
     int c;            // the lane's column
-    __device__ __forceinline__ int zz(int k) const { return tab[k * 8 + c]; }             // INV_ZIGZAG[k*8+c]
-    __device__ __forceinline__ int deq(int k) const { return tab[64 + k * 8 + c]; }       // SCALE[z]*q[z], z = zz (decode)
-    __device__ __forceinline__ float deqf(int k) const { return __int_as_float(tab[64 + k * 8 + c]); }   // the same as f32 bits (fill_qtable<true, true>)
-    __device__ __forceinline__ int scale(int k) const { return tab[128 + k * 8 + c]; }    // DCT_SCALE_FACTOR[k*8+c] (encode); << 16 in the float encoders (fill_qtable<true, true>)
-    __device__ __forceinline__ float rcp(int k) const { return __int_as_float(tab[192 + k * 8 + c]); }   // biased 1/q (encode)
+    __device__ __forceinline__ float rcp(int k) const { return __int_as_float(tab[(k * 8 + c) * 4 + 0]); }   // biased 1/q (encode)
+    __device__ __forceinline__ int scale(int k) const { return tab[(k * 8 + c) * 4 + 1]; }    // DCT_SCALE_FACTOR[k*8+c] (encode); << 16 in the float encoders (fill_qtable<true, true>)
+    __device__ __forceinline__ int zz(int k) const { return tab[(k * 8 + c) * 4 + 2]; }       // INV_ZIGZAG[k*8+c]
+    __device__ __forceinline__ int deq(int k) const { return tab[(k * 8 + c) * 4 + 3]; }      // SCALE[z]*q[z], z = zz (decode)
+    __device__ __forceinline__ float deqf(int k) const { return __int_as_float(tab[(k * 8 + c) * 4 + 3]); }   // the same as f32 bits (fill_qtable<true, true>)
 };
-// The 64-entry tables live in LDS (kQTabDwords per copy), written once per wavefront / workgroup with four
-// coalesced 256-byte loads, so that the per-lane constants cost LDS reads instead of 32 scattered vector
-// memory loads per lane (which would put more bytes through the CU's texture-addresser path than the pixels
-// and coefficients themselves).  Layout: [0] zigzag position, [1] deq, [2] scale, [3] rcp (float bits).
+// The 64-entry tables live in LDS (kQTabDwords per copy), written once per wavefront / workgroup with coalesced loads and one
+// 16-byte store per lane, so that the per-lane constants cost LDS reads instead of 32 scattered vector memory loads per lane
+// (which would put more bytes through the CU's texture-addresser path than the pixels and coefficients themselves).
 constexpr int kQTabDwords = 4 * 64;
+template <bool ENC, bool FLT = false>
+__device__ __forceinline__ int4 load_qentry(const QTab *qt, int lane)   // this lane's table entry (two coalesced global loads)
+{
+    int4 e;
+    e.x = ENC ? __float_as_int(qt->rcp[lane]) : 0;
+    e.y = ENC ? (FLT ? (kScale[lane] << 16) : kScale[lane]) : 0;   // float encoders: second operand of mulhi24 (quant_scale)
+    e.z = kInvZigzag[lane];
+    e.w = FLT ? __float_as_int((float)qt->deq[lane]) : qt->deq[lane];   // float form: deq < 2^24 (checked on the host)
+    return e;
+}
 template <bool ENC, bool FLT = false>
 __device__ __forceinline__ void fill_qtable(int *tab, const QTab *qt, int lane)
 {
-    tab[lane] = kInvZigzag[lane];
-    tab[64 + lane] = FLT ? __float_as_int((float)qt->deq[lane]) : qt->deq[lane];   // float form: deq < 2^24 (checked on the host)
-    if (ENC) {
-        tab[128 + lane] = FLT ? (kScale[lane] << 16) : kScale[lane];   // float encoders: second operand of mulhi24 (quant_pair_f)
-        tab[192 + lane] = __float_as_int(qt->rcp[lane]);
-    }
+    reinterpret_cast<int4 *>(tab)[lane] = load_qentry<ENC, FLT>(qt, lane);
 }
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d)
 {
@@ -590,6 +597,7 @@ __device__ __forceinline__ void f_cols_to_rows(f2 (&x)[8], int *mb, int i, int m
 //                 multiplies next); `biased` = quotient + 1.5 * 2^23 carries the quotient's two's complement in its low mantissa
 //                 bits (|quotient| < 2^15), so a 16-bit store of the register's low half IS the reference's `as i16` -- one
 //                 packed add for the pair instead of two float -> int conversions.
+//   residual_f    trunc(delta / 2) << 8 of a pixel pair (src/common.rs:118-119, :304), see there.
 __device__ __forceinline__ f2 quant_scale(f2 m, int scale16)
 {
     f2 n;
@@ -597,19 +605,39 @@ __device__ __forceinline__ f2 quant_scale(f2 m, int scale16)
     for (int s = 0; s < 2; s++) n[s] = (float)mulhi24((int)m[s], scale16);
     return n;
 }
-__device__ __forceinline__ f2 quant_div(f2 n, float rcp, f2 &biased)
+// magic = 1.5 * 2^23 (kQuantMagic), handed in as a KERNEL ARGUMENT: with the literal the compiler splits the packed add into two
+// v_add_f32 (extract-of-binop-with-constant), with an opaque operand it stays one v_pk_add_f32.
+constexpr float kQuantMagic = 12582912.0f;
+__device__ __forceinline__ f2 quant_div(f2 n, float rcp, float magic, f2 &biased)
 {
     const f2 q = f2trunc(n * f2s(rcp));
-    biased = q + f2s(12582912.0f);
+    biased = q + f2s(magic);
     return q;
 }
-__device__ __forceinline__ f2 quant_pair_f(f2 m, int scale16, float rcp, f2 &biased) { return quant_div(quant_scale(m, scale16), rcp, biased); }
+__device__ __forceinline__ f2 quant_pair_f(f2 m, int scale16, float rcp, float magic, f2 &biased)
+{
+    return quant_div(quant_scale(m, scale16), rcp, magic, biased);
+}
+// calc_residuals + the head of encode_subblock_delta (src/common.rs:118-119, :304) for a pixel pair: (delta / 2) << 8 with Rust's
+// truncating division, delta = src - prediction in [-255, 255].  t = delta / 2 is a multiple of 1/2 with |t| <= 127.5;
+// t * (1 - 2^-10) moves every value less than 1/8 toward zero, so halves leave their tie (toward zero) and integers stay nearest to
+// themselves: round-to-nearest of it IS trunc(t).  The rounding is the fma's own: delta * (1/2 - 2^-11) + 1.5 * 2^23 lands on the
+// integer grid of [2^23, 2^24) (the product is exact inside the fma, 8 x 11 bits); the second fma takes the magic off and scales by
+// 256, exactly (r * 256 and 1.5 * 2^31 are representable, their difference is a small integer).  One v_pk_add_f32 + two v_pk_fma_f32
+// per pair, against v_pk_add + v_pk_mul + 2 v_trunc + v_pk_mul.  pfv_selfcheck part 5 runs it for all 511 x 511 (delta, delta) pairs.
+__device__ __forceinline__ f2 residual_f(f2 src, f2 pred)
+{
+    const f2 d = src - pred;
+    const float c = 0.5f - 1.0f / 2048.0f;
+    const f2 r = f2{__builtin_fmaf(d[0], c, kQuantMagic), __builtin_fmaf(d[1], c, kQuantMagic)};
+    return f2{__builtin_fmaf(r[0], 256.0f, -256.0f * kQuantMagic), __builtin_fmaf(r[1], 256.0f, -256.0f * kQuantMagic)};
+}
 // the 16 bits a ds_write_b16 / a global 16-bit store takes from the biased quotient
 __device__ __forceinline__ int16_t quant_low16(float biased) { return (int16_t)__float_as_int(biased); }
 // Forward, float form: x = row-layout samples in 24.8 fixed point AS FLOATS ((px - 128) * 256 or trunc(d / 2) * 256); leaves the
 // quantised coefficients (column layout, as floats) in x and scatters them in zigzag order into the coefficient stage.
 // The quantiser itself is the integer one of forward_half (exact division by reciprocal).
-__device__ __forceinline__ void forward_half_f(f2 (&x)[8], int *xw, int m, int i, const LaneQ &lq)
+__device__ __forceinline__ void forward_half_f(f2 (&x)[8], int *xw, int m, int i, const LaneQ &lq, float magic)
 {
     int *mb = xw + m * kMBPitch;
     ffdct8(x);   // dct_transform_rows (both subblocks)
@@ -620,16 +648,24 @@ __device__ __forceinline__ void forward_half_f(f2 (&x)[8], int *xw, int m, int i
     for (int k = 0; k < 8; k++) {
         const int zz = lq.zz(k);
         f2 biased;
-        x[k] = quant_pair_f(x[k], lq.scale(k), lq.rcp(k), biased);
+        x[k] = quant_pair_f(x[k], lq.scale(k), lq.rcp(k), magic, biased);
 #pragma unroll
         for (int s = 0; s < 2; s++) stage[s * 64 + zz] = quant_low16(biased[s]);
     }
     wave_lds_sync();
 }
-// Inverse, float form: c = quantised coefficients in column layout (floats) -> row-layout t = floor(x / 256) (floats); the
-// callers add the prediction / 128 and clamp.  lq.deqf = SCALE[z] * q[z] as float (fill_qtable<true, true>).
-// bias: added to the result (an integer; the i-frame path's + 128 rides in the final fma)
-__device__ __forceinline__ void inverse_half_f(f2 (&c)[8], int *xw, int m, int i, const LaneQ &lq, float bias = 0.0f)
+// Inverse, float form: c = quantised coefficients in column layout (floats) -> row layout.  lq.deqf = SCALE[z] * q[z] as float
+// (fill_qtable<true, true>).
+//   PIXEL = false (p-frames): t = floor(x / 256) = x >> 8 as floats; the caller adds the prediction and clamps.
+//   PIXEL = true  (i-frames): x / 256 + (127.5 + 1/512), NOT floored: the caller's v_cvt_pk_u8_f32 rounds to nearest even and
+//           saturates, and x / 256 is a multiple of 1/256, so the fraction of the sum lies in [0.502, 1.498] above floor(x / 256) + 127
+//           and the conversion yields clamp((x >> 8) + 128, 0, 255) -- src/common.rs:321 -- without a v_floor_f32 per pixel
+//           (iframe_pixel_f; pfv_selfcheck part 6 runs it for every |x| < 2^24, tools/ubench/cvt_pk_u8_rounding.hip shows the
+//           instruction's rounding rule on its own).
+constexpr float kPixelBias = 127.501953125f;   // 128 - 1/2 + 1/512
+__device__ __forceinline__ f2 iframe_pixel_f(f2 x) { return x * f2s(1.0f / 256.0f) + f2s(kPixelBias); }   // one v_pk_fma_f32; exact wherever the result matters (|x / 256| < 2^15)
+template <bool PIXEL>
+__device__ __forceinline__ void inverse_half_f(f2 (&c)[8], int *xw, int m, int i, const LaneQ &lq)
 {
     int *mb = xw + m * kMBPitch;
 #pragma unroll
@@ -638,7 +674,7 @@ __device__ __forceinline__ void inverse_half_f(f2 (&c)[8], int *xw, int m, int i
     f_cols_to_rows(c, mb, i, m & 3);
     fidct8(c);   // dct_inverse_transform_rows
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = f2floor(c[k] * f2s(1.0f / 256.0f) + f2s(bias));     // (v >> 8) + bias: |v| < 2^24, exact
+    for (int k = 0; k < 8; k++) c[k] = PIXEL ? iframe_pixel_f(c[k]) : f2floor(c[k] * f2s(1.0f / 256.0f));     // v >> 8: |v| < 2^24, exact
 }
 // 16 reconstructed pixels (floats, integer-valued) -> saturated bytes: v_cvt_pk_u8_f32 clamps to 0..255 and places the byte
 __device__ __forceinline__ uint4 pack_row_f(const f2 (&px)[8])
@@ -668,10 +704,10 @@ __device__ __forceinline__ void unpack_row_f(const uint4 &row, f2 (&px)[8])
 template <bool FLT>
 __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           int16_t *__restrict__ coef, uint8_t *__restrict__ recon,
-                                                          const QTab *__restrict__ qtabs)
+                                                          const QTab *__restrict__ qtabs, float qmagic)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
-    __shared__ int qtab_lds[kStripsPerWG][kQTabDwords];
+    __shared__ __attribute__((aligned(16))) int qtab_lds[kStripsPerWG][kQTabDwords];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
@@ -699,11 +735,11 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
             unpack_row_f(rows[h], x);
 #pragma unroll
             for (int k = 0; k < 8; k++) x[k] = x[k] * f2s(256.0f) - f2s(32768.0f);   // (px - 128) << 8, src/common.rs:291
-            forward_half_f(x, xw, m, i, lq);
+            forward_half_f(x, xw, m, i, lq, qmagic);
             store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
             wave_lds_sync();   // the stage has been read back before the region is reused
             if (recon) {
-                inverse_half_f(x, xw, m, i, lq, 128.0f);                              // + 128; the pack saturates to 0..255 (src/common.rs:321)
+                inverse_half_f<true>(x, xw, m, i, lq);                                // (v >> 8) + 128, clamped: by the pack's rounding + saturation (src/common.rs:321)
                 if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row_f(x);
             }
         } else {
@@ -972,7 +1008,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
 
 // Geometry of one p-frame tile (128 x 64 px = 4 vertically stacked strips) as seen by one wavefront.
 #ifndef PFV_PENC_WAVES
-#define PFV_PENC_WAVES 5   // wavefronts per SIMD the p-frame encoder is compiled for (tuning constant: VGPR budget 96; measured best of 4/5/6)
+#define PFV_PENC_WAVES 6   // wavefronts per SIMD the p-frame encoder is compiled for (tuning constant: VGPR budget 80, LDS 26 KiB per workgroup)
 #endif
 struct TilePos {
     StripPos sp;        // this wavefront's strip
@@ -1092,7 +1128,7 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
 template <bool FLT>
 __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos &tp, const SearchOut &so, const uint4 (&rows)[2], int *xw,
                                                int lane, int8_t *__restrict__ mv_out, uint8_t *__restrict__ has_out,
-                                               int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const int *qtab_lds)
+                                               int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const int *qtab_lds, float qmagic)
 {
     const StripPos &sp = tp.sp;
     const PlaneGeom &p = g.p[sp.plane];
@@ -1120,14 +1156,13 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
                 unpack_row_f(srow, x);
                 unpack_row_f(so.patch[h], pp);
 #pragma unroll
-                for (int k = 0; k < 8; k++)   // calc_residuals (:118-119), delta / 2 truncating, << 8 (:304)
-                    x[k] = f2trunc((x[k] - pp[k]) * f2s(0.5f)) * f2s(256.0f);
-                forward_half_f(x, xw, m, i, lq);
+                for (int k = 0; k < 8; k++) x[k] = residual_f(x[k], pp[k]);   // calc_residuals (:118-119), delta / 2 truncating, << 8 (:304)
+                forward_half_f(x, xw, m, i, lq, qmagic);
                 store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
                 wave_lds_sync();
                 if (h == 0) KMARK(9);
                 if (recon) {
-                    inverse_half_f(x, xw, m, i, lq);
+                    inverse_half_f<false>(x, xw, m, i, lq);
 #pragma unroll
                     for (int k = 0; k < 8; k++) {   // apply_residuals (:98-104): prev + 2 * min(t, 127), saturated by the pack
                         const f2 t = f2{__builtin_fminf(x[k][0], 127.0f), __builtin_fminf(x[k][1], 127.0f)};
@@ -1184,17 +1219,18 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
 //     ---- workgroup barrier: window released ----
 //     transform + reconstruct + store; the exchange region lives in the wavefront's own window slice
 // LDS per workgroup: 17 KiB window (+ 16 bytes in front of it: the 1-pixel level reads one dword to the left of the
-// leftmost candidate of the first window row) + 9 KiB reduction regions + 1 KiB quantiser tables.
+// leftmost candidate of the first window row) + 9 KiB reduction regions (each wavefront's region holds its copy of the
+// quantiser table after the search).
 template <bool FLT>
-__global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PENC_WAVES, PFV_PENC_WAVES))) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs,
-                                                          float min_err, int neg2)
+                                                          float min_err, int neg2, float qmagic)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win_lds[16 + kWinAlloc];
     __shared__ __attribute__((aligned(16))) int red_lds[kStripsPerWG][kRedDwords];
-    __shared__ int qtab_lds[kQTabDwords];
+    static_assert(kRedDwords >= kQTabDwords, "the quantiser table moves into the wavefront's reduction region after its search");
     uint8_t *win = win_lds + 16;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
@@ -1202,7 +1238,10 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const TilePos cur = locate_tile(g, vt, wave);
     const PlaneGeom &p = g.p[cur.sp.plane];
-    if (wave == 0) fill_qtable<true, FLT>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
+    // Quantiser constants: loaded now, stored into the wavefront's OWN reduction region once its search is over (the region is
+    // dead then): no separate LDS array -- 26 KiB per workgroup lets a CU hold six workgroups instead of five -- and no
+    // cross-wavefront dependency.
+    const int4 qentry = load_qentry<true, FLT>(qtabs + p.qsel, lane);
 
     KMARK(0);
 #ifdef PFV_KPROF
@@ -1226,12 +1265,14 @@ __global__ __launch_bounds__(kThreads, PFV_PENC_WAVES) void k_enc_pframe(FrameGe
     so.cx = so.cy = 0; so.coded = false;
     so.patch[0] = so.patch[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, neg2, so);
+    wave_lds_sync();                                              // the search's last reads of the region are complete
+    reinterpret_cast<int4 *>(red_lds[wave])[lane] = qentry;
     KMARK(7);
     __syncthreads();   // window released by every wavefront
     KMARK(8);
     if (cur.wave_valid)
         penc_transform<FLT>(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
-                       recon, qtab_lds);
+                       recon, red_lds[wave], qmagic);
     KMARK(11);
 }
 
@@ -1243,7 +1284,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
                                                           uint8_t *__restrict__ frames_out)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
-    __shared__ int qtab_lds[kStripsPerWG][kQTabDwords];
+    __shared__ __attribute__((aligned(16))) int qtab_lds[kStripsPerWG][kQTabDwords];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
@@ -1305,7 +1346,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
                                                           uint8_t *__restrict__ frames_out)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
-    __shared__ int qtab_lds[kStripsPerWG][kQTabDwords];
+    __shared__ __attribute__((aligned(16))) int qtab_lds[kStripsPerWG][kQTabDwords];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
     const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;

@@ -13,6 +13,9 @@
  *           every intermediate compared (the 1-D transforms run 32 x `arg` times)
  *   part 4  the L1 worst-case blocks behind enc_float_exact: sign patterns that maximise each transform output, at full
  *           amplitude, forward and inverse, every quality
+ *   part 5  residual_f (trunc(delta / 2) << 8 by two fused multiply-adds) for every (source, prediction) byte pair
+ *   part 6  the i-frame pixel without a floor (iframe_pixel_f + v_cvt_pk_u8_f32's round-to-nearest-even and saturation) for every
+ *           inverse-transform output |x| < 2^24                                                 vs  clamp((x >> 8) + 128, 0, 255)
  * checked = evaluations performed, mismatches = how many differed (saturating at 2^32 - 1); first_bad = {operand a, operand b,
  * got, want} of the lowest-numbered failing evaluation, when there is one. */
 #ifndef PFV_SELFCHECK_H

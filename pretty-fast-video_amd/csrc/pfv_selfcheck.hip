@@ -21,18 +21,42 @@ __device__ __forceinline__ void chk_report(ChkDev *r, long long a, long long b, 
 
 // part 0: quant_div + quant_low16, every n in [-8192, 8192] x every q in [1, 65535] (one workgroup per q; rcp[q] = QTab::rcp as
 // make_qtab builds it, on the host)
-__global__ __launch_bounds__(256) void k_chk_quant_div(const float *__restrict__ rcp, ChkDev *res)
+__global__ __launch_bounds__(256) void k_chk_quant_div(const float *__restrict__ rcp, float magic, ChkDev *res)
 {
     const int q = (int)blockIdx.x + 1;
     const float r = rcp[q];
     for (int t = (int)threadIdx.x; t <= 8192; t += 256) {
         const int n0 = t, n1 = -t;
         f2 biased;
-        const f2 got = quant_div(f2{(float)n0, (float)n1}, r, biased);
+        const f2 got = quant_div(f2{(float)n0, (float)n1}, r, magic, biased);
         const int w0 = n0 / q, w1 = n1 / q;                               // src/dct.rs:95: i32 `/` truncates toward zero
         if ((int)got[0] != w0 || quant_low16(biased[0]) != (int16_t)w0) chk_report(res, n0, q, (int)got[0], w0);
         if ((int)got[1] != w1 || quant_low16(biased[1]) != (int16_t)w1) chk_report(res, n1, q, (int)got[1], w1);
     }
+}
+
+// part 5: residual_f, every (source, prediction) byte pair -- thread = one source byte, loop over the predictions; the second
+// half of the pair carries the negated delta
+__global__ __launch_bounds__(256) void k_chk_residual(ChkDev *res)
+{
+    const int a = (int)threadIdx.x;
+    for (int b = 0; b < 256; b++) {
+        const f2 got = residual_f(f2{(float)a, (float)b}, f2{(float)b, (float)a});
+        const int w0 = tdiv2(a - b) * 256, w1 = tdiv2(b - a) * 256;       // src/common.rs:118-119 (i16 delta), :304 (delta / 2 truncating, << 8)
+        if (got[0] != (float)w0) chk_report(res, a, b, (long long)got[0], w0);
+        if (got[1] != (float)w1) chk_report(res, b, a, (long long)got[1], w1);
+    }
+}
+
+// part 6: the i-frame pixel, iframe_pixel_f + v_cvt_pk_u8_f32, for every inverse-transform output |x| < 2^24 (thread = (x, -x))
+__global__ __launch_bounds__(256) void k_chk_iframe_pixel(ChkDev *res)
+{
+    const int x = (int)(blockIdx.x * 256u + threadIdx.x);                 // 0 .. 2^24 - 1
+    const f2 p = iframe_pixel_f(f2{(float)x, (float)-x});
+    const unsigned got = __builtin_amdgcn_cvt_pk_u8_f32(p[1], 1u, __builtin_amdgcn_cvt_pk_u8_f32(p[0], 0u, 0u));
+    const int w0 = min(max((x >> 8) + 128, 0), 255), w1 = min(max((-x >> 8) + 128, 0), 255);     // src/common.rs:321
+    if ((int)(got & 255u) != w0) chk_report(res, x, 0, got & 255u, w0);
+    if ((int)((got >> 8) & 255u) != w1) chk_report(res, -x, 0, (got >> 8) & 255u, w1);
 }
 
 // the distinct values of DCT_SCALE_FACTOR (src/dct.rs:4-13)
@@ -52,7 +76,7 @@ __global__ __launch_bounds__(256) void k_chk_quant_scale(ChkDev *res)
 }
 
 // part 2: the composed quantiser, every |m| < 2^23 x every SCALE x nq quantiser values (qs / rcps on the device)
-__global__ __launch_bounds__(256) void k_chk_quant_pair(const int *__restrict__ qs, const float *__restrict__ rcps, int nq, ChkDev *res)
+__global__ __launch_bounds__(256) void k_chk_quant_pair(const int *__restrict__ qs, const float *__restrict__ rcps, int nq, float magic, ChkDev *res)
 {
     const int m = (int)(blockIdx.x * 256u + threadIdx.x);
     for (int k = 0; k < 10; k++) {
@@ -60,7 +84,7 @@ __global__ __launch_bounds__(256) void k_chk_quant_pair(const int *__restrict__ 
         const int n0 = (int)(((long long)m * S) >> 16), n1 = (int)(((long long)-m * S) >> 16);
         for (int j = 0; j < nq; j++) {
             f2 biased;
-            const f2 got = quant_pair_f(f2{(float)m, (float)-m}, S << 16, rcps[j], biased);
+            const f2 got = quant_pair_f(f2{(float)m, (float)-m}, S << 16, rcps[j], magic, biased);
             const int w0 = n0 / qs[j], w1 = n1 / qs[j];
             if ((int)got[0] != w0 || quant_low16(biased[0]) != (int16_t)w0) chk_report(res, m, ((long long)S << 32) | (unsigned)qs[j], (int)got[0], w0);
             if ((int)got[1] != w1 || quant_low16(biased[1]) != (int16_t)w1) chk_report(res, -m, ((long long)S << 32) | (unsigned)qs[j], (int)got[1], w1);
@@ -86,7 +110,7 @@ __device__ __forceinline__ unsigned chk_hash(unsigned long long x)
 // The closed loop of the encoders on a PAIR of 8x8 blocks held by one thread, integer form next to float form, every
 // intermediate compared.  in[s][r * 8 + c]: 24.8 fixed-point samples ((px - 128) << 8 or (delta / 2) << 8, src/common.rs:291, :304).
 // tabs[t0 .. t0 + nt): the tables to quantise with.  ident: what to report as operand a.  Returns values compared.
-__device__ unsigned chk_closed_loop(const int (&in)[2][64], const ChkTab *tabs, int t0, int nt, ChkDev *res, long long ident)
+__device__ unsigned chk_closed_loop(const int (&in)[2][64], const ChkTab *tabs, int t0, int nt, float magic, ChkDev *res, long long ident)
 {
     unsigned n_cmp = 0;
     int A[2][64];
@@ -132,7 +156,7 @@ __device__ unsigned chk_closed_loop(const int (&in)[2][64], const ChkTab *tabs, 
         // quantise (src/dct.rs:88-99, raster-indexed tables) and dequantise (src/dct.rs:75-86: QTab::deq is already permuted)
         for (int i = 0; i < 64; i++) {
             f2 biased;
-            const f2 qf = quant_pair_f(X[i], kScale[i] << 16, T.qt.rcp[i], biased);
+            const f2 qf = quant_pair_f(X[i], kScale[i] << 16, T.qt.rcp[i], magic, biased);
             for (int s = 0; s < 2; s++) {
                 const int n = (int)(((long long)A[s][i] * kScale[i]) >> 16);
                 const int16_t c = (int16_t)(n / T.q[i]);
@@ -182,7 +206,7 @@ __device__ unsigned chk_closed_loop(const int (&in)[2][64], const ChkTab *tabs, 
 // part 3: random blocks.  Thread = one pair of blocks; kind = pair & 3: 0 random pixels (i-frame input), 1 residual of two random
 // pixel blocks, 2 full-swing 0 / 255 pixels, 3 full-swing +-255 residuals.  Tables: [quality][intra_l, intra_c, inter_l, inter_c];
 // i-frame kinds run the 22 intra tables, residual kinds the 22 inter tables.
-__global__ __launch_bounds__(64) void k_chk_blocks(const ChkTab *__restrict__ tabs, unsigned long long seed, unsigned n_pairs, ChkDev *res,
+__global__ __launch_bounds__(64) void k_chk_blocks(const ChkTab *__restrict__ tabs, unsigned long long seed, unsigned n_pairs, float magic, ChkDev *res,
                                                    unsigned long long *n_cmp_out)
 {
     const unsigned pair = blockIdx.x * 64u + threadIdx.x;
@@ -201,14 +225,14 @@ __global__ __launch_bounds__(64) void k_chk_blocks(const ChkTab *__restrict__ ta
         }
     unsigned long long cmp = 0;
     for (int quality = 0; quality < 11; quality++)
-        cmp += chk_closed_loop(in, tabs, quality * 4 + ((kind & 1) ? 2 : 0), 2, res, pair);
+        cmp += chk_closed_loop(in, tabs, quality * 4 + ((kind & 1) ? 2 : 0), 2, magic, res, pair);
     if (n_cmp_out) atomicAdd(n_cmp_out, cmp);
 }
 
 // part 4a: L1 worst cases of the forward transform -- the block A * sgn(F[u][r]) * sgn(F[v][c]) drives output (u, v) to its
 // largest possible magnitude (and its negation to the most negative).  Thread = (u, v, sign, i-frame / residual amplitude).
 // fsign[u * 8 + k] = sign of d out[u] / d in[k] of the 1-D forward transform.
-__global__ __launch_bounds__(64) void k_chk_worst_forward(const ChkTab *__restrict__ tabs, const signed char *__restrict__ fsign, ChkDev *res,
+__global__ __launch_bounds__(64) void k_chk_worst_forward(const ChkTab *__restrict__ tabs, const signed char *__restrict__ fsign, float magic, ChkDev *res,
                                                           unsigned long long *n_cmp_out)
 {
     const int id = (int)(blockIdx.x * 64u + threadIdx.x);                 // 0 .. 255
@@ -225,7 +249,7 @@ __global__ __launch_bounds__(64) void k_chk_worst_forward(const ChkTab *__restri
         }
     unsigned long long cmp = 0;
     for (int quality = 0; quality < 11; quality++)
-        cmp += chk_closed_loop(in, tabs, quality * 4 + (resid ? 2 : 0), 2, res, 1000000 + id);
+        cmp += chk_closed_loop(in, tabs, quality * 4 + (resid ? 2 : 0), 2, magic, res, 1000000 + id);
     if (n_cmp_out) atomicAdd(n_cmp_out, cmp);
 }
 

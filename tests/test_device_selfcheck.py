@@ -11,6 +11,8 @@ MI355X itself, exhaustively where the operand space allows it:
   part 3   2^20 random 8x8 blocks (pixels / residuals / full-swing patterns) through the closed loop of both forms at every
            quality's tables: 2^20 x (16 + 22 x 16) 1-D transforms, every intermediate compared
   part 4   the L1 worst-case blocks behind enc_float_exact (forward and inverse), every quality
+  part 5   trunc(delta / 2) << 8 by two fused multiply-adds (residual_f), every (source, prediction) byte pair
+  part 6   the i-frame pixel without v_floor (v_cvt_pk_u8_f32 rounds to nearest even and saturates), every |x| < 2^24
 The emulator runs of the same entry point (small ranges) keep the check itself honest in the GPU-less container."""
 import ctypes
 
@@ -60,6 +62,16 @@ def test_gpu_float_butterflies_worst_case_blocks(gpu_ctx):
     assert run_part(gpu_ctx, 4) == 2 * 256 * PER_BLOCK + 128 * 44 * 2 * 128
 
 
+@pytest.mark.gpu
+def test_gpu_residual_by_fma_exhaustive(gpu_ctx):
+    assert run_part(gpu_ctx, 5) == 2 * 256 * 256
+
+
+@pytest.mark.gpu
+def test_gpu_iframe_pixel_without_floor_exhaustive(gpu_ctx):
+    assert run_part(gpu_ctx, 6) == (1 << 24) * 2
+
+
 def test_emu_selfcheck_small_ranges(emu_ctx):
     """the same entry point on the CPU emulator (IEEE f32 on the host): small slices of every part"""
     assert run_part(emu_ctx, 0, 96) == 96 * 2 * 8193
@@ -67,3 +79,5 @@ def test_emu_selfcheck_small_ranges(emu_ctx):
     assert run_part(emu_ctx, 2, 8) == 8 * 256 * 2 * 10 * 24
     assert run_part(emu_ctx, 3, 256) == 256 * PER_BLOCK
     assert run_part(emu_ctx, 4) == 2 * 256 * PER_BLOCK + 128 * 44 * 2 * 128
+    assert run_part(emu_ctx, 5) == 2 * 256 * 256
+    assert run_part(emu_ctx, 6, 1024) == 1024 * 256 * 2
