@@ -1008,7 +1008,8 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
 
 // Geometry of one p-frame tile (128 x 64 px = 4 vertically stacked strips) as seen by one wavefront.
 #ifndef PFV_PENC_WAVES
-#define PFV_PENC_WAVES 6   // wavefronts per SIMD the p-frame encoder is compiled for (tuning constant: VGPR budget 80, LDS 26 KiB per workgroup)
+#define PFV_PENC_WAVES 5   // wavefronts per SIMD the p-frame encoder is compiled for: 94 VGPRs, 27 KiB of LDS per workgroup.  Six was tried in round 3 (quantiser
+                           // table moved into the wavefronts' reduction regions -> 26 KiB; 80 VGPRs cost 16 spills): 619 vs 585 us on one box
 #endif
 struct TilePos {
     StripPos sp;        // this wavefront's strip
@@ -1219,8 +1220,7 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
 //     ---- workgroup barrier: window released ----
 //     transform + reconstruct + store; the exchange region lives in the wavefront's own window slice
 // LDS per workgroup: 17 KiB window (+ 16 bytes in front of it: the 1-pixel level reads one dword to the left of the
-// leftmost candidate of the first window row) + 9 KiB reduction regions (each wavefront's region holds its copy of the
-// quantiser table after the search).
+// leftmost candidate of the first window row) + 9 KiB reduction regions + 1 KiB quantiser tables.
 template <bool FLT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PENC_WAVES, PFV_PENC_WAVES))) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
 {
     __shared__ __attribute__((aligned(16))) uint8_t win_lds[16 + kWinAlloc];
     __shared__ __attribute__((aligned(16))) int red_lds[kStripsPerWG][kRedDwords];
-    static_assert(kRedDwords >= kQTabDwords, "the quantiser table moves into the wavefront's reduction region after its search");
+    __shared__ __attribute__((aligned(16))) int qtab_lds[kQTabDwords];
     uint8_t *win = win_lds + 16;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
@@ -1238,10 +1238,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
     const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const TilePos cur = locate_tile(g, vt, wave);
     const PlaneGeom &p = g.p[cur.sp.plane];
-    // Quantiser constants: loaded now, stored into the wavefront's OWN reduction region once its search is over (the region is
-    // dead then): no separate LDS array -- 26 KiB per workgroup lets a CU hold six workgroups instead of five -- and no
-    // cross-wavefront dependency.
-    const int4 qentry = load_qentry<true, FLT>(qtabs + p.qsel, lane);
+    if (wave == 0) fill_qtable<true, FLT>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
 
     KMARK(0);
 #ifdef PFV_KPROF
@@ -1265,14 +1262,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
     so.cx = so.cy = 0; so.coded = false;
     so.patch[0] = so.patch[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, neg2, so);
-    wave_lds_sync();                                              // the search's last reads of the region are complete
-    reinterpret_cast<int4 *>(red_lds[wave])[lane] = qentry;
     KMARK(7);
     __syncthreads();   // window released by every wavefront
     KMARK(8);
     if (cur.wave_valid)
         penc_transform<FLT>(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
-                       recon, red_lds[wave], qmagic);
+                       recon, qtab_lds, qmagic);
     KMARK(11);
 }
 
