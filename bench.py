@@ -206,8 +206,9 @@ class StreamSet:
     """S independent streams of one geometry resident in HBM: `n_frames` synthetic frames per stream (generated on the
     device from (seed, t)), an encoder session and a decoder session S streams wide, and the buffers between them."""
 
-    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, fused_crop=True):
+    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, fused_crop=True, kind="pan"):
         self.pkg, self.ctx, self.W, self.H, self.Q, self.S, self.n_frames = pkg, ctx, W, H, Q, len(seeds), n_frames
+        self.kind = kind
         self.seeds = [int(s) for s in seeds]
         lib = pkg._lib.load()
         self.fb = int(lib.pfv_frame_bytes(W, H))
@@ -222,7 +223,7 @@ class StreamSet:
         if fused_crop:
             self.dec.set_output_dev(self.out_frames)       # retframe crop (src/dec.rs:209-211) fused into decode
         for t in range(n_frames):
-            ctx.synth_frames_dev(W, H, self.seeds, t, self.frame_ptr(t))
+            ctx.synth_frames_dev(W, H, self.seeds, t, self.frame_ptr(t), kind=kind)
         ctx.sync()
 
     def _alloc(self, n):
@@ -344,6 +345,70 @@ def entropy_side(ss, timer, args):
             "note": "encode only, frames in HBM -> .pfv packet payloads in HBM: k_enc_iframe/k_enc_pframe + the device entropy "
                     "stage, HIP-event time over whole passes; two_stream_*: the stage on a second HIP stream with "
                     "double-buffered encode outputs"}
+
+
+def low_motion_side(pkg, ctx, timer, W, H, Q, seeds, n_frames, default_kern_ms, default_coded, reps=4):
+    """The same launch shape on LOW-MOTION content (static background, four moving noisy rectangles: about a quarter of a p-frame's
+    macroblocks are coded, the rest skipped -- src/common.rs:221-222 transforms nothing for those): what the skip-aware transform of
+    k_enc_pframe (tile-level compaction of the coded macroblocks) buys where there is something to skip."""
+    L = pkg._lib
+    off_ms = None
+    if not EMU:     # the same content with the compaction switched off (sessions read the option when they are created)
+        ctx.set_option(L.PFV_OPT_TILE_COMPACTION, 0)
+        try:
+            ss0 = StreamSet(pkg, ctx, W, H, Q, seeds[:max(1, len(seeds) // 1)], n_frames, kind="low_motion")
+            ss0.step()
+            ctx.sync()
+            marks = []
+            ss0.step(on_launch=lambda name=None, a=None, b=None: timer.stamp() if name is None else (marks.append((a, b)) if name == "k_enc_pframe" else None))
+            ctx.sync()
+            off_ms = float(np.mean([timer.ms(a, b) for a, b in marks]))
+            ss0.close()
+        finally:
+            ctx.set_option(L.PFV_OPT_TILE_COMPACTION, 1)
+    floor_ms = None
+    if not EMU:     # nothing coded at all (the background alone): what is left of k_enc_pframe is its search -- the floor of any skip-aware scheme
+        ss0 = StreamSet(pkg, ctx, W, H, Q, seeds, min(n_frames, 3), kind="static")
+        ss0.step()
+        ctx.sync()
+        marks = []
+        ss0.step(on_launch=lambda name=None, a=None, b=None: timer.stamp() if name is None else (marks.append((a, b)) if name == "k_enc_pframe" else None))
+        ctx.sync()
+        floor_ms = float(np.mean([timer.ms(a, b) for a, b in marks]))
+        floor_coded = ss0.coded_fraction()
+        ss0.close()
+    ss = StreamSet(pkg, ctx, W, H, Q, seeds, n_frames, kind="low_motion")
+    ev = {k: [] for k in BYTES_PER_MB}
+
+    def on_launch(name=None, a=None, b=None):
+        if name is None:
+            return timer.stamp()
+        ev[name].append((a, b))
+        return None
+    ss.step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ss.step(on_launch=on_launch)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    ss.verify()
+    coded = ss.coded_fraction()
+    kern_ms = {k: float(np.mean([timer.ms(a, b) for a, b in v])) for k, v in ev.items() if v}
+    launch_mbs = ss.S * ss.n_mb
+    res = {"value": reps * n_frames * launch_mbs / el, "unit": "macroblocks/s (encode+decode)", "pframe_coded_fraction": round(coded, 4),
+           "kernels_avg_launch_ms": kern_ms,
+           "k_enc_pframe_vs_default_workload": kern_ms["k_enc_pframe"] / default_kern_ms["k_enc_pframe"] if "k_enc_pframe" in default_kern_ms else None,
+           "k_enc_pframe_frac_of_hbm_peak": launch_mbs * BYTES_PER_MB_PENC / (kern_ms["k_enc_pframe"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "k_enc_pframe_ms_without_tile_compaction": off_ms,
+           "k_enc_pframe_ms_nothing_coded": floor_ms, "nothing_coded_actual_coded_fraction": floor_coded if floor_ms else None,
+           "k_enc_pframe_ms_perfect_compaction_bound": (floor_ms + coded * (default_kern_ms["k_enc_pframe"] - floor_ms) / default_coded) if floor_ms and default_coded else None,
+           "note": "same streams-per-launch, geometry, quality and seeds as the headline; content kind low_motion (pfv_synth_frames_kind_dev). "
+                   "nothing_coded: content kind static, every macroblock skipped = the search alone; perfect_compaction_bound = that floor + the "
+                   "coded share of what transforming costs on the default workload (floor + coded * (default - floor) / default_coded): what a "
+                   "transform that skipped every skipped macroblock at no cost would take"}
+    ss.close()
+    return res
 
 
 def single_stream_side(pkg, ctx, Q, reps=6):
@@ -707,6 +772,7 @@ def main():
                 ss.close()
             else:
                 ss.close()                            # give the 4.5 GB of resident input back first
+                extra["low_motion"] = low_motion_side(pkg, ctx, timer, W, H, Q, [int(r[1]) for r in mine], NF, kern_ms, coded_frac)
                 extra["single_stream"] = single_stream_side(pkg, ctx, Q)
                 extra["batch_encoder_end_to_end"] = batch_encoder_side(pkg, ctx, Q)
                 extra["config4"] = stream_4k_side(pkg, ctx, Q, pkg.synth.SEED)

@@ -76,8 +76,11 @@ PFV_API const char *pfv_version(void);
  *       PFV_ENC_TRANSFORM_AUTO (default)  in f32 where that is provably the same arithmetic -- every intermediate an integer
  *                                          below 2^24 for the session's tables, checked at session creation; always true for
  *                                          quality 0..10 -- and in i32 otherwise
- *       PFV_ENC_TRANSFORM_INT             always the i32 kernels */
-typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1 } pfv_option;
+ *       PFV_ENC_TRANSFORM_INT             always the i32 kernels
+ *   PFV_OPT_TILE_COMPACTION  1 (default): the p-frame encoder transforms only CODED macroblocks where that saves work -- a
+ *       skipped macroblock is not transformed by the reference either (src/common.rs:221-222) -- by moving the coded macroblocks of
+ *       a 128 x 64 tile together before the transform phase; 0: every wavefront transforms its own strip (measurements) */
+typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2 } pfv_option;
 enum { PFV_ENC_TRANSFORM_AUTO = 0, PFV_ENC_TRANSFORM_INT = 1 };
 PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value);
 PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value);
@@ -158,6 +161,14 @@ PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int wi
  * array) as packed Y|U|V frames back to back in frames_dev.  Byte-identical to synth.SyntheticStream(w, h, seed).frame(t). */
 PFV_API int pfv_synth_frames_dev(pfv_ctx *ctx, int width, int height, int n_streams, const uint64_t *seeds, int t,
                                  uint8_t *frames_dev);
+/* The same with the content kind chosen: PFV_SYNTH_PAN (what pfv_synth_frames_dev generates: the whole texture pans, noise on
+ * half the macroblocks: ~85 % of a quality-5 p-frame is coded) or PFV_SYNTH_LOW_MOTION (static background, four noisy rectangles
+ * of about a quarter of the frame's width and height moving over it: ~25 % coded, the rest skipped, src/common.rs:221-222).
+ * PFV_SYNTH_STATIC: the background alone (every p-frame macroblock skipped: the floor of the p-frame encoder, its search).
+ * Byte-identical to synth.SyntheticStream(w, h, seed, kind).frame(t). */
+enum { PFV_SYNTH_PAN = 0, PFV_SYNTH_LOW_MOTION = 1, PFV_SYNTH_STATIC = 2 };
+PFV_API int pfv_synth_frames_kind_dev(pfv_ctx *ctx, int width, int height, int n_streams, const uint64_t *seeds, int t, int kind,
+                                      uint8_t *frames_dev);
 
 /* ------------------------------------------------------------------ device memory helpers */
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);

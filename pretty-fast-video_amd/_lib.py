@@ -27,6 +27,7 @@ PFV_ERR_STATE = -9
 
 # pfv_ctx_set_option
 PFV_OPT_ENC_TRANSFORM = 1
+PFV_OPT_TILE_COMPACTION = 2
 PFV_ENC_TRANSFORM_AUTO, PFV_ENC_TRANSFORM_INT = 0, 1
 
 
@@ -69,6 +70,7 @@ SIGNATURES = [
     ("pfv_rgb_to_yuv420_dev", c_int, [_P, _P, c_int, c_int, _P]),
     ("pfv_yuv420_to_rgb_dev", c_int, [_P, _P, c_int, c_int, _P]),
     ("pfv_synth_frames_dev", c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    ("pfv_synth_frames_kind_dev", c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     ("pfv_dev_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
     ("pfv_dev_free", c_int, [_P, _P]),
     ("pfv_host_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
@@ -167,8 +169,14 @@ def load():
         raise PfvError(PFV_ERR_NO_DEVICE, f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = ctypes.CDLL(path)
+    older = path != DEFAULT_LIB and os.environ.get("PFV_HIP_LIB_OLDER") == "1"   # A/B runs against a build of an earlier commit (tools/ab_prev.sh)
     for name, restype, argtypes in SIGNATURES:
-        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        try:
+            fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        except AttributeError:
+            if older:
+                continue
+            raise
         fn.restype = restype
         fn.argtypes = argtypes
     _lib, _lib_path = lib, path

@@ -82,12 +82,16 @@ class Context:
     def free(self, ptr: int):
         self.check(self._lib.pfv_dev_free(self.handle, ctypes.c_void_p(ptr)))
 
-    def synth_frames_dev(self, width: int, height: int, seeds, t: int, frames_dev: int):
+    def synth_frames_dev(self, width: int, height: int, seeds, t: int, frames_dev: int, kind="pan"):
         """frame t of len(seeds) synthetic streams (synth.SyntheticStream bytes) written on the device, asynchronously on
-        the context's stream, into frames_dev (len(seeds) packed Y|U|V frames back to back)"""
+        the context's stream, into frames_dev (len(seeds) packed Y|U|V frames back to back); kind: "pan" | "low_motion" | "static" """
         sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
-        self.check(self._lib.pfv_synth_frames_dev(self.handle, int(width), int(height), int(sd.size), ptr(sd), int(t),
-                                                  ctypes.c_void_p(int(frames_dev))))
+        k = {"pan": 0, "low_motion": 1, "static": 2}[kind]
+        if k == 0:
+            self.check(self._lib.pfv_synth_frames_dev(self.handle, int(width), int(height), int(sd.size), ptr(sd), int(t), ctypes.c_void_p(int(frames_dev))))
+            return
+        self.check(self._lib.pfv_synth_frames_kind_dev(self.handle, int(width), int(height), int(sd.size), ptr(sd), int(t), k,
+                                                       ctypes.c_void_p(int(frames_dev))))
 
     def host_array(self, nbytes: int) -> np.ndarray:
         """uint8 array over page-locked host memory (freed when the context closes)"""

@@ -61,6 +61,7 @@ struct pfv_ctx {
     int n_cus = 256;             // compute units of the device (persistent-kernel grid sizing)
     bool capturing = false;      // a pfv_graph_begin is open on the stream
     int opt_enc_transform = PFV_ENC_TRANSFORM_AUTO;   // pfv_ctx_set_option(PFV_OPT_ENC_TRANSFORM)
+    int opt_tile_compaction = 1;                      // pfv_ctx_set_option(PFV_OPT_TILE_COMPACTION)
 };
 
 static thread_local std::string g_tls_err;
@@ -104,6 +105,10 @@ PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value)
         if (value != PFV_ENC_TRANSFORM_AUTO && value != PFV_ENC_TRANSFORM_INT) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENC_TRANSFORM: unknown value");
         ctx->opt_enc_transform = value;
         return PFV_OK;
+    case PFV_OPT_TILE_COMPACTION:
+        if (value != 0 && value != 1) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_TILE_COMPACTION: 0 or 1");
+        ctx->opt_tile_compaction = value;
+        return PFV_OK;
     default:
         return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_set_option: unknown option");
     }
@@ -113,6 +118,7 @@ PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value)
     if (!ctx || !value) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_get_option: bad argument");
     switch (option) {
     case PFV_OPT_ENC_TRANSFORM: *value = ctx->opt_enc_transform; return PFV_OK;
+    case PFV_OPT_TILE_COMPACTION: *value = ctx->opt_tile_compaction; return PFV_OK;
     default: return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_get_option: unknown option");
     }
 }
@@ -486,11 +492,11 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     if (ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT)
         hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
                                                                        (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
-                                                                       nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic);
+                                                                       nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic, ctx->opt_tile_compaction ? kPencCompactMax : 0);
     else
         hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
                                                                         (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
-                                                                        nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic);
+                                                                        nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic, ctx->opt_tile_compaction ? kPencCompactMax : 0);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mv_out, d_mv, n * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -636,8 +642,14 @@ PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int wi
 // packed Y|U|V frames back to back into frames_dev.  Same bytes as synth.SyntheticStream(width, height, seed).frame(t).
 PFV_API int pfv_synth_frames_dev(pfv_ctx *ctx, int width, int height, int n_streams, const uint64_t *seeds, int t, uint8_t *frames_dev)
 {
+    return pfv_synth_frames_kind_dev(ctx, width, height, n_streams, seeds, t, PFV_SYNTH_PAN, frames_dev);
+}
+PFV_API int pfv_synth_frames_kind_dev(pfv_ctx *ctx, int width, int height, int n_streams, const uint64_t *seeds, int t, int kind,
+                                      uint8_t *frames_dev)
+{
     if (!ctx) return fail(nullptr, PFV_ERR_BAD_ARG, "null ctx");
-    if (!seeds || !frames_dev || width <= 0 || height <= 0 || (width & 1) || (height & 1) || n_streams <= 0 || n_streams > 65535 || t < 0)
+    if (!seeds || !frames_dev || width <= 0 || height <= 0 || (width & 1) || (height & 1) || n_streams <= 0 || n_streams > 65535 || t < 0 ||
+        (kind != PFV_SYNTH_PAN && kind != PFV_SYNTH_LOW_MOTION && kind != PFV_SYNTH_STATIC))
         return fail(ctx, PFV_ERR_BAD_ARG, "pfv_synth_frames_dev: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     void *sd = nullptr;
@@ -646,8 +658,13 @@ PFV_API int pfv_synth_frames_dev(pfv_ctx *ctx, int width, int height, int n_stre
     // pageable source: the runtime stages the few bytes before returning, the caller's array is free again
     HIP_TRY(ctx, hipMemcpyAsync(sd, seeds, (size_t)n_streams * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     const long n = (long)width * height;
-    hipLaunchKernelGGL(k_synth_frames, dim3((unsigned)((n + kThreads - 1) / kThreads), 3, (unsigned)n_streams), dim3(kThreads), 0, ctx->stream,
-                       width, height, t, (const uint64_t *)sd, frames_dev, (long)pfv_frame_bytes(width, height));
+    const dim3 grid((unsigned)((n + kThreads - 1) / kThreads), 3, (unsigned)n_streams);
+    if (kind != PFV_SYNTH_PAN)
+        hipLaunchKernelGGL(k_synth_frames_low_motion, grid, dim3(kThreads), 0, ctx->stream, width, height, t, (const uint64_t *)sd, frames_dev,
+                           (long)pfv_frame_bytes(width, height), kind == PFV_SYNTH_LOW_MOTION ? kSynthObjects : 0);
+    else
+        hipLaunchKernelGGL(k_synth_frames, grid, dim3(kThreads), 0, ctx->stream, width, height, t, (const uint64_t *)sd, frames_dev,
+                           (long)pfv_frame_bytes(width, height));
     return launch_check(ctx, "k_synth_frames");
 }
 
@@ -803,6 +820,7 @@ struct pfv_enc_session {
     QTab *qtab_dev = nullptr;       // intra_l, intra_c, inter_l, inter_c
     float px_err = 0.0f;
     bool flt = false;                        // the closed loop may run in f32 (enc_float_exact holds for all four tables)
+    bool tile_compaction = true;             // PFV_OPT_TILE_COMPACTION at creation
     uint8_t *prev[2] = {nullptr, nullptr};   // ping-pong prev_frame, padded, n_streams wide
     int cur = 0;                             // prev[cur] is the current prev_frame
     // staging for the host-buffer entry points
@@ -868,6 +886,7 @@ PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int qual
         int rc = make_qtab(ctx, q[i], &tabs[i]);
         if (rc) { delete s; return rc; }
     }
+    s->tile_compaction = ctx->opt_tile_compaction != 0;
     s->flt = ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT && enc_float_exact(q[0], 128.0 * 256.0) && enc_float_exact(q[1], 128.0 * 256.0) &&
              enc_float_exact(q[2], 127.0 * 256.0) && enc_float_exact(q[3], 127.0 * 256.0);
     size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
@@ -940,10 +959,10 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
     if (s->flt)
         hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
-            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic);
+            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic, s->tile_compaction ? kPencCompactMax : 0);
     else
         hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
-            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic);
+            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic, s->tile_compaction ? kPencCompactMax : 0);
     int rc = launch_check(ctx, "k_enc_pframe");
     if (rc) return rc;
     s->cur = nxt;

@@ -813,6 +813,7 @@ __device__ unsigned long long pfv_kprof[kProfRows][16];
 // wavefront-private LDS region (8 ds_write_b32 + 2 ds_read_b128 per lane: LDS-pipe work) so that lane c ends up with
 // the 8 row-pair partials of candidate c and adds them with plain VALU adds -- instead of all-reducing all 8 values over
 // the 8 lanes with 24 DPP adds and building 8 keys in every lane.
+constexpr int kPencCompactMax = 16;   // k_enc_pframe: a tile's coded macroblocks are moved together when there are at most this many (see there)
 constexpr int kRedPitch = 72;   // dwords per macroblock: 64 used; 72 = 8 (mod 32) spreads the 4 macroblocks of a 32-lane group over the banks
 constexpr int kRedDwords = kStripMB * kRedPitch;
 struct SearchLane {
@@ -1124,24 +1125,86 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
     }
 }
 
-// Phase 2: block headers, residual transform, coefficient + reconstruction stores.  xw: this wavefront's
-// exchange region (lives in the wavefront's own part of the window buffer that has just been released).
+// One half (h: rows 0..7 or 8..15 = two subblocks per lane) of the residual pipeline of a wavefront's 8 macroblock slots:
+// calc_residuals -> encode_subblock_delta -> [store(): the zigzag stage xw now holds the quantised coefficients of the 8 slots]
+// -> decode_subblock -> apply_residuals (src/common.rs:108-123, 300-311, 313-325, 98-104).  Returns the lane's reconstructed
+// 16-pixel row.  A slot whose source row equals its prediction row (skipped or empty slot) yields zero coefficients and the
+// prediction itself.
+template <bool FLT, class Store>
+__device__ __forceinline__ uint4 penc_half(const uint4 &srow, const uint4 &prow, int *xw, int m, int i, const LaneQ &lq, float qmagic, bool want_recon,
+                                           Store &&store)
+{
+    uint4 out = prow;
+    if (FLT) {
+        f2 x[8], pp[8];
+        unpack_row_f(srow, x);
+        unpack_row_f(prow, pp);
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = residual_f(x[k], pp[k]);   // calc_residuals (:118-119), delta / 2 truncating, << 8 (:304)
+        forward_half_f(x, xw, m, i, lq, qmagic);
+        store();
+        wave_lds_sync();
+        if (want_recon) {
+            inverse_half_f<false>(x, xw, m, i, lq);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {   // apply_residuals (:98-104): prev + 2 * min(t, 127), saturated by the pack
+                const f2 t = f2{__builtin_fminf(x[k][0], 127.0f), __builtin_fminf(x[k][1], 127.0f)};
+                pp[k] = pp[k] + t * f2s(2.0f);
+            }
+            out = pack_row_f(pp);
+        }
+    } else {
+        int v[2][8], pp[2][8];
+        unpack_row(srow, v);
+        unpack_row(prow, pp);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                int d = v[s][k] - pp[s][k];                       // calc_residuals (:118-119); |d| <= 255
+                v[s][k] = (int)((unsigned)tdiv2(d) << 8);         // (:304)
+            }
+        }
+        forward_half(v, xw, m, i, lq, true);
+        store();
+        wave_lds_sync();
+        if (want_recon) {
+            inverse_half(v, xw, m, i, lq);
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+#pragma unroll
+                for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
+                    pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
+            }
+            out = pack_row(pp);
+        }
+    }
+    return out;
+}
+
+// What a skipped macroblock leaves behind (src/common.rs:221-222 returns subblocks: None, :281-283 copies the patch): zero
+// coefficients (API contract: fixed 512-byte stride) and the prediction as reconstruction.  Called by the 8 lanes of the macroblock.
+__device__ __forceinline__ void penc_store_skipped(int16_t *coef_mb, uint8_t *dst, long pw, int i, const uint4 (&patch)[2])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) st_stream(&reinterpret_cast<uint4 *>(coef_mb)[j * 8 + i], make_uint4(0, 0, 0, 0));
+    if (dst) {
+        *reinterpret_cast<uint4 *>(dst) = patch[0];
+        *reinterpret_cast<uint4 *>(dst + 8 * pw) = patch[1];
+    }
+}
+
+// Phase 2, strip form: the wavefront transforms its own 8 macroblocks (all of them when any is coded: a skipped one takes its
+// prediction as its source).  xw: this wavefront's exchange region (its own part of the window buffer that has just been released).
 template <bool FLT>
 __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos &tp, const SearchOut &so, const uint4 (&rows)[2], int *xw,
-                                               int lane, int8_t *__restrict__ mv_out, uint8_t *__restrict__ has_out,
-                                               int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const int *qtab_lds, float qmagic)
+                                               int lane, int16_t *__restrict__ coef, uint8_t *__restrict__ recon, const int *qtab_lds, float qmagic)
 {
     const StripPos &sp = tp.sp;
     const PlaneGeom &p = g.p[sp.plane];
     const int m = lane >> 3, i = lane & 7;
     const bool mb_valid = m < sp.n_mb, coded = so.coded;
     const int mbx = sp.x0 + m * 16;
-    if (i == 0 && mb_valid) {
-        long mbi = (long)sp.stream * g.mbs_per_frame + sp.mb_first + m;
-        mv_out[mbi * 2 + 0] = (int8_t)so.cx;
-        mv_out[mbi * 2 + 1] = (int8_t)so.cy;
-        has_out[mbi] = coded ? 1 : 0;
-    }
     int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx : nullptr;
 
@@ -1151,64 +1214,56 @@ __device__ __forceinline__ void penc_transform(const FrameGeom &g, const TilePos
         for (int h = 0; h < 2; h++) {
             // a skipped macroblock (None in the reference, zero coefficients here) takes its prediction as its source:
             // zero residual -> zero coefficients -> reconstruction = prediction, without masking 16 values per pass
-            const uint4 srow = coded ? rows[h] : so.patch[h];
-            if (FLT) {
-                f2 x[8], pp[8];
-                unpack_row_f(srow, x);
-                unpack_row_f(so.patch[h], pp);
+            const uint4 o = penc_half<FLT>(coded ? rows[h] : so.patch[h], so.patch[h], xw, m, i, lq, qmagic, recon != nullptr,
+                                           [&]() { store_coef_half(xw, coef_mb0, sp.n_mb, lane, h); });
+            if (h == 0) KMARK(9);
+            if (recon && mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = o;
+        }
+    } else if (mb_valid) {
+        penc_store_skipped(coef_mb0 + m * 256, dst, p.pw, i, so.patch);   // every macroblock of the strip is skipped
+    }
+}
+
+// Phase 2, compacted form (skip-aware transform): the tile's CODED macroblocks have been renumbered 0 .. n_coded-1 in tile
+// order and their source / prediction rows staged in LDS; this wavefront transforms slots 8 * wave .. 8 * wave + 7 and stores the
+// results at the macroblocks' own places.  slot_orig: LDS, per slot of the TILE the macroblock's place (strip << 3 | macroblock
+// in the strip).  Lanes of an empty slot (slot >= n_coded) carry zeros and store nothing.
+template <bool FLT>
+__device__ __forceinline__ void penc_transform_compact(const FrameGeom &g, const TilePos &tp, int wave, int n_coded, const int *slot_orig,
+                                                       const uint4 *staged, int *xw, int lane, int16_t *__restrict__ coef,
+                                                       uint8_t *__restrict__ recon, const int *qtab_lds, float qmagic)
+{
+    const PlaneGeom &p = g.p[tp.sp.plane];
+    const int m = lane >> 3, i = lane & 7;
+    const int slot = wave * 8 + m;
+    const bool has = slot < n_coded;
+    // the tile's first strip starts at macroblock row plane_ty * kStripsPerWG; strip s of the tile is s macroblock rows further down
+    const long tile_mb0 = (long)tp.sp.stream * g.mbs_per_frame + p.mb0 + (long)(tp.plane_ty * kStripsPerWG) * p.bw + tp.sp.sx * kStripMB;
+    const LaneQ lq{qtab_lds, i};
+    const uint4 *sl = staged + (has ? slot : 0) * 32 + i * 4;   // the lane's 64 staged bytes: source rows 0 / 8, prediction rows 0 / 8
 #pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = residual_f(x[k], pp[k]);   // calc_residuals (:118-119), delta / 2 truncating, << 8 (:304)
-                forward_half_f(x, xw, m, i, lq, qmagic);
-                store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
-                wave_lds_sync();
-                if (h == 0) KMARK(9);
-                if (recon) {
-                    inverse_half_f<false>(x, xw, m, i, lq);
+    for (int h = 0; h < 2; h++) {
+        // the rows are fetched half by half (the staging area lives until the tile is done): 8 registers live instead of 16
+        uint4 srow = sl[h], prow = sl[2 + h];
+        if (!has) srow = prow = make_uint4(0, 0, 0, 0);
+        const uint4 o = penc_half<FLT>(srow, prow, xw, m, i, lq, qmagic, recon != nullptr, [&]() {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {   // apply_residuals (:98-104): prev + 2 * min(t, 127), saturated by the pack
-                        const f2 t = f2{__builtin_fminf(x[k][0], 127.0f), __builtin_fminf(x[k][1], 127.0f)};
-                        pp[k] = pp[k] + t * f2s(2.0f);
-                    }
-                    if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row_f(pp);
-                }
-                if (h == 0) KMARK(10);
-            } else {
-                int v[2][8], pp[2][8];
-                unpack_row(srow, v);
-                unpack_row(so.patch[h], pp);
-#pragma unroll
-                for (int s = 0; s < 2; s++) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        int d = v[s][k] - pp[s][k];                       // calc_residuals (:118-119); |d| <= 255
-                        v[s][k] = (int)((unsigned)tdiv2(d) << 8);         // (:304)
-                    }
-                }
-                forward_half(v, xw, m, i, lq, true);
-                store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
-                wave_lds_sync();
-                if (recon) {
-                    inverse_half(v, xw, m, i, lq);
-#pragma unroll
-                    for (int s = 0; s < 2; s++) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++)   // apply_residuals (:98-104); v == 0 for skipped blocks: copy (:281-283)
-                            pp[s][k] = min(max(pp[s][k] + 2 * v[s][k], 0), 255);
-                    }
-                    if (mb_valid) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row(pp);
+            for (int j = 0; j < 2; j++) {   // the stage's 128 16-byte chunks, 16 per slot, to the slots' macroblocks
+                const int ch = j * 64 + lane, sc = wave * 8 + (ch >> 4);
+                if (sc < n_coded) {
+                    const int og = slot_orig[sc];
+                    int16_t *mb = coef + (tile_mb0 + (long)(og >> 3) * p.bw + (og & 7)) * 256;
+                    st_stream(&reinterpret_cast<uint4 *>(mb)[h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(xw)[ch]);
                 }
             }
-        }
-    } else {
-        // every macroblock of the strip is skipped: zero coefficients (API contract; the reference has None)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int ch = j * 64 + lane;
-            if ((ch >> 5) < sp.n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[ch], make_uint4(0, 0, 0, 0));
-        }
-        if (recon && mb_valid) {
-            *reinterpret_cast<uint4 *>(dst) = so.patch[0];
-            *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = so.patch[1];
+        });
+        if (recon && has) {
+            // the macroblock's place is looked up HERE, after the pipeline (an LDS read cannot move up across its hand-offs): the
+            // row pointer is not alive during the transforms, which need every register they can get
+            const int orig = slot_orig[slot];
+            uint8_t *dst = recon + (long)tp.sp.stream * g.pad_frame_bytes + p.pad_off +
+                           (long)((tp.plane_ty * kStripsPerWG + (orig >> 3)) * 16 + i + 8 * h) * p.pw + tp.sp.x0 + (orig & 7) * 16;
+            *reinterpret_cast<uint4 *>(dst) = o;
         }
     }
 }
@@ -1226,7 +1281,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs,
-                                                          float min_err, int neg2, float qmagic)
+                                                          float min_err, int neg2, float qmagic, int compact_max)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win_lds[16 + kWinAlloc];
     __shared__ __attribute__((aligned(16))) int red_lds[kStripsPerWG][kRedDwords];
@@ -1263,11 +1318,62 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
     so.patch[0] = so.patch[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) penc_search(g, cur, win, red_lds[wave], rows, lane, min_err, neg2, so);
     KMARK(7);
-    __syncthreads();   // window released by every wavefront
+    const bool mb_valid = cur.wave_valid && m < cur.sp.n_mb;
+    if (i == 0 && mb_valid) {   // block headers (DeltaEncodedMacroBlock.motion_x / _y, subblocks.is_some(); src/common.rs:14-19)
+        const long mbi = (long)cur.sp.stream * g.mbs_per_frame + cur.sp.mb_first + m;
+        mv_out[mbi * 2 + 0] = (int8_t)so.cx;
+        mv_out[mbi * 2 + 1] = (int8_t)so.cy;
+        has_out[mbi] = so.coded ? 1 : 0;
+    }
+    // Which macroblocks of the TILE are coded: one bit per macroblock, a byte per strip, published in the last 8 dwords of the
+    // last reduction region (no search touches them: kRedPitch * kStripMB - 8 = 568 is past the last partial sum).
+    constexpr int kMaskAt = (kStripsPerWG - 1) * kRedDwords + kRedDwords - 8;
+    int *red_all = &red_lds[0][0];
+    {
+        const unsigned long long bal = __ballot(so.coded);
+        unsigned mine = 0;
+#pragma unroll
+        for (int k = 0; k < kStripMB; k++) mine |= (unsigned)((bal >> (8 * k)) & 1ull) << k;
+        if (lane == 0) red_all[kMaskAt + wave] = (int)mine;
+    }
+    __syncthreads();   // window released by every wavefront; the strips' masks are visible
     KMARK(8);
-    if (cur.wave_valid)
-        penc_transform<FLT>(g, cur, so, rows, reinterpret_cast<int *>(win + win_first_issue(wave) * 1024), lane, mv_out, has_out, coef,
-                       recon, qtab_lds, qmagic);
+    unsigned tile_mask = 0;
+#pragma unroll
+    for (int k = 0; k < kStripsPerWG; k++) tile_mask |= (unsigned)__builtin_amdgcn_readfirstlane(red_all[kMaskAt + k]) << (8 * k);
+    int n_coded = __builtin_popcount(tile_mask), strips_coded = 0;
+#pragma unroll
+    for (int k = 0; k < kStripsPerWG; k++) strips_coded += ((tile_mask >> (8 * k)) & 0xffu) ? 1 : 0;
+    int *xw = reinterpret_cast<int *>(win + win_first_issue(wave) * 1024);
+    // Skip-aware transform.  The reference transforms nothing for a skipped macroblock (src/common.rs:221-222); a wavefront,
+    // however, runs the transform for all 8 of its macroblocks as soon as one of them is coded.  When the tile's coded
+    // macroblocks fit fewer wavefronts than the strips that hold them (and at most kCompactMax, which is what the staging
+    // area takes), they are moved together: rows through LDS, one more barrier, and only ceil(n / 8) wavefronts transform.
+    // compact_max: kCompactMax, or 0 to switch the compaction off (pfv_ctx_set_option(PFV_OPT_TILE_COMPACTION, 0): measurements).
+    constexpr int kCompactMax = kPencCompactMax;          // 16 slots x 512 B = 8 KiB of the 9 KiB of reduction regions
+    constexpr int kSlotOrigAt = kCompactMax * 128;        // dwords; the slots' places follow the staging area
+    static_assert(kSlotOrigAt + kCompactMax <= kMaskAt, "staging area + slot table must fit below the strip masks");
+    static_assert(kStripsPerWG * 8 <= 32, "one bit per macroblock of the tile");
+    if (n_coded <= compact_max && ((n_coded + 7) >> 3) < strips_coded) {   // workgroup-uniform
+        uint4 *stage4 = reinterpret_cast<uint4 *>(red_all);
+        const int place = wave * 8 + m;
+        if (so.coded) {
+            const int slot = __builtin_popcount(tile_mask & ((1u << place) - 1u));
+            uint4 *sl = stage4 + slot * 32 + i * 4;         // 64 bytes per lane: source rows, prediction rows
+            sl[0] = rows[0]; sl[1] = rows[1]; sl[2] = so.patch[0]; sl[3] = so.patch[1];
+            if (i == 0) red_all[kSlotOrigAt + slot] = place;
+        } else if (mb_valid) {
+            const PlaneGeom &pp = g.p[cur.sp.plane];
+            penc_store_skipped(coef + ((long)cur.sp.stream * g.mbs_per_frame + cur.sp.mb_first + m) * 256,
+                               recon ? recon + (long)cur.sp.stream * g.pad_frame_bytes + pp.pad_off + (long)(cur.sp.y0 + i) * pp.pw + cur.sp.x0 + m * 16 : nullptr,
+                               pp.pw, i, so.patch);
+        }
+        __syncthreads();   // rows staged
+        if (wave * 8 < n_coded)
+            penc_transform_compact<FLT>(g, cur, wave, n_coded, red_all + kSlotOrigAt, stage4, xw, lane, coef, recon, qtab_lds, qmagic);
+    } else if (cur.wave_valid) {
+        penc_transform<FLT>(g, cur, so, rows, xw, lane, coef, recon, qtab_lds, qmagic);
+    }
     KMARK(11);
 }
 

@@ -8,6 +8,10 @@
 //                  defined on the plane enlarged by a 32-pixel margin on every side
 //   frame t      : the texture window displaced by motion(t) = ((3t mod 23) - 11, (2t mod 17) - 8) luma pixels
 //                  (floor-halved for chroma), + noise in [-16, 16] on the macroblocks whose hash bit is set, clipped
+//   kind 1 ("low motion"): the texture window stays put (static background, no noise: a p-frame skips it) and four
+//                  rectangles of about a quarter of the frame's width and height each -- own texture, noise in [-16, 16] on
+//                  every pixel, moving a few pixels per frame -- cover about a quarter of the area; their edges are not
+//                  aligned to macroblocks, so tiles with a few coded macroblocks occur next to fully coded and fully skipped ones
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,6 +36,67 @@ __device__ __forceinline__ uint64_t synth_hash(uint64_t idx, uint64_t seed)
 __device__ __forceinline__ int floordiv2(int v) { return v >> 1; }
 
 // grid: (ceil(max plane pixels / 256), 3 planes, n_streams); one thread per pixel
+constexpr int kSynthObjects = 4;
+// geometry of object j of a stream at frame t, in LUMA pixels (pretty-fast-video_amd/synth.py: SyntheticStream._object)
+struct SynthObject { int x, y, w, h; };
+__device__ __forceinline__ SynthObject synth_object(uint64_t seed, int j, int t, int width, int height)
+{
+    const uint64_t hsh = synth_hash((uint64_t)j, seed + 31337ull);
+    SynthObject o;
+    o.w = ((width / 4 + (int)((hsh & 0xffffull) % (uint64_t)(width / 16 + 1))) & ~1);
+    o.h = ((height / 4 + (int)(((hsh >> 16) & 0xffffull) % (uint64_t)(height / 16 + 1))) & ~1);
+    if (o.w < 2) o.w = 2;
+    if (o.h < 2) o.h = 2;
+    if (o.w > width) o.w = width;
+    if (o.h > height) o.h = height;
+    const int rx = width - o.w + 1, ry = height - o.h + 1;
+    const int x0 = (int)(((hsh >> 32) & 0xffffull) % (uint64_t)rx), y0 = (int)(((hsh >> 48) & 0xffffull) % (uint64_t)ry);
+    const uint64_t h2 = synth_hash((uint64_t)j, seed + 424243ull);
+    const int vx = (int)((h2 & 0xffull) % 13ull) - 6, vy = (int)(((h2 >> 8) & 0xffull) % 9ull) - 4;
+    o.x = (((x0 + vx * t) % rx) + rx) % rx;
+    o.y = (((y0 + vy * t) % ry) + ry) % ry;
+    return o;
+}
+// smooth texture value at (tx, ty) of a tw-pixel-wide texture (synth.py: _texture)
+__device__ __forceinline__ int synth_texel(int tx, int ty, int tw, uint64_t tseed)
+{
+    const int gw = tw / 8 + 2;
+    const int gy = ty >> 3, fy = ty & 7, gx = tx >> 3, fx = tx & 7;
+    const int g00 = (int)(synth_hash((uint64_t)(gy * gw + gx), tseed) & 0xff);
+    const int g01 = (int)(synth_hash((uint64_t)(gy * gw + gx + 1), tseed) & 0xff);
+    const int g10 = (int)(synth_hash((uint64_t)((gy + 1) * gw + gx), tseed) & 0xff);
+    const int g11 = (int)(synth_hash((uint64_t)((gy + 1) * gw + gx + 1), tseed) & 0xff);
+    const int top = (8 - fx) * g00 + fx * g01, bot = (8 - fx) * g10 + fx * g11;
+    int v = ((8 - fy) * top + fy * bot) >> 6;
+    v += (int)(synth_hash((uint64_t)((long)ty * tw + tx), tseed ^ 0x5EEDull) % 7ull) - 3;
+    return min(max(v, 0), 255);
+}
+
+// kind 1: static background + moving noisy rectangles; same grid as k_synth_frames
+__global__ __launch_bounds__(kThreads) void k_synth_frames_low_motion(int width, int height, int t, const uint64_t *__restrict__ seeds,
+                                                                       uint8_t *__restrict__ frames, long frame_bytes, int n_objects)
+{
+    const int p = blockIdx.y, stream = blockIdx.z;
+    const int w = p ? width >> 1 : width, h = p ? height >> 1 : height;
+    const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= (long)w * h) return;
+    const int y = (int)(idx / w), x = (int)(idx - (long)y * w);
+    const uint64_t seed = seeds[stream];
+    int v = synth_texel(kSynthMargin + x, kSynthMargin + y, w + 2 * kSynthMargin, seed + 101ull * (uint64_t)p);
+    for (int j = 0; j < n_objects; j++) {   // later objects lie on top; none: kind 2, the static background alone
+        SynthObject o = synth_object(seed, j, t, width, height);
+        if (p) { o.x >>= 1; o.y >>= 1; o.w >>= 1; o.h >>= 1; }
+        const int lx = x - o.x, ly = y - o.y;
+        if (lx >= 0 && lx < o.w && ly >= 0 && ly < o.h) {
+            v = synth_texel(lx, ly, o.w, seed + 101ull * (uint64_t)p + 1009ull * (uint64_t)(j + 1));
+            v += (int)(synth_hash((uint64_t)((long)ly * o.w + lx), seed + 104729ull * (uint64_t)t + 13ull * (uint64_t)p + 977ull * (uint64_t)(j + 1)) % 33ull) - 16;
+            v = min(max(v, 0), 255);
+        }
+    }
+    const long plane_off = p == 0 ? 0 : (long)width * height + (long)(p - 1) * (long)(width >> 1) * (height >> 1);
+    frames[(long)stream * frame_bytes + plane_off + idx] = (uint8_t)v;
+}
+
 __global__ __launch_bounds__(kThreads) void k_synth_frames(int width, int height, int t, const uint64_t *__restrict__ seeds,
                                                             uint8_t *__restrict__ frames, long frame_bytes)
 {

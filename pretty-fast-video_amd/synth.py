@@ -8,6 +8,11 @@ threshold of 7.5 per pixel, src/enc.rs:41 + src/common.rs:209) so that both skip
 p-frame macroblocks occur in roughly equal numbers.  Everything is a counter-based 64-bit integer hash (splitmix64
 finaliser) evaluated with numpy uint64 arithmetic -- no floats, no library RNG state -- so
 the same bytes come out on every machine.
+
+``kind="low_motion"``: the texture stays put (a static background that a p-frame skips, src/common.rs:221-222) and four
+rectangles of about a quarter of the frame's width and height -- own texture, +-16 noise on every pixel, a few pixels of
+motion per frame, edges not aligned to macroblocks -- move over it: about a quarter of a quality-5 p-frame is coded.
+``kind="static"``: the background alone -- every p-frame macroblock is skipped (the floor of the p-frame encoder: its search).
 """
 from __future__ import annotations
 
@@ -42,18 +47,52 @@ def _texture(h: int, w: int, seed: int) -> np.ndarray:
     return np.clip(tex + fine, 0, 255)
 
 
+N_OBJECTS = 4
+
+
 class SyntheticStream:
-    def __init__(self, width: int, height: int, seed: int = SEED):
-        assert width % 2 == 0 and height % 2 == 0
-        self.width, self.height, self.seed = width, height, seed
+    def __init__(self, width: int, height: int, seed: int = SEED, kind: str = "pan"):
+        assert width % 2 == 0 and height % 2 == 0 and kind in ("pan", "low_motion", "static")
+        self.width, self.height, self.seed, self.kind = width, height, seed, kind
         self._dims = [(height, width), (height // 2, width // 2), (height // 2, width // 2)]
         self._tex = [_texture(h + 2 * _MARGIN, w + 2 * _MARGIN, seed + 101 * p) for p, (h, w) in enumerate(self._dims)]
+        self._obj_tex = {}
+
+    def _object(self, j: int, t: int):
+        """(x, y, w, h) of object j at frame t in luma pixels (csrc/pfv_synth_kernels.hip: synth_object)"""
+        W, H = self.width, self.height
+        hsh = int(_hash64(np.array([j]), self.seed + 31337)[0])
+        ow = max(2, min(W, (W // 4 + (hsh & 0xFFFF) % (W // 16 + 1)) & ~1))
+        oh = max(2, min(H, (H // 4 + ((hsh >> 16) & 0xFFFF) % (H // 16 + 1)) & ~1))
+        rx, ry = W - ow + 1, H - oh + 1
+        x0, y0 = ((hsh >> 32) & 0xFFFF) % rx, ((hsh >> 48) & 0xFFFF) % ry
+        h2 = int(_hash64(np.array([j]), self.seed + 424243)[0])
+        vx, vy = (h2 & 0xFF) % 13 - 6, ((h2 >> 8) & 0xFF) % 9 - 4
+        return (x0 + vx * t) % rx, (y0 + vy * t) % ry, ow, oh
+
+    def _plane_low_motion(self, t: int, p: int) -> np.ndarray:
+        h, w = self._dims[p]
+        img = self._tex[p][_MARGIN:_MARGIN + h, _MARGIN:_MARGIN + w].copy()
+        for j in range(N_OBJECTS if self.kind == "low_motion" else 0):      # "static": the background alone
+            ox, oy, ow, oh = self._object(j, t)
+            if p:
+                ox, oy, ow, oh = ox >> 1, oy >> 1, ow >> 1, oh >> 1
+            if ow == 0 or oh == 0:
+                continue
+            key = (p, j)
+            if key not in self._obj_tex:
+                self._obj_tex[key] = _texture(oh, ow, self.seed + 101 * p + 1009 * (j + 1))
+            noise = (_hash64(np.arange(oh * ow), self.seed + 104729 * t + 13 * p + 977 * (j + 1)) % np.uint64(33)).astype(np.int32).reshape(oh, ow) - 16
+            img[oy:oy + oh, ox:ox + ow] = np.clip(self._obj_tex[key] + noise, 0, 255)
+        return img.astype(np.uint8)
 
     @staticmethod
     def motion(t: int):
         return (3 * t) % 23 - 11, (2 * t) % 17 - 8
 
     def plane(self, t: int, p: int) -> np.ndarray:
+        if self.kind != "pan":
+            return self._plane_low_motion(t, p)
         h, w = self._dims[p]
         ox, oy = self.motion(t)
         if p:

@@ -66,10 +66,52 @@ def check_encode_plane_delta(pkg, ctx, oracle, px, ref, q, px_err, clear):
     return enc, dec
 
 
-def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames, gop=15, threads=1):
+def check_sparse_coded_tiles(pkg, ctx, oracle, seed=21, sizes=((256, 128), (400, 200), (130, 70), (1040, 64))):
+    """p-frame planes in which only SOME macroblocks are coded, in every arrangement the tile-level compaction of k_enc_pframe
+    distinguishes (src/common.rs:221-222: a skipped macroblock is not transformed; the kernel moves a tile's coded macroblocks
+    together when they fit fewer wavefronts than the strips that hold them): one coded macroblock per strip, 8 / 9 / 16 / 17 per
+    tile, all in one strip, random densities, ragged tiles (partial strips, missing strips) -- every output against the oracle"""
+    _, _, pl, pcq, px_err = oracle.qtables(5)
+    rng = np.random.default_rng(seed)
+    n_cases = 0
+    for (w, h) in sizes:
+        base = smooth_plane(h, w, seed + w)
+        ph, pw = pad16(h), pad16(w)
+        bw, bh = pw // 16, ph // 16
+        ref = np.zeros((ph, pw), np.uint8)
+        ref[:h, :w] = base                      # prediction == source wherever the source is left alone: SSD 0 -> skipped
+        patterns = []
+        for dens in (0.03, 0.1, 0.25, 0.5, 0.8):
+            patterns.append(rng.random((bh, bw)) < dens)
+        one_per_strip = np.zeros((bh, bw), bool); one_per_strip[:, ::8] = True
+        patterns.append(one_per_strip)
+        col = np.zeros((bh, bw), bool); col[:, min(3, bw - 1)] = True
+        patterns.append(col)
+        rowp = np.zeros((bh, bw), bool); rowp[0::4, :] = True               # one full strip per tile
+        patterns.append(rowp)
+        for n in (8, 9, 16, 17):                                            # exactly n coded macroblocks in the first tile, scattered
+            pat = np.zeros((bh, bw), bool)
+            cells = [(y, x) for y in range(min(4, bh)) for x in range(min(8, bw))]
+            for k in rng.permutation(len(cells))[:min(n, len(cells))]:
+                pat[cells[k]] = True
+            patterns.append(pat)
+        for pat in patterns:
+            px = base.astype(np.int32).copy()
+            mask = np.repeat(np.repeat(pat, 16, 0), 16, 1)[:h, :w]
+            px = np.where(mask, px + rng.integers(-60, 61, px.shape), px)
+            px = np.clip(px, 0, 255).astype(np.uint8)
+            for q, clear in ((pl, 0), (pcq, 128)):
+                enc, _ = check_encode_plane_delta(pkg, ctx, oracle, px, ref, q, px_err, clear)
+                n_cases += 1
+            got = enc.has_coeff.reshape(bh, bw).astype(bool)
+            assert got.sum() >= 0.5 * (pat & (np.add.outer(np.arange(bh) * 16, np.zeros(bw, int)) < h)).sum()   # the perturbed macroblocks are coded
+    return n_cases
+
+
+def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames, gop=15, threads=1, kind="pan"):
     """encode n_frames of n_streams synthetic streams (i-frame every `gop`), decode them again,
     compare everything with the oracle stream by stream."""
-    streams = [pkg.SyntheticStream(width, height, seed=pkg.synth.SEED + 17 * s) for s in range(n_streams)]
+    streams = [pkg.SyntheticStream(width, height, seed=pkg.synth.SEED + 17 * s, kind=kind) for s in range(n_streams)]
     enc = pkg.EncoderSession(ctx, width, height, quality, n_streams)
     tabs = pkg.qtables_from_quality(quality)
     dec = pkg.DecoderSession(ctx, width, height, np.stack(tabs[:4]), n_streams)
@@ -119,7 +161,7 @@ def check_session(pkg, ctx, oracle, width, height, quality, n_streams, n_frames,
     return stats
 
 
-def check_session_batched_dev(pkg, ctx, oracle, width, height, quality, seeds, n_frames=2, gop=15, threads=1):
+def check_session_batched_dev(pkg, ctx, oracle, width, height, quality, seeds, n_frames=2, gop=15, threads=1, kind="pan"):
     """The BENCHED shape (bench.py StreamSet.step): len(seeds) streams in ONE launch per frame operation through the
     device-pointer entry points, frames generated on the device, retframe crop fused into the decode kernels -- and then
     every byte of every stream (coefficients, motion vectors, skip flags, encoder reconstruction, decoder framebuffer,
@@ -140,7 +182,7 @@ def check_session_batched_dev(pkg, ctx, oracle, width, height, quality, seeds, n
     out = np.empty((S, fb), np.uint8)
     stats = {"coded": 0, "mbs": 0, "streams": S}
     for t in range(n_frames):
-        ctx.synth_frames_dev(width, height, seeds, t, d_frames)
+        ctx.synth_frames_dev(width, height, seeds, t, d_frames, kind=kind)
         if t % gop == 0:
             enc.encode_iframe_dev(d_frames, d_coef)
             dec.decode_iframe_dev(d_coef)
@@ -158,7 +200,7 @@ def check_session_batched_dev(pkg, ctx, oracle, width, height, quality, seeds, n
             stats["mbs"] += has.size
         recon, fbuf = enc.prev_frame(), dec.framebuffer()
         for s in (0, S - 1):          # the device generator against synth.py for the first and the last stream
-            assert np.array_equal(frames[s], pkg.SyntheticStream(width, height, seed=int(seeds[s])).frame(t)), f"frame {t} stream {s}: generator"
+            assert np.array_equal(frames[s], pkg.SyntheticStream(width, height, seed=int(seeds[s]), kind=kind).frame(t)), f"frame {t} stream {s}: generator"
         for s in range(S):
             if t % gop == 0:
                 ocoef = oencs[s].encode_iframe(frames[s])

@@ -22,6 +22,11 @@ def test_emu_plane_ops(pkg, emu_ctx, oracle, w, h, quality):
     pc.check_encode_plane_delta(pkg, emu_ctx, oracle, px, ref, pcq, px_err, 128)
 
 
+def test_emu_sparse_coded_tiles(pkg, emu_ctx, oracle):
+    """tile-level compaction of the coded macroblocks (skip-aware transform)"""
+    assert pc.check_sparse_coded_tiles(pkg, emu_ctx, oracle, sizes=((256, 128), (130, 70))) == 48
+
+
 def test_emu_golden_vectors(pkg, emu_ctx, oracle):
     pc.check_golden(pkg, emu_ctx, oracle)
 
@@ -33,6 +38,12 @@ def test_emu_trap_vectors(pkg, emu_ctx, oracle):
 def test_emu_session_two_streams(pkg, emu_ctx, oracle):
     stats = pc.check_session(pkg, emu_ctx, oracle, 64, 48, 5, n_streams=2, n_frames=3)
     assert 0 < stats["coded"] < stats["mbs"]
+
+
+def test_emu_session_low_motion(pkg, emu_ctx, oracle):
+    """static background + moving objects: tiles with few coded macroblocks take the compaction path, reconstruction included"""
+    stats = pc.check_session(pkg, emu_ctx, oracle, 272, 144, 5, n_streams=2, n_frames=4, kind="low_motion")
+    assert 0.05 < stats["coded"] / stats["mbs"] < 0.6
 
 
 def test_emu_session_batched_dev(pkg, emu_ctx, oracle):

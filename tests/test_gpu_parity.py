@@ -91,6 +91,17 @@ def test_pframe_plane(pkg, gpu_ctx, oracle, quality, w, h, dx, dy):
         assert enc.has_coeff.sum() < enc.has_coeff.size      # the skip path ran too
 
 
+def test_pframe_sparse_coded_tiles(pkg, gpu_ctx, oracle):
+    """tile-level compaction of the coded macroblocks (skip-aware transform), both encoder forms"""
+    assert pc.check_sparse_coded_tiles(pkg, gpu_ctx, oracle) == 96
+    L = pkg._lib
+    gpu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_INT)
+    try:
+        assert pc.check_sparse_coded_tiles(pkg, gpu_ctx, oracle, sizes=((256, 128), (130, 70))) == 48
+    finally:
+        gpu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_AUTO)
+
+
 def test_pframe_noise_and_ties(pkg, gpu_ctx, oracle):
     """white noise (no gradient: many near-ties), a flat plane (exact ties everywhere: the
     centre must win) and a reference identical to the source (zero error)"""
@@ -144,6 +155,27 @@ def test_bad_arguments(pkg, gpu_ctx, oracle):
 def test_session_small_gop_multistream(pkg, gpu_ctx, oracle):
     stats = pc.check_session(pkg, gpu_ctx, oracle, 176, 144, 5, n_streams=3, n_frames=6, gop=4)
     assert 0 < stats["coded"] < stats["mbs"]
+
+
+def test_session_low_motion_content(pkg, gpu_ctx, oracle):
+    """static background + moving objects (~25 % coded): tiles with a few coded macroblocks take the skip-aware (compacted)
+    transform; closed-loop reconstruction, decoder and cropped output against the oracle -- small, 1080p, and the batched
+    device-pointer form; both encoder forms"""
+    stats = pc.check_session(pkg, gpu_ctx, oracle, 640, 360, 5, n_streams=3, n_frames=6, gop=4, kind="low_motion")
+    assert 0.1 < stats["coded"] / stats["mbs"] < 0.5
+    stats = pc.check_session(pkg, gpu_ctx, oracle, 1920, 1080, 5, n_streams=1, n_frames=3, threads=os.cpu_count() or 1, kind="low_motion")
+    assert 0.15 < stats["coded"] / stats["mbs"] < 0.45
+    for q in (2, 8):
+        pc.check_session(pkg, gpu_ctx, oracle, 400, 200, q, n_streams=2, n_frames=3, kind="low_motion")
+    seeds = [pkg.synth.SEED + 17 * k for k in range(8)]
+    pc.check_session_batched_dev(pkg, gpu_ctx, oracle, 1920, 1080, 5, seeds, n_frames=2, threads=min(32, len(os.sched_getaffinity(0))), kind="low_motion")
+    oracle.L.pfvo_pool_shutdown()
+    L = pkg._lib
+    gpu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_INT)
+    try:
+        pc.check_session(pkg, gpu_ctx, oracle, 640, 360, 5, n_streams=2, n_frames=3, kind="low_motion")
+    finally:
+        gpu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_AUTO)
 
 
 def test_session_odd_chroma_geometry(pkg, gpu_ctx, oracle):
