@@ -13,12 +13,15 @@ Workloads (BASELINE.json `configs`):
 Inputs (the raw frames) are resident in HBM before the timed region starts; coefficients / motion vectors /
 reconstructed frames never leave HBM.  Entropy coding is outside `value` (reported beside it).
 
-N > 1: one process per GPU.  `python bench.py --gpus N` launches its own N ranks (re-executes itself under
-torch.distributed.run on 127.0.0.1); when it is already running under torchrun (RANK / WORLD_SIZE set, which is how the
-driver starts it) it uses those.  Streams are independent (src/enc.rs:12-26: an Encoder shares nothing with another), so
-they are sharded across ranks with NO data-path collective ("weak" scaling: fixed work per GPU); RCCL carries only the
-assignment-table broadcast and the final counter reduction.  With fewer GPUs than ranks (developer dry run on a one-GPU
-box) every rank uses device 0 and the control plane runs on gloo; the JSON says so (`rccl_ranks`: 0).
+N > 1: one process per GPU.  `python bench.py --gpus N` launches its own N ranks (one child process per rank, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); when it is already running under torchrun (those variables set,
+which is how the driver starts it) it uses them.  Streams are independent (src/enc.rs:12-26: an Encoder shares nothing
+with another), so they are sharded across ranks with NO data-path collective ("weak" scaling: fixed work per GPU); RCCL
+-- called through the library (pfv_comm_*, librccl.so), NOT through torch.distributed, so an N > 1 rank is the same
+torch-free process as the N = 1 run -- carries only the assignment-table broadcast, the barriers and the final counter
+reduction; the ncclUniqueId reaches the ranks over a TCP rendezvous on MASTER_ADDR (pretty-fast-video_amd/comm.py).  With
+fewer GPUs than ranks (developer dry run on a one-GPU box) every rank uses device 0 and the control plane stays on the
+rendezvous sockets (RCCL refuses two ranks on one device); the JSON says so (`rccl_ranks`: 0, backend "tcp").
 
 The JSON line also carries
   roofline     -- dominant kernel (k_enc_pframe): algorithmic bytes per launch (1284 B per macroblock, SURVEY.md
@@ -65,6 +68,9 @@ def parse():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None, help="frames per step (gop1080p: 15; config5: 300)")
     ap.add_argument("--quality", type=int, default=5)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N = 1: still create the (1-rank) RCCL communicator and run the table broadcast, the barriers and the counter "
+                         "reduction through it -- the code path of an N > 1 rank, on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy", action="store_true", help="skip the extra encode_to_payload measurement (device entropy stage)")
     ap.add_argument("--no-extra", action="store_true", help="skip the single-stream and config-4 side measurements")
@@ -76,16 +82,17 @@ def parse():
 
 
 def self_launch(args) -> int:
-    """`python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU on this node)."""
+    """`python bench.py --gpus N` without a launcher: become the launcher (one child process per GPU on this node)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(abs(p.wait()) for p in procs)
 
 
 # ---------------------------------------------------------------------------------------------------------------- helpers
@@ -613,49 +620,38 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import __graft_entry__ as graft
-    # torch only where it is needed -- N > 1, for torch.distributed.  Its wheel bundles a second HIP / HSA runtime; with both
-    # runtimes in one process every launch of a small kernel costs about twice as much host time (measured: a 4K single-stream
-    # pass of 600 launches takes 14.2 ms without `import torch`, 25.7 ms with it), which would be charged to the kernels of
-    # the single-stream workloads.  At N = 1 the timed region is bracketed by hipDeviceSynchronize through the C ABI instead.
-    torch = dist = None
+    # No torch anywhere: its wheel bundles a second HIP / HSA runtime, and with both runtimes in one process every launch of a
+    # small kernel costs about twice as much host time (measured in round 2: a 4K single-stream pass of 600 launches takes 14.2 ms
+    # without `import torch`, 25.7 ms with it).  The ranks of an N > 1 job talk through pretty-fast-video_amd/comm.py: RCCL via the
+    # library on the context's own stream, the ncclUniqueId over a TCP rendezvous.
     stdout_fd = None
-    if world > 1:
-        # the contract is ONE line on stdout: libraries that chat on fd 1 (gloo prints its rendezvous there) go to stderr
+    if world > 1 or args.force_comm:
+        # the contract is ONE line on stdout: anything a library prints on fd 1 (RCCL's version banner) goes to stderr
         sys.stdout.flush()
         stdout_fd = os.dup(1)
         os.dup2(2, 1)
-        import torch
-        import torch.distributed as dist
 
     if EMU:
         import conftest                               # tests/conftest.py: g++ build of the kernel sources on the fiber emulator
         os.environ["PFV_HIP_LIB"] = conftest.build_emulator()
-        dev, backend, share, local_rank = None, "gloo", False, 0
-    elif world > 1:
-        n_dev = torch.cuda.device_count()
-        # fewer devices than ranks (developer dry run of the N > 1 control flow on a one-GPU box): every rank on device 0,
-        # control plane on gloo (RCCL refuses two ranks on one device)
-        share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1" or n_dev < world
-        if share:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-        backend = "gloo" if share else "nccl"
-        graft.build_hip()
+        share, local_rank = True, 0
     else:
-        dev, backend, share = None, None, False
         graft.build_hip()
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    cdev = dev if backend == "nccl" else None         # where control-plane tensors live
-
+        share = False
     pkg = graft.load_package()
     from importlib import import_module
     shard = import_module("pretty_fast_video_amd.shard")
+    commlib = import_module("pretty_fast_video_amd.comm")
+    if world > 1 and not EMU:
+        n_dev = int(pkg._lib.load().pfv_device_count())
+        # fewer devices than ranks (developer dry run of the N > 1 control flow on a one-GPU box): every rank on device 0,
+        # control plane on the rendezvous sockets (RCCL refuses two ranks on one device)
+        share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1" or n_dev < world
+        if share:
+            local_rank = 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_comm = world > 1 or (args.force_comm and not EMU)
+    rdzv = commlib.Rendezvous(rank, world) if use_comm else None
 
     Q = args.quality
     if args.workload == "config5":
@@ -670,13 +666,14 @@ def main():
         table = np.stack([sid % world, pkg.synth.SEED + sid, sid], axis=1)
     else:
         table = shard.assign_streams(n_streams_total=S * world, world=world, base_seed=pkg.synth.SEED)
-    if world > 1:
-        table = shard.broadcast_table(table, rank, dist, cdev)
+    ctx = pkg.Context(local_rank)
+    comm = commlib.Comm(ctx, rdzv, use_rccl=not share) if use_comm else None
+    if use_comm:
+        table = comm.broadcast_array(np.asarray(table, dtype=np.int64) if rank == 0 else np.zeros_like(np.asarray(table, dtype=np.int64)))
     mine = shard.streams_of_rank(table, rank)
     assert len(mine) == S
 
-    ctx = pkg.Context(local_rank)
-    timer = Timer(ctx, dev)
+    timer = Timer(ctx, None)
     ss = StreamSet(pkg, ctx, W, H, Q, [int(r[1]) for r in mine], NF)      # synthetic input generated in HBM: [NF][S][frame_bytes]
     n_mb = ss.n_mb
 
@@ -694,10 +691,8 @@ def main():
         ctx.sync()
         if not EMU:
             ctx.device_sync()                         # hipDeviceSynchronize (what torch.cuda.synchronize() does)
-            if torch is not None:
-                torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if use_comm:
+            comm.barrier()                            # RCCL: a 1-element all-reduce on the context's stream + synchronise
 
     for _ in range(args.warmup):
         ss.step()
@@ -717,8 +712,9 @@ def main():
     ent = None if args.no_entropy else entropy_side(ss, timer, args)
 
     total_mb, el_max = float(args.steps) * NF * S * n_mb, el
-    if world > 1:
-        total_mb, el_max, _ = shard.gather_counters(total_mb, el, 0, dist, cdev)      # sum of macroblocks, max of seconds
+    if use_comm:
+        total_mb = float(comm.allreduce([total_mb], "sum")[0])        # whole-job macroblocks
+        el_max = float(comm.allreduce([el], "max")[0])                # the slowest rank's time
 
     if rank == 0:
         launch_mbs = S * n_mb
@@ -745,9 +741,10 @@ def main():
             "vs_baseline": None,
             "dtype": "i32 (encoder transforms evaluated in exact f32; decoders i32)",
             "data": f"synthetic, generated on the device ({S} distinct integer-hash texture streams per GPU, seed per stream; quality {Q})",
-            "rccl_ranks": world if backend == "nccl" and world > 1 else 0,
-            "control_plane": {"backend": backend if world > 1 else None, "shared_gpu": bool(share), "emulated": EMU,
-                              "collectives": "assignment-table broadcast + counter all-reduce only (no data-path collective)"},
+            "rccl_ranks": world if comm is not None and comm.backend == "rccl" else 0,
+            "control_plane": {"backend": comm.backend if comm is not None else None, "shared_gpu": bool(share and world > 1), "emulated": EMU,
+                              "collectives": "assignment-table broadcast + barriers + counter all-reduce only (no data-path collective); "
+                                             "RCCL through libpfv_hip.so (pfv_comm_*), no torch in the process"},
             "config": {"workload": name, "streams_per_gpu": S, "frames_per_step": NF, "macroblocks_per_frame": n_mb, "quality": Q,
                        "pframe_coded_fraction": round(coded_frac, 4), "parallelism": f"streams sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "k_enc_pframe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -792,10 +789,11 @@ def main():
 
     ss.close()
     timer.close()
+    if use_comm:
+        comm.barrier()
+        comm.close()
+        rdzv.close()
     ctx.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

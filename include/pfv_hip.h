@@ -58,6 +58,8 @@ typedef struct pfv_ctx pfv_ctx;
 /* ------------------------------------------------------------------ context */
 /* Replaces the `num_threads` / rayon::ThreadPool slot of Encoder::new (src/enc.rs:37,54)
  * and Decoder::new (src/dec.rs:38,125): the parallel resource is a device + stream. */
+/* number of HIP devices visible to the process (0 when there is none) */
+PFV_API int pfv_device_count(void);
 PFV_API int pfv_ctx_create(int device, pfv_ctx **out);
 PFV_API void pfv_ctx_destroy(pfv_ctx *ctx);
 PFV_API int pfv_ctx_sync(pfv_ctx *ctx);
@@ -154,6 +156,28 @@ PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int s
  * src/common.rs:538-556).  width, height even.  Device-resident buffers. */
 PFV_API int pfv_rgb_to_yuv420_dev(pfv_ctx *ctx, const uint8_t *rgb_dev, int width, int height, uint8_t *frame_dev);
 PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int width, int height, uint8_t *rgb_dev);
+
+/* ------------------------------------------------------------------ multi-GPU control plane (one process per GPU, RCCL over xGMI)
+ * The path shards by stream and by GOP (src/enc.rs:12-26, 84-97): no data-path collective exists.  These carry the few hundred
+ * bytes that do travel -- the assignment table (broadcast) and the per-rank counters (reduction / gather) -- on the context's
+ * HIP stream.  Rank 0 creates the id, every rank of the job gets the same 128 bytes over the launcher's own channel
+ * (pretty-fast-video_amd/comm.py: TCP on MASTER_ADDR) and calls pfv_comm_init on the context of ITS device.  librccl.so is
+ * opened at run time; PFV_ERR_NO_DEVICE when it is missing.  world = 1 is legal (a 1-rank communicator). */
+typedef struct pfv_comm pfv_comm;
+enum { PFV_COMM_SUM = 0, PFV_COMM_MAX = 1 };
+PFV_API int pfv_comm_unique_id(uint8_t id_out[128]);
+PFV_API int pfv_comm_init(pfv_ctx *ctx, int rank, int world, const uint8_t id[128], pfv_comm **out);
+PFV_API int pfv_comm_rank(const pfv_comm *c);
+PFV_API int pfv_comm_world(const pfv_comm *c);
+/* in-place collectives on DEVICE buffers, asynchronous on the context's stream */
+PFV_API int pfv_comm_broadcast_dev(pfv_comm *c, void *buf_dev, size_t bytes, int root);
+PFV_API int pfv_comm_allreduce_f64_dev(pfv_comm *c, double *buf_dev, size_t count, int op);
+PFV_API int pfv_comm_allgather_dev(pfv_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+/* host values (count <= 64): staged through the device, reduced on the stream, synchronised */
+PFV_API int pfv_comm_allreduce_f64(pfv_comm *c, double *values, size_t count, int op);
+/* all ranks have arrived and everything enqueued before on their streams is done */
+PFV_API int pfv_comm_barrier(pfv_comm *c);
+PFV_API void pfv_comm_destroy(pfv_comm *c);
 
 /* ------------------------------------------------------------------ synthetic workload (not a reference interface)
  * The reference's fixtures are Git-LFS stubs; tests and benchmarks run on an integer-only synthetic video (SURVEY.md

@@ -26,6 +26,7 @@ PFV_ERR_IO = -8
 PFV_ERR_STATE = -9
 
 # pfv_ctx_set_option
+PFV_COMM_SUM, PFV_COMM_MAX = 0, 1
 PFV_OPT_ENC_TRANSFORM = 1
 PFV_OPT_TILE_COMPACTION = 2
 PFV_ENC_TRANSFORM_AUTO, PFV_ENC_TRANSFORM_INT = 0, 1
@@ -40,6 +41,7 @@ class PfvError(RuntimeError):
 # (name, restype, argtypes) -- must list every PFV_API symbol of include/pfv_hip.h
 _P = c_void_p
 SIGNATURES = [
+    ("pfv_device_count", c_int, []),
     ("pfv_ctx_create", c_int, [c_int, POINTER(_P)]),
     ("pfv_ctx_destroy", None, [_P]),
     ("pfv_ctx_sync", c_int, [_P]),
@@ -69,6 +71,16 @@ SIGNATURES = [
     ("pfv_double_dev", c_int, [_P, _P, _P, c_int, c_int]),
     ("pfv_rgb_to_yuv420_dev", c_int, [_P, _P, c_int, c_int, _P]),
     ("pfv_yuv420_to_rgb_dev", c_int, [_P, _P, c_int, c_int, _P]),
+    ("pfv_comm_unique_id", c_int, [_P]),
+    ("pfv_comm_init", c_int, [_P, c_int, c_int, _P, POINTER(_P)]),
+    ("pfv_comm_rank", c_int, [_P]),
+    ("pfv_comm_world", c_int, [_P]),
+    ("pfv_comm_broadcast_dev", c_int, [_P, _P, c_size_t, c_int]),
+    ("pfv_comm_allreduce_f64_dev", c_int, [_P, _P, c_size_t, c_int]),
+    ("pfv_comm_allgather_dev", c_int, [_P, _P, _P, c_size_t]),
+    ("pfv_comm_allreduce_f64", c_int, [_P, _P, c_size_t, c_int]),
+    ("pfv_comm_barrier", c_int, [_P]),
+    ("pfv_comm_destroy", None, [_P]),
     ("pfv_synth_frames_dev", c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     ("pfv_synth_frames_kind_dev", c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     ("pfv_dev_alloc", c_int, [_P, c_size_t, POINTER(_P)]),

@@ -123,6 +123,13 @@ PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value)
     }
 }
 
+PFV_API int pfv_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 PFV_API int pfv_ctx_create(int device, pfv_ctx **out)
 {
     if (!out) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_ctx_create: out is null");
@@ -2689,6 +2696,8 @@ int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *che
     cleanup();
     return PFV_OK;
 }
+
+#include "pfv_comm.hip"   // multi-GPU control plane on RCCL (pfv_comm_*)
 
 #ifdef PFV_ENT_PROFILE   // experiment builds only (tools/ent_profile.py): the timestamp rows of kernel `kern` (0 scan, 1 pack)
 extern "C" __attribute__((visibility("default"))) int pfv_debug_ent_profile(int kern, unsigned long long *out, int n_groups)

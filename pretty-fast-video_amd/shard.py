@@ -3,8 +3,10 @@
 Streams (separate Encoder / Decoder instances, src/enc.rs:12-26, src/dec.rs:15-28) share
 nothing, so stream s simply runs on rank ``s % world``.  No pixel or coefficient ever crosses
 GPUs; the only exchanges are control-plane: one broadcast of the assignment table and one
-reduction of the per-rank counters.  Works with any torch.distributed backend (RCCL on the
-GPU node, gloo in the CPU tests).
+reduction of the per-rank counters.  On the GPU node they run on RCCL through the library
+(comm.py / csrc/pfv_comm.hip, no torch in the process); ``broadcast_table`` / ``gather_counters``
+below are the same two exchanges over a torch.distributed group -- gloo in the CPU tests
+(tests/test_sharding.py).
 """
 from __future__ import annotations
 

@@ -236,6 +236,43 @@ def test_session_4k_roundtrip_property(pkg, gpu_ctx):
     dec.close()
 
 
+def test_rccl_one_rank_communicator(pkg, gpu_ctx):
+    """the control plane of the multi-GPU path on the real RCCL: a 1-rank communicator on the MI355X box runs the very entry
+    points the 8-GPU job uses (pfv_comm_*: ncclCommInitRank, ncclBroadcast, ncclAllReduce, ncclAllGather on the context's
+    stream, device buffers) -- through comm.Comm as bench.py drives it, and directly"""
+    from importlib import import_module
+    commlib = import_module("pretty_fast_video_amd.comm")
+    shard = import_module("pretty_fast_video_amd.shard")
+    rdzv = commlib.Rendezvous(0, 1)
+    comm = commlib.Comm(gpu_ctx, rdzv, use_rccl=True)
+    assert comm.backend == "rccl" and comm.handle is not None
+    lib = gpu_ctx._lib
+    assert lib.pfv_comm_rank(comm.handle) == 0 and lib.pfv_comm_world(comm.handle) == 1
+    table = shard.assign_streams(96, 1, pkg.synth.SEED)
+    assert np.array_equal(comm.broadcast_array(table), table)
+    assert comm.allreduce([1175040.0 * 15, 3.5], "sum").tolist() == [1175040.0 * 15, 3.5]
+    assert comm.allreduce([0.0123, -7.0], "max").tolist() == [0.0123, -7.0]
+    comm.barrier()
+    # device-buffer forms
+    src = np.arange(256, dtype=np.uint8)
+    d_a, d_b = gpu_ctx.alloc(256), gpu_ctx.alloc(256)
+    gpu_ctx.upload(d_a, src)
+    gpu_ctx.check(lib.pfv_comm_allgather_dev(comm.handle, ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), 256))
+    out = np.empty(256, np.uint8)
+    gpu_ctx.download(out, d_b)
+    assert np.array_equal(out, src)
+    vals = np.array([1.5, 2.5, -3.0])
+    gpu_ctx.upload(d_a, vals)
+    gpu_ctx.check(lib.pfv_comm_allreduce_f64_dev(comm.handle, ctypes.c_void_p(d_a), 3, pkg._lib.PFV_COMM_MAX))
+    back = np.empty(3)
+    gpu_ctx.download(back, d_a)
+    assert back.tolist() == [1.5, 2.5, -3.0]
+    assert lib.pfv_comm_broadcast_dev(comm.handle, ctypes.c_void_p(d_a), 24, 5) == pkg._lib.PFV_ERR_BAD_ARG      # root outside the job
+    gpu_ctx.free(d_a); gpu_ctx.free(d_b)
+    comm.close()
+    rdzv.close()
+
+
 def test_blit_dev(pkg, gpu_ctx, oracle):
     """VideoPlane::blit (src/plane.rs:20-29) on device planes vs the oracle's pfvo_blit: random + corner rectangles"""
     assert pc.check_blit_dev(pkg, gpu_ctx, oracle) >= 200

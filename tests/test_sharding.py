@@ -140,6 +140,49 @@ def test_gop_sharding_gloo_world2(pkg, oracle):
     assert shard.splice_stream(want[:shard.HEADER_BYTES], parts) == want
 
 
+def _comm_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import __graft_entry__ as g
+    g.load_package()
+    from importlib import import_module
+    commlib = import_module("pretty_fast_video_amd.comm")
+    rdzv = commlib.Rendezvous(rank, world)
+    got = rdzv.bcast(b"table-bytes" if rank == 0 else None)
+    parts = rdzv.gather(bytes([rank]) * (rank + 1))
+    allp = rdzv.allgather(b"r%d" % rank)
+    rdzv.barrier()
+    comm = commlib.Comm(None, rdzv, use_rccl=False)                 # the socket backend of the same collectives
+    tab = comm.broadcast_array(np.arange(12, dtype=np.int64).reshape(4, 3) * (rank == 0))
+    s = comm.allreduce([rank + 1.0, 10.0 * rank], "sum")
+    m = comm.allreduce([rank + 1.0, 10.0 * rank], "max")
+    comm.barrier()
+    q.put((rank, got, parts, allp, tab.tolist(), s.tolist(), m.tolist(), comm.backend))
+    rdzv.close()
+
+
+def test_tcp_rendezvous_and_socket_collectives_world3():
+    """comm.py without a GPU: the rendezvous that carries the ncclUniqueId, and the socket backend of broadcast / all-reduce /
+    barrier that stands in for RCCL when ranks share a device"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, parts, allp, tab, s, m, backend in res:
+        assert got == b"table-bytes" and allp == [b"r0", b"r1", b"r2"] and backend == "tcp"
+        assert parts == ([b"\x00", b"\x01\x01", b"\x02\x02\x02"] if rank == 0 else None)
+        assert tab == (np.arange(12).reshape(4, 3)).tolist()
+        assert s == [6.0, 30.0] and m == [3.0, 20.0]
+
+
 def _run_bench(extra_args, env_extra=None):
     import json
     import subprocess
@@ -156,10 +199,11 @@ def _run_bench(extra_args, env_extra=None):
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run, both ranks
     run the product's session path (kernel sources on the CPU emulator; PFV_BENCH_EMU=1 is test-only) on their own streams,
-    the control plane (table broadcast, counter reduction) runs on gloo, rank 0 prints the line."""
+    the control plane (table broadcast, barriers, counter reduction) runs on the TCP rendezvous of comm.py (RCCL needs a GPU per
+    rank), rank 0 prints the line."""
     res = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--streams", "2", "--width", "64", "--height", "48", "--frames", "3",
                       "--no-entropy"])
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["control_plane"]["backend"] == "gloo"
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["control_plane"]["backend"] == "tcp"
     assert res["rccl_ranks"] == 0 and res["control_plane"]["emulated"] is True
     # whole-job count: 2 ranks x 2 streams x 3 frames x 20 macroblocks per step
     assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 2 * 2 * 3 * 20) < 1e-6
