@@ -213,19 +213,31 @@ class StreamSet:
     """S independent streams of one geometry resident in HBM: `n_frames` synthetic frames per stream (generated on the
     device from (seed, t)), an encoder session and a decoder session S streams wide, and the buffers between them."""
 
-    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, fused_crop=True, kind="pan"):
+    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, fused_crop=True, kind="pan", dec_ctx=None):
+        """dec_ctx: a second context (= a second HIP stream) for the decoder: the decode of frame t then runs beside the encode of
+        frame t + 1 (which needs only the encoder's own reconstruction), the encode outputs alternate between two buffer sets
+        and device-side events order the two streams (pfv_ctx_wait_event).  For a batch that fills the GPU this buys little
+        (both sides are VALU-bound); for one stream, whose launches cover a fraction of the device, it is the natural schedule:
+        Encoder and Decoder are independent objects (src/enc.rs:12-26, src/dec.rs:15-28)."""
         self.pkg, self.ctx, self.W, self.H, self.Q, self.S, self.n_frames = pkg, ctx, W, H, Q, len(seeds), n_frames
-        self.kind = kind
+        self.kind, self.dec_ctx = kind, dec_ctx
         self.seeds = [int(s) for s in seeds]
         lib = pkg._lib.load()
         self.fb = int(lib.pfv_frame_bytes(W, H))
         S = self.S
         self.enc = pkg.EncoderSession(ctx, W, H, Q, S)
-        self.dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), S)
+        self.dec = pkg.DecoderSession(dec_ctx or ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), S)
         self.n_mb = self.enc.total_blocks
         self._bufs = []
         self.frames = self._alloc(n_frames * S * self.fb)
         self.coef, self.mv, self.has = self._alloc(S * self.n_mb * 512), self._alloc(S * self.n_mb * 2), self._alloc(S * self.n_mb)
+        self.sets = [(self.coef, self.mv, self.has)]
+        self.ev_enc = self.ev_dec = None
+        if dec_ctx is not None:
+            self.sets.append((self._alloc(S * self.n_mb * 512), self._alloc(S * self.n_mb * 2), self._alloc(S * self.n_mb)))
+            self.ev_enc = [ctx.event(), ctx.event()]
+            self.ev_dec = [dec_ctx.event(), dec_ctx.event()]
+            self._dec_pending = [False, False]
         self.out_frames = self._alloc(S * self.fb)
         if fused_crop:
             self.dec.set_output_dev(self.out_frames)       # retframe crop (src/dec.rs:209-211) fused into decode
@@ -254,6 +266,8 @@ class StreamSet:
         brackets around the launches of the first `sample_frames` frames of the pass (every launch of the default
         workload; a 2-GOP sample of a 300-frame stream, whose 20-microsecond launches the event calls would otherwise slow)"""
         enc, dec = self.enc, self.dec
+        if self.dec_ctx is not None:
+            return self._step_two_streams(gop)
         ev = on_launch
         for t in range(self.n_frames):
             on_launch = ev if t < sample_frames else None
@@ -275,7 +289,34 @@ class StreamSet:
                     on_launch("k_enc_pframe", a, b)
                     on_launch("k_dec_pframe", b, on_launch())
 
+    def _step_two_streams(self, gop):
+        enc, dec, ectx, dctx = self.enc, self.dec, self.ctx, self.dec_ctx
+        for t in range(self.n_frames):
+            k = t & 1
+            coef, mv, has = self.sets[k]
+            if self._dec_pending[k]:
+                ectx.wait_event(self.ev_dec[k])           # the decode that last read this buffer set is done
+            f = self.frame_ptr(t)
+            if t % gop == 0:
+                enc.encode_iframe_dev(f, coef)
+            else:
+                enc.encode_pframe_dev(f, mv, has, coef)
+            ectx.record(self.ev_enc[k])
+            dctx.wait_event(self.ev_enc[k])
+            if t % gop == 0:
+                dec.decode_iframe_dev(coef)
+            else:
+                dec.decode_pframe_dev(mv, has, coef)
+            dctx.record(self.ev_dec[k])
+            self._dec_pending[k] = True
+
+    def sync(self):
+        self.ctx.sync()
+        if self.dec_ctx is not None:
+            self.dec_ctx.sync()
+
     def verify(self):
+        self.sync()
         self.dec.check()
         assert np.array_equal(self.enc.prev_frame(), self.dec.framebuffer()), "decoder framebuffer != encoder reconstruction"
 
@@ -287,17 +328,23 @@ class StreamSet:
     def wall(self, reps, gop=GOP):
         """macroblocks/s of `reps` passes by the host clock (sync on both sides)"""
         self.step(gop)
-        self.ctx.sync()
+        self.sync()
         t0 = time.perf_counter()
         for _ in range(reps):
             self.step(gop)
-        self.ctx.sync()
+        self.sync()
         el = time.perf_counter() - t0
         return reps * self.n_frames * self.S * self.n_mb / el
 
     def close(self):
+        self.sync()
         self.enc.close()
         self.dec.close()
+        if self.ev_enc:
+            for e in self.ev_enc:
+                self.ctx.event_destroy(e)
+            for e in self.ev_dec:
+                self.dec_ctx.event_destroy(e)
         for p in self._bufs:
             self.ctx.free(p)
         self._bufs = []
@@ -420,12 +467,19 @@ def low_motion_side(pkg, ctx, timer, W, H, Q, seeds, n_frames, default_kern_ms, 
 
 def single_stream_side(pkg, ctx, Q, reps=6):
     """The reference's caller is ONE Encoder per stream (src/enc.rs:125-173): what a single 1080p stream (and 8 of them)
-    gets at kernel scope, with one launch per frame operation and with a whole GOP replayed as one HIP graph."""
+    gets at kernel scope, with one launch per frame operation, with a whole GOP replayed as one HIP graph, and with the
+    decoder on its own context (second HIP stream): decode of frame t beside the encode of frame t + 1."""
     out = {}
+    dctx = pkg.Context(ctx.device)
     for S in (1, 8):
-        ss = StreamSet(pkg, ctx, 1920, 1080, Q, [pkg.synth.SEED + 17 * k for k in range(S)], GOP)
+        seeds = [pkg.synth.SEED + 17 * k for k in range(S)]
+        ss = StreamSet(pkg, ctx, 1920, 1080, Q, seeds, GOP)
         r = {"launches": ss.wall(reps)}
         ss.verify()
+        ss2 = StreamSet(pkg, ctx, 1920, 1080, Q, seeds, GOP, dec_ctx=dctx)
+        r["decoder_on_second_stream"] = ss2.wall(reps)
+        ss2.verify()
+        ss2.close()
         try:
             r["hip_graph"] = graph_rate(ss, reps)
             ss.verify()
@@ -433,6 +487,7 @@ def single_stream_side(pkg, ctx, Q, reps=6):
             r["hip_graph_error"] = str(e)[:200]
         out[f"streams_{S}"] = r
         ss.close()
+    dctx.close()
     out["unit"] = "macroblocks/s (encode+decode, 1080p GOP-15, kernel scope, host clock incl. launch overhead)"
     return out
 
@@ -467,6 +522,13 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None):
     res["kernel_only"] = {"value": ss.wall(2), "frames": n_frames,
                           "note": "one launch per frame operation, 48 720 macroblocks per launch"}
     ss.verify()
+    if own:     # the same stream with the decoder on its own context (second HIP stream): decode of frame t beside the encode of frame t + 1
+        dctx = pkg.Context(ctx.device)
+        ss2 = StreamSet(pkg, ctx, W, H, Q, [seed], min(n_frames, 60), dec_ctx=dctx)
+        res["kernel_only"]["decoder_on_second_stream"] = ss2.wall(4)
+        ss2.verify()
+        ss2.close()
+        dctx.close()
     # (ii)
     pcie_frames = min(pcie_frames, n_frames)
     host = ss.host_frames(0, pcie_frames)

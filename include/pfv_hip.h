@@ -81,8 +81,15 @@ PFV_API const char *pfv_version(void);
  *       PFV_ENC_TRANSFORM_INT             always the i32 kernels
  *   PFV_OPT_TILE_COMPACTION  1 (default): the p-frame encoder transforms only CODED macroblocks where that saves work -- a
  *       skipped macroblock is not transformed by the reference either (src/common.rs:221-222) -- by moving the coded macroblocks of
- *       a 128 x 64 tile together before the transform phase; 0: every wavefront transforms its own strip (measurements) */
-typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2 } pfv_option;
+ *       a 128 x 64 tile together before the transform phase; 0: every wavefront transforms its own strip (measurements)
+ *   PFV_OPT_LANE_MAPPING  how the four codec kernels spread a macroblock over lanes:
+ *       PFV_LANES_AUTO (default)   by grid size: 8 lanes per macroblock (a wavefront = a strip of 8 macroblocks) for launches that
+ *                                  fill the device, 16 (a wavefront = 4 macroblocks, half as long) for launches of fewer than
+ *                                  4 096 strips -- one or two 1080p streams per launch, the reference's own usage
+ *                                  (src/enc.rs:125-173)
+ *       PFV_LANES_PER_MB_8 / PFV_LANES_PER_MB_16   force one of them */
+typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2, PFV_OPT_LANE_MAPPING = 3 } pfv_option;
+enum { PFV_LANES_AUTO = 0, PFV_LANES_PER_MB_8 = 1, PFV_LANES_PER_MB_16 = 2 };
 enum { PFV_ENC_TRANSFORM_AUTO = 0, PFV_ENC_TRANSFORM_INT = 1 };
 PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value);
 PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value);
@@ -94,6 +101,11 @@ PFV_API int pfv_event_create(pfv_ctx *ctx, pfv_event **out);
 PFV_API int pfv_event_record(pfv_event *e);
 PFV_API int pfv_event_elapsed_ms(pfv_event *start, pfv_event *stop, float *ms);
 PFV_API void pfv_event_destroy(pfv_event *e);
+/* Ordering between contexts (each has its own HIP stream): ctx's stream waits, on the device, for an event recorded on another
+ * context's stream.  This is how a decoder on one context consumes what an encoder on another produces while the encoder is
+ * already working on the next frame -- Encoder and Decoder are independent objects in the reference (src/enc.rs:12-26,
+ * src/dec.rs:15-28), and for a single stream the device is far from full with one of them. */
+PFV_API int pfv_ctx_wait_event(pfv_ctx *ctx, pfv_event *e);
 
 /* HIP graphs over the `*_dev` entry points.  The reference's caller is one Encoder per stream, one call per frame
  * (src/enc.rs:125-173); for a single stream the launches, not the kernels, are the cost.  Every `*_dev` call made between

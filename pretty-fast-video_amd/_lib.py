@@ -29,6 +29,8 @@ PFV_ERR_STATE = -9
 PFV_COMM_SUM, PFV_COMM_MAX = 0, 1
 PFV_OPT_ENC_TRANSFORM = 1
 PFV_OPT_TILE_COMPACTION = 2
+PFV_OPT_LANE_MAPPING = 3
+PFV_LANES_AUTO, PFV_LANES_PER_MB_8, PFV_LANES_PER_MB_16 = 0, 1, 2
 PFV_ENC_TRANSFORM_AUTO, PFV_ENC_TRANSFORM_INT = 0, 1
 
 
@@ -55,6 +57,7 @@ SIGNATURES = [
     ("pfv_event_record", c_int, [_P]),
     ("pfv_event_elapsed_ms", c_int, [_P, _P, POINTER(c_float)]),
     ("pfv_event_destroy", None, [_P]),
+    ("pfv_ctx_wait_event", c_int, [_P, _P]),
     ("pfv_graph_begin", c_int, [_P]),
     ("pfv_graph_end", c_int, [_P, POINTER(_P)]),
     ("pfv_graph_launch", c_int, [_P]),

@@ -66,6 +66,22 @@ class Context:
         self.check(self._lib.pfv_ctx_get_option(self.handle, int(option), ctypes.byref(v)))
         return int(v.value)
 
+    # timing / ordering events on this context's stream (pfv_event_*)
+    def event(self):
+        h = ctypes.c_void_p()
+        self.check(self._lib.pfv_event_create(self.handle, ctypes.byref(h)))
+        return h
+
+    def record(self, ev):
+        self.check(self._lib.pfv_event_record(ev))
+
+    def wait_event(self, ev):
+        """this context's stream waits on the device for an event recorded on another context's stream"""
+        self.check(self._lib.pfv_ctx_wait_event(self.handle, ev))
+
+    def event_destroy(self, ev):
+        self._lib.pfv_event_destroy(ev)
+
     def device_sync(self):
         """hipDeviceSynchronize: every stream of the device"""
         self.check(self._lib.pfv_device_sync(self.handle))

@@ -62,6 +62,7 @@ struct pfv_ctx {
     bool capturing = false;      // a pfv_graph_begin is open on the stream
     int opt_enc_transform = PFV_ENC_TRANSFORM_AUTO;   // pfv_ctx_set_option(PFV_OPT_ENC_TRANSFORM)
     int opt_tile_compaction = 1;                      // pfv_ctx_set_option(PFV_OPT_TILE_COMPACTION)
+    int opt_lane_mapping = PFV_LANES_AUTO;            // pfv_ctx_set_option(PFV_OPT_LANE_MAPPING)
 };
 
 static thread_local std::string g_tls_err;
@@ -109,6 +110,10 @@ PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value)
         if (value != 0 && value != 1) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_TILE_COMPACTION: 0 or 1");
         ctx->opt_tile_compaction = value;
         return PFV_OK;
+    case PFV_OPT_LANE_MAPPING:
+        if (value != PFV_LANES_AUTO && value != PFV_LANES_PER_MB_8 && value != PFV_LANES_PER_MB_16) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_LANE_MAPPING: unknown value");
+        ctx->opt_lane_mapping = value;
+        return PFV_OK;
     default:
         return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_set_option: unknown option");
     }
@@ -119,6 +124,7 @@ PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value)
     switch (option) {
     case PFV_OPT_ENC_TRANSFORM: *value = ctx->opt_enc_transform; return PFV_OK;
     case PFV_OPT_TILE_COMPACTION: *value = ctx->opt_tile_compaction; return PFV_OK;
+    case PFV_OPT_LANE_MAPPING: *value = ctx->opt_lane_mapping; return PFV_OK;
     default: return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_get_option: unknown option");
     }
 }
@@ -223,6 +229,14 @@ PFV_API int pfv_event_elapsed_ms(pfv_event *start, pfv_event *stop, float *ms)
     if (!start || !stop || !ms) return fail(start ? start->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_event_elapsed_ms: bad argument");
     HIP_TRY(stop->ctx, hipEventSynchronize(stop->ev));
     HIP_TRY(stop->ctx, hipEventElapsedTime(ms, start->ev, stop->ev));
+    return PFV_OK;
+}
+// the context's stream waits (on the device, not the host) for an event recorded on ANOTHER context's stream
+PFV_API int pfv_ctx_wait_event(pfv_ctx *ctx, pfv_event *e)
+{
+    if (!ctx || !e) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_wait_event: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e->ev, 0));
     return PFV_OK;
 }
 PFV_API void pfv_event_destroy(pfv_event *e)
@@ -425,6 +439,56 @@ static inline unsigned strip_blocks(const FrameGeom &g)
     return (unsigned)((strips + kStripsPerWG - 1) / kStripsPerWG);
 }
 
+// Lane mapping of the four codec kernels (pfv_kernels.hip, "Lane mappings"): 8 lanes per macroblock for launches that fill the
+// device, 16 for small ones.  Measured on one MI355X (profiles/r03_lane_mappings.txt; 1080p GOP-15 encode+decode, M macroblocks/s,
+// 8 vs 16 lanes): 1 stream (1 530 strips) 533 vs 567, 2 streams 687 vs 709, 4 streams (6 120 strips) 894 vs 865, one 4K stream
+// (6 090 strips) 985 vs 925 -- the crossover lies between 3 060 and 6 090 strips.  PFV_OPT_LANE_MAPPING overrides the choice.
+constexpr long kSmallGridStrips = 4096;
+static inline bool use_small_grid(int opt, const FrameGeom &g)
+{
+    if (opt == PFV_LANES_PER_MB_8) return false;
+    if (opt == PFV_LANES_PER_MB_16) return true;
+    return (long)g.strips_per_frame * g.n_streams < kSmallGridStrips;
+}
+static inline unsigned half_strip_blocks(const FrameGeom &g)
+{
+    long waves = 2 * (long)g.strips_per_frame * g.n_streams;
+    return (unsigned)((waves + kStripsPerWG - 1) / kStripsPerWG);
+}
+static void launch_enc_iframe(pfv_ctx *ctx, bool flt, bool small, const FrameGeom &g, const uint8_t *src, int16_t *coef, uint8_t *recon, const QTab *qt)
+{
+    if (small) {
+        if (flt) hipLaunchKernelGGL((k_enc_iframe<true, 16>), dim3(half_strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, src, coef, recon, qt, kQuantMagic);
+        else hipLaunchKernelGGL((k_enc_iframe<false, 16>), dim3(half_strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, src, coef, recon, qt, kQuantMagic);
+    } else {
+        if (flt) hipLaunchKernelGGL((k_enc_iframe<true, 8>), dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, src, coef, recon, qt, kQuantMagic);
+        else hipLaunchKernelGGL((k_enc_iframe<false, 8>), dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, src, coef, recon, qt, kQuantMagic);
+    }
+}
+static void launch_enc_pframe(pfv_ctx *ctx, bool flt, bool small, bool compaction, const FrameGeom &g, const uint8_t *src, const uint8_t *ref, int8_t *mv,
+                              uint8_t *has, int16_t *coef, uint8_t *recon, const QTab *qt, float min_err)
+{
+    if (small) {
+        if (flt) hipLaunchKernelGGL(k_enc_pframe16<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads16), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic);
+        else hipLaunchKernelGGL(k_enc_pframe16<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads16), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic);
+    } else {
+        const int cmax = compaction ? kPencCompactMax : 0;
+        if (flt) hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic, cmax);
+        else hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic, cmax);
+    }
+}
+static void launch_dec_iframe(pfv_ctx *ctx, bool small, const FrameGeom &g, const int16_t *coef, uint8_t *out, const QTab *qt, uint8_t *frames_out)
+{
+    if (small) hipLaunchKernelGGL(k_dec_iframe<16>, dim3(half_strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef, out, qt, frames_out);
+    else hipLaunchKernelGGL(k_dec_iframe<8>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef, out, qt, frames_out);
+}
+static void launch_dec_pframe(pfv_ctx *ctx, bool small, const FrameGeom &g, const int8_t *mv, const uint8_t *has, const int16_t *coef, const uint8_t *ref,
+                              uint8_t *out, const QTab *qt, int *flag, uint8_t *frames_out)
+{
+    if (small) hipLaunchKernelGGL(k_dec_pframe<16>, dim3(half_strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, mv, has, coef, ref, out, qt, flag, frames_out);
+    else hipLaunchKernelGGL(k_dec_pframe<8>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, mv, has, coef, ref, out, qt, flag, frames_out);
+}
+
 static int launch_check(pfv_ctx *ctx, const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -462,12 +526,8 @@ PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, cons
     if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     // encode only: the forward transform is exact in f32 for any table
-    if (ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT)
-        hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
-                                                                       ctx->qtab_dev, kQuantMagic);
-    else
-        hipLaunchKernelGGL(k_enc_iframe<false>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (int16_t *)d_coef, nullptr,
-                                                                        ctx->qtab_dev, kQuantMagic);
+    launch_enc_iframe(ctx, ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT, use_small_grid(ctx->opt_lane_mapping, g), g, (const uint8_t *)d_src, (int16_t *)d_coef,
+                      nullptr, ctx->qtab_dev);
     if ((rc = launch_check(ctx, "k_enc_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -496,14 +556,8 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
     float min_err = px_err * px_err * 256.0f;   // src/common.rs:209
-    if (ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT)
-        hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
-                                                                       (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
-                                                                       nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic, ctx->opt_tile_compaction ? kPencCompactMax : 0);
-    else
-        hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, (const uint8_t *)d_src, (const uint8_t *)d_ref,
-                                                                        (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef,
-                                                                        nullptr, ctx->qtab_dev, min_err, -2, kQuantMagic, ctx->opt_tile_compaction ? kPencCompactMax : 0);
+    launch_enc_pframe(ctx, ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT, use_small_grid(ctx->opt_lane_mapping, g), ctx->opt_tile_compaction != 0, g,
+                      (const uint8_t *)d_src, (const uint8_t *)d_ref, (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef, nullptr, ctx->qtab_dev, min_err);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(mv_out, d_mv, n * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -527,8 +581,7 @@ PFV_API int pfv_decode_plane_into(pfv_ctx *ctx, const int16_t *coef, int bw, int
     if ((rc = ensure_scratch(ctx, 1, coef_bytes, &d_coef))) return rc;
     if ((rc = ensure_scratch(ctx, 5, pad_bytes, &d_out))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_coef, coef, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_dec_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const int16_t *)d_coef, (uint8_t *)d_out,
-                                                                   ctx->qtab_dev, (uint8_t *)nullptr);
+    launch_dec_iframe(ctx, use_small_grid(ctx->opt_lane_mapping, g), g, (const int16_t *)d_coef, (uint8_t *)d_out, ctx->qtab_dev, nullptr);
     if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(target, d_out, pad_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -558,9 +611,8 @@ PFV_API int pfv_decode_plane_delta(pfv_ctx *ctx, const int8_t *mv, const uint8_t
     HIP_TRY(ctx, hipMemcpyAsync(d_mv, mv, n * 2, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_has, has_coef, n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_dec_pframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, (const int8_t *)d_mv, (const uint8_t *)d_has,
-                                                                   (const int16_t *)d_coef, (const uint8_t *)d_ref,
-                                                                   (uint8_t *)d_out, ctx->qtab_dev, ctx->flag_dev, (uint8_t *)nullptr);
+    launch_dec_pframe(ctx, use_small_grid(ctx->opt_lane_mapping, g), g, (const int8_t *)d_mv, (const uint8_t *)d_has, (const int16_t *)d_coef, (const uint8_t *)d_ref,
+                      (uint8_t *)d_out, ctx->qtab_dev, ctx->flag_dev, nullptr);
     if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
     int flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -828,6 +880,7 @@ struct pfv_enc_session {
     float px_err = 0.0f;
     bool flt = false;                        // the closed loop may run in f32 (enc_float_exact holds for all four tables)
     bool tile_compaction = true;             // PFV_OPT_TILE_COMPACTION at creation
+    int lane_mapping = PFV_LANES_AUTO;       // PFV_OPT_LANE_MAPPING at creation
     uint8_t *prev[2] = {nullptr, nullptr};   // ping-pong prev_frame, padded, n_streams wide
     int cur = 0;                             // prev[cur] is the current prev_frame
     // staging for the host-buffer entry points
@@ -859,6 +912,7 @@ struct pfv_dec_session {
     FrameGeom geom;
     QTab *qtab_dev = nullptr;
     uint8_t *fb[2] = {nullptr, nullptr};     // ping-pong framebuffer
+    int lane_mapping = PFV_LANES_AUTO;       // PFV_OPT_LANE_MAPPING at creation
     int cur = 0;
     int *flag_dev = nullptr;
     uint8_t *frames_out = nullptr;           // optional fused retframe output (pfv_dec_set_output_dev)
@@ -894,6 +948,7 @@ PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int qual
         if (rc) { delete s; return rc; }
     }
     s->tile_compaction = ctx->opt_tile_compaction != 0;
+    s->lane_mapping = ctx->opt_lane_mapping;
     s->flt = ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT && enc_float_exact(q[0], 128.0 * 256.0) && enc_float_exact(q[1], 128.0 * 256.0) &&
              enc_float_exact(q[2], 127.0 * 256.0) && enc_float_exact(q[3], 127.0 * 256.0);
     size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
@@ -944,10 +999,7 @@ PFV_API int pfv_enc_iframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
-    if (s->flt)
-        hipLaunchKernelGGL(k_enc_iframe<true>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0, kQuantMagic);
-    else
-        hipLaunchKernelGGL(k_enc_iframe<false>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0, kQuantMagic);
+    launch_enc_iframe(ctx, s->flt, use_small_grid(s->lane_mapping, g), g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0);
     int rc = launch_check(ctx, "k_enc_iframe");
     if (rc) return rc;
     s->cur = nxt;
@@ -964,12 +1016,8 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     FrameGeom g = with_base_alignment(s->geom, frames_dev);
     int nxt = s->cur ^ 1;
     float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
-    if (s->flt)
-        hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
-            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic, s->tile_compaction ? kPencCompactMax : 0);
-    else
-        hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream,
-            g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev, s->prev[nxt], s->qtab_dev + 2, min_err, -2, kQuantMagic, s->tile_compaction ? kPencCompactMax : 0);
+    launch_enc_pframe(ctx, s->flt, use_small_grid(s->lane_mapping, g), s->tile_compaction, g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev,
+                      s->prev[nxt], s->qtab_dev + 2, min_err);
     int rc = launch_check(ctx, "k_enc_pframe");
     if (rc) return rc;
     s->cur = nxt;
@@ -1271,6 +1319,7 @@ PFV_API int pfv_dec_session_create(pfv_ctx *ctx, int width, int height, const in
     }
     pfv_dec_session *s = new pfv_dec_session();
     s->ctx = ctx; s->width = width; s->height = height; s->n_streams = n_streams; s->n_qtables = n_qtables;
+    s->lane_mapping = ctx->opt_lane_mapping;
     s->geom = frame_geom(width, height, n_streams);
     size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
     hipError_t e = hipMalloc((void **)&s->qtab_dev, tabs.size() * sizeof(QTab));
@@ -1340,7 +1389,7 @@ PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, cons
     int rc = dec_geom(s, qidx, &g);
     if (rc) return rc;
     int nxt = s->cur ^ 1;
-    hipLaunchKernelGGL(k_dec_iframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef_dev, s->fb[nxt], s->qtab_dev, fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
+    launch_dec_iframe(ctx, use_small_grid(s->lane_mapping, g), g, coef_dev, s->fb[nxt], s->qtab_dev, fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
     if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
     s->cur = nxt;
     if (s->frames_out && !fused_output_ok(s)) return pfv_dec_get_frame_dev(s, s->frames_out);
@@ -1358,9 +1407,8 @@ PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const u
     int rc = dec_geom(s, qidx, &g);
     if (rc) return rc;
     int nxt = s->cur ^ 1;
-    hipLaunchKernelGGL(k_dec_pframe, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, 
-        g, mv_dev, has_coef_dev, coef_dev, s->fb[s->cur], s->fb[nxt], s->qtab_dev, s->flag_dev,
-        fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
+    launch_dec_pframe(ctx, use_small_grid(s->lane_mapping, g), g, mv_dev, has_coef_dev, coef_dev, s->fb[s->cur], s->fb[nxt], s->qtab_dev, s->flag_dev,
+                      fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
     if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
     s->cur = nxt;
     if (s->frames_out && !fused_output_ok(s)) return pfv_dec_get_frame_dev(s, s->frames_out);

@@ -408,6 +408,28 @@ __device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *
         if (mb < n_mb) buf[j] = ld_stream(&reinterpret_cast<const uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)]);
     }
 }
+// The same for the small-grid lane mapping (16 lanes per macroblock, see "Lane mappings" below): the wavefront's 8 slots are the
+// two halves of 4 macroblocks -- slot s = macroblock (half_strip * 4 + s / 2), half s % 2 -- so the stage is 4 WHOLE macroblocks,
+// 2 KiB contiguous in the coefficient buffer.
+__device__ __forceinline__ void store_coef_quads(const int *stage, int16_t *coef_mb0, int n_mb, int lane, int half_strip)
+{
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int ch = j * 64 + lane;
+        int mb = half_strip * 4 + (ch >> 5);
+        if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[half_strip * 128 + ch], reinterpret_cast<const uint4 *>(stage)[ch]);
+    }
+}
+__device__ __forceinline__ void fetch_coef_quads(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int half_strip)
+{
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int ch = j * 64 + lane;
+        int mb = half_strip * 4 + (ch >> 5);
+        buf[j] = make_uint4(0, 0, 0, 0);
+        if (mb < n_mb) buf[j] = ld_stream(&reinterpret_cast<const uint4 *>(coef_mb0)[half_strip * 128 + ch]);
+    }
+}
 __device__ __forceinline__ void stage_coef_half(int *stage, const uint4 (&buf)[2], int lane)
 {
 #pragma unroll
@@ -701,27 +723,40 @@ __device__ __forceinline__ void unpack_row_f(const uint4 &row, f2 (&px)[8])
 // reference: VideoPlane::encode_plane (src/common.rs:351-386) fused with the
 // VideoPlane::decode_plane that Encoder::encode_iframe runs on its output
 // (src/enc.rs:84-97).  recon == nullptr -> encode only (plane-level operator).
-template <bool FLT>
+// Lane mappings.  LPM = lanes per macroblock.
+//   LPM = 8  (batch mapping, what everything above describes): the wavefront owns a strip of 8 macroblocks; lane (m, i) owns rows
+//            i and i + 8 of macroblock m and runs the half-macroblock pipeline twice (h = 0, 1).
+//   LPM = 16 (small-grid mapping): the wavefront owns HALF a strip (4 macroblocks); lane = (macroblock, h, i) owns the ONE row
+//            8 h + i and runs the pipeline once -- its 8-lane group ("slot" = lane >> 3 = 2 * macroblock + h) is what the
+//            transposes, the quantiser tables and the zigzag stage see as "a macroblock's 8 lanes".  Twice the wavefronts, each half
+//            as long: when a launch has fewer than a couple of wavefronts per SIMD (one 1080p stream: 1.5), its duration is the
+//            serial time of ONE wavefront, and this mapping halves that (the reference's caller is one Encoder per stream,
+//            src/enc.rs:125-173).  Same results, bit for bit; the host picks by grid size (pfv_capi.hip: use_small_grid).
+template <bool FLT, int LPM = 8>
 __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           int16_t *__restrict__ coef, uint8_t *__restrict__ recon,
                                                           const QTab *__restrict__ qtabs, float qmagic)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
     __shared__ __attribute__((aligned(16))) int qtab_lds[kStripsPerWG][kQTabDwords];
+    constexpr int kPasses = LPM == 8 ? 2 : 1;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
-    const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
+    const int gw = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
+    const int gstrip = LPM == 8 ? gw : gw >> 1, half_strip = LPM == 8 ? 0 : gw & 1;
     if (gstrip >= g.strips_per_frame * g.n_streams) return;   // no cross-wavefront sync in this kernel
     const StripPos sp = locate_strip(g, gstrip);
+    if (half_strip * 4 >= sp.n_mb) return;
     const PlaneGeom &p = g.p[sp.plane];
-    const int m = lane >> 3, i = lane & 7;
+    const int slot = lane >> 3, i = lane & 7;
+    const int m = LPM == 8 ? slot : half_strip * 4 + (slot >> 1);   // macroblock within the strip
     int *xw = xchg[wave];
 
     fill_qtable<true, FLT>(qtab_lds[wave], qtabs + p.qsel, lane);
     const uint8_t *plane = src + (long)sp.stream * g.src_frame_bytes + p.src_off;
-    uint4 rows[2];
-    rows[0] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i);
-    rows[1] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8);
+    uint4 rows[kPasses];
+#pragma unroll
+    for (int pass = 0; pass < kPasses; pass++) rows[pass] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8 * (LPM == 8 ? pass : (slot & 1)));
 
     wave_lds_sync();
     const LaneQ lq{qtab_lds[wave], i};
@@ -729,32 +764,35 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
     uint8_t *dst = recon ? recon + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16
                          : nullptr;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int pass = 0; pass < kPasses; pass++) {
+        const int h = LPM == 8 ? pass : (slot & 1);
         if (FLT) {
             f2 x[8];
-            unpack_row_f(rows[h], x);
+            unpack_row_f(rows[pass], x);
 #pragma unroll
             for (int k = 0; k < 8; k++) x[k] = x[k] * f2s(256.0f) - f2s(32768.0f);   // (px - 128) << 8, src/common.rs:291
-            forward_half_f(x, xw, m, i, lq, qmagic);
-            store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+            forward_half_f(x, xw, slot, i, lq, qmagic);
+            if (LPM == 8) store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+            else store_coef_quads(xw, coef_mb0, sp.n_mb, lane, half_strip);
             wave_lds_sync();   // the stage has been read back before the region is reused
             if (recon) {
-                inverse_half_f<true>(x, xw, m, i, lq);                                // (v >> 8) + 128, clamped: by the pack's rounding + saturation (src/common.rs:321)
+                inverse_half_f<true>(x, xw, slot, i, lq);                             // (v >> 8) + 128, clamped: by the pack's rounding + saturation (src/common.rs:321)
                 if (m < sp.n_mb) *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = pack_row_f(x);
             }
         } else {
             int v[2][8];
-            unpack_row(rows[h], v);
+            unpack_row(rows[pass], v);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) v[s][k] = (int)((unsigned)(v[s][k] - 128) << 8);   // src/common.rs:291
             }
-            forward_half(v, xw, m, i, lq, true);
-            store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+            forward_half(v, xw, slot, i, lq, true);
+            if (LPM == 8) store_coef_half(xw, coef_mb0, sp.n_mb, lane, h);
+            else store_coef_quads(xw, coef_mb0, sp.n_mb, lane, half_strip);
             wave_lds_sync();   // the stage has been read back before the region is reused
             if (recon) {
-                inverse_half(v, xw, m, i, lq);
+                inverse_half(v, xw, slot, i, lq);
 #pragma unroll
                 for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -1377,39 +1415,283 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
     KMARK(11);
 }
 
+// ================================================================== P-frame encode, small-grid lane mapping (16 lanes per macroblock)
+// The same tile decomposition as k_enc_pframe (128 x 64 pixels, one reference window in LDS), EIGHT wavefronts per workgroup:
+// wavefront w owns half h = w & 1 of strip w >> 1, i.e. 4 macroblocks; lane (mb, r) = (lane >> 4, lane & 15) owns source row r of
+// its macroblock for the search (half the dot products of the row-pair form per lane, the partial sums of a candidate come from 16
+// lanes) and, as slot = lane >> 3 = (mb, r >> 3), one half of it for the transform -- one pass of the half-macroblock pipeline
+// instead of two.  A wavefront's serial length roughly halves; that is what a launch lasts when it has only one or two
+// wavefronts per SIMD (see "Lane mappings").  The exchange regions of wavefronts 0..3 live in the released window, those of
+// 4..7 in the released reduction regions.  No tile compaction here (it serves throughput on full devices).
+constexpr int kThreads16 = 64 * 2 * kStripsPerWG;       // 8 wavefronts
+constexpr int kWaves16 = 2 * kStripsPerWG;
+constexpr int kRedPitch16 = 144;                        // dwords per macroblock: 8 candidates x 16 lanes; 144 = 16 (mod 64): the 4 macroblocks of a wavefront
+                                                        // write 64 different banks
+static_assert(4 * kRedPitch16 <= kRedDwords, "the 16-lane reduction layout fits the reduction region");
+static_assert(kStripsPerWG * kXchgDwords * 4 <= kWinAlloc && kStripsPerWG * kXchgDwords <= kWaves16 * kRedDwords, "exchange regions of 8 wavefronts");
+__device__ __forceinline__ constexpr int win_first_issue16(int w) { return (w * kWinIssues + kWaves16 - 1) / kWaves16; }
+constexpr int kRowRor8 = 0x128;                         // DPP row_ror:8: lane r <-> r ^ 8 inside each 16 lanes
+
+__device__ __forceinline__ int mb_sum16(int v)
+{
+    v = mb_sum(v);
+    return v + dpp<kRowRor8>(v);
+}
+
+struct SearchLane16 {
+    int neg2, ord, dy, dx;
+    int *wr;            // &red[mb][0][r]: the lane's partial for candidate c goes to wr[c * 16]
+    const int4 *rd;     // &red[mb][c][8 * (r >> 3)]: eight of the sixteen partials of this lane's candidate c = r & 7
+};
+__device__ __forceinline__ SearchLane16 make_search_lane16(int *red, int mb, int r, int neg2)
+{
+    SearchLane16 sl;
+    const int c = r & 7;
+    sl.neg2 = neg2;
+    sl.ord = c + 1;
+    const int b9 = c < 4 ? c : c + 1;
+    sl.dy = b9 / 3 - 1;
+    sl.dx = b9 - (b9 / 3) * 3 - 1;
+    sl.wr = red + mb * kRedPitch16 + r;
+    sl.rd = reinterpret_cast<const int4 *>(red + mb * kRedPitch16 + c * 16 + (r & 8));
+    return sl;
+}
+
+// One search level, one source row per lane (see search_level for the arithmetic: SSD = sum a^2 - 2 sum ab + sum b^2 in u32,
+// accept rule = lexicographic minimum of (error, visiting order), src/common.rs:154-204).  wrow0: window row of the lane's row.
+template <int S, bool FIRST, bool BOUNDS>
+__device__ __forceinline__ void search_level16(const uint8_t *win, int wrow0, int wcol0, const uint4 &a, int a2, int mbx, int mby, int pw, int ph,
+                                               SearchState &st, const SearchLane16 &sl)
+{
+    const int sh = (st.cx - 1) & 3;                // step 1: phase of the leftmost candidate
+    const int col = S >= 4 ? (wcol0 + st.cx - S) : (S == 2 ? wcol0 + st.cx - 4 : wcol0 + ((st.cx - 1) & ~3));
+    int part[3][3];
+#pragma unroll
+    for (int my = -1; my <= 1; my++) {
+        const uint8_t *rp = win + (wrow0 + st.cy + my * S) * kWinStride + col;
+        const bool centre_known = !FIRST && my == 0;   // (0,0) is not evaluated again (:176)
+        unsigned ab[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
+        if (S == 8) {          // col = 8 (mod 16): 8-, 16-, 8-byte pieces; candidates at dwords 0, 2, 4 of an 8-dword span
+            const uint2 p0 = *reinterpret_cast<const uint2 *>(rp), p2 = *reinterpret_cast<const uint2 *>(rp + 24);
+            const uint4 p1 = *reinterpret_cast<const uint4 *>(rp + 8);
+            const unsigned d[8] = {p0.x, p0.y, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y};
+            const unsigned q23 = sq2(d[2], d[3], 0), q45 = sq2(d[4], d[5], 0);
+            bb[0] = sq2(d[0], d[1], q23); bb[1] = q23 + q45; bb[2] = sq2(d[6], d[7], q45);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (centre_known && c == 1) continue;
+                ab[c] = dot_ab(a, d[2 * c], d[2 * c + 1], d[2 * c + 2], d[2 * c + 3], 0);
+            }
+        } else if (S == 4) {   // dword, two 8-byte pieces, dword; candidates at dwords 0, 1, 2 of a 6-dword span
+            const unsigned *t = reinterpret_cast<const unsigned *>(rp);
+            const uint2 ta = *reinterpret_cast<const uint2 *>(rp + 4), tb = *reinterpret_cast<const uint2 *>(rp + 12);
+            const unsigned d[6] = {t[0], ta.x, ta.y, tb.x, tb.y, t[5]};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (centre_known && c == 1) continue;
+                ab[c] = dot_ab(a, d[c], d[c + 1], d[c + 2], d[c + 3], 0);
+            }
+            const unsigned q23 = sq2(d[2], d[3], 0);
+            if (centre_known) {
+                bb[0] = sq2(d[0], d[1], q23);
+                bb[2] = sq2(d[4], d[5], q23);
+            } else {
+                const unsigned y = __builtin_amdgcn_udot4(d[1], d[1], q23, false), z = __builtin_amdgcn_udot4(d[4], d[4], 0, false);
+                bb[0] = __builtin_amdgcn_udot4(d[0], d[0], y, false);
+                bb[1] = y + z;
+                bb[2] = __builtin_amdgcn_udot4(d[5], d[5], q23 + z, false);
+            }
+        } else {
+            const unsigned *t = reinterpret_cast<const unsigned *>(rp);
+            unsigned rt[6], dT[5];
+#pragma unroll
+            for (int k = 0; k < 6; k++) rt[k] = t[k];
+            if (S == 1) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) dT[k] = __builtin_amdgcn_alignbyte(rt[k + 1], rt[k], sh);   // bytes from (cx - 1) + 4k
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (centre_known && c == 1) continue;
+                unsigned e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (S == 2) {   // cx is a multiple of 4 after steps 8 and 4: candidates 2 bytes before, on, 2 bytes after a dword boundary
+                        const int o = k + (c >> 1);
+                        e[k] = c == 1 ? rt[k + 1] : __builtin_amdgcn_alignbyte(rt[o + 1], rt[o], 2);
+                    } else {
+                        e[k] = c ? __builtin_amdgcn_alignbyte(dT[k + 1], dT[k], c) : dT[k];
+                    }
+                }
+                ab[c] = dot_ab(a, e[0], e[1], e[2], e[3], 0);
+                bb[c] = sq4(e[0], e[1], e[2], e[3], 0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) part[my + 1][c] = __mul24((int)ab[c], sl.neg2) + (int)bb[c];
+    }
+    int ord = 0;
+#pragma unroll
+    for (int my = -1; my <= 1; my++) {
+#pragma unroll
+        for (int mx = -1; mx <= 1; mx++) {
+            if (my == 0 && mx == 0) continue;
+            sl.wr[ord * 16] = part[my + 1][mx + 1];
+            ord++;
+        }
+    }
+    wave_lds_sync();
+    const int4 x = sl.rd[0], y = sl.rd[1];
+    wave_lds_sync();
+    const int half = ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+    const int err = a2 + half + dpp<kRowRor8>(half);
+    bool valid = true;
+    if (BOUNDS) {
+        const int oy = mby + st.cy + sl.dy * S, ox = mbx + st.cx + sl.dx * S;
+        valid = oy >= 0 && oy <= ph - 16 && ox >= 0 && ox <= pw - 16;        // :171, :182
+    }
+    const unsigned key = valid ? (((unsigned)err << 4) | (unsigned)sl.ord) : 0xffffffffu;
+    const unsigned centre = FIRST ? ((unsigned)(a2 + mb_sum16(part[1][1])) << 4) : ((unsigned)st.err << 4);
+    const unsigned best = min(mb_min(key), centre);
+    const int bo = (int)(best & 15u);
+    st.err = (int)(best >> 4);
+    st.cy += ((int)((0x2A501u >> (2 * bo)) & 3u) - 1) * S;
+    st.cx += ((int)((0x24891u >> (2 * bo)) & 3u) - 1) * S;
+}
+
+template <bool FLT>
+__global__ __launch_bounds__(kThreads16) void k_enc_pframe16(FrameGeom g, const uint8_t *__restrict__ src, const uint8_t *__restrict__ ref,
+                                                            int8_t *__restrict__ mv_out, uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
+                                                            uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs, float min_err, int neg2,
+                                                            float qmagic)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t win_lds[16 + kWinAlloc];
+    __shared__ __attribute__((aligned(16))) int red_lds[kWaves16][kRedDwords];
+    __shared__ __attribute__((aligned(16))) int qtab_lds[kQTabDwords];
+    uint8_t *win = win_lds + 16;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int strip = wave >> 1, half_strip = wave & 1;
+    const int slot = lane >> 3, i = lane & 7, mb = lane >> 4, r = lane & 15;
+    const int m = half_strip * 4 + mb;                      // macroblock within the strip
+    const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const TilePos cur = locate_tile(g, vt, strip);
+    const PlaneGeom &p = g.p[cur.sp.plane];
+    if (wave == 0) fill_qtable<true, FLT>(qtab_lds, qtabs + p.qsel, lane);
+    {   // the window: 17 wave-wide 1 KiB loads dealt to 8 wavefronts (see issue_window)
+        const uint8_t *refp = ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off;
+        for (int q = win_first_issue16(wave); q < win_first_issue16(wave + 1); q++) {
+            const int c = q * 64 + lane;
+            const int row = c / kWinChunksPerRow, col = c - row * kWinChunksPerRow;
+            const int y = min(max(cur.winy0 + row, 0), p.ph - 1), x = min(max(cur.winx0 + col * 16, 0), p.pw - 16);
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t *)(refp + (long)y * p.pw + x), (lds_void_t *)(win + c * 16), 16, 0, 0);
+        }
+    }
+    const bool wave_valid = cur.wave_valid && half_strip * 4 < cur.sp.n_mb;
+    const bool mb_valid = wave_valid && m < cur.sp.n_mb;
+    uint4 row = make_uint4(0, 0, 0, 0);
+    if (wave_valid) row = load_src16(src + (long)cur.sp.stream * g.src_frame_bytes + p.src_off, p, cur.sp.x0 + m * 16, cur.sp.y0 + r);
+    __syncthreads();   // window complete
+    int cx = 0, cy = 0;
+    bool coded = false;
+    uint4 patch = make_uint4(0, 0, 0, 0);
+    if (wave_valid) {
+        const int mbx = cur.sp.x0 + m * 16, mby = cur.sp.y0;
+        const int wcol0 = mbx - cur.winx0, wrow0 = mby - cur.winy0 + r;
+        unsigned s2 = __builtin_amdgcn_udot4(row.w, row.w, __builtin_amdgcn_udot4(row.z, row.z, __builtin_amdgcn_udot4(row.y, row.y, __builtin_amdgcn_udot4(row.x, row.x, 0, false), false), false), false);
+        const int a2 = mb_sum16((int)s2);
+        SearchState st;
+        st.cx = 0; st.cy = 0; st.err = 0;
+        const SearchLane16 sl = make_search_lane16(red_lds[wave], mb, r, neg2);
+        // the whole half strip at least 15 px inside the plane: no bounds tests (wave-uniform)
+        const int hx0 = cur.sp.x0 + half_strip * 64;
+        const bool interior = hx0 >= 16 && hx0 + 64 + 16 <= p.pw && cur.sp.y0 >= 16 && cur.sp.y0 + 32 <= p.ph;
+        if (interior) {
+            search_level16<8, true, false>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+            search_level16<4, false, false>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+            search_level16<2, false, false>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+            search_level16<1, false, false>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+        } else {
+            search_level16<8, true, true>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+            search_level16<4, false, true>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+            search_level16<2, false, true>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+            search_level16<1, false, true>(win, wrow0, wcol0, row, a2, mbx, mby, p.pw, p.ph, st, sl);
+        }
+        coded = mb_valid && !((float)st.err <= min_err);     // skip decision (src/common.rs:209, :221), compared in f32
+        cx = st.cx; cy = st.cy;
+        const int wx = wcol0 + cx, shp = wx & 3;           // the lane's row of the chosen patch (get_block of the reconstruction, :261)
+        const unsigned *d = reinterpret_cast<const unsigned *>(win + (wrow0 + cy) * kWinStride + (wx & ~3));
+        const unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+        patch = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, shp), __builtin_amdgcn_alignbyte(d2, d1, shp), __builtin_amdgcn_alignbyte(d3, d2, shp),
+                           __builtin_amdgcn_alignbyte(d4, d3, shp));
+    }
+    const long mbi = (long)cur.sp.stream * g.mbs_per_frame + cur.sp.mb_first + m;
+    if (r == 0 && mb_valid) {
+        mv_out[mbi * 2 + 0] = (int8_t)cx;
+        mv_out[mbi * 2 + 1] = (int8_t)cy;
+        has_out[mbi] = coded ? 1 : 0;
+    }
+    __syncthreads();   // window and reduction regions released by every wavefront
+    if (!wave_valid) return;
+    int *xw = wave < kStripsPerWG ? reinterpret_cast<int *>(win) + wave * kXchgDwords : &red_lds[0][0] + (wave - kStripsPerWG) * kXchgDwords;
+    int16_t *coef_mb0 = coef + ((long)cur.sp.stream * g.mbs_per_frame + cur.sp.mb_first) * 256;
+    uint8_t *dst = recon ? recon + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off + (long)(cur.sp.y0 + r) * p.pw + cur.sp.x0 + m * 16 : nullptr;
+    if (__any(coded)) {
+        const LaneQ lq{qtab_lds, i};
+        const uint4 o = penc_half<FLT>(coded ? row : patch, patch, xw, slot, i, lq, qmagic, recon != nullptr,
+                                       [&]() { store_coef_quads(xw, coef_mb0, cur.sp.n_mb, lane, half_strip); });
+        if (recon && mb_valid) *reinterpret_cast<uint4 *>(dst) = o;
+    } else if (mb_valid) {   // the 16 lanes of a skipped macroblock: zero coefficients (2 x 16 bytes each), prediction as reconstruction
+        uint4 *cm = reinterpret_cast<uint4 *>(coef_mb0 + m * 256);
+        st_stream(&cm[r], make_uint4(0, 0, 0, 0));
+        st_stream(&cm[16 + r], make_uint4(0, 0, 0, 0));
+        if (dst) *reinterpret_cast<uint4 *>(dst) = patch;
+    }
+}
+
 // ================================================================== I-frame decode
 // reference: VideoPlane::decode_plane / decode_plane_into (src/common.rs:423-446, 477-496)
 // frames_out != nullptr: also write the cropped, tightly packed retframe (n_streams frames).
+template <int LPM = 8>
 __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ out, const QTab *__restrict__ qtabs,
                                                           uint8_t *__restrict__ frames_out)
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
     __shared__ __attribute__((aligned(16))) int qtab_lds[kStripsPerWG][kQTabDwords];
+    constexpr int kPasses = LPM == 8 ? 2 : 1;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
-    const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
+    const int gw = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
+    const int gstrip = LPM == 8 ? gw : gw >> 1, half_strip = LPM == 8 ? 0 : gw & 1;     // see "Lane mappings"
     if (gstrip >= g.strips_per_frame * g.n_streams) return;
     const StripPos sp = locate_strip(g, gstrip);
+    if (half_strip * 4 >= sp.n_mb) return;
     const PlaneGeom &p = g.p[sp.plane];
-    const int m = lane >> 3, i = lane & 7;
+    const int slot = lane >> 3, i = lane & 7;
+    const int m = LPM == 8 ? slot : half_strip * 4 + (slot >> 1);
     int *xw = xchg[wave];
 
     const int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
-    uint4 cbuf[2][2];
-    fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
-    fetch_coef_half(cbuf[1], coef_mb0, sp.n_mb, lane, 1);
+    uint4 cbuf[kPasses][2];
+    if (LPM == 8) {
+        fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
+        fetch_coef_half(cbuf[kPasses - 1], coef_mb0, sp.n_mb, lane, 1);
+    } else {
+        fetch_coef_quads(cbuf[0], coef_mb0, sp.n_mb, lane, half_strip);
+    }
     fill_qtable<false>(qtab_lds[wave], qtabs + p.qsel, lane);
     wave_lds_sync();
     const LaneQ lq{qtab_lds[wave], i};
     uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + sp.x0 + m * 16;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        stage_coef_half(xw, cbuf[h], lane);
+    for (int pass = 0; pass < kPasses; pass++) {
+        const int h = LPM == 8 ? pass : (slot & 1);
+        stage_coef_half(xw, cbuf[pass], lane);
         wave_lds_sync();
         int v[2][8];
-        gather_half(v, xw, m, lq);
-        inverse_half(v, xw, m, i, lq);
+        gather_half(v, xw, slot, lq);
+        inverse_half(v, xw, slot, i, lq);
 #pragma unroll
         for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -1440,6 +1722,7 @@ __device__ __forceinline__ uint4 load_unaligned16(const uint8_t *p)
                       __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
 }
 
+template <int LPM = 8>
 __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8_t *__restrict__ mv,
                                                           const uint8_t *__restrict__ has, const int16_t *__restrict__ coef,
                                                           const uint8_t *__restrict__ ref, uint8_t *__restrict__ out,
@@ -1448,13 +1731,17 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
 {
     __shared__ __attribute__((aligned(16))) int xchg[kStripsPerWG][kXchgDwords];
     __shared__ __attribute__((aligned(16))) int qtab_lds[kStripsPerWG][kQTabDwords];
+    constexpr int kPasses = LPM == 8 ? 2 : 1;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform -> SGPRs
-    const int gstrip = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
+    const int gw = xcd_remap((int)blockIdx.x, (int)gridDim.x) * kStripsPerWG + wave;
+    const int gstrip = LPM == 8 ? gw : gw >> 1, half_strip = LPM == 8 ? 0 : gw & 1;     // see "Lane mappings"
     if (gstrip >= g.strips_per_frame * g.n_streams) return;
     const StripPos sp = locate_strip(g, gstrip);
+    if (half_strip * 4 >= sp.n_mb) return;
     const PlaneGeom &p = g.p[sp.plane];
-    const int m = lane >> 3, i = lane & 7;
+    const int slot = lane >> 3, i = lane & 7;
+    const int m = LPM == 8 ? slot : half_strip * 4 + (slot >> 1);
     int *xw = xchg[wave];
     const bool mb_valid = m < sp.n_mb;
     const long mbi = (long)sp.stream * g.mbs_per_frame + sp.mb_first + (mb_valid ? m : 0);
@@ -1472,20 +1759,25 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
             mx = 0; my = 0;
         }
     }
-    // second round trip: coefficients (only if some macroblock of the strip has any) and patch rows
+    // second round trip: coefficients (only if some macroblock of the wavefront has any) and patch rows
     const bool any_coded = __any(coded);
     const int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
-    uint4 cbuf[2][2];
+    uint4 cbuf[kPasses][2];
     if (any_coded) {
-        fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
-        fetch_coef_half(cbuf[1], coef_mb0, sp.n_mb, lane, 1);
+        if (LPM == 8) {
+            fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
+            fetch_coef_half(cbuf[kPasses - 1], coef_mb0, sp.n_mb, lane, 1);
+        } else {
+            fetch_coef_quads(cbuf[0], coef_mb0, sp.n_mb, lane, half_strip);
+        }
     }
-    uint4 patch[2];
-    patch[0] = patch[1] = make_uint4(0, 0, 0, 0);
-    if (mb_valid) {   // the lane's two rows of the motion-compensated patch (get_block, :327-339)
+    uint4 patch[kPasses];
+#pragma unroll
+    for (int pass = 0; pass < kPasses; pass++) patch[pass] = make_uint4(0, 0, 0, 0);
+    if (mb_valid) {   // the lane's rows of the motion-compensated patch (get_block, :327-339)
         const uint8_t *rp = ref + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(mby + my + i) * p.pw + (mbx + mx);
-        patch[0] = load_unaligned16(rp);
-        patch[1] = load_unaligned16(rp + 8 * (long)p.pw);
+#pragma unroll
+        for (int pass = 0; pass < kPasses; pass++) patch[pass] = load_unaligned16(rp + 8 * (long)(LPM == 8 ? pass : (slot & 1)) * p.pw);
     }
     uint8_t *dst = out + (long)sp.stream * g.pad_frame_bytes + p.pad_off + (long)(sp.y0 + i) * p.pw + mbx;
     uint8_t *crop = frames_out ? frames_out + (long)sp.stream * g.src_frame_bytes + p.src_off : nullptr;
@@ -1494,14 +1786,15 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
         wave_lds_sync();
         const LaneQ lq{qtab_lds[wave], i};
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            stage_coef_half(xw, cbuf[h], lane);
+        for (int pass = 0; pass < kPasses; pass++) {
+            const int h = LPM == 8 ? pass : (slot & 1);
+            stage_coef_half(xw, cbuf[pass], lane);
             wave_lds_sync();
             int v[2][8], pp[2][8];
             const int codedmask = coded ? -1 : 0;
-            gather_half(v, xw, m, lq);
-            inverse_half(v, xw, m, i, lq);
-            unpack_row(patch[h], pp);
+            gather_half(v, xw, slot, lq);
+            inverse_half(v, xw, slot, i, lq);
+            unpack_row(patch[pass], pp);
 #pragma unroll
             for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -1514,11 +1807,11 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
             }
         }
     } else if (mb_valid) {
-        *reinterpret_cast<uint4 *>(dst) = patch[0];
-        *reinterpret_cast<uint4 *>(dst + 8 * (long)p.pw) = patch[1];
-        if (crop) {
-            store_cropped16(crop, p, mbx, sp.y0 + i, patch[0]);
-            store_cropped16(crop, p, mbx, sp.y0 + i + 8, patch[1]);
+#pragma unroll
+        for (int pass = 0; pass < kPasses; pass++) {
+            const int h = LPM == 8 ? pass : (slot & 1);
+            *reinterpret_cast<uint4 *>(dst + (long)(8 * h) * p.pw) = patch[pass];
+            if (crop) store_cropped16(crop, p, mbx, sp.y0 + i + 8 * h, patch[pass]);
         }
     }
 }

@@ -126,6 +126,7 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, in
         valid = (lane & 15) >= n;
         from = valid ? lane - n : lane;
     }
+    else if (ctrl >= 0x121 && ctrl <= 0x12f) from = (lane & ~15) | (((lane & 15) - (ctrl & 15)) & 15);   // row_ror:n (rotate right inside 16 lanes)
     else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));                       // row_mirror
     else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));                          // row_half_mirror
     else if (ctrl == 0x142) { valid = lane >= 16; from = valid ? ((lane & ~15) - 1) : lane; }   // row_bcast:15

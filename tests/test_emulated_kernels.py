@@ -11,6 +11,22 @@ import pytest
 import parity_cases as pc
 import stream_cases as sc
 
+# Both lane mappings of the codec kernels (pfv_kernels.hip, "Lane mappings").  At these sizes the automatic choice is the
+# small-grid mapping (16 lanes per macroblock); the kernel-level tests below run a second time with the batch mapping (8 lanes per
+# macroblock) forced.  The stream-level tests (containers, batch objects) run once, on the automatic choice.
+_BOTH_MAPPINGS = ("plane_ops", "golden", "trap", "session", "sparse_coded", "bad_motion", "gop_graph", "colour", "blit")
+
+
+@pytest.fixture(autouse=True, params=["auto", "lanes8"])
+def lane_mapping(request, pkg, emu_ctx):
+    L = pkg._lib
+    if request.param == "lanes8":
+        if not any(k in request.node.name for k in _BOTH_MAPPINGS):
+            pytest.skip("stream-level test: automatic lane mapping only")
+        emu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_PER_MB_8)
+    yield request.param
+    emu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_AUTO)
+
 
 @pytest.mark.parametrize("w,h", [(64, 48), (50, 38), (144, 16), (400, 80)])   # 400x80 has interior strips (bounds-check-free search path)
 @pytest.mark.parametrize("quality", [0, 5, 10])

@@ -13,6 +13,17 @@ import stream_cases as sc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["lanes8", "lanes16"])
+def lane_mapping(request, pkg, gpu_ctx):
+    """every test of this file runs under BOTH lane mappings of the codec kernels (pfv_kernels.hip, "Lane mappings": 8 lanes per
+    macroblock = the batch mapping, 16 = the small-grid mapping the library picks for launches of fewer than 4 096 strips), forced
+    through pfv_ctx_set_option; sessions pick the option up when they are created"""
+    L = pkg._lib
+    gpu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_PER_MB_8 if request.param == "lanes8" else L.PFV_LANES_PER_MB_16)
+    yield request.param
+    gpu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_AUTO)
+
+
 def test_native_library_is_the_one_loaded(pkg, gpu_ctx):
     """the in-tree gfx950 build must be what runs (no emulator, no fallback)"""
     assert pkg._lib._lib_path == pkg._lib.DEFAULT_LIB

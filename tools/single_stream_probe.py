@@ -11,6 +11,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 g.build_hip()
 pkg = g.load_package()
 ctx = pkg.Context(0)
+if os.environ.get("PFV_PROBE_LANES"):      # force a lane mapping (pfv_kernels.hip, "Lane mappings")
+    ctx.set_option(pkg._lib.PFV_OPT_LANE_MAPPING, {"8": pkg._lib.PFV_LANES_PER_MB_8, "16": pkg._lib.PFV_LANES_PER_MB_16}[os.environ["PFV_PROBE_LANES"]])
 ss = bench.StreamSet(pkg, ctx, 1920, 1080, 5, [pkg.synth.SEED + 17 * k for k in range(S)], bench.GOP)
 rate = ss.wall(reps)
 ss.verify()
