@@ -50,6 +50,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 GOP = 15
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMDS, GPU_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMD16, peak engine clock
+VALU_CYCLES_PER_INSTR = 4.2     # issue cost of one wave64 VALU instruction of the encoders' mix (profiles/r02_ubench_valu_rates2.txt: 4.1-4.4)
 BYTES_PER_MB_PENC = 1284        # src 256 + ref 256 + coef 512 + mv/flag 4 + recon 256
 # algorithmic bytes per macroblock of the other three codec kernels + 256 for the retframe crop the
 # decode kernels fuse (src/dec.rs:195-197, 209-211)
@@ -155,13 +157,13 @@ def cpu_baseline(width, height, quality, frames_one_stream, n_mb, budget_s=12.0)
     best = max(trials, key=trials.get)
     rate, reps, el = run(best, 40, max(2.0, budget_s / 4), record=True)
     ora.L.pfvo_pool_shutdown()
-    return {"value": rate, "unit": "macroblocks/s", "cores": best, "kind": "port",
+    return {"value": rate, "unit": "macroblocks/s", "cores": best, "threads": best, "kind": "port",
             "value_best": rate, "threads_best": best, "value_1thread": trials[1],
             "trials_threads_to_value": {str(k): round(v) for k, v in trials.items()}, **facts,
             "pframe_encode_value": penc["n"] / penc["s"] if penc["s"] > 0 else None,
             "sample": f"{reps} x GOP-{len(frames_one_stream)} encode+decode of one {width}x{height} stream ({reps * len(frames_one_stream) * n_mb} "
                       f"macroblocks, {el:.1f} s) on the best pool size; C oracle = port of the reference's algorithm with its per-plane "
-                      f"fork/join over a persistent pool (`cores` = threads used; host_cpus / cgroup_cpu_quota / affinity_cpus = what "
+                      f"fork/join over a persistent pool (`threads` = pool size used -- `cores` repeats it because the bench contract names that field; host_cpus / cgroup_cpu_quota / affinity_cpus = what "
                       f"this container may use of the node)"}
 
 
@@ -660,15 +662,15 @@ def traffic_from_profiles(S, W, H, Q):
         pm = json.load(open(path))
         c = pm["config"]
         if (int(c["streams"]), int(c["width"]), int(c["height"]), int(c["quality"])) != (S, W, H, Q):
-            return None, None, None
+            return None, None, None, None
         k = pm["kernels"]["k_enc_pframe"]
         import __graft_entry__ as graft
         built, here = pm.get("build_id"), graft.hip_build_id()
         src = f"profiles/pmc_traffic.json (rocprofv3 --pmc passes on build {built}; this run's library is build {here}" + \
               (")" if built == here else " -- a different build of the kernels)")
-        return k["traffic_bytes"], k.get("valu_wave_instructions"), src + "; quoted, not measured in this run"
+        return k["traffic_bytes"], k.get("valu_wave_instructions"), src + "; quoted, not measured in this run", k.get("wavefronts")
     except (OSError, KeyError, ValueError):
-        return None, None, None
+        return None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------- main
@@ -781,11 +783,20 @@ def main():
     if rank == 0:
         launch_mbs = S * n_mb
         achieved = launch_mbs * BYTES_PER_MB_PENC / (pe_ms * 1e-3) / 1e9
-        traffic, n_valu, traffic_source = traffic_from_profiles(S, W, H, Q)
-        valu = None
+        traffic, n_valu, traffic_source, traffic_waves = traffic_from_profiles(S, W, H, Q)
+        valu = issue = None
         if n_valu:
-            valu = {"wave_instructions_per_launch": n_valu, "simd_cycles_per_instruction": pe_ms * 1e-3 * 2.4e9 * 1024 / n_valu,
+            valu = {"wave_instructions_per_launch": n_valu, "simd_cycles_per_instruction": pe_ms * 1e-3 * GPU_CLOCK_HZ * N_SIMDS / n_valu,
                     "note": "SQ_INSTS_VALU from the committed PMC pass, this run's launch time, 1024 SIMDs x 2.4 GHz"}
+            # the roof that binds before HBM does: VALU issue.  A wave64 instruction of the kernel's mix occupies its SIMD16 for 4 cycles
+            # (4.1-4.4 measured, profiles/r02_ubench_valu_rates2.txt); the issue floor is the launch's instruction count at that rate
+            # on all 1024 SIMDs with no stall at all
+            n_waves = traffic_waves or (launch_mbs / 8)
+            floor_us = n_valu * VALU_CYCLES_PER_INSTR / N_SIMDS / GPU_CLOCK_HZ * 1e6
+            issue = {"bound": "valu-issue", "valu_per_wavefront": n_valu / n_waves, "cycles_per_instr": pe_ms * 1e-3 * GPU_CLOCK_HZ * N_SIMDS / n_valu,
+                     "issue_floor_us": floor_us, "frac_of_issue_floor": floor_us / (pe_ms * 1e3),
+                     "assumed_cycles_per_instr_at_the_floor": VALU_CYCLES_PER_INSTR, "simds": N_SIMDS, "clock_hz": GPU_CLOCK_HZ,
+                     "source": traffic_source}
         if args.workload == "config5":
             name = f"config5: one {W}x{H} {NF}-frame GOP-{GOP} stream per GPU (seed = base + rank), encode+decode, one launch per frame operation"
         else:
@@ -813,7 +824,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": launch_mbs * BYTES_PER_MB_PENC,
                          "avg_launch_ms": pe_ms, "macroblocks_per_launch": launch_mbs,
-                         "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC, "valu": valu},
+                         "algorithmic_bytes_per_macroblock": BYTES_PER_MB_PENC, "valu": valu, "issue": issue},
         }
         res["pframe_encode"] = {"value": launch_mbs / (pe_ms * 1e-3), "unit": "macroblocks/s",
                                 "note": "k_enc_pframe alone (motion search + residual DCT + closed-loop reconstruction), HIP-event time"}

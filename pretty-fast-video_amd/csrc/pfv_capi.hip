@@ -2747,20 +2747,4 @@ int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *che
 
 #include "pfv_comm.hip"   // multi-GPU control plane on RCCL (pfv_comm_*)
 
-#ifdef PFV_ENT_PROFILE   // experiment builds only (tools/ent_profile.py): the timestamp rows of kernel `kern` (0 scan, 1 pack)
-extern "C" __attribute__((visibility("default"))) int pfv_debug_ent_profile(int kern, unsigned long long *out, int n_groups)
-{
-    hipDeviceSynchronize();
-    const size_t row = sizeof(unsigned long long) * 16;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pfv::ent_prof), row * (size_t)n_groups, row * pfv::kEntProfGroups * (size_t)kern) != hipSuccess) return -1;
-    return 0;
-}
-#endif
-
-#ifdef PFV_KPROF   // experiment builds only (tools/kprof.py): the timestamp rows of the last k_enc_pframe launch
-extern "C" __attribute__((visibility("default"))) int pfv_debug_kprof(unsigned long long *out, int n_rows)
-{
-    hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pfv::pfv_kprof), sizeof(unsigned long long) * 16 * (size_t)n_rows) == hipSuccess ? 0 : -1;
-}
-#endif
+#include "pfv_prof_host.h"   // experiment builds only: fetch the phase timestamps (empty in the shipped build)

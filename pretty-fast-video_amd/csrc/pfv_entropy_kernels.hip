@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pfv_prof.h"   // ENT_MARK: phase timestamps of the experiment builds, empty otherwise
+
 namespace pfv {
 
 constexpr int kEntThreads = 256;                    // subblocks per workgroup of k_ent_scan / k_ent_pack
@@ -82,16 +84,6 @@ struct EntBufs {
     uint32_t *sizes;           // [S] payload bytes or kEntErr*
     uint8_t *payload;          // [S][cap_bytes]
 };
-
-#ifdef PFV_ENT_PROFILE   // experiment builds only: clock64 of lane 0 at the marks, one row of 16 per workgroup (tools/ent_profile.py)
-constexpr int kEntProfGroups = 1 << 15;
-__device__ unsigned long long ent_prof[2][kEntProfGroups][16];
-#define ENT_MARK(kern, i) do { if (threadIdx.x == 0 && prof_row_ < kEntProfGroups) ent_prof[kern][prof_row_][i] = clock64(); } while (0)
-#define ENT_MARK0() const unsigned prof_row_ = blockIdx.y * gridDim.x + blockIdx.x
-#else
-#define ENT_MARK(kern, i) do {} while (0)
-#define ENT_MARK0() do {} while (0)
-#endif
 
 __device__ __forceinline__ void ent_wave_lds_sync()
 {

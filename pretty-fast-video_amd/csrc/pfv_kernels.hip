@@ -36,6 +36,7 @@
 #include <stdint.h>
 
 #include "pfv_device.h"
+#include "pfv_prof.h"   // KMARK: phase timestamps of the experiment builds, empty otherwise
 
 namespace pfv {
 
@@ -838,14 +839,6 @@ __device__ __forceinline__ unsigned sq2(unsigned x, unsigned y, unsigned acc)
 }
 __device__ __forceinline__ unsigned sq4(unsigned b0, unsigned b1, unsigned b2, unsigned b3, unsigned acc) { return sq2(b2, b3, sq2(b0, b1, acc)); }
 
-#ifdef PFV_KPROF   // experiment builds only (tools/kprof.py): clock64 of thread 0 at the marks, one row of 16 per workgroup
-constexpr int kProfRows = 1 << 16;
-__device__ unsigned long long pfv_kprof[kProfRows][16];
-#define KMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < kProfRows) pfv_kprof[blockIdx.x][i] = clock64(); } while (0)
-#else
-#define KMARK(i) do {} while (0)
-#endif
-
 // What one lane of a macroblock needs to finalise "its" candidate of a search level: after the dot products every
 // lane holds a partial sum (its two rows) for each of the 8 neighbours; the partials are transposed through a small
 // wavefront-private LDS region (8 ds_write_b32 + 2 ds_read_b128 per lane: LDS-pipe work) so that lane c ends up with
@@ -932,11 +925,7 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
     } else
 #pragma unroll
     for (int my = -1; my <= 1; my++) {
-#ifdef PFV_ABL_LDSLINEAR   // ablation experiment only (results invalid): lane-linear addresses, 16 bytes apart -> (almost) no bank conflicts
-        const uint8_t *rp = win + ((threadIdx.x & 63) * 16 + (my + 1) * 4096 + (col & 12));
-#else
         const uint8_t *rp = win + (wrow0 + st.cy + my * S) * kWinStride + col;
-#endif
         const bool centre_known = !FIRST && my == 0;   // (0,0) is not evaluated again (:176)
         unsigned ab[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
         if (S == 4) {   // dword, 16-byte, dword; candidates at dwords 0, 1, 2 of a 6-dword span
@@ -1334,12 +1323,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
     if (wave == 0) fill_qtable<true, FLT>(qtab_lds, qtabs + p.qsel, lane);   // one copy per workgroup (a tile lies in one plane)
 
     KMARK(0);
-#ifdef PFV_KPROF
-    if (threadIdx.x == 0 && blockIdx.x < kProfRows) {   // where the workgroup runs: HW_ID (cu / sh / se ids) and XCC_ID
-        pfv_kprof[blockIdx.x][12] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        pfv_kprof[blockIdx.x][13] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
-    }
-#endif
+    KMARK_WHERE();
     issue_window(p, ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off, cur, win, wave, lane);
     uint4 rows[2];
     rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
