@@ -64,8 +64,15 @@ constexpr int kWinAlloc = kWinIssues * 1024;                                    
 __device__ __forceinline__ constexpr int win_first_issue(int w) { return (w * kWinIssues + kStripsPerWG - 1) / kStripsPerWG; }
 static_assert(win_first_issue(kStripsPerWG) == kWinIssues, "window issue split");
 constexpr int kMBPitch = 2 * 64;                   // dwords per macroblock in the exchange region (bank spread by XOR swizzle)
+// The zigzag stage (the exchange region's second use): 64 dwords of coefficients per 8-lane slot, slots kStagePitch dwords apart.
+// 16-bit scatters / gathers are serviced 32 lanes = 4 slots at a time on 32 banks; at a pitch of 64 the four slots' identical
+// zigzag patterns fell on identical banks (4-way conflict on every access); 72 = 8 (mod 32) moves them 8 banks apart, and a row
+// of zigzag positions spans at most 16 dwords.
+constexpr int kStagePitch = 72;
+constexpr int kStageChunks = kStagePitch / 4;      // 16-byte chunks per slot: 16 of coefficients + 2 of padding
 constexpr int kXchgDwords = kStripMB * kMBPitch;   // per wavefront: 1024 dwords = 4 KiB
 static_assert(kXchgDwords * 4 <= 4 * 1024, "exchange region must fit a wavefront's smallest window slice");
+static_assert(kStripMB * kStagePitch <= kXchgDwords && kStagePitch % 4 == 0, "padded stage fits the exchange region, chunks stay 16-byte aligned");
 
 // ------------------------------------------------------------------ small helpers
 __host__ __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -390,13 +397,15 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
 // Coefficients of one HALF (h = 0: subblocks 0,1; h = 1: subblocks 2,3) of every macroblock of
 // the strip <-> LDS stage (8 macroblocks x 256 B).  Global side: 256-byte runs, 16 B per lane.
+// 16-byte chunk ch (16 per slot) of the padded stage
+__device__ __forceinline__ int stage_chunk(int ch) { return (ch >> 4) * kStageChunks + (ch & 15); }
 __device__ __forceinline__ void store_coef_half(const int *stage, int16_t *coef_mb0, int n_mb, int lane, int h)
 {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         int ch = j * 64 + lane;   // 16-byte chunk of the stage; 16 chunks per macroblock half
         int mb = ch >> 4;
-        if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(stage)[ch]);
+        if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[mb * 32 + h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(stage)[stage_chunk(ch)]);
     }
 }
 __device__ __forceinline__ void fetch_coef_half(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int h)
@@ -418,7 +427,7 @@ __device__ __forceinline__ void store_coef_quads(const int *stage, int16_t *coef
     for (int j = 0; j < 2; j++) {
         int ch = j * 64 + lane;
         int mb = half_strip * 4 + (ch >> 5);
-        if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[half_strip * 128 + ch], reinterpret_cast<const uint4 *>(stage)[ch]);
+        if (mb < n_mb) st_stream(&reinterpret_cast<uint4 *>(coef_mb0)[half_strip * 128 + ch], reinterpret_cast<const uint4 *>(stage)[stage_chunk(ch)]);
     }
 }
 __device__ __forceinline__ void fetch_coef_quads(uint4 (&buf)[2], const int16_t *coef_mb0, int n_mb, int lane, int half_strip)
@@ -434,7 +443,7 @@ __device__ __forceinline__ void fetch_coef_quads(uint4 (&buf)[2], const int16_t 
 __device__ __forceinline__ void stage_coef_half(int *stage, const uint4 (&buf)[2], int lane)
 {
 #pragma unroll
-    for (int j = 0; j < 2; j++) reinterpret_cast<uint4 *>(stage)[j * 64 + lane] = buf[j];
+    for (int j = 0; j < 2; j++) reinterpret_cast<uint4 *>(stage)[stage_chunk(j * 64 + lane)] = buf[j];
 }
 
 // ------------------------------------------------------------------ half-macroblock pipelines (per lane: 2 subblocks)
@@ -454,7 +463,7 @@ __device__ __forceinline__ void forward_half(int (&v)[2][8], int *xw, int m, int
     rows_to_cols2(v, mb, i, m & 3);
     fdct8(v[0]);   // dct_transform_columns
     fdct8(v[1]);
-    int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 128;
+    int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * (2 * kStagePitch);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int scale = lq.scale(k), zz = lq.zz(k);
@@ -498,7 +507,7 @@ __device__ __forceinline__ void inverse_half(int (&v)[2][8], int *xw, int m, int
 // gather the lane's column of quantised coefficients out of the zigzag-ordered stage
 __device__ __forceinline__ void gather_half(int (&v)[2][8], const int *xw, int m, const LaneQ &lq)
 {
-    const int16_t *stage = reinterpret_cast<const int16_t *>(xw) + m * 128;
+    const int16_t *stage = reinterpret_cast<const int16_t *>(xw) + m * (2 * kStagePitch);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int zz = lq.zz(k);
@@ -666,7 +675,7 @@ __device__ __forceinline__ void forward_half_f(f2 (&x)[8], int *xw, int m, int i
     ffdct8(x);   // dct_transform_rows (both subblocks)
     f_rows_to_cols(x, mb, i, m & 3);
     ffdct8(x);   // dct_transform_columns
-    int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * 128;
+    int16_t *stage = reinterpret_cast<int16_t *>(xw) + m * (2 * kStagePitch);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int zz = lq.zz(k);
@@ -1280,7 +1289,7 @@ __device__ __forceinline__ void penc_transform_compact(const FrameGeom &g, const
                 if (sc < n_coded) {
                     const int og = slot_orig[sc];
                     int16_t *mb = coef + (tile_mb0 + (long)(og >> 3) * p.bw + (og & 7)) * 256;
-                    st_stream(&reinterpret_cast<uint4 *>(mb)[h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(xw)[ch]);
+                    st_stream(&reinterpret_cast<uint4 *>(mb)[h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(xw)[stage_chunk(ch)]);
                 }
             }
         });
