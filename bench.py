@@ -218,8 +218,8 @@ class StreamSet:
     def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, fused_crop=True, kind="pan", dec_ctx=None):
         """dec_ctx: a second context (= a second HIP stream) for the decoder, for wall_pipelined(): the decoder works through pass
         k - 1 while the encoder works through pass k -- Encoder and Decoder are independent objects (src/enc.rs:12-26,
-        src/dec.rs:15-28), and one stream's launches cover a fraction of the device.  The encode outputs of a whole pass are kept
-        (two alternating sets of n_frames buffers); the two streams meet ONCE per pass (pfv_ctx_wait_event)."""
+        src/dec.rs:15-28), and one stream's launches cover a fraction of the device.  The encode outputs of a GOP are kept (two
+        alternating sets of GOP buffers); the two streams meet ONCE per GOP (pfv_ctx_wait_event)."""
         self.pkg, self.ctx, self.W, self.H, self.Q, self.S, self.n_frames = pkg, ctx, W, H, Q, len(seeds), n_frames
         self.kind, self.dec_ctx = kind, dec_ctx
         self.seeds = [int(s) for s in seeds]
@@ -235,7 +235,7 @@ class StreamSet:
         self.ev_enc = self.ev_dec = None
         if dec_ctx is not None:
             one = lambda: (self._alloc(S * self.n_mb * 512), self._alloc(S * self.n_mb * 2), self._alloc(S * self.n_mb))
-            self.pass_sets = [[one() for _ in range(n_frames)] for _ in range(2)]
+            self.pass_sets = [[one() for _ in range(min(n_frames, GOP))] for _ in range(2)]
             self.ev_enc = [ctx.event(), ctx.event()]
             self.ev_dec = [dec_ctx.event(), dec_ctx.event()]
         self.out_frames = self._alloc(S * self.fb)
@@ -288,38 +288,41 @@ class StreamSet:
                     on_launch("k_dec_pframe", b, on_launch())
 
     def wall_pipelined(self, reps, gop=GOP):
-        """macroblocks/s of `reps` passes, decoder one pass behind the encoder on its own stream (host clock, both streams
-        synchronised on both sides); every pass is encoded AND decoded inside the timed region"""
+        """macroblocks/s of `reps` passes with the decoder ONE GOP behind the encoder on its own stream (host clock, both streams
+        synchronised on both sides); every GOP is encoded AND decoded inside the timed region.  The encode outputs of a GOP go to one
+        of two alternating sets of `gop` buffers; the streams meet once per GOP."""
         enc, dec, ectx, dctx = self.enc, self.dec, self.ctx, self.dec_ctx
+        gops = [(t0, min(gop, self.n_frames - t0)) for t0 in range(0, self.n_frames, gop)]      # (first frame, frames) of a pass
 
-        def enc_pass(k):
-            for t in range(self.n_frames):
-                coef, mv, has = self.pass_sets[k & 1][t]
-                if t % gop == 0:
+        def enc_gop(j, t0, n):
+            for t in range(t0, t0 + n):
+                coef, mv, has = self.pass_sets[j & 1][t - t0]
+                if t == t0:
                     enc.encode_iframe_dev(self.frame_ptr(t), coef)
                 else:
                     enc.encode_pframe_dev(self.frame_ptr(t), mv, has, coef)
-            ectx.record(self.ev_enc[k & 1])
+            ectx.record(self.ev_enc[j & 1])
 
-        def dec_pass(k):
-            dctx.wait_event(self.ev_enc[k & 1])                  # the pass's encode outputs are complete
-            for t in range(self.n_frames):
-                coef, mv, has = self.pass_sets[k & 1][t]
-                if t % gop == 0:
+        def dec_gop(j, t0, n):
+            dctx.wait_event(self.ev_enc[j & 1])                  # the GOP's encode outputs are complete
+            for t in range(t0, t0 + n):
+                coef, mv, has = self.pass_sets[j & 1][t - t0]
+                if t == t0:
                     dec.decode_iframe_dev(coef)
                 else:
                     dec.decode_pframe_dev(mv, has, coef)
-            dctx.record(self.ev_dec[k & 1])
+            dctx.record(self.ev_dec[j & 1])
 
-        def run(n):
-            for k in range(n + 1):
-                if k < n:
-                    if k >= 2:
-                        ectx.wait_event(self.ev_dec[k & 1])      # the decode that last read this set of buffers is done
-                    enc_pass(k)
-                if k >= 1:
-                    dec_pass(k - 1)
-        run(2)
+        def run(n_passes):
+            units = [g for _ in range(n_passes) for g in gops]
+            for j in range(len(units) + 1):
+                if j < len(units):
+                    if j >= 2:
+                        ectx.wait_event(self.ev_dec[j & 1])      # the decode that last read this set of buffers is done
+                    enc_gop(j, *units[j])
+                if j >= 1:
+                    dec_gop(j - 1, *units[j - 1])
+        run(1)
         self.sync()
         t0 = time.perf_counter()
         run(reps)
@@ -496,7 +499,7 @@ def single_stream_side(pkg, ctx, Q, reps=6):
         r = {"launches": ss.wall(reps)}
         ss.verify()
         ss2 = StreamSet(pkg, ctx, 1920, 1080, Q, seeds, GOP, dec_ctx=dctx)
-        r["decoder_one_gop_behind_on_second_stream"] = ss2.wall_pipelined(reps)
+        r["decoder_one_gop_behind_on_second_stream"] = ss2.wall_pipelined(4 * reps)
         ss2.verify()
         ss2.close()
         try:
@@ -541,10 +544,10 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None):
     res["kernel_only"] = {"value": ss.wall(2), "frames": n_frames,
                           "note": "one launch per frame operation, 48 720 macroblocks per launch"}
     ss.verify()
-    if own:     # the same stream with the decoder on its own context (second HIP stream), one 60-frame pass behind the encoder
+    if own:     # the same stream with the decoder on its own context (second HIP stream), one GOP behind the encoder
         dctx = pkg.Context(ctx.device)
         ss2 = StreamSet(pkg, ctx, W, H, Q, [seed], min(n_frames, 60), dec_ctx=dctx)
-        res["kernel_only"]["decoder_one_pass_behind_on_second_stream"] = ss2.wall_pipelined(4)
+        res["kernel_only"]["decoder_one_gop_behind_on_second_stream"] = ss2.wall_pipelined(4)
         ss2.verify()
         ss2.close()
         dctx.close()

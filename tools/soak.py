@@ -30,12 +30,21 @@ with pkg.Context(0) as ctx:
     while time.time() < t_end:
         s = seed0 + it
         r = np.random.default_rng(s)
+        # round 3: every iteration under a random lane mapping / compaction setting / content kind
+        L = pkg._lib
+        lanes = [L.PFV_LANES_AUTO, L.PFV_LANES_PER_MB_8, L.PFV_LANES_PER_MB_16][int(r.integers(0, 3))]
+        ctx.set_option(L.PFV_OPT_LANE_MAPPING, lanes)
+        ctx.set_option(L.PFV_OPT_TILE_COMPACTION, int(r.integers(0, 4) != 0))
+        ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_INT if int(r.integers(0, 6)) == 0 else L.PFV_ENC_TRANSFORM_AUTO)
+        kind = ["pan", "low_motion", "static"][int(r.integers(0, 3))]
+        stats["lanes8"] = stats.get("lanes8", 0) + (lanes == L.PFV_LANES_PER_MB_8)
         pc.fuzz_plane_ops(pkg, ctx, oracle, n_cases=25, seed=s, max_w=700, max_h=300)
         stats["plane_cases"] += 25
         w, h = 2 * int(r.integers(1, 200)), 2 * int(r.integers(1, 120))
         q = int(r.integers(0, 11))
         S = int(r.integers(1, 4))
-        pc.check_session(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=int(r.integers(2, 6)), gop=int(r.integers(1, 5)))
+        pc.check_session(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=int(r.integers(2, 6)), gop=int(r.integers(1, 5)), kind=kind)
+        stats["sparse_tile_cases"] = stats.get("sparse_tile_cases", 0) + pc.check_sparse_coded_tiles(pkg, ctx, oracle, seed=s, sizes=((2 * int(r.integers(40, 300)), 2 * int(r.integers(20, 120))),))
         stats["sessions"] += 1
         stats["entropy_payloads"] += pc.check_device_entropy(pkg, ctx, oracle, w, h, n_streams=S, seed=s)
         nf, gop = int(r.integers(2, 7)), int(r.integers(1, 4))
