@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1: still create the (1-rank) RCCL communicator and run the table broadcast, the barriers and the counter "
                          "reduction through it -- the code path of an N > 1 rank, on a one-GPU box")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU of this very workload under rocprofv3 (three short child runs); "
+                         "roofline.traffic / roofline.issue then quote profiles/pmc_traffic.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy", action="store_true", help="skip the extra encode_to_payload measurement (device entropy stage)")
     ap.add_argument("--no-extra", action="store_true", help="skip the single-stream and config-4 side measurements")
@@ -693,6 +696,51 @@ def traffic_from_profiles(S, W, H, Q):
         return None, None, None, None
 
 
+def live_pmc(args, S, W, H, Q, NF, per_pass_timeout=150):
+    """HBM traffic and VALU instruction count of k_enc_pframe on THIS workload, measured now: three short child runs of this script under
+    `rocprofv3 --kernel-trace --pmc <counter>` (one counter group per run, as MI355X_MICROARCH.md prescribes: FETCH_SIZE, WRITE_SIZE,
+    SQ_INSTS_VALU + SQ_WAVES), parsed like tools/pmc_traffic.py (FETCH_SIZE in KiB and doubled: the gfx950 half-count correction).
+    None when rocprofv3 is missing or a pass fails / times out -- the line then quotes profiles/pmc_traffic.json as before."""
+    import csv
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-two-stream", "--no-extra", "--no-entropy",
+             "--no-live-pmc", "--no-verify", "--streams", str(S), "--width", str(W), "--height", str(H), "--frames", str(NF), "--quality", str(Q),
+             "--workload", args.workload]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="pfv_pmc_")
+    try:
+        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_WAVES"])):
+            d = os.path.join(tmp, name)
+            env = dict(os.environ, TMPDIR=tmp)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", *counters, "-f", "csv", "-d", d, "-o", name, "--", *child], cwd=tmp, env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=per_pass_timeout)
+            if r.returncode != 0:
+                return None
+            files = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if not files:
+                return None
+            acc = {}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if re.search(r"pfv::k_enc_pframe", row.get("Kernel_Name", "")):
+                        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in counters:
+                if not acc.get(c):
+                    return None
+                out[c] = sum(acc[c]) / len(acc[c])
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"traffic_bytes": out["FETCH_SIZE"] * 1024 * 2 + out["WRITE_SIZE"] * 1024, "read_bytes": out["FETCH_SIZE"] * 1024 * 2,
+            "write_bytes": out["WRITE_SIZE"] * 1024, "valu_wave_instructions": out["SQ_INSTS_VALU"], "wavefronts": out["SQ_WAVES"]}
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -804,10 +852,17 @@ def main():
         launch_mbs = S * n_mb
         achieved = launch_mbs * BYTES_PER_MB_PENC / (pe_ms * 1e-3) / 1e9
         traffic, n_valu, traffic_source, traffic_waves = traffic_from_profiles(S, W, H, Q)
+        live = None
+        if world == 1 and not EMU and not args.no_live_pmc:
+            live = live_pmc(args, S, W, H, Q, NF)     # child processes on the same GPU (288 GB: room for their copy of the workload)
+            if live:
+                traffic, n_valu, traffic_waves = live["traffic_bytes"], live["valu_wave_instructions"], live["wavefronts"]
+                traffic_source = ("measured in this run: three child runs of this workload under rocprofv3 --kernel-trace --pmc (FETCH_SIZE x 2 KiB + WRITE_SIZE KiB; "
+                                  "SQ_INSTS_VALU, SQ_WAVES), means over the k_enc_pframe launches")
         valu = issue = None
         if n_valu:
             valu = {"wave_instructions_per_launch": n_valu, "simd_cycles_per_instruction": pe_ms * 1e-3 * GPU_CLOCK_HZ * N_SIMDS / n_valu,
-                    "note": "SQ_INSTS_VALU from the committed PMC pass, this run's launch time, 1024 SIMDs x 2.4 GHz"}
+                    "note": "SQ_INSTS_VALU (see traffic_source), this run's launch time, 1024 SIMDs x 2.4 GHz"}
             # the roof that binds before HBM does: VALU issue.  A wave64 instruction of the kernel's mix occupies its SIMD16 for 4 cycles
             # (4.1-4.4 measured, profiles/r02_ubench_valu_rates2.txt); the issue floor is the launch's instruction count at that rate
             # on all 1024 SIMDs with no stall at all
