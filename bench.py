@@ -696,7 +696,7 @@ def traffic_from_profiles(S, W, H, Q):
         return None, None, None, None
 
 
-def live_pmc(args, S, W, H, Q, NF, per_pass_timeout=150):
+def live_pmc(args, S, W, H, Q, NF, per_pass_timeout=60):
     """HBM traffic and VALU instruction count of k_enc_pframe on THIS workload, measured now: three short child runs of this script under
     `rocprofv3 --kernel-trace --pmc <counter>` (one counter group per run, as MI355X_MICROARCH.md prescribes: FETCH_SIZE, WRITE_SIZE,
     SQ_INSTS_VALU + SQ_WAVES), parsed like tools/pmc_traffic.py (FETCH_SIZE in KiB and doubled: the gfx950 half-count correction).
@@ -707,6 +707,9 @@ def live_pmc(args, S, W, H, Q, NF, per_pass_timeout=150):
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
+        return None
+    # already running under a profiler (rocprofv3 -- python bench.py): do not nest one inside it
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-two-stream", "--no-extra", "--no-entropy",
              "--no-live-pmc", "--no-verify", "--streams", str(S), "--width", str(W), "--height", str(H), "--frames", str(NF), "--quality", str(Q),
