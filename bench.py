@@ -495,13 +495,13 @@ def single_stream_side(pkg, ctx, Q, reps=6):
     the streams meet once per GOP (a per-FRAME hand-over between the streams was measured too: slower than one stream, the
     cross-queue signalling costs more than a 1080p frame's kernels take)."""
     out = {}
-    dctx = pkg.Context(ctx.device)
+    ectx, dctx = pkg.Context(ctx.device, priority=1), pkg.Context(ctx.device, priority=-1)     # two-context schedule: encoder stream high, decoder stream low
     for S in (1, 8):
         seeds = [pkg.synth.SEED + 17 * k for k in range(S)]
         ss = StreamSet(pkg, ctx, 1920, 1080, Q, seeds, GOP)
         r = {"launches": ss.wall(reps)}
         ss.verify()
-        ss2 = StreamSet(pkg, ctx, 1920, 1080, Q, seeds, GOP, dec_ctx=dctx)
+        ss2 = StreamSet(pkg, ectx, 1920, 1080, Q, seeds, GOP, dec_ctx=dctx)
         r["decoder_one_gop_behind_on_second_stream"] = ss2.wall_pipelined(4 * reps)
         ss2.verify()
         ss2.close()
@@ -513,6 +513,7 @@ def single_stream_side(pkg, ctx, Q, reps=6):
         out[f"streams_{S}"] = r
         ss.close()
     dctx.close()
+    ectx.close()
     out["unit"] = "macroblocks/s (encode+decode, 1080p GOP-15, kernel scope, host clock incl. launch overhead)"
     return out
 
@@ -548,12 +549,13 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None):
                           "note": "one launch per frame operation, 48 720 macroblocks per launch"}
     ss.verify()
     if own:     # the same stream with the decoder on its own context (second HIP stream), one GOP behind the encoder
-        dctx = pkg.Context(ctx.device)
-        ss2 = StreamSet(pkg, ctx, W, H, Q, [seed], min(n_frames, 60), dec_ctx=dctx)
+        ectx, dctx = pkg.Context(ctx.device, priority=1), pkg.Context(ctx.device, priority=-1)
+        ss2 = StreamSet(pkg, ectx, W, H, Q, [seed], min(n_frames, 60), dec_ctx=dctx)
         res["kernel_only"]["decoder_one_gop_behind_on_second_stream"] = ss2.wall_pipelined(4)
         ss2.verify()
         ss2.close()
         dctx.close()
+        ectx.close()
     # (ii)
     pcie_frames = min(pcie_frames, n_frames)
     host = ss.host_frames(0, pcie_frames)

@@ -61,6 +61,10 @@ typedef struct pfv_ctx pfv_ctx;
 /* number of HIP devices visible to the process (0 when there is none) */
 PFV_API int pfv_device_count(void);
 PFV_API int pfv_ctx_create(int device, pfv_ctx **out);
+/* The same with a priority for the context's HIP stream: > 0 the device's greatest, < 0 its least, 0 the default.  When an
+ * encoder and a decoder work side by side on two contexts (a transcoder; bench.py's single-stream schedule), the encoder's launches
+ * are the critical path and the decoder's fill the gaps: encoder context high, decoder context low. */
+PFV_API int pfv_ctx_create_prio(int device, int priority, pfv_ctx **out);
 PFV_API void pfv_ctx_destroy(pfv_ctx *ctx);
 PFV_API int pfv_ctx_sync(pfv_ctx *ctx);
 /* hipDeviceSynchronize on the context's device (all streams) */

@@ -45,6 +45,7 @@ _P = c_void_p
 SIGNATURES = [
     ("pfv_device_count", c_int, []),
     ("pfv_ctx_create", c_int, [c_int, POINTER(_P)]),
+    ("pfv_ctx_create_prio", c_int, [c_int, c_int, POINTER(_P)]),
     ("pfv_ctx_destroy", None, [_P]),
     ("pfv_ctx_sync", c_int, [_P]),
     ("pfv_device_sync", c_int, [_P]),

@@ -15,10 +15,12 @@ from . import _lib
 
 
 class Context:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, priority: int = 0):
+        """priority: > 0 / < 0 = the device's greatest / least HIP stream priority for this context's stream (pfv_ctx_create_prio)"""
         self._lib = _lib.load()
         h = ctypes.c_void_p()
-        rc = self._lib.pfv_ctx_create(int(device), ctypes.byref(h))
+        rc = (self._lib.pfv_ctx_create_prio(int(device), int(priority), ctypes.byref(h)) if priority else
+              self._lib.pfv_ctx_create(int(device), ctypes.byref(h)))
         if rc != _lib.PFV_OK:
             msg = self._lib.pfv_last_error(None)
             raise _lib.PfvError(rc, msg.decode() if msg else "")

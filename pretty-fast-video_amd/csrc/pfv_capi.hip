@@ -136,7 +136,9 @@ PFV_API int pfv_device_count(void)
     return n;
 }
 
-PFV_API int pfv_ctx_create(int device, pfv_ctx **out)
+PFV_API int pfv_ctx_create(int device, pfv_ctx **out) { return pfv_ctx_create_prio(device, 0, out); }
+
+PFV_API int pfv_ctx_create_prio(int device, int priority, pfv_ctx **out)
 {
     if (!out) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_ctx_create: out is null");
     *out = nullptr;
@@ -154,7 +156,13 @@ PFV_API int pfv_ctx_create(int device, pfv_ctx **out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
     }
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (priority == 0) {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    } else {   // the device's greatest / least stream priority
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, priority > 0 ? greatest : least);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->qtab_dev, 4 * sizeof(QTab));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->qtab_host, 4 * sizeof(QTab), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->flag_dev, sizeof(int));

@@ -284,6 +284,36 @@ def test_rccl_one_rank_communicator(pkg, gpu_ctx):
     rdzv.close()
 
 
+def test_context_stream_priorities(pkg, oracle):
+    """pfv_ctx_create_prio: contexts on the device's greatest / least stream priority produce the same bytes (an encoder on the
+    high one, a decoder on the low one, ordered by pfv_ctx_wait_event: the two-context schedule of bench.py)"""
+    with pkg.Context(0, priority=1) as ectx, pkg.Context(0, priority=-1) as dctx:
+        pc.check_session(pkg, ectx, oracle, 176, 144, 5, n_streams=2, n_frames=3)
+        pc.check_session(pkg, dctx, oracle, 176, 144, 5, n_streams=2, n_frames=3)
+        w, h = 320, 240
+        enc = pkg.EncoderSession(ectx, w, h, 5, 1)
+        dec = pkg.DecoderSession(dctx, w, h, np.stack(pkg.qtables_from_quality(5)[:4]), 1)
+        nb, fb = enc.total_blocks, enc.frame_bytes
+        d_f, d_c, d_m, d_h = ectx.alloc(fb), ectx.alloc(nb * 512), ectx.alloc(nb * 2), ectx.alloc(nb)
+        ev = ectx.event()
+        for t in range(4):
+            ectx.synth_frames_dev(w, h, [pkg.synth.SEED], t, d_f)
+            if t == 0:
+                enc.encode_iframe_dev(d_f, d_c)
+            else:
+                enc.encode_pframe_dev(d_f, d_m, d_h, d_c)
+            ectx.record(ev)
+            dctx.wait_event(ev)
+            if t == 0:
+                dec.decode_iframe_dev(d_c)
+            else:
+                dec.decode_pframe_dev(d_m, d_h, d_c)
+            dctx.sync()                       # the next encode overwrites the buffers the decoder reads
+            assert np.array_equal(enc.prev_frame(), dec.framebuffer()), t
+        ectx.event_destroy(ev)
+        enc.close(); dec.close()
+
+
 def test_blit_dev(pkg, gpu_ctx, oracle):
     """VideoPlane::blit (src/plane.rs:20-29) on device planes vs the oracle's pfvo_blit: random + corner rectangles"""
     assert pc.check_blit_dev(pkg, gpu_ctx, oracle) >= 200
