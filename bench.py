@@ -896,6 +896,7 @@ def main():
             "data": f"synthetic, generated on the device ({S} distinct integer-hash texture streams per GPU, seed per stream; quality {Q})",
             "rccl_ranks": world if comm is not None and comm.backend == "rccl" else 0,
             "control_plane": {"backend": comm.backend if comm is not None else None, "shared_gpu": bool(share and world > 1), "emulated": EMU,
+                              "rccl_error": comm.rccl_error if comm is not None else None,
                               "collectives": "assignment-table broadcast + barriers + counter all-reduce only (no data-path collective); "
                                              "RCCL through libpfv_hip.so (pfv_comm_*), no torch in the process"},
             "config": {"workload": name, "streams_per_gpu": S, "frames_per_step": NF, "macroblocks_per_frame": n_mb, "quality": Q,

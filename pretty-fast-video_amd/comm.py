@@ -153,20 +153,53 @@ class Rendezvous:
 class Comm:
     """broadcast / all-reduce / barrier for the job: RCCL on device buffers when `use_rccl`, the rendezvous sockets otherwise"""
 
-    def __init__(self, ctx, rdzv: Rendezvous, use_rccl: bool):
+    def __init__(self, ctx, rdzv: Rendezvous, use_rccl: bool, init_timeout: float = 180.0):
         self.ctx, self.rdzv, self.rank, self.world = ctx, rdzv, rdzv.rank, rdzv.world
         self.handle = None
         self.backend = "tcp"
+        self.rccl_error = None        # why RCCL is not in use although it was asked for
         if use_rccl:
-            lib = ctx._lib
-            uid = np.zeros(128, np.uint8)
-            if self.rank == 0:
-                ctx.check(lib.pfv_comm_unique_id(uid.ctypes.data_as(ctypes.c_void_p)))
-            uid = np.frombuffer(rdzv.bcast(uid.tobytes() if self.rank == 0 else None), np.uint8).copy()
+            self._init_rccl(init_timeout)
+
+    def _init_rccl(self, timeout: float):
+        """ncclCommInitRank is collective and blocks until every rank has joined; if it fails or does not come back on ANY rank,
+        ALL ranks carry on with the socket backend (the job only needs a broadcast, a few barriers and one reduction) and the
+        bench line says so (`rccl_ranks` 0, `control_plane.rccl_error`) instead of hanging the node."""
+        import threading
+        lib, ctx = self.ctx._lib, self.ctx
+        uid = np.zeros(128, np.uint8)
+        err = None
+        if self.rank == 0:
+            rc = lib.pfv_comm_unique_id(uid.ctypes.data_as(ctypes.c_void_p))
+            if rc != 0:
+                err = f"pfv_comm_unique_id: {rc} {(lib.pfv_last_error(None) or b'').decode()}"
+        uid = np.frombuffer(self.rdzv.bcast(uid.tobytes() if self.rank == 0 else None), np.uint8).copy()
+        box = {}
+
+        def run():
             h = ctypes.c_void_p()
-            ctx.check(lib.pfv_comm_init(ctx.handle, self.rank, self.world, uid.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
-            self.handle = h
-            self.backend = "rccl"
+            box["rc"] = lib.pfv_comm_init(ctx.handle, self.rank, self.world, uid.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h))
+            box["h"] = h
+        if err is None and uid.any():
+            t = threading.Thread(target=run, daemon=True)
+            t.start()
+            t.join(timeout)
+            if t.is_alive():
+                err = f"pfv_comm_init did not return within {timeout:.0f} s"
+            elif box["rc"] != 0:
+                err = f"pfv_comm_init: {box['rc']} {(lib.pfv_last_error(ctx.handle) or b'').decode()}"
+        elif err is None:
+            err = "rank 0 could not create the ncclUniqueId"
+        # every rank learns whether all of them made it
+        verdicts = self.rdzv.allgather((err or "").encode())
+        bad = [f"rank {r}: {v.decode()}" for r, v in enumerate(verdicts) if v]
+        if bad:
+            self.rccl_error = "; ".join(bad)[:500]
+            if err is None and box.get("h") is not None and box["h"].value:
+                lib.pfv_comm_destroy(box["h"])
+            return
+        self.handle = box["h"]
+        self.backend = "rccl"
 
     def broadcast_array(self, a: np.ndarray, root: int = 0) -> np.ndarray:
         """root's array (same shape and dtype on every rank) to everyone"""

@@ -183,6 +183,64 @@ def test_tcp_rendezvous_and_socket_collectives_world3():
         assert s == [6.0, 30.0] and m == [3.0, 20.0]
 
 
+def _fallback_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import ctypes
+    import __graft_entry__ as g
+    g.load_package()
+    from importlib import import_module
+    commlib = import_module("pretty_fast_video_amd.comm")
+
+    class FakeLib:                      # stands in for libpfv_hip.so: rank 1's ncclCommInitRank "fails"
+        destroyed = 0
+
+        def pfv_comm_unique_id(self, p):
+            ctypes.memset(p, 7, 128)
+            return 0
+
+        def pfv_comm_init(self, ctx, r, w, uid, out):
+            ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = ctypes.c_void_p(0x1234)
+            return -2 if r == 1 else 0
+
+        def pfv_last_error(self, ctx):
+            return b"ncclCommInitRank: unhandled system error"
+
+        def pfv_comm_destroy(self, h):
+            FakeLib.destroyed += 1
+
+    class FakeCtx:
+        handle = ctypes.c_void_p(1)
+        _lib = FakeLib()
+
+    rdzv = commlib.Rendezvous(rank, world)
+    comm = commlib.Comm(FakeCtx(), rdzv, use_rccl=True, init_timeout=30.0)
+    s = comm.allreduce([1.0 + rank], "sum")
+    comm.barrier()
+    q.put((rank, comm.backend, comm.rccl_error, s.tolist(), FakeLib.destroyed))
+    rdzv.close()
+
+
+def test_rccl_init_failure_on_one_rank_sends_every_rank_to_the_socket_backend():
+    """ncclCommInitRank failing (or hanging) on any rank must not take the job down: all ranks agree over the rendezvous, the one
+    that had succeeded destroys its communicator, everyone carries on with the socket collectives and reports why"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, backend, err, s, destroyed in res:
+        assert backend == "tcp" and "rank 1" in err and "unhandled system error" in err and s == [3.0]
+        assert destroyed == (1 if rank == 0 else 0)
+
+
 def _run_bench(extra_args, env_extra=None):
     import json
     import subprocess
