@@ -61,11 +61,17 @@ class Rendezvous:
             while len(self.peers) < self.world - 1:
                 c, _ = ls.accept()
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                hello = self._recv_exact(c, len(token) + 4)
+                c.settimeout(5.0)                     # a stray connection must not stall the job
+                try:
+                    hello = self._recv_exact(c, len(token) + 4)
+                except (OSError, ConnectionError):
+                    c.close()
+                    continue
                 if hello[:len(token)] != token:
                     c.close()
                     continue
                 r = struct.unpack("<i", hello[len(token):])[0]
+                c.settimeout(timeout)
                 self.peers[r] = c
                 c.sendall(b"OK")
         else:
@@ -74,13 +80,14 @@ class Rendezvous:
                     try:
                         c = socket.create_connection((addr, base + k), timeout=2.0)
                         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                        c.settimeout(timeout)
+                        c.settimeout(3.0)             # whoever listens there may not be rank 0 (the walk passes other services' ports)
                         c.sendall(token + struct.pack("<i", self.rank))
                         if self._recv_exact(c, 2) == b"OK":
+                            c.settimeout(timeout)
                             self.sock = c
                             break
                         c.close()
-                    except OSError:
+                    except (OSError, ConnectionError):
                         continue
                 if self.sock is not None:
                     break
