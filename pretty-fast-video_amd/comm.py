@@ -71,18 +71,27 @@ class Rendezvous:
                     c.close()
                     continue
                 r = struct.unpack("<i", hello[len(token):])[0]
+                try:
+                    c.sendall(b"OK")
+                    if self._recv_exact(c, 2) != b"GO":   # the rank confirms it is still there (it may have given up on this
+                        raise ConnectionError             # connection while it sat in the backlog, and come back on a new one)
+                except (OSError, ConnectionError):
+                    c.close()
+                    continue
                 c.settimeout(timeout)
+                if r in self.peers:
+                    self.peers[r].close()
                 self.peers[r] = c
-                c.sendall(b"OK")
         else:
             while True:
                 for k in range(16):
                     try:
                         c = socket.create_connection((addr, base + k), timeout=2.0)
                         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                        c.settimeout(3.0)             # whoever listens there may not be rank 0 (the walk passes other services' ports)
+                        c.settimeout(10.0)            # whoever listens there may not be rank 0 (the walk passes other services' ports)
                         c.sendall(token + struct.pack("<i", self.rank))
                         if self._recv_exact(c, 2) == b"OK":
+                            c.sendall(b"GO")
                             c.settimeout(timeout)
                             self.sock = c
                             break
