@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not collect FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU of this very workload under rocprofv3 (three short child runs); "
                          "roofline.traffic / roofline.issue then quote profiles/pmc_traffic.json")
+    ap.add_argument("--serial-gops", action="store_true",
+                    help="config5: one launch per FRAME operation (48 720 macroblocks per launch at 4K) instead of the GOP-batched default (frame t of every "
+                         "GOP of the stream per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-entropy", action="store_true", help="skip the extra encode_to_payload measurement (device entropy stage)")
     ap.add_argument("--no-extra", action="store_true", help="skip the single-stream and config-4 side measurements")
@@ -232,6 +235,7 @@ class StreamSet:
         self.enc = pkg.EncoderSession(ctx, W, H, Q, S)
         self.dec = pkg.DecoderSession(dec_ctx or ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), S)
         self.n_mb = self.enc.total_blocks
+        self.launch_streams = S                                 # slots per launch
         self._bufs = []
         self.frames = self._alloc(n_frames * S * self.fb)
         self.coef, self.mv, self.has = self._alloc(S * self.n_mb * 512), self._alloc(S * self.n_mb * 2), self._alloc(S * self.n_mb)
@@ -289,6 +293,20 @@ class StreamSet:
                 if on_launch:
                     on_launch("k_enc_pframe", a, b)
                     on_launch("k_dec_pframe", b, on_launch())
+
+    def encode_pack_pass(self, sets):
+        """encode every resident frame and build its packet payload on the device (entropy_side); sets: two alternating sets of
+        encode output buffers"""
+        enc = self.enc
+        for t in range(self.n_frames):
+            f = self.frame_ptr(t)
+            c, m, h = sets[t & 1]
+            if t % GOP == 0:
+                enc.encode_iframe_dev(f, c)
+                enc.pack_iframe_dev(c)
+            else:
+                enc.encode_pframe_dev(f, m, h, c)
+                enc.pack_pframe_dev(m, h, c)
 
     def wall_pipelined(self, reps, gop=GOP):
         """macroblocks/s of `reps` passes with the decoder ONE GOP behind the encoder on its own stream (host clock, both streams
@@ -373,25 +391,154 @@ class StreamSet:
         self._bufs = []
 
 
+class GopBatchSet:
+    """ONE stream per GPU (or S of them), its frames resident in HBM in display order, and the GOPs of the stream -- not different
+    videos -- in the slots of the sessions: encode_iframe never reads prev_frame and overwrites all of it (src/enc.rs:84-97),
+    decode_plane_into overwrites the framebuffer (src/common.rs:477-496), so the I P P ... runs of a stream are independent and frame t of
+    EVERY GOP goes into one launch per frame operation (include/pfv_hip.h: pfv_enc_session_set_frame_stride / _set_window).  The
+    coefficients, motion vectors and frames produced are those of the serial frame-by-frame pass
+    (tests: check_gop_batched_session; pfv_gop_encoder writes the same .pfv bytes); what changes is the launch shape: a 300-frame 4K stream is
+    15 + 15 launches of 20 x 48 720 macroblocks instead of 300 + 300 launches of 48 720.  The decoded frames land in display order
+    (strided fused crop)."""
+
+    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, gop=GOP, kind="pan"):
+        self.pkg, self.ctx, self.W, self.H, self.Q, self.S, self.n_frames, self.gop = pkg, ctx, W, H, Q, len(seeds), n_frames, gop
+        self.seeds = [int(s) for s in seeds]
+        self.kind, self.dec_ctx = kind, None
+        lib = pkg._lib.load()
+        self.fb = fb = int(lib.pfv_frame_bytes(W, H))
+        self.n_gops = (n_frames + gop - 1) // gop
+        assert self.S == 1 or n_frames % gop == 0, "several streams: equal GOPs only (slot = stream x GOPs + GOP needs one stride)"
+        self.slots = self.S * self.n_gops
+        self.enc = pkg.EncoderSession(ctx, W, H, Q, self.slots)
+        self.dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), self.slots)
+        self.n_mb = self.enc.total_blocks
+        self.launch_streams = self.slots
+        self._bufs = []
+        n = self.slots
+        self.frames = self._alloc(self.S * n_frames * fb)        # [stream][frame in display order][frame_bytes]
+        self.out_frames = self._alloc(self.S * n_frames * fb)    # the decoded stream, display order
+        self.coef, self.mv, self.has = self._alloc(n * self.n_mb * 512), self._alloc(n * self.n_mb * 2), self._alloc(n * self.n_mb)
+        self.enc.set_frame_stride(gop * fb)
+        for s, seed in enumerate(self.seeds):
+            for t in range(n_frames):
+                ctx.synth_frames_dev(W, H, [seed], t, self.frames + (s * n_frames + t) * fb, kind=kind)
+        ctx.sync()
+
+    def _alloc(self, n):
+        p = self.ctx.alloc(max(int(n), 16))
+        self._bufs.append(p)
+        return p
+
+    def active(self, t):
+        """slots that have a frame t: all of them, or all but the last when the stream's last GOP is short"""
+        if self.S > 1:
+            return self.slots
+        return sum(1 for g in range(self.n_gops) if g * self.gop + t < self.n_frames)
+
+    def host_frames_at(self, stream, t):
+        a = np.empty(self.fb, np.uint8)
+        self.ctx.download(a, self.frames + (stream * self.n_frames + t) * self.fb)
+        return a
+
+    def host_frames(self, stream, count):
+        return [self.host_frames_at(stream, t) for t in range(count)]
+
+    def step(self, gop=None, on_launch=None, sample_frames=None):
+        """the whole stream once: frame t of every GOP per launch, t = 0 .. gop - 1"""
+        enc, dec, fb = self.enc, self.dec, self.fb
+        for t in range(min(self.gop, self.n_frames)):
+            n = self.active(t)
+            if n != self.slots or t == 0:
+                enc.set_window(0, n)
+                dec.set_window(0, n)
+            dec.set_output_strided_dev(self.out_frames + t * fb, self.gop * fb)
+            f = self.frames + t * fb
+            a = on_launch and on_launch()
+            if t == 0:
+                enc.encode_iframe_dev(f, self.coef)
+                b = on_launch and on_launch()
+                dec.decode_iframe_dev(self.coef)
+                if on_launch:
+                    on_launch("k_enc_iframe", a, b)
+                    on_launch("k_dec_iframe", b, on_launch())
+            else:
+                enc.encode_pframe_dev(f, self.mv, self.has, self.coef)
+                b = on_launch and on_launch()
+                dec.decode_pframe_dev(self.mv, self.has, self.coef)
+                if on_launch:
+                    on_launch("k_enc_pframe", a, b)
+                    on_launch("k_dec_pframe", b, on_launch())
+
+    def encode_pack_pass(self, sets):
+        enc, fb = self.enc, self.fb
+        for t in range(min(self.gop, self.n_frames)):
+            n = self.active(t)
+            if n != self.slots or t == 0:
+                enc.set_window(0, n)
+            c, m, h = sets[t & 1]
+            if t == 0:
+                enc.encode_iframe_dev(self.frames, c)
+                enc.pack_iframe_dev(c)
+            else:
+                enc.encode_pframe_dev(self.frames + t * fb, m, h, c)
+                enc.pack_pframe_dev(m, h, c)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def verify(self):
+        """decoder == encoder for every GOP that ran to the last step, and the display-order output holds each GOP's last frame"""
+        self.sync()
+        self.dec.check()
+        n = self.active(min(self.gop, self.n_frames) - 1)
+        a, b = self.enc.prev_frame(), self.dec.framebuffer()
+        assert np.array_equal(a[:n], b[:n]), "decoder framebuffer != encoder reconstruction"
+        last = np.empty(self.fb, np.uint8)
+        t = min(self.gop, self.n_frames) - 1
+        self.ctx.download(last, self.out_frames + t * self.fb)
+        pf = self.pkg.VideoFrame.from_packed(self.W, self.H, b[0], padded=True)
+        H, W = self.H, self.W
+        want = np.concatenate([pf.plane_y.image()[:H, :W].reshape(-1), pf.plane_u.image()[:H // 2, :W // 2].reshape(-1),
+                               pf.plane_v.image()[:H // 2, :W // 2].reshape(-1)])
+        assert np.array_equal(last, want), "display-order output frame != crop of the framebuffer"
+
+    def coded_fraction(self):
+        h = np.empty(self.slots * self.n_mb, np.uint8)
+        self.ctx.download(h, self.has)
+        return float(h[: self.active(min(self.gop, self.n_frames) - 1) * self.n_mb].mean())
+
+    def wall(self, reps, gop=None):
+        self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.step()
+        self.sync()
+        el = time.perf_counter() - t0
+        return reps * self.n_frames * self.S * self.n_mb / el
+
+    def close(self):
+        self.sync()
+        self.enc.close()
+        self.dec.close()
+        for p in self._bufs:
+            self.ctx.free(p)
+        self._bufs = []
+
+
 def entropy_side(ss, timer, args):
     """beside the headline (never part of `value`): the encoder alone with its entropy stage on the device, i.e. frames in
     HBM -> packet payloads in HBM (k_enc_* + k_ent_*), whole passes timed with HIP events"""
     enc, ctx, S, n_mb = ss.enc, ss.ctx, ss.S, ss.n_mb
     # two sets of encode outputs: with the stage on its own HIP stream the k_ent_* kernels of frame t overlap k_enc_pframe
     # of frame t+1; pack(t+1) orders later main-stream work behind pack(t)'s reads
-    second = (ctx.alloc(S * n_mb * 512), ctx.alloc(S * n_mb * 2), ctx.alloc(S * n_mb))
+    L = ss.launch_streams
+    second = (ctx.alloc(L * n_mb * 512), ctx.alloc(L * n_mb * 2), ctx.alloc(L * n_mb))
     sets = [(ss.coef, ss.mv, ss.has), second]
 
     def encode_pass():
-        for t in range(ss.n_frames):
-            f = ss.frame_ptr(t)
-            c, m, h = sets[t & 1]
-            if t % GOP == 0:
-                enc.encode_iframe_dev(f, c)
-                enc.pack_iframe_dev(c)
-            else:
-                enc.encode_pframe_dev(f, m, h, c)
-                enc.pack_pframe_dev(m, h, c)
+        ss.encode_pack_pass(sets)
 
     def measure(async_stream):
         enc.enable_entropy(async_stream=async_stream)
@@ -533,7 +680,7 @@ def graph_rate(ss, reps):
     return reps * ss.n_frames * ss.S * ss.n_mb / el
 
 
-def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None):
+def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop_batched_rate=None):
     """BASELINE config #4 at the three scopes of SURVEY.md section 8d: one 3840x2160 GOP-15 stream; (i) kernels only, frames
     and coefficients resident in HBM; (ii) + PCIe through the host-buffer session entry points (a 30-frame sample); (iii) end
     to end, ALL frames: Encoder -> .pfv bytes -> Decoder (device entropy stage on the encoder side, host bit parser with
@@ -546,8 +693,18 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None):
     n_frames = ss.n_frames
     res = {"config": f"{W}x{H}, {n_frames} frames, GOP-{GOP}, quality {Q}, seed {seed}", "macroblocks_per_frame": ss.n_mb}
     res["kernel_only"] = {"value": ss.wall(2), "frames": n_frames,
-                          "note": "one launch per frame operation, 48 720 macroblocks per launch"}
+                          "note": "one launch per frame operation, 48 720 macroblocks per launch (the serial pass)"}
     ss.verify()
+    if gop_batched_rate is None and own:
+        ss.close()                                        # one resident copy of the 3.7 GB of frames at a time
+        gb = GopBatchSet(pkg, ctx, W, H, Q, [seed], n_frames)
+        gop_batched_rate = gb.wall(2)
+        gb.verify()
+        gb.close()
+        ss = StreamSet(pkg, ctx, W, H, Q, [seed], n_frames)
+    res["kernel_only"]["gop_batched"] = {"value": gop_batched_rate, "gops_per_launch": (n_frames + GOP - 1) // GOP,
+                                         "note": "frame t of every GOP of the stream in one launch per frame operation (GopBatchSet): same coefficients and "
+                                                 "frames, 15 + 15 launches of 20 x 48 720 macroblocks instead of 300 + 300 of 48 720"}
     if own:     # the same stream with the decoder on its own context (second HIP stream), one GOP behind the encoder
         ectx, dctx = pkg.Context(ctx.device, priority=1), pkg.Context(ctx.device, priority=-1)
         ss2 = StreamSet(pkg, ectx, W, H, Q, [seed], min(n_frames, 60), dec_ctx=dctx)
@@ -715,7 +872,7 @@ def live_pmc(args, S, W, H, Q, NF, per_pass_timeout=60):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-two-stream", "--no-extra", "--no-entropy",
              "--no-live-pmc", "--no-verify", "--streams", str(S), "--width", str(W), "--height", str(H), "--frames", str(NF), "--quality", str(Q),
-             "--workload", args.workload]
+             "--workload", args.workload] + (["--serial-gops"] if args.serial_gops else [])
     out = {}
     tmp = tempfile.mkdtemp(prefix="pfv_pmc_")
     try:
@@ -811,7 +968,11 @@ def main():
     assert len(mine) == S
 
     timer = Timer(ctx, None)
-    ss = StreamSet(pkg, ctx, W, H, Q, [int(r[1]) for r in mine], NF)      # synthetic input generated in HBM: [NF][S][frame_bytes]
+    gop_batched = args.workload == "config5" and not args.serial_gops
+    if gop_batched:       # the GOPs of the stream are the slots of a launch; frames resident in display order
+        ss = GopBatchSet(pkg, ctx, W, H, Q, [int(r[1]) for r in mine], NF)
+    else:
+        ss = StreamSet(pkg, ctx, W, H, Q, [int(r[1]) for r in mine], NF)  # synthetic input generated in HBM: [NF][S][frame_bytes]
     n_mb = ss.n_mb
 
     ev = {k: [] for k in BYTES_PER_MB}
@@ -834,6 +995,7 @@ def main():
     for _ in range(args.warmup):
         ss.step()
     timer.reserve(args.steps * 4 * min(NF, 2 * GOP) + 64)
+    t_setup = time.perf_counter()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -854,7 +1016,7 @@ def main():
         el_max = float(comm.allreduce([el], "max")[0])                # the slowest rank's time
 
     if rank == 0:
-        launch_mbs = S * n_mb
+        launch_mbs = ss.launch_streams * n_mb        # macroblocks of a full launch (GOP-batched: every GOP of the stream)
         achieved = launch_mbs * BYTES_PER_MB_PENC / (pe_ms * 1e-3) / 1e9
         traffic, n_valu, traffic_source, traffic_waves = traffic_from_profiles(S, W, H, Q)
         live = None
@@ -877,8 +1039,12 @@ def main():
                      "issue_floor_us": floor_us, "frac_of_issue_floor": floor_us / (pe_ms * 1e3),
                      "assumed_cycles_per_instr_at_the_floor": VALU_CYCLES_PER_INSTR, "simds": N_SIMDS, "clock_hz": GPU_CLOCK_HZ,
                      "source": traffic_source}
-        if args.workload == "config5":
-            name = f"config5: one {W}x{H} {NF}-frame GOP-{GOP} stream per GPU (seed = base + rank), encode+decode, one launch per frame operation"
+        if gop_batched:
+            name = (f"config5: one {W}x{H} {NF}-frame GOP-{GOP} stream per GPU (seed = base + rank), encode+decode, GOP-batched: frame t of all "
+                    f"{ss.n_gops} GOPs of the stream in one launch per frame operation ({ss.n_gops} x {n_mb} macroblocks per launch; same coefficients, "
+                    f"packets and frames as the serial pass -- an i-frame never reads prev_frame, src/enc.rs:84-97); frames resident in display order")
+        elif args.workload == "config5":
+            name = f"config5: one {W}x{H} {NF}-frame GOP-{GOP} stream per GPU (seed = base + rank), encode+decode, one launch per frame operation (--serial-gops)"
         else:
             name = f"{W}x{H} YUV420 GOP-{GOP} encode+decode, {S} independent streams per GPU batched per launch"
         res = {
@@ -900,6 +1066,7 @@ def main():
                               "collectives": "assignment-table broadcast + barriers + counter all-reduce only (no data-path collective); "
                                              "RCCL through libpfv_hip.so (pfv_comm_*), no torch in the process"},
             "config": {"workload": name, "streams_per_gpu": S, "frames_per_step": NF, "macroblocks_per_frame": n_mb, "quality": Q,
+                       "slots_per_launch": ss.launch_streams, "gop_batched": bool(gop_batched),
                        "pframe_coded_fraction": round(coded_frac, 4), "parallelism": f"streams sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "k_enc_pframe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -919,8 +1086,14 @@ def main():
         if world == 1 and not args.no_extra and not EMU:
             extra = {}
             if args.workload == "config5":
-                extra["config4"] = stream_4k_side(pkg, ctx, Q, ss.seeds[0], ss=ss) if (W, H) == (3840, 2160) else None
-                ss.close()
+                seed0 = ss.seeds[0]
+                if gop_batched:
+                    batched_rate = ss.wall(2)
+                    ss.close()                        # the serial figure needs the frames in its own layout
+                    extra["config4"] = stream_4k_side(pkg, ctx, Q, seed0, n_frames=NF, gop_batched_rate=batched_rate) if (W, H) == (3840, 2160) else None
+                else:
+                    extra["config4"] = stream_4k_side(pkg, ctx, Q, seed0, ss=ss) if (W, H) == (3840, 2160) else None
+                    ss.close()
             else:
                 ss.close()                            # give the 4.5 GB of resident input back first
                 extra["low_motion"] = low_motion_side(pkg, ctx, timer, W, H, Q, [int(r[1]) for r in mine], NF, kern_ms, coded_frac)

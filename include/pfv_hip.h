@@ -256,6 +256,18 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
 PFV_API int pfv_enc_iframe(pfv_enc_session *s, const uint8_t *frames, int16_t *coef_out);
 PFV_API int pfv_enc_pframe(pfv_enc_session *s, const uint8_t *frames, int8_t *mv_out, uint8_t *has_coef_out,
                            int16_t *coef_out);
+/* GOP-batched use of a session.  The n_streams slots of a session need not be different videos: encode_iframe never reads
+ * prev_frame and overwrites every plane of it (src/enc.rs:84-97), so the GOPs of ONE stream are independent of each other and
+ * can occupy the slots -- frame t of every GOP in one launch (bench.py --workload config5; pfv_gop_encoder below).
+ *   pfv_enc_session_set_frame_stride: bytes between the input frames of consecutive slots (0 = packed, the default).  With
+ *       the stream's frames resident in display order and equal GOPs of G frames, stride = G * pfv_frame_bytes and
+ *       frames_dev = first frame + t * pfv_frame_bytes make slot g read frame g * G + t.
+ *   pfv_enc_session_set_window: the following pfv_enc_*frame_dev / pfv_enc_pack_*_dev calls work on slots
+ *       [first, first + count) only (a shorter last GOP); the buffers keep their full-width layout, entries of other slots are
+ *       left alone.  A slot left out of a frame step keeps no usable prev_frame: its next frame must be an i-frame.
+ * The host-buffer entry points need the full window and packed frames (PFV_ERR_STATE otherwise). */
+PFV_API int pfv_enc_session_set_frame_stride(pfv_enc_session *s, size_t stride_bytes);
+PFV_API int pfv_enc_session_set_window(pfv_enc_session *s, int first, int count);
 /* device pointer of stream `stream`'s current prev_frame (padded Y|U|V), for checks */
 PFV_API const uint8_t *pfv_enc_prev_frame_dev(pfv_enc_session *s, int stream);
 /* copy prev_frame of all streams (padded) to host: n_streams * pfv_padded_frame_bytes */
@@ -327,10 +339,16 @@ PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev);
  * kernels store each reconstructed row twice: padded framebuffer + cropped retframe), saving the
  * separate blit pass.  NULL switches it off. */
 PFV_API int pfv_dec_set_output_dev(pfv_dec_session *s, uint8_t *frames_out_dev);
+/* The same with `stride_bytes` (>= pfv_frame_bytes; 0 = packed) between the retframes of consecutive slots, and the slot window
+ * of the *_dev calls -- the decoder-side halves of the GOP-batched use described at pfv_enc_session_set_window
+ * (decode_plane_into overwrites the whole framebuffer, src/common.rs:477-496): with stride = G * pfv_frame_bytes and
+ * frames_out_dev = first frame + t * pfv_frame_bytes the decoded stream appears in display order. */
+PFV_API int pfv_dec_set_output_strided_dev(pfv_dec_session *s, uint8_t *frames_out_dev, size_t stride_bytes);
+PFV_API int pfv_dec_session_set_window(pfv_dec_session *s, int first, int count);
 PFV_API int pfv_dec_get_frame(pfv_dec_session *s, uint8_t *frames_out);
 /* padded framebuffer of all streams to host */
 PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host);
-/* asynchronous bad-motion-vector flag raised by the last *_dev p-frame decode(s); reading it syncs. */
+/* asynchronous bad-motion-vector flag (one per slot) raised by the last *_dev p-frame decode(s); reading it syncs. */
 PFV_API int pfv_dec_check(pfv_dec_session *s);
 
 /* ------------------------------------------------------------------ stream-level session objects

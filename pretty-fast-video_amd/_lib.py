@@ -102,6 +102,8 @@ SIGNATURES = [
     ("pfv_enc_pframe_dev", c_int, [_P, _P, _P, _P, _P]),
     ("pfv_enc_iframe", c_int, [_P, _P, _P]),
     ("pfv_enc_pframe", c_int, [_P, _P, _P, _P, _P]),
+    ("pfv_enc_session_set_frame_stride", c_int, [_P, c_size_t]),
+    ("pfv_enc_session_set_window", c_int, [_P, c_int, c_int]),
     ("pfv_enc_prev_frame_dev", _P, [_P, c_int]),
     ("pfv_enc_prev_frame", c_int, [_P, _P]),
     ("pfv_payload_worst_case", c_size_t, [c_int, c_int]),
@@ -125,6 +127,8 @@ SIGNATURES = [
     ("pfv_dec_pframe", c_int, [_P, _P, _P, _P, _P]),
     ("pfv_dec_get_frame_dev", c_int, [_P, _P]),
     ("pfv_dec_set_output_dev", c_int, [_P, _P]),
+    ("pfv_dec_set_output_strided_dev", c_int, [_P, _P, c_size_t]),
+    ("pfv_dec_session_set_window", c_int, [_P, c_int, c_int]),
     ("pfv_dec_get_frame", c_int, [_P, _P]),
     ("pfv_dec_framebuffer", c_int, [_P, _P]),
     ("pfv_dec_check", c_int, [_P]),

@@ -891,6 +891,8 @@ struct pfv_enc_session {
     int lane_mapping = PFV_LANES_AUTO;       // PFV_OPT_LANE_MAPPING at creation
     uint8_t *prev[2] = {nullptr, nullptr};   // ping-pong prev_frame, padded, n_streams wide
     int cur = 0;                             // prev[cur] is the current prev_frame
+    int win_first = 0, win_count = 0;        // slot window of the *_dev / pack calls (pfv_enc_session_set_window)
+    size_t in_stride = 0;                    // bytes between the input frames of consecutive slots (0: packed)
     // staging for the host-buffer entry points
     uint8_t *st_frames = nullptr;
     int16_t *st_coef = nullptr;
@@ -922,8 +924,11 @@ struct pfv_dec_session {
     uint8_t *fb[2] = {nullptr, nullptr};     // ping-pong framebuffer
     int lane_mapping = PFV_LANES_AUTO;       // PFV_OPT_LANE_MAPPING at creation
     int cur = 0;
-    int *flag_dev = nullptr;
+    int *flag_dev = nullptr;                 // [n_streams]: a p-frame decode met a motion vector that leaves the plane
+    std::vector<int> flags_host;
     uint8_t *frames_out = nullptr;           // optional fused retframe output (pfv_dec_set_output_dev)
+    size_t out_stride = 0;                   // bytes between the output frames of consecutive slots (0: packed)
+    int win_first = 0, win_count = 0;        // slot window of the *_dev calls (pfv_dec_session_set_window)
     int16_t *st_coef = nullptr;
     int8_t *st_mv = nullptr;
     uint8_t *st_has = nullptr;
@@ -947,6 +952,7 @@ PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int qual
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     pfv_enc_session *s = new pfv_enc_session();
     s->ctx = ctx; s->width = width; s->height = height; s->n_streams = n_streams;
+    s->win_count = n_streams;
     s->geom = frame_geom(width, height, n_streams);
     int32_t q[4][64];
     pfv_qtables_from_quality(quality, q[0], q[1], q[2], q[3], &s->px_err);
@@ -999,18 +1005,64 @@ PFV_API void pfv_enc_session_destroy(pfv_enc_session *s)
     delete s;
 }
 
+// Slots [first, first + count) of a session: everything the kernels index by stream is a base pointer + stream x stride, so a
+// window is the same launch on shifted base pointers with n_streams = count.  Does not touch the ping-pong index: a frame step may
+// consist of several windows (pfv_gop_encoder: the GOPs still running at step t need not be neighbours).
+static FrameGeom enc_win_geom(const pfv_enc_session *s, int count, const uint8_t *frames_win)
+{
+    FrameGeom g = s->geom;
+    g.n_streams = count;
+    if (s->in_stride) {
+        g.src_frame_bytes = (long)s->in_stride;
+        if (s->in_stride % 16)
+            for (int i = 0; i < 3; i++) g.p[i].fast_src = 0;
+    }
+    return with_base_alignment(g, frames_win);
+}
+static int enc_launch(pfv_enc_session *s, bool pframe, int first, int count, const uint8_t *frames_dev, int8_t *mv_dev, uint8_t *has_dev,
+                      int16_t *coef_dev)
+{
+    pfv_ctx *ctx = s->ctx;
+    const size_t stride = s->in_stride ? s->in_stride : (size_t)s->geom.src_frame_bytes;
+    const uint8_t *src = frames_dev + (size_t)first * stride;
+    const size_t mb0 = (size_t)first * (size_t)s->geom.mbs_per_frame, pad0 = (size_t)first * (size_t)s->geom.pad_frame_bytes;
+    const FrameGeom g = enc_win_geom(s, count, src);
+    const int nxt = s->cur ^ 1;
+    if (pframe) {
+        const float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
+        launch_enc_pframe(ctx, s->flt, use_small_grid(s->lane_mapping, g), s->tile_compaction, g, src, s->prev[s->cur] + pad0, mv_dev + mb0 * 2,
+                          has_dev + mb0, coef_dev + mb0 * 256, s->prev[nxt] + pad0, s->qtab_dev + 2, min_err);
+        return launch_check(ctx, "k_enc_pframe");
+    }
+    launch_enc_iframe(ctx, s->flt, use_small_grid(s->lane_mapping, g), g, src, coef_dev + mb0 * 256, s->prev[nxt] + pad0, s->qtab_dev + 0);
+    return launch_check(ctx, "k_enc_iframe");
+}
+
+PFV_API int pfv_enc_session_set_window(pfv_enc_session *s, int first, int count)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (first < 0 || count <= 0 || first > s->n_streams - count) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_enc_session_set_window: window outside [0, n_streams)");
+    s->win_first = first; s->win_count = count;
+    return PFV_OK;
+}
+PFV_API int pfv_enc_session_set_frame_stride(pfv_enc_session *s, size_t bytes)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (bytes && bytes < (size_t)s->geom.src_frame_bytes) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_enc_session_set_frame_stride: stride below pfv_frame_bytes");
+    s->in_stride = bytes;
+    return PFV_OK;
+}
+static bool enc_full_window(const pfv_enc_session *s) { return s->win_first == 0 && s->win_count == s->n_streams && s->in_stride == 0; }
+
 PFV_API int pfv_enc_iframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, int16_t *coef_dev)
 {
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (!frames_dev || !coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_iframe_dev: null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    FrameGeom g = with_base_alignment(s->geom, frames_dev);
-    int nxt = s->cur ^ 1;
-    launch_enc_iframe(ctx, s->flt, use_small_grid(s->lane_mapping, g), g, frames_dev, coef_dev, s->prev[nxt], s->qtab_dev + 0);
-    int rc = launch_check(ctx, "k_enc_iframe");
+    int rc = enc_launch(s, false, s->win_first, s->win_count, frames_dev, nullptr, nullptr, coef_dev);
     if (rc) return rc;
-    s->cur = nxt;
+    s->cur ^= 1;
     return PFV_OK;
 }
 
@@ -1021,14 +1073,9 @@ PFV_API int pfv_enc_pframe_dev(pfv_enc_session *s, const uint8_t *frames_dev, in
     pfv_ctx *ctx = s->ctx;
     if (!frames_dev || !mv_dev || !has_coef_dev || !coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_pframe_dev: null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    FrameGeom g = with_base_alignment(s->geom, frames_dev);
-    int nxt = s->cur ^ 1;
-    float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209
-    launch_enc_pframe(ctx, s->flt, use_small_grid(s->lane_mapping, g), s->tile_compaction, g, frames_dev, s->prev[s->cur], mv_dev, has_coef_dev, coef_dev,
-                      s->prev[nxt], s->qtab_dev + 2, min_err);
-    int rc = launch_check(ctx, "k_enc_pframe");
+    int rc = enc_launch(s, true, s->win_first, s->win_count, frames_dev, mv_dev, has_coef_dev, coef_dev);
     if (rc) return rc;
-    s->cur = nxt;
+    s->cur ^= 1;
     return PFV_OK;
 }
 
@@ -1049,6 +1096,7 @@ PFV_API int pfv_enc_iframe(pfv_enc_session *s, const uint8_t *frames, int16_t *c
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (!frames || !coef_out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_iframe: null buffer");
+    if (!enc_full_window(s)) return fail(ctx, PFV_ERR_STATE, "pfv_enc_iframe: the host-buffer entry points work on all slots, packed (reset the window / frame stride)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = enc_staging(s);
     if (rc) return rc;
@@ -1067,6 +1115,7 @@ PFV_API int pfv_enc_pframe(pfv_enc_session *s, const uint8_t *frames, int8_t *mv
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (!frames || !mv_out || !has_coef_out || !coef_out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_enc_pframe: null buffer");
+    if (!enc_full_window(s)) return fail(ctx, PFV_ERR_STATE, "pfv_enc_pframe: the host-buffer entry points work on all slots, packed (reset the window / frame stride)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = enc_staging(s);
     if (rc) return rc;
@@ -1144,22 +1193,28 @@ PFV_API int pfv_enc_entropy_enable(pfv_enc_session *s, size_t payload_cap)
     return PFV_OK;
 }
 
-static int ent_pack(pfv_enc_session *s, bool pframe, const int8_t *mv_dev, const uint8_t *has_dev, const int16_t *coef_dev)
+// slots [first, first + count): every buffer of the stage is indexed by stream, so a window is the same launches on shifted bases
+static int ent_pack_win(pfv_enc_session *s, bool pframe, int first, int count, const int8_t *mv_dev, const uint8_t *has_dev, const int16_t *coef_dev)
 {
     pfv_ctx *ctx = s->ctx;
     if (!s->ent_on) return fail(ctx, PFV_ERR_STATE, "call pfv_enc_entropy_enable first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     EntFrame f{};
     f.total_blocks = s->geom.mbs_per_frame;
-    f.n_streams = s->n_streams;
+    f.n_streams = count;
     f.n_groups = (f.total_blocks * 4 + kEntThreads - 1) / kEntThreads;
     f.pframe = pframe ? 1 : 0;
     f.cap_bytes = s->ent_cap;
     f.ones16 = 0x00010001u;
     f.qidx[0] = pframe ? 2 : 0;                    // intra_l, intra_c, intra_c / inter_l, inter_c, inter_c
     f.qidx[1] = f.qidx[2] = pframe ? 3 : 1;        // (enc.rs:296-298, :409-411)
+    const size_t k = (size_t)first, tb = (size_t)f.total_blocks, ng = (size_t)f.n_groups;
     EntBufs b = s->ent;
-    b.coef = coef_dev; b.mv = mv_dev; b.has = has_dev;
+    b.coef = coef_dev + k * tb * 256;
+    b.mv = mv_dev ? mv_dev + k * tb * 2 : nullptr;
+    b.has = has_dev ? has_dev + k * tb : nullptr;
+    b.syms += k * ng * kEntGroupSyms; b.groups += k * ng; b.hist += k * 16; b.codes += k; b.sizes += k;
+    b.payload += k * (size_t)s->ent_cap;
     const dim3 per_sb((unsigned)f.n_groups, (unsigned)f.n_streams);
     hipStream_t st = ctx->stream;
     if (s->ent_stream) {   // inputs are complete once the main stream reaches this point
@@ -1181,6 +1236,10 @@ static int ent_pack(pfv_enc_session *s, bool pframe, const int8_t *mv_dev, const
     s->ev_cur ^= 1;
     s->ev_prev_valid = true;
     return PFV_OK;
+}
+static int ent_pack(pfv_enc_session *s, bool pframe, const int8_t *mv_dev, const uint8_t *has_dev, const int16_t *coef_dev)
+{
+    return ent_pack_win(s, pframe, s->win_first, s->win_count, mv_dev, has_dev, coef_dev);
 }
 // Runs the stage on its own HIP stream (1) or on the context's stream (0, default).  With 1 the caller must alternate
 // between TWO sets of device buffers for the encode outputs it packs; pfv_enc_payload_sizes / _fetch synchronise with the
@@ -1327,6 +1386,7 @@ PFV_API int pfv_dec_session_create(pfv_ctx *ctx, int width, int height, const in
     }
     pfv_dec_session *s = new pfv_dec_session();
     s->ctx = ctx; s->width = width; s->height = height; s->n_streams = n_streams; s->n_qtables = n_qtables;
+    s->win_count = n_streams;
     s->lane_mapping = ctx->opt_lane_mapping;
     s->geom = frame_geom(width, height, n_streams);
     size_t pad_bytes = (size_t)s->geom.pad_frame_bytes * n_streams;
@@ -1334,8 +1394,8 @@ PFV_API int pfv_dec_session_create(pfv_ctx *ctx, int width, int height, const in
     if (e == hipSuccess) e = hipMemcpy(s->qtab_dev, tabs.data(), tabs.size() * sizeof(QTab), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&s->fb[0], pad_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&s->fb[1], pad_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->flag_dev, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(s->flag_dev, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->flag_dev, (size_t)n_streams * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(s->flag_dev, 0, (size_t)n_streams * sizeof(int));
     if (e != hipSuccess) {
         int rc = hip_fail(ctx, e, "pfv_dec_session_create");
         pfv_dec_session_destroy(s);
@@ -1364,14 +1424,42 @@ PFV_API int pfv_dec_set_output_dev(pfv_dec_session *s, uint8_t *frames_out_dev)
 {
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     s->frames_out = frames_out_dev;
+    s->out_stride = 0;
     return PFV_OK;
 }
+PFV_API int pfv_dec_set_output_strided_dev(pfv_dec_session *s, uint8_t *frames_out_dev, size_t stride_bytes)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (stride_bytes && stride_bytes < (size_t)s->geom.src_frame_bytes)
+        return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_set_output_strided_dev: stride below pfv_frame_bytes (the slots' frames would overlap)");
+    s->frames_out = frames_out_dev;
+    s->out_stride = stride_bytes;
+    return PFV_OK;
+}
+PFV_API int pfv_dec_session_set_window(pfv_dec_session *s, int first, int count)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (first < 0 || count <= 0 || first > s->n_streams - count) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_session_set_window: window outside [0, n_streams)");
+    s->win_first = first; s->win_count = count;
+    return PFV_OK;
+}
+static bool dec_full_window(const pfv_dec_session *s) { return s->win_first == 0 && s->win_count == s->n_streams && s->out_stride == 0; }
 
+// geometry of the retframe output: stride between the slots' frames; 16-byte vector stores need an aligned base and stride
+static FrameGeom dec_out_geom(const pfv_dec_session *s, FrameGeom g, const uint8_t *out_base)
+{
+    if (s->out_stride) {
+        g.src_frame_bytes = (long)s->out_stride;
+        if (s->out_stride % 16)
+            for (int i = 0; i < 3; i++) g.p[i].fast_src = 0;
+    }
+    return with_base_alignment(g, out_base);
+}
 // the decode kernels can write the retframe themselves only with 16-byte vector stores
 static bool fused_output_ok(const pfv_dec_session *s)
 {
     if (!s->frames_out) return false;
-    FrameGeom g = with_base_alignment(s->geom, s->frames_out);
+    FrameGeom g = dec_out_geom(s, s->geom, s->frames_out);
     return g.p[0].fast_src && g.p[1].fast_src && g.p[2].fast_src;
 }
 
@@ -1386,6 +1474,33 @@ static int dec_geom(pfv_dec_session *s, const uint8_t qidx[3], FrameGeom *g)
     }
     return PFV_OK;
 }
+static int dec_crop_win(pfv_dec_session *s, int first, int count, uint8_t *frames_out_dev, size_t out_stride);
+
+// Slots [first, first + count) of a session (see enc_launch): same launch on shifted bases, ping-pong index untouched.
+static int dec_launch(pfv_dec_session *s, bool pframe, int first, int count, const int8_t *mv_dev, const uint8_t *has_dev, const int16_t *coef_dev,
+                      const uint8_t qidx[3])
+{
+    pfv_ctx *ctx = s->ctx;
+    FrameGeom g;
+    int rc = dec_geom(s, qidx, &g);
+    if (rc) return rc;
+    const size_t ostride = s->out_stride ? s->out_stride : (size_t)s->geom.src_frame_bytes;
+    const size_t mb0 = (size_t)first * (size_t)s->geom.mbs_per_frame, pad0 = (size_t)first * (size_t)s->geom.pad_frame_bytes;
+    const bool fused = fused_output_ok(s);
+    uint8_t *crop = fused ? s->frames_out + (size_t)first * ostride : nullptr;
+    g = dec_out_geom(s, g, s->frames_out);
+    g.n_streams = count;
+    const int nxt = s->cur ^ 1;
+    if (pframe) {
+        launch_dec_pframe(ctx, use_small_grid(s->lane_mapping, g), g, mv_dev + mb0 * 2, has_dev + mb0, coef_dev + mb0 * 256, s->fb[s->cur] + pad0,
+                          s->fb[nxt] + pad0, s->qtab_dev, s->flag_dev + first, crop);
+        rc = launch_check(ctx, "k_dec_pframe");
+    } else {
+        launch_dec_iframe(ctx, use_small_grid(s->lane_mapping, g), g, coef_dev + mb0 * 256, s->fb[nxt] + pad0, s->qtab_dev, crop);
+        rc = launch_check(ctx, "k_dec_iframe");
+    }
+    return rc;
+}
 
 PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, const uint8_t qidx[3])
 {
@@ -1393,14 +1508,10 @@ PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, cons
     pfv_ctx *ctx = s->ctx;
     if (!coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_dev: null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    FrameGeom g;
-    int rc = dec_geom(s, qidx, &g);
+    int rc = dec_launch(s, false, s->win_first, s->win_count, nullptr, nullptr, coef_dev, qidx);
     if (rc) return rc;
-    int nxt = s->cur ^ 1;
-    launch_dec_iframe(ctx, use_small_grid(s->lane_mapping, g), g, coef_dev, s->fb[nxt], s->qtab_dev, fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
-    if ((rc = launch_check(ctx, "k_dec_iframe"))) return rc;
-    s->cur = nxt;
-    if (s->frames_out && !fused_output_ok(s)) return pfv_dec_get_frame_dev(s, s->frames_out);
+    s->cur ^= 1;
+    if (s->frames_out && !fused_output_ok(s)) return dec_crop_win(s, s->win_first, s->win_count, s->frames_out, s->out_stride);
     return PFV_OK;
 }
 
@@ -1411,30 +1522,33 @@ PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const u
     pfv_ctx *ctx = s->ctx;
     if (!mv_dev || !has_coef_dev || !coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_dev: null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    FrameGeom g;
-    int rc = dec_geom(s, qidx, &g);
+    int rc = dec_launch(s, true, s->win_first, s->win_count, mv_dev, has_coef_dev, coef_dev, qidx);
     if (rc) return rc;
-    int nxt = s->cur ^ 1;
-    launch_dec_pframe(ctx, use_small_grid(s->lane_mapping, g), g, mv_dev, has_coef_dev, coef_dev, s->fb[s->cur], s->fb[nxt], s->qtab_dev, s->flag_dev,
-                      fused_output_ok(s) ? s->frames_out : (uint8_t *)nullptr);
-    if ((rc = launch_check(ctx, "k_dec_pframe"))) return rc;
-    s->cur = nxt;
-    if (s->frames_out && !fused_output_ok(s)) return pfv_dec_get_frame_dev(s, s->frames_out);
+    s->cur ^= 1;
+    if (s->frames_out && !fused_output_ok(s)) return dec_crop_win(s, s->win_first, s->win_count, s->frames_out, s->out_stride);
     return PFV_OK;
 }
 
-PFV_API int pfv_dec_check(pfv_dec_session *s)
+// one flag per slot (k_dec_pframe raises flag[stream]); PFV_ERR_BAD_MV when any is set, all cleared
+static int dec_check_flags(pfv_dec_session *s, std::vector<int> *which)
 {
-    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
-    int flag = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&flag, s->flag_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    s->flags_host.assign((size_t)s->n_streams, 0);
+    HIP_TRY(ctx, hipMemcpyAsync(s->flags_host.data(), s->flag_dev, (size_t)s->n_streams * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (flag) {
-        HIP_TRY(ctx, hipMemsetAsync(s->flag_dev, 0, sizeof(int), ctx->stream));
+    bool any = false;
+    for (int k = 0; k < s->n_streams; k++) any = any || s->flags_host[(size_t)k] != 0;
+    if (which) *which = s->flags_host;
+    if (any) {
+        HIP_TRY(ctx, hipMemsetAsync(s->flag_dev, 0, (size_t)s->n_streams * sizeof(int), ctx->stream));
         return fail(ctx, PFV_ERR_BAD_MV, "motion vector points outside the reference plane (src/common.rs:258-259)");
     }
     return PFV_OK;
+}
+PFV_API int pfv_dec_check(pfv_dec_session *s)
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    return dec_check_flags(s, nullptr);
 }
 
 static int dec_staging(pfv_dec_session *s)
@@ -1454,6 +1568,7 @@ PFV_API int pfv_dec_iframe(pfv_dec_session *s, const int16_t *coef, const uint8_
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (!coef) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe: null buffer");
+    if (!dec_full_window(s)) return fail(ctx, PFV_ERR_STATE, "pfv_dec_iframe: the host-buffer entry points work on all slots, packed (reset the window / output stride)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = dec_staging(s);
     if (rc) return rc;
@@ -1470,6 +1585,7 @@ PFV_API int pfv_dec_pframe(pfv_dec_session *s, const int8_t *mv, const uint8_t *
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (!mv || !has_coef || !coef) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe: null buffer");
+    if (!dec_full_window(s)) return fail(ctx, PFV_ERR_STATE, "pfv_dec_pframe: the host-buffer entry points work on all slots, packed (reset the window / output stride)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = dec_staging(s);
     if (rc) return rc;
@@ -1516,6 +1632,7 @@ PFV_API int pfv_dec_iframe_sparse(pfv_dec_session *s, const uint32_t *idx, const
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (n && (!idx || !val)) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_sparse: null buffer");
+    if (!dec_full_window(s)) return fail(ctx, PFV_ERR_STATE, "pfv_dec_iframe_sparse: the host-buffer entry points work on all slots, packed (reset the window / output stride)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = dec_upload_sparse(s, idx, val, n);
     if (rc) return rc;
@@ -1529,6 +1646,7 @@ PFV_API int pfv_dec_pframe_sparse(pfv_dec_session *s, const int8_t *mv, const ui
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (!mv || !has_coef || (n && (!idx || !val))) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_sparse: null buffer");
+    if (!dec_full_window(s)) return fail(ctx, PFV_ERR_STATE, "pfv_dec_pframe_sparse: the host-buffer entry points work on all slots, packed (reset the window / output stride)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = dec_upload_sparse(s, idx, val, n);
     if (rc) return rc;
@@ -1539,16 +1657,29 @@ PFV_API int pfv_dec_pframe_sparse(pfv_dec_session *s, const int8_t *mv, const ui
     return pfv_dec_check(s);
 }
 
+static int dec_crop_win(pfv_dec_session *s, int first, int count, uint8_t *frames_out_dev, size_t out_stride)
+{
+    pfv_ctx *ctx = s->ctx;
+    FrameGeom g = s->geom;
+    g.n_streams = count;
+    if (out_stride) {
+        g.src_frame_bytes = (long)out_stride;
+        if (out_stride % 16)
+            for (int i = 0; i < 3; i++) g.p[i].fast_src = 0;
+    }
+    uint8_t *dst = frames_out_dev + (size_t)first * (size_t)g.src_frame_bytes;
+    g = with_base_alignment(g, dst);
+    dim3 grid(128, 3, g.n_streams);
+    hipLaunchKernelGGL(k_crop_frames, grid, dim3(kThreads), 0, ctx->stream, g, s->fb[s->cur] + (size_t)first * (size_t)g.pad_frame_bytes, dst);
+    return launch_check(ctx, "k_crop_frames");
+}
 PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev)
 {
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
     if (!frames_out_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_get_frame_dev: null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    FrameGeom g = with_base_alignment(s->geom, frames_out_dev);
-    dim3 grid(128, 3, g.n_streams);
-    hipLaunchKernelGGL(k_crop_frames, grid, dim3(kThreads), 0, ctx->stream, g, s->fb[s->cur], frames_out_dev);
-    return launch_check(ctx, "k_crop_frames");
+    return dec_crop_win(s, 0, s->n_streams, frames_out_dev, 0);
 }
 
 PFV_API int pfv_dec_get_frame(pfv_dec_session *s, uint8_t *frames_out)

@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
 // reference: VideoPlane::decode_plane_delta / _into (src/common.rs:448-475, 498-521) ->
 // decode_block_delta (:254-285).  ref and out are distinct buffers (ping-pong): the
 // reference reads every patch from the old plane before it writes anything (:498-521).
-// err_flag is set when a motion vector leaves the plane (:258-259 debug_assert); the
+// err_flag[stream] is set when a motion vector leaves the plane (:258-259 debug_assert); the
 // vector is then treated as (0,0) so that no out-of-bounds access happens.
 __device__ __forceinline__ uint4 load_unaligned16(const uint8_t *p)
 {
@@ -1748,7 +1748,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     if (mb_valid) {
         int sx = mbx + mx, sy = mby + my;
         if (sx < 0 || sx > p.pw - 16 || sy < 0 || sy > p.ph - 16) {
-            if (i == 0) atomicOr(err_flag, 1);
+            if (i == 0) atomicOr(err_flag + sp.stream, 1);   // one flag per stream of the launch
             mx = 0; my = 0;
         }
     }

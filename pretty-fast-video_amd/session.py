@@ -87,6 +87,13 @@ class EncoderSession(_Geometry):
         self.ctx.check(self.ctx._lib.pfv_enc_pframe_dev(self.handle, ctypes.c_void_p(frames_dev), ctypes.c_void_p(mv_dev),
                                                         ctypes.c_void_p(has_dev), ctypes.c_void_p(coef_dev)))
 
+    # GOP-batched use: the slots hold the GOPs of one stream (include/pfv_hip.h, pfv_enc_session_set_window) -----------
+    def set_frame_stride(self, stride_bytes: int = 0):
+        self.ctx.check(self.ctx._lib.pfv_enc_session_set_frame_stride(self.handle, int(stride_bytes)))
+
+    def set_window(self, first: int = 0, count: int | None = None):
+        self.ctx.check(self.ctx._lib.pfv_enc_session_set_window(self.handle, int(first), int(self.n_streams - first if count is None else count)))
+
     # device entropy stage (RLE + Huffman + bit packing of enc.rs:237-470 on the device) ---------------
     def enable_entropy(self, payload_cap: int = 0, async_stream: bool = False):
         """allocate the stage; payload_cap = bytes per stream (0: worst case for the geometry).  async_stream: run it
@@ -202,6 +209,13 @@ class DecoderSession(_Geometry):
     def set_output_dev(self, frames_dev):
         """fuse the retframe crop into the decode kernels (None switches it off)"""
         self.ctx.check(self.ctx._lib.pfv_dec_set_output_dev(self.handle, ctypes.c_void_p(frames_dev or 0)))
+
+    def set_output_strided_dev(self, frames_dev, stride_bytes: int):
+        """retframes of consecutive slots `stride_bytes` apart (GOP-batched decode: the stream appears in display order)"""
+        self.ctx.check(self.ctx._lib.pfv_dec_set_output_strided_dev(self.handle, ctypes.c_void_p(frames_dev or 0), int(stride_bytes)))
+
+    def set_window(self, first: int = 0, count: int | None = None):
+        self.ctx.check(self.ctx._lib.pfv_dec_session_set_window(self.handle, int(first), int(self.n_streams - first if count is None else count)))
 
     def get_frame_dev(self, frames_dev: int):
         self.ctx.check(self.ctx._lib.pfv_dec_get_frame_dev(self.handle, ctypes.c_void_p(frames_dev)))

@@ -225,6 +225,87 @@ def check_session_batched_dev(pkg, ctx, oracle, width, height, quality, seeds, n
     return stats
 
 
+def check_gop_batched_session(pkg, ctx, oracle, width, height, quality, n_frames, gop, seed=None, kind="pan", threads=1):
+    """GOP-batched use of the sessions (include/pfv_hip.h, pfv_enc_session_set_window): ONE stream, frames resident on the device in
+    display order, the slots of one encoder / decoder session hold its GOPs (an i-frame never reads prev_frame, src/enc.rs:84-97), frame
+    t of every GOP in one launch per frame operation -- input stride = gop frames, a shorter last GOP through the slot window, device
+    entropy stage on the window, decoded frames written back in display order (strided fused crop).  Every coefficient, motion vector,
+    skip flag, packet payload byte and decoded pixel against the oracle's SERIAL encoder run over the same frames in display order."""
+    import ctypes
+    L = _oracle_serializers(oracle)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    seed = pkg.synth.SEED if seed is None else int(seed)
+    n_gops = (n_frames + gop - 1) // gop
+    enc = pkg.EncoderSession(ctx, width, height, quality, n_gops)
+    dec = pkg.DecoderSession(ctx, width, height, np.stack(pkg.qtables_from_quality(quality)[:4]), n_gops)
+    enc.enable_entropy()
+    nb, fb = enc.total_blocks, enc.frame_bytes
+    d_frames, d_out = ctx.alloc(n_frames * fb), ctx.alloc(n_frames * fb)
+    for t in range(n_frames):
+        ctx.synth_frames_dev(width, height, [seed], t, d_frames + t * fb, kind=kind)
+    frames = np.empty((n_frames, fb), np.uint8)
+    ctx.download(frames, d_frames)
+    ctx.upload(d_out, np.full(n_frames * fb, 0xA5, np.uint8))
+    d_coef, d_mv, d_has = ctx.alloc(n_gops * nb * 512), ctx.alloc(n_gops * nb * 2), ctx.alloc(n_gops * nb)
+    enc.set_frame_stride(gop * fb)
+    # the serial oracle over the display order
+    oenc = oracle.encoder(width, height, quality, threads)
+    want = []
+    ref = np.zeros(int(ctx._lib.pfv_payload_worst_case(width, height)) + 64, np.uint8)
+    for f in range(n_frames):
+        if f % gop == 0:
+            ocoef = oenc.encode_iframe(frames[f]); omv = ohas = None
+            n = L.pfvo_serialize_iframe(P(ocoef), nb, P(ref), ref.size)
+        else:
+            omv, ohas, ocoef = oenc.encode_pframe(frames[f])
+            n = L.pfvo_serialize_pframe(P(omv), P(ohas), P(ocoef), nb, P(ref), ref.size)
+        pf = pkg.VideoFrame.from_packed(width, height, oenc.prev_frame(), padded=True)
+        crop = np.concatenate([pf.plane_y.image()[:height, :width].reshape(-1), pf.plane_u.image()[:height // 2, :width // 2].reshape(-1),
+                               pf.plane_v.image()[:height // 2, :width // 2].reshape(-1)])
+        want.append((ocoef.copy(), None if omv is None else omv.copy(), None if ohas is None else ohas.copy(), ref[:n].tobytes(), crop))
+    coef, mv, has = np.empty((n_gops, nb, 256), np.int16), np.empty((n_gops, nb, 2), np.int8), np.empty((n_gops, nb), np.uint8)
+    launches = 0
+    for t in range(min(gop, n_frames)):
+        count = sum(1 for g in range(n_gops) if g * gop + t < n_frames)      # GOPs that have a frame t: a prefix (only the last may be short)
+        enc.set_window(0, count)
+        dec.set_window(0, count)
+        dec.set_output_strided_dev(d_out + t * fb, gop * fb)
+        if t == 0:
+            enc.encode_iframe_dev(d_frames, d_coef)
+            enc.pack_iframe_dev(d_coef)
+            dec.decode_iframe_dev(d_coef)
+        else:
+            enc.encode_pframe_dev(d_frames + t * fb, d_mv, d_has, d_coef)
+            enc.pack_pframe_dev(d_mv, d_has, d_coef)
+            dec.decode_pframe_dev(d_mv, d_has, d_coef)
+        launches += 1
+        dec.check()
+        sizes = enc.payload_sizes()
+        ctx.download(coef, d_coef); ctx.download(mv, d_mv); ctx.download(has, d_has)
+        for g in range(count):
+            f = g * gop + t
+            ocoef, omv, ohas, opay, _ = want[f]
+            assert np.array_equal(coef[g], ocoef), f"frame {f} (GOP {g}, step {t}): coefficients differ from the serial oracle"
+            if t:
+                assert np.array_equal(mv[g], omv), f"frame {f}: motion vectors differ"
+                assert np.array_equal(has[g], ohas), f"frame {f}: skip flags differ"
+            assert int(sizes[g]) == len(opay) and enc.payload(g, len(opay)) == opay, f"frame {f}: packet payload differs from the serial oracle"
+    out = np.empty((n_frames, fb), np.uint8)
+    ctx.download(out, d_out)
+    for f in range(n_frames):
+        assert np.array_equal(out[f], want[f][4]), f"frame {f}: decoded frame (display order) differs from the serial oracle"
+    # the host-buffer entry points refuse a partial window / a stride instead of guessing
+    try:
+        enc.encode_iframe(np.zeros((n_gops, fb), np.uint8))
+        raise AssertionError("host-buffer encode accepted a strided session")
+    except pkg.PfvError as e:
+        assert e.code == pkg._lib.PFV_ERR_STATE
+    for p in (d_frames, d_out, d_coef, d_mv, d_has):
+        ctx.free(p)
+    enc.close(); dec.close()
+    return {"gops": n_gops, "launches_per_operation": launches, "frames": n_frames}
+
+
 def check_golden(pkg, ctx, oracle):
     """the HIP path against the committed known-answer vectors (tests/golden/hotpath_vectors.npz)"""
     import os

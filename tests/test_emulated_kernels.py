@@ -56,6 +56,13 @@ def test_emu_session_two_streams(pkg, emu_ctx, oracle):
     assert 0 < stats["coded"] < stats["mbs"]
 
 
+def test_emu_session_gop_batched(pkg, emu_ctx, oracle):
+    """the GOPs of ONE stream in the slots of one session: 11 frames, GOP 4 -> slots of 4, 4 and 3 frames (window shrinks at step 3)"""
+    r = pc.check_gop_batched_session(pkg, emu_ctx, oracle, 64, 48, 5, n_frames=11, gop=4)
+    assert r == {"gops": 3, "launches_per_operation": 4, "frames": 11}
+    pc.check_gop_batched_session(pkg, emu_ctx, oracle, 50, 38, 2, n_frames=6, gop=3)       # ragged planes: byte-wise crop path
+
+
 def test_emu_session_low_motion(pkg, emu_ctx, oracle):
     """static background + moving objects: tiles with few coded macroblocks take the compaction path, reconstruction included"""
     stats = pc.check_session(pkg, emu_ctx, oracle, 272, 144, 5, n_streams=2, n_frames=4, kind="low_motion")

@@ -219,6 +219,18 @@ def test_benched_shape_96_streams_1080p_vs_oracle(pkg, gpu_ctx, oracle):
     assert stats["mbs"] == 96 * 12240 and 0 < stats["coded"] < stats["mbs"]
 
 
+@pytest.mark.parametrize("geom", [(3840, 2160, 31), (1920, 1080, 61)])
+def test_gop_batched_session_vs_serial_oracle(pkg, gpu_ctx, oracle, geom):
+    """GOP-batched sessions (BASELINE configs #4 / #5 as bench.py --workload config5 runs them): the GOPs of ONE stream in the slots of a
+    launch -- 4K x 31 frames (GOPs of 15, 15 and 1: the window shrinks after the i-frame step) and 1080p x 61 frames (five GOPs) -- with
+    every coefficient, header, device-built packet payload and display-order decoded frame against the oracle's SERIAL encoder."""
+    w, h, n = geom
+    threads = min(32, len(os.sched_getaffinity(0)))
+    r = pc.check_gop_batched_session(pkg, gpu_ctx, oracle, w, h, 5, n_frames=n, gop=15, threads=threads)
+    oracle.L.pfvo_pool_shutdown()
+    assert r["gops"] == (n + 14) // 15 and r["launches_per_operation"] == 15 and r["frames"] == n
+
+
 def test_session_4k_roundtrip_property(pkg, gpu_ctx):
     """BASELINE config #4 geometry (3840x2160, 48 720 MB/frame): size-independent property --
     the decoder's framebuffer equals the encoder's closed-loop reconstruction for every frame
@@ -388,7 +400,7 @@ def test_extreme_aspect_ratios(pkg, gpu_ctx, oracle, geom):
     """the widest / tallest frames the container can describe (u16 dimensions, src/enc.rs:195-196)"""
     w, h = geom
     stats = pc.check_session(pkg, gpu_ctx, oracle, w, h, 5, n_streams=1, n_frames=2, gop=15, threads=os.cpu_count() or 1)
-    assert stats is None or True
+    assert stats["mbs"] == pkg._lib.load().pfv_total_blocks(w, h) and 0 <= stats["coded"] <= stats["mbs"]     # one p-frame, every macroblock accounted for
     assert pc.check_device_entropy(pkg, gpu_ctx, oracle, w, h, n_streams=1, seed=w + h, kinds=("typical",)) == 2
 
 

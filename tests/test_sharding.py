@@ -270,9 +270,12 @@ def test_bench_self_launch_two_ranks():
 
 def test_bench_config5_single_rank_fields():
     """config-5 workload (one stream per GPU, seed = base + rank) and the cpu_baseline fields, at a toy geometry"""
-    res = _run_bench(["--workload", "config5", "--steps", "1", "--warmup", "0", "--width", "64", "--height", "48", "--frames", "4",
+    res = _run_bench(["--workload", "config5", "--steps", "1", "--warmup", "0", "--width", "64", "--height", "48", "--frames", "19",
                       "--no-entropy"])
     assert res["n_gpus"] == 1 and res["config"]["workload"].startswith("config5") and res["config"]["streams_per_gpu"] == 1
+    # GOP-batched by default: the 15 + 4 frames are two GOPs = two slots per launch; the whole-job count still is frames x macroblocks
+    assert res["config"]["gop_batched"] is True and res["config"]["slots_per_launch"] == 2
+    assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 19 * 20) < 1e-6
     cb = res["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cgroup_cpu_quota", "affinity_cpus", "value_1thread", "value_best",
               "threads_best"):
