@@ -680,13 +680,14 @@ def graph_rate(ss, reps):
     return reps * ss.n_frames * ss.S * ss.n_mb / el
 
 
-def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop_batched_rate=None):
+def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop_batched_rate=None, W=3840, H=2160):
     """BASELINE config #4 at the three scopes of SURVEY.md section 8d: one 3840x2160 GOP-15 stream; (i) kernels only, frames
-    and coefficients resident in HBM; (ii) + PCIe through the host-buffer session entry points (a 30-frame sample); (iii) end
-    to end, ALL frames: Encoder -> .pfv bytes -> Decoder (device entropy stage on the encoder side, host bit parser with
-    look-ahead threads on the decoder side).  The producer's frame (generated on the device, brought to the host) is outside
-    the timed encode call; a decoded frame is checked against the closed-loop reconstruction of the session path."""
-    W, H = 3840, 2160
+    and coefficients resident in HBM -- one launch per frame operation, and GOP-batched (frame t of every GOP per launch); (ii) + PCIe
+    through the host-buffer session entry points on page-locked buffers (a 30-frame sample); (iii) end to end, ALL frames: GopEncoder
+    -> .pfv bytes -> GopDecoder (producer frames in page-locked memory, uploads on a copy stream under the previous batch's kernels,
+    device entropy stage; GOP-parallel host bit parser on the way back), with the frame-by-frame Encoder / Decoder objects beside them
+    (same bytes).  The producer's frames (generated on the device, brought to page-locked host memory) are outside the timed calls; a
+    decoded frame is checked against the closed-loop reconstruction of the session path."""
     own = ss is None
     if own:
         ss = StreamSet(pkg, ctx, W, H, Q, [seed], n_frames)
@@ -713,64 +714,94 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop
         ss2.close()
         dctx.close()
         ectx.close()
-    # (ii)
+    # (ii) + PCIe: the host-buffer session entry points on PAGE-LOCKED buffers (pfv_host_alloc), synchronous per frame
+    import ctypes
+    lib = pkg._lib.load()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     pcie_frames = min(pcie_frames, n_frames)
-    host = ss.host_frames(0, pcie_frames)
+    fbytes, n_mb = ss.fb, ss.n_mb
+    host_all = ctx.host_array(n_frames * fbytes).reshape(n_frames, fbytes)      # the producer's frames, page-locked, display order
+    ctx.download(host_all.reshape(-1), ss.frame_ptr(0) if hasattr(ss, "frame_ptr") else ss.frames)
     enc = pkg.EncoderSession(ctx, W, H, Q, 1)
     dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), 1)
+    pin = {k: ctx.host_array(n) for k, n in (("coef", n_mb * 512), ("mv", n_mb * 2), ("has", n_mb), ("out", fbytes))}
+    qi, qp = np.array([0, 1, 1], np.uint8), np.array([2, 3, 3], np.uint8)
     t0 = time.perf_counter()
     for t in range(pcie_frames):
         if t % GOP == 0:
-            dec.decode_iframe(enc.encode_iframe(host[t]))
+            ctx.check(lib.pfv_enc_iframe(enc.handle, P(host_all[t]), P(pin["coef"])))
+            ctx.check(lib.pfv_dec_iframe(dec.handle, P(pin["coef"]), P(qi)))
         else:
-            dec.decode_pframe(*enc.encode_pframe(host[t]))
-        dec.get_frame()
+            ctx.check(lib.pfv_enc_pframe(enc.handle, P(host_all[t]), P(pin["mv"]), P(pin["has"]), P(pin["coef"])))
+            ctx.check(lib.pfv_dec_pframe(dec.handle, P(pin["mv"]), P(pin["has"]), P(pin["coef"]), P(qp)))
+        ctx.check(lib.pfv_dec_get_frame(dec.handle, P(pin["out"])))
     el = time.perf_counter() - t0
-    res["pcie_inclusive"] = {"value": pcie_frames * ss.n_mb / el, "frames": pcie_frames,
-                             "note": "host-buffer session entry points, pageable numpy buffers, synchronous per frame"}
+    res["pcie_inclusive"] = {"value": pcie_frames * n_mb / el, "frames": pcie_frames,
+                             "note": "host-buffer session entry points on page-locked buffers (pfv_host_alloc): frame up, coefficients down and up "
+                                     "again, decoded frame down; synchronous per frame"}
     recon_last = enc.prev_frame()[0]
     enc.close()
     dec.close()
-    del host
-    # (iii)
-    buf = io.BytesIO()
-    e = pkg.Encoder(buf, W, H, 30, Q, ctx)
-    t_enc = 0.0
-    for t in range(n_frames):
-        vf = pkg.VideoFrame.from_packed(W, H, ss.host_frames_at(0, t))
-        t0 = time.perf_counter()
-        (e.encode_iframe if t % GOP == 0 else e.encode_pframe)(vf)
-        t_enc += time.perf_counter() - t0
-    t0 = time.perf_counter()
-    e.finish()
-    t_enc += time.perf_counter() - t0
-    e.close()
+    for a in pin.values():
+        ctx.host_free(a)
     if own:
         ss.close()
-    data = buf.getvalue()
-    d = pkg.Decoder(data, ctx)
-    n = [0]
-    last = [None]
-
-    def onvideo(fr):
-        n[0] += 1
-        if n[0] == pcie_frames:
-            last[0] = fr.packed()
-    t0 = time.perf_counter()
-    while d.advance_frame(onvideo):
-        pass
-    t_dec = time.perf_counter() - t0
-    d.close()
-    assert n[0] == n_frames
-    pf = pkg.VideoFrame.from_packed(W, H, recon_last, padded=True)     # decoded frame == the session path's reconstruction, cropped
+    pf = pkg.VideoFrame.from_packed(W, H, recon_last, padded=True)     # frame pcie_frames - 1 as the session path reconstructs it, cropped
     want = np.concatenate([pf.plane_y.image()[:H, :W].reshape(-1), pf.plane_u.image()[:H // 2, :W // 2].reshape(-1),
                            pf.plane_v.image()[:H // 2, :W // 2].reshape(-1)])
-    assert np.array_equal(last[0], want), "decoded .pfv frame != encoder reconstruction"
+    ny, nc = W * H, (W // 2) * (H // 2)
+    facts = host_cpu_facts()
+    quota = facts["cgroup_cpu_quota"] if isinstance(facts["cgroup_cpu_quota"], (int, float)) else (facts["affinity_cpus"] or facts["host_cpus"])
+    parse_threads = int(max(1, min(32, round(quota)) - 1))
+
+    # (iii) end to end, ALL frames, through the GOP-batched objects: page-locked planes -> copy stream -> k_enc_* + device entropy stage
+    # for frame t of every GOP of a batch -> .pfv bytes; .pfv bytes -> GOP-parallel packet parse -> k_dec_* -> frames in page-locked memory
+    def run_objects(make_enc, make_dec, raw):
+        buf = io.BytesIO()
+        e = make_enc(buf)
+        t0 = time.perf_counter()
+        for t in range(n_frames):
+            f = host_all[t]
+            planes = (f[:ny], f[ny:ny + nc], f[ny + nc:])
+            if raw:
+                (e.encode_iframe if t % GOP == 0 else e.encode_pframe)(planes)
+            else:
+                (e.encode_iframe if t % GOP == 0 else e.encode_pframe)(pkg.VideoFrame.from_packed(W, H, f))
+        e.finish()
+        t_enc = time.perf_counter() - t0
+        e.close()
+        data = buf.getvalue()
+        d = make_dec(data)
+        n, ok = [0], [None]
+
+        def onvideo(*fr):
+            n[0] += 1
+            if n[0] == pcie_frames:
+                got = np.concatenate(fr) if raw else fr[0].packed()
+                ok[0] = bool(np.array_equal(got, want))
+        t0 = time.perf_counter()
+        while d.advance_frame(onvideo):
+            pass
+        t_dec = time.perf_counter() - t0
+        d.close()
+        assert n[0] == n_frames and ok[0], "decoded .pfv frame != encoder reconstruction"
+        return data, t_enc, t_dec
+
+    gops = 10
+    data, t_enc, t_dec = run_objects(lambda buf: pkg.GopEncoder(buf, W, H, 30, Q, ctx, max_gops=gops, max_gop_frames=GOP),
+                                     lambda data: pkg.GopDecoder(data, ctx, max_gops=2 * gops, max_gop_frames=GOP, threads=parse_threads, raw=True), True)
     res["end_to_end"] = {"frames": n_frames, "stream_bytes": len(data), "bits_per_pixel": round(len(data) * 8 / (n_frames * W * H), 3),
-                         "encode_value": n_frames * ss.n_mb / t_enc, "decode_value": n_frames * ss.n_mb / t_dec,
-                         "value": n_frames * ss.n_mb / (t_enc + t_dec),
-                         "note": "Encoder -> .pfv bytes -> Decoder objects, every frame of the stream (single stream, synchronous per "
-                                 "frame, pinned staging; a decoded frame checked against the encoder's reconstruction)"}
+                         "encode_value": n_frames * n_mb / t_enc, "decode_value": n_frames * n_mb / t_dec,
+                         "value": n_frames * n_mb / (t_enc + t_dec), "gops_per_batch": {"encoder": gops, "decoder": 2 * gops}, "parse_threads": parse_threads,
+                         "upload_GBps_equivalent": n_frames * fbytes / t_enc / 1e9,
+                         "note": "GopEncoder -> .pfv bytes -> GopDecoder (pfv_gop_encoder / pfv_gop_decoder: frame t of every GOP of a batch per launch), every "
+                                 "frame of the stream, producer frames in page-locked memory, decoded frames delivered from page-locked memory; a decoded frame "
+                                 "checked against the encoder's reconstruction"}
+    sdata, s_enc, s_dec = run_objects(lambda buf: pkg.Encoder(buf, W, H, 30, Q, ctx), lambda data: pkg.Decoder(data, ctx), False)
+    assert sdata == data, "GOP-batched and serial encoder objects wrote different .pfv streams"
+    res["end_to_end"]["serial_objects"] = {"encode_value": n_frames * n_mb / s_enc, "decode_value": n_frames * n_mb / s_dec,
+                                           "note": "Encoder -> .pfv -> Decoder, one frame per call and per launch (the same bytes: checked)"}
+    ctx.host_free(host_all.reshape(-1))
     res["unit"] = "macroblocks/s"
     return res
 

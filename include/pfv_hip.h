@@ -416,6 +416,51 @@ PFV_API long pfv_batch_decoder_dense_steps(const pfv_batch_decoder *b);
 PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **frames_out);
 PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
 
+/* ------------------------------------------------------------------ GOP-batched encoder / decoder of ONE stream
+ * enc::Encoder (src/enc.rs:12-188) and dec::Decoder (src/dec.rs:15-224) with the same calls, bytes and frames as pfv_encoder /
+ * pfv_decoder, but with the independent GOPs of the stream as the slots of every kernel launch: encode_iframe never reads
+ * prev_frame and overwrites every plane of it (src/enc.rs:84-97), decode_plane_into overwrites the framebuffer
+ * (src/common.rs:477-496), so the runs I P P ... of one stream can be worked on side by side -- frame t of every run of a batch
+ * in ONE launch per stage.  A single 4K stream then fills the device the way 20 streams do.
+ *   max_gops        runs ("groups") per batch = slots per launch; a group starts at every i-frame
+ *   max_gop_frames  frames of a group inside one batch; a longer run continues in the next batch (its reference frame is
+ *                   carried over on the device), and so does a stream that starts with p-frames
+ *   payload_budget  device bytes for the packet payloads of one batch (0: the batch's raw frame bytes, at least 16 MiB);
+ *                   PFV_ERR_NOMEM from the call that completes a batch whose payloads do not fit
+ * Encoder: the planes may be reused when an encode call returns; frames are uploaded on a copy stream while the kernels of the
+ * previous batch run.  A packet reaches pfv_gop_encoder_drain when its batch is complete (max_gops groups seen, flush, finish);
+ * the byte stream is the one pfv_encoder writes.  After an error the stream is incomplete and every call returns PFV_ERR_STATE.
+ * Decoder: one scan of the packet headers (type:u8, len:u32, src/dec.rs:179-180) cuts a batch, the packets of a frame step are
+ * bit-parsed in parallel on n_threads workers + the caller (step t + 1 under the device work of step t), frames are delivered in
+ * stream order, with the results (1 / 0 / error) the sequential loop gives call by call -- a packet that does not parse leaves
+ * the framebuffer alone, and the frames behind a failed i-frame decode against the previous run's last frame, as they do there.
+ * y / u / v of the callback stay valid until the call that starts the next batch. */
+typedef struct pfv_gop_encoder pfv_gop_encoder;
+typedef struct pfv_gop_decoder pfv_gop_decoder;
+PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int max_gops, int max_gop_frames,
+                                   size_t payload_budget, pfv_gop_encoder **out);
+PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+PFV_API int pfv_gop_encoder_encode_dropframe(pfv_gop_encoder *e);
+PFV_API int pfv_gop_encoder_flush(pfv_gop_encoder *e);
+PFV_API int pfv_gop_encoder_finish(pfv_gop_encoder *e);
+PFV_API int pfv_gop_encoder_drain(pfv_gop_encoder *e, const uint8_t **data, size_t *len);
+PFV_API int pfv_gop_encoder_bytes(pfv_gop_encoder *e, const uint8_t **data, size_t *len);
+PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e);
+PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e);
+PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, int max_gops, int max_gop_frames, int n_threads,
+                                   pfv_gop_decoder **out);
+PFV_API int pfv_gop_decoder_width(const pfv_gop_decoder *d);
+PFV_API int pfv_gop_decoder_height(const pfv_gop_decoder *d);
+PFV_API int pfv_gop_decoder_framerate(const pfv_gop_decoder *d);
+PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d);
+/* Decoder::reset (src/dec.rs:148-152).  Like the reference's, it does not rewind the framebuffer; this decoder has decoded ahead of
+ * the frames it delivered, so a stream whose first packet is a p-frame continues from the last DECODED frame after a reset. */
+PFV_API int pfv_gop_decoder_reset(pfv_gop_decoder *d);
+PFV_API int pfv_gop_decoder_advance_frame(pfv_gop_decoder *d, pfv_video_cb onvideo, void *user);
+PFV_API int pfv_gop_decoder_advance_delta(pfv_gop_decoder *d, double delta, pfv_video_cb onvideo, void *user);
+PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d);
+
 /* packet payload serialisers alone (write_iframe_packet / write_pframe_packet bodies, src/enc.rs:237-320, 332-470);
  * return the payload size (0 on error); the payload is copied to `out` when it fits `cap` */
 PFV_API size_t pfv_serialize_iframe_payload(const int16_t *coef, int total_blocks, uint8_t *out, size_t cap);

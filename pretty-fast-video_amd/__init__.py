@@ -15,9 +15,9 @@ from .context import Context, Graph
 from .plane import VideoPlane, EncodedIPlane, EncodedPPlane
 from .frame import VideoFrame
 from .session import EncoderSession, DecoderSession, qtables_from_quality
-from .enc import BatchEncoder, Encoder
-from .dec import BatchDecoder, Decoder, DecodeError
+from .enc import BatchEncoder, Encoder, GopEncoder
+from .dec import BatchDecoder, Decoder, DecodeError, GopDecoder
 from .synth import SyntheticStream
 
 __all__ = ["Context", "Graph", "VideoPlane", "VideoFrame", "EncodedIPlane", "EncodedPPlane", "EncoderSession",
-           "DecoderSession", "Encoder", "BatchEncoder", "Decoder", "BatchDecoder", "DecodeError", "qtables_from_quality", "PfvError", "SyntheticStream", "_lib"]
+           "DecoderSession", "Encoder", "BatchEncoder", "GopEncoder", "Decoder", "BatchDecoder", "GopDecoder", "DecodeError", "qtables_from_quality", "PfvError", "SyntheticStream", "_lib"]

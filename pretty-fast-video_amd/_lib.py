@@ -155,6 +155,25 @@ SIGNATURES = [
     ("pfv_batch_decoder_dense_steps", ctypes.c_long, [_P]),
     ("pfv_batch_decoder_advance", c_int, [_P, POINTER(_P)]),
     ("pfv_batch_decoder_destroy", None, [_P]),
+    ("pfv_gop_encoder_create", c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_size_t, POINTER(_P)]),
+    ("pfv_gop_encoder_encode_iframe", c_int, [_P, _P, _P, _P]),
+    ("pfv_gop_encoder_encode_pframe", c_int, [_P, _P, _P, _P]),
+    ("pfv_gop_encoder_encode_dropframe", c_int, [_P]),
+    ("pfv_gop_encoder_flush", c_int, [_P]),
+    ("pfv_gop_encoder_finish", c_int, [_P]),
+    ("pfv_gop_encoder_drain", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
+    ("pfv_gop_encoder_bytes", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
+    ("pfv_gop_encoder_batches", ctypes.c_long, [_P]),
+    ("pfv_gop_encoder_destroy", None, [_P]),
+    ("pfv_gop_decoder_create", c_int, [_P, _P, c_size_t, c_int, c_int, c_int, POINTER(_P)]),
+    ("pfv_gop_decoder_width", c_int, [_P]),
+    ("pfv_gop_decoder_height", c_int, [_P]),
+    ("pfv_gop_decoder_framerate", c_int, [_P]),
+    ("pfv_gop_decoder_batches", ctypes.c_long, [_P]),
+    ("pfv_gop_decoder_reset", c_int, [_P]),
+    ("pfv_gop_decoder_advance_frame", c_int, [_P, _P, _P]),
+    ("pfv_gop_decoder_advance_delta", c_int, [_P, ctypes.c_double, _P, _P]),
+    ("pfv_gop_decoder_destroy", None, [_P]),
     ("pfv_serialize_iframe_payload", c_size_t, [_P, c_int, _P, c_size_t]),
     ("pfv_serialize_pframe_payload", c_size_t, [_P, _P, _P, c_int, _P, c_size_t]),
     ("pfv_parse_iframe_payload", c_int, [_P, c_size_t, c_int, c_int, _P, _P]),

@@ -118,6 +118,13 @@ class Context:
         self._pinned.append(p.value)
         return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(nbytes),))
 
+    def host_free(self, arr: np.ndarray):
+        """give a host_array() block back before the context closes (the array must not be used afterwards)"""
+        p = arr.ctypes.data
+        if p in self._pinned:
+            self._pinned.remove(p)
+            self.check(self._lib.pfv_host_free(self.handle, ctypes.c_void_p(p)))
+
     def upload(self, dst_dev: int, src: np.ndarray):
         src = np.ascontiguousarray(src)
         self.check(self._lib.pfv_dev_upload(self.handle, ctypes.c_void_p(dst_dev), src.ctypes.data_as(ctypes.c_void_p),

@@ -2884,6 +2884,8 @@ int pfv_selfcheck_float_path(pfv_ctx *ctx, int part, uint64_t arg, uint64_t *che
     return PFV_OK;
 }
 
+#include "pfv_gop.hip"    // GOP-batched stream objects (pfv_gop_encoder, pfv_gop_decoder)
+
 #include "pfv_comm.hip"   // multi-GPU control plane on RCCL (pfv_comm_*)
 
 #include "pfv_prof_host.h"   // experiment builds only: fetch the phase timestamps (empty in the shipped build)

@@ -725,4 +725,40 @@ __global__ void __launch_bounds__(kEntThreads) k_ent_gather(EntFrame f, EntBufs 
     for (uint32_t i = blockIdx.x * kEntThreads + threadIdx.x; i < n; i += gridDim.x * kEntThreads) dst[i] = src[i];
 }
 
+// ---------------------------------------------------------------------------------------------------- retained payloads
+// pfv_gop_encoder runs a whole batch of frame steps without a host round trip and collects the batch afterwards, so the payloads
+// of every step have to outlive the step: after the pack of a step ONE thread appends the payloads of the step's slots to a device
+// arena (16-byte aligned starts) -- entries[slot] = {offset, size}; an error marker, or a payload the arena has no room for, keeps
+// the marker as its size and nothing is copied -- and k_ent_gather_entries moves the bytes there.
+struct EntEntry {
+    unsigned long long offset;
+    uint32_t size;             // payload bytes, kEntErrOversize or kEntErrCapacity
+    uint32_t reserved;
+};
+__global__ void k_ent_retain(const uint32_t *sizes, int count, unsigned long long *cursor, unsigned long long cap, EntEntry *entries)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long cur = *cursor;
+    for (int k = 0; k < count; k++) {
+        EntEntry e{cur, sizes[k], 0u};
+        if (e.size < kEntErrCapacity) {
+            const unsigned long long need = ((unsigned long long)e.size + 15ull) & ~15ull;
+            if (cur + need > cap) e.size = kEntErrCapacity;
+            else cur += need;
+        }
+        entries[k] = e;
+    }
+    *cursor = cur;
+}
+__global__ void __launch_bounds__(kEntThreads) k_ent_gather_entries(EntFrame f, EntBufs b, const EntEntry *entries, uint8_t *arena)
+{
+    const int stream = (int)blockIdx.y;
+    const EntEntry e = entries[stream];
+    if (e.size >= kEntErrCapacity) return;
+    const uint4 *src = (const uint4 *)(b.payload + (size_t)stream * f.cap_bytes);
+    uint4 *dst = (uint4 *)(arena + e.offset);
+    const uint32_t n = (e.size + 15u) >> 4;
+    for (uint32_t i = blockIdx.x * kEntThreads + threadIdx.x; i < n; i += gridDim.x * kEntThreads) dst[i] = src[i];
+}
+
 }  // namespace pfv

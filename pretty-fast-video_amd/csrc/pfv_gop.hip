@@ -1,0 +1,841 @@
+// pfv_gop.hip -- GOP-batched stream objects (included by pfv_capi.hip; uses its sessions, PinnedBuf and the host parsers).
+//
+// enc::Encoder / dec::Decoder (src/enc.rs:12-188, src/dec.rs:15-224) for ONE stream, with the independent GOPs of the stream as the
+// slots of every launch.  encode_iframe never reads prev_frame and overwrites all three planes of it (src/enc.rs:84-97);
+// decode_plane_into overwrites the whole framebuffer (src/common.rs:477-496): the runs I P P ... of a stream share nothing, so frame
+// t of EVERY run of a batch goes through one launch per stage instead of one launch per frame.  A single 4K stream then fills the
+// device like 20 streams do (bench.py --workload config5: 0.97 G -> 1.39 G macroblocks/s at kernel scope).  The bytes written and the
+// frames delivered are those of the frame-by-frame objects (pfv_encoder / pfv_decoder); only WHEN they appear differs: a packet
+// leaves when its batch is complete.
+//
+//   batch        up to max_gops runs ("groups") of up to max_gop_frames frames; a group starts at an i-frame.  A run longer than
+//                max_gop_frames continues in slot 0 of the next batch (its reference frame is carried over, one device copy), and so
+//                does a stream that starts with p-frames (prev_frame = new_padded, src/enc.rs:46).
+//   frame step   t = 0 .. longest group - 1: the slots whose group has a frame t, as maximal runs of neighbouring slots of one frame
+//                type (normally ONE launch: all groups are equally long but the last).  The ping-pong index of the session
+//                flips once per step; a slot that sits a step out never reads its stale side (its next frame is an i-frame, or the
+//                state is copied explicitly: failed packets on the decoder side).
+#pragma once
+
+namespace {
+
+struct GopPacket {
+    uint8_t type;     // 1 i-frame, 2 p-frame, 3 drop frame (src/enc.rs:175-180)
+    int slot, t;
+};
+
+struct GopEncBatch {
+    std::vector<int> len;              // frames per group; slot = index
+    std::vector<uint8_t> first_type;   // 1: the group starts with an i-frame; 2: it continues a run (or the stream starts with p-frames)
+    std::vector<GopPacket> order;      // packets of the batch in stream order
+    bool in_flight = false;            // kernels enqueued, payloads not yet collected
+    int steps = 0;                     // frame steps enqueued (longest group)
+    uint8_t *frames_dev = nullptr;     // [max_gop_frames][max_gops][frame_bytes]
+    uint8_t *arena = nullptr;          // retained payloads of the batch
+    EntEntry *entries_dev = nullptr;   // [max_gop_frames][max_gops]
+    unsigned long long *cursor_dev = nullptr;
+    hipEvent_t ev_uploaded = nullptr, ev_done = nullptr;
+    void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; steps = 0; }
+    int frames() const { int n = 0; for (int l : len) n += l; return n; }
+};
+
+}  // namespace
+
+struct pfv_gop_encoder {
+    pfv_ctx *ctx = nullptr;
+    pfv_enc_session *hot = nullptr;
+    int width = 0, height = 0, max_gops = 0, max_len = 0;
+    size_t frame_bytes = 0, total_blocks = 0, arena_cap = 0;
+    GopEncBatch batch[2];
+    int cur = 0;                           // batch being filled
+    hipStream_t copy_stream = nullptr;
+    int16_t *coef = nullptr;               // encode outputs of one step, max_gops wide
+    int8_t *mv = nullptr;
+    uint8_t *has = nullptr;
+    bool cont_valid = false;               // a group is open across the batch boundary: where its prev_frame lives
+    int cont_buf = 0, cont_slot = 0;
+    PinnedBuf<EntEntry> entries_host;
+    PinnedBuf<uint8_t> payload_host;
+    unsigned long long *cursor_host = nullptr;   // page-locked
+    std::vector<uint8_t> out, drained;
+    bool finished = false, failed = false;
+    long frames_in = 0, batches = 0;
+};
+
+// ---- helpers of both objects
+template <class F>
+static void gop_runs(const std::vector<int> &key, F &&fn)   // maximal runs of equal non-negative keys over neighbouring slots
+{
+    const int n = (int)key.size();
+    for (int a = 0; a < n;) {
+        if (key[(size_t)a] < 0) { a++; continue; }
+        int b = a + 1;
+        while (b < n && key[(size_t)b] == key[(size_t)a]) b++;
+        fn(a, b - a, key[(size_t)a]);
+        a = b;
+    }
+}
+
+static void gop_put_header(std::vector<uint8_t> &o, int width, int height, int framerate, int quality)
+{
+    int32_t q[4][64];
+    pfv_qtables_from_quality(quality, q[0], q[1], q[2], q[3], nullptr);
+    static const char magic[8] = {'P', 'F', 'V', 'I', 'D', 'E', 'O', 0};      // common.rs:1
+    o.insert(o.end(), magic, magic + 8);
+    put_u32(o, 211);                                                           // common.rs:2
+    put_u16(o, (unsigned)width); put_u16(o, (unsigned)height); put_u16(o, (unsigned)framerate);
+    put_u16(o, 4);
+    for (int t = 0; t < 4; t++)                                                // intra_l, intra_c, inter_l, inter_c (enc.rs:199-215)
+        for (int i = 0; i < 64; i++) put_u16(o, (unsigned)q[t][i]);
+}
+
+// every frame step of a batch, enqueued without a host round trip
+static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
+{
+    pfv_ctx *ctx = e->ctx;
+    pfv_enc_session *s = e->hot;
+    const int G = (int)B.len.size();
+    if (G == 0 || B.in_flight) return PFV_OK;
+    HIP_TRY(ctx, hipEventRecord(B.ev_uploaded, e->copy_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, B.ev_uploaded, 0));
+    const size_t pad = (size_t)s->geom.pad_frame_bytes;
+    if (B.first_type[0] == 2 && e->cont_valid) {   // slot 0 continues the run the previous batch left open: carry its reference frame over
+        const uint8_t *src = s->prev[e->cont_buf] + (size_t)e->cont_slot * pad;
+        uint8_t *dst = s->prev[s->cur];
+        if (src != dst) HIP_TRY(ctx, hipMemcpyAsync(dst, src, pad, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(B.cursor_dev, 0, sizeof(unsigned long long), ctx->stream));
+    int steps = 0;
+    for (int l : B.len) steps = std::max(steps, l);
+    const int cur0 = s->cur;
+    std::vector<int> key((size_t)G);
+    EntFrame f{};
+    f.cap_bytes = s->ent_cap;
+    for (int t = 0; t < steps; t++) {
+        for (int k = 0; k < G; k++) key[(size_t)k] = B.len[(size_t)k] > t ? (t == 0 ? B.first_type[(size_t)k] : 2) : -1;
+        const uint8_t *frames_t = B.frames_dev + (size_t)t * (size_t)e->max_gops * e->frame_bytes;
+        int rc = PFV_OK;
+        gop_runs(key, [&](int first, int count, int type) {
+            if (!rc) rc = enc_launch(s, type == 2, first, count, frames_t, e->mv, e->has, e->coef);
+            if (!rc) rc = ent_pack_win(s, type == 2, first, count, e->mv, e->has, e->coef);
+            if (rc) return;
+            EntEntry *ent = B.entries_dev + (size_t)t * (size_t)e->max_gops + (size_t)first;
+            EntBufs b = s->ent;
+            b.sizes += first;
+            b.payload += (size_t)first * (size_t)s->ent_cap;
+            hipLaunchKernelGGL(k_ent_retain, dim3(1), dim3(64), 0, ctx->stream, b.sizes, count, B.cursor_dev, (unsigned long long)e->arena_cap, ent);
+            f.n_streams = count;
+            hipLaunchKernelGGL(k_ent_gather_entries, dim3(32, (unsigned)count), dim3(kEntThreads), 0, ctx->stream, f, b, ent, B.arena);
+            rc = launch_check(ctx, "k_ent_retain / k_ent_gather_entries");
+        });
+        if (rc) return rc;
+        s->cur ^= 1;
+    }
+    // the last group may go on in the next batch: its reference frame is in the buffer its last step wrote
+    e->cont_valid = true;
+    e->cont_slot = G - 1;
+    e->cont_buf = (cur0 + B.len[(size_t)G - 1]) & 1;
+    HIP_TRY(ctx, hipEventRecord(B.ev_done, ctx->stream));
+    B.steps = steps;
+    B.in_flight = true;
+    e->batches++;
+    return PFV_OK;
+}
+
+// wait for a batch, bring its payloads over and write its packets in stream order
+static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
+{
+    pfv_ctx *ctx = e->ctx;
+    if (!B.in_flight) {   // nothing was encoded: only drop frames can be pending
+        for (const GopPacket &p : B.order)
+            if (p.type == 3) put_packet(e->out, 1, nullptr);
+        B.clear();
+        return PFV_OK;
+    }
+    const size_t n_ent = (size_t)B.steps * (size_t)e->max_gops;
+    // the batch is complete on the device; its results come over on the copy stream (idle: every upload was waited for), NOT behind
+    // the kernels of the next batch, which may already be queued on the context's stream
+    HIP_TRY(ctx, hipEventSynchronize(B.ev_done));
+    HIP_TRY(ctx, hipMemcpyAsync(e->entries_host.data(), B.entries_dev, n_ent * sizeof(EntEntry), hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(e->cursor_host, B.cursor_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
+    const size_t used = (size_t)*e->cursor_host;
+    int rc = PFV_OK;
+    for (const GopPacket &p : B.order) {
+        if (p.type == 3) continue;
+        const uint32_t sz = e->entries_host.data()[(size_t)p.t * (size_t)e->max_gops + (size_t)p.slot].size;
+        if (sz == kEntErrOversize) rc = PFV_ERR_FORMAT;
+        else if (sz == kEntErrCapacity && rc == PFV_OK) rc = PFV_ERR_NOMEM;
+    }
+    if (rc) {
+        e->failed = true;
+        return fail(ctx, rc, rc == PFV_ERR_FORMAT ? "coefficient needs more than 15 size bits (src/rle.rs:44)"
+                                                  : "the batch's packet payloads exceed the payload budget given to pfv_gop_encoder_create");
+    }
+    if (!e->payload_host.resize(std::max<size_t>(used, 1 << 20))) { e->failed = true; return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging"); }
+    if (used) {
+        HIP_TRY(ctx, hipMemcpyAsync(e->payload_host.data(), B.arena, used, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
+    }
+    for (const GopPacket &p : B.order) {
+        if (p.type == 3) { put_packet(e->out, 1, nullptr); continue; }   // src/enc.rs:175-180
+        const EntEntry &en = e->entries_host.data()[(size_t)p.t * (size_t)e->max_gops + (size_t)p.slot];
+        e->out.push_back(p.type);                                         // packet header (src/enc.rs:301-305, :453-457)
+        put_u32(e->out, en.size);
+        e->out.insert(e->out.end(), e->payload_host.data() + en.offset, e->payload_host.data() + en.offset + en.size);
+    }
+    B.clear();
+    return PFV_OK;
+}
+
+// the batch being filled is complete: enqueue it, turn to the other one (collecting what it still holds)
+static int gop_enc_rotate(pfv_gop_encoder *e)
+{
+    int rc = gop_enc_submit(e, e->batch[e->cur]);
+    if (rc) { e->failed = true; return rc; }
+    e->cur ^= 1;
+    return gop_enc_collect(e, e->batch[e->cur]);
+}
+
+static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+static int gop_enc_frame(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    pfv_ctx *ctx = e->ctx;
+    if (!y || !u || !v) return fail(ctx, PFV_ERR_BAD_ARG, "null plane");
+    if (e->finished) return fail(ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:80)");
+    if (e->failed) return fail(ctx, PFV_ERR_STATE, "an earlier batch failed: the stream is incomplete");
+    const int rc = gop_enc_frame_inner(e, type, y, u, v);
+    if (rc) e->failed = true;          // a frame is missing from the stream from here on (the reference's Encoder would have panicked)
+    return rc;
+}
+static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+{
+    pfv_ctx *ctx = e->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    GopEncBatch *B = &e->batch[e->cur];
+    int rc = PFV_OK;
+    if (type == 1) {
+        if ((int)B->len.size() == e->max_gops) { if ((rc = gop_enc_rotate(e))) return rc; B = &e->batch[e->cur]; }
+        B->len.push_back(0); B->first_type.push_back(1);
+    } else if (B->len.empty() || B->len.back() == e->max_len) {
+        // a p-frame with no open group in this batch: the run continues from the previous batch (or the stream starts with p-frames)
+        if (!B->len.empty()) { if ((rc = gop_enc_rotate(e))) return rc; B = &e->batch[e->cur]; }
+        B->len.push_back(0); B->first_type.push_back(2);
+    }
+    const int slot = (int)B->len.size() - 1, t = B->len.back()++;
+    // the three planes go straight to their place in the step's frame array (VideoFrame, src/frame.rs:3-9: no packing on the host)
+    uint8_t *dst = B->frames_dev + ((size_t)t * (size_t)e->max_gops + (size_t)slot) * e->frame_bytes;
+    const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst + ny, u, nc, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst + ny + nc, v, nc, hipMemcpyHostToDevice, e->copy_stream));
+    B->order.push_back(GopPacket{(uint8_t)type, slot, t});
+    e->frames_in++;
+    // the caller's planes are free again when the call returns (they are being read by the copy engine until then; the kernels of the
+    // previous batch run underneath)
+    HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
+    return PFV_OK;
+}
+
+extern "C" {
+
+PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
+{
+    if (!e) return;
+    pfv_ctx *ctx = e->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    for (GopEncBatch &B : e->batch) {
+        if (B.frames_dev) (void)hipFree(B.frames_dev);
+        if (B.arena) (void)hipFree(B.arena);
+        if (B.entries_dev) (void)hipFree(B.entries_dev);
+        if (B.cursor_dev) (void)hipFree(B.cursor_dev);
+        if (B.ev_uploaded) (void)hipEventDestroy(B.ev_uploaded);
+        if (B.ev_done) (void)hipEventDestroy(B.ev_done);
+    }
+    if (e->coef) (void)hipFree(e->coef);
+    if (e->mv) (void)hipFree(e->mv);
+    if (e->has) (void)hipFree(e->has);
+    if (e->cursor_host) (void)hipHostFree(e->cursor_host);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    pfv_enc_session_destroy(e->hot);
+    delete e;
+}
+
+// Encoder::new (src/enc.rs:37-73) + the batch shape.  max_gops: groups per batch = slots per launch; max_gop_frames: frames a group may
+// have inside one batch (a longer run continues in the next batch); payload_budget: bytes of device memory for the packet payloads of
+// ONE batch (0: the batch's raw frame bytes, at least 16 MiB) -- a batch whose payloads exceed it fails with PFV_ERR_NOMEM.
+PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int max_gops, int max_gop_frames,
+                                   size_t payload_budget, pfv_gop_encoder **out)
+{
+    if (!ctx || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_gop_encoder_create: bad argument");
+    *out = nullptr;
+    if (framerate < 0 || framerate > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "framerate must fit u16 (src/enc.rs:197)");
+    if (max_gops <= 0 || max_gop_frames <= 0 || max_gops > 4096 || max_gop_frames > 4096)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_gop_encoder_create: max_gops and max_gop_frames must be in 1..4096");
+    pfv_enc_session *hot = nullptr;
+    int rc = pfv_enc_session_create(ctx, width, height, quality, max_gops, &hot);
+    if (rc) return rc;
+    pfv_gop_encoder *e = new pfv_gop_encoder();
+    e->ctx = ctx; e->hot = hot; e->width = width; e->height = height; e->max_gops = max_gops; e->max_len = max_gop_frames;
+    e->frame_bytes = pfv_frame_bytes(width, height);
+    e->total_blocks = (size_t)pfv_total_blocks(width, height);
+    const size_t cap_frames = (size_t)max_gops * (size_t)max_gop_frames, nmb = (size_t)max_gops * e->total_blocks;
+    e->arena_cap = payload_budget ? payload_budget : std::max<size_t>(cap_frames * e->frame_bytes, (size_t)16 << 20);
+    e->arena_cap = (e->arena_cap + 15) & ~(size_t)15;
+    hipError_t he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+    for (GopEncBatch &B : e->batch) {
+        if (he == hipSuccess) he = hipMalloc((void **)&B.frames_dev, cap_frames * e->frame_bytes);
+        if (he == hipSuccess) he = hipMalloc((void **)&B.arena, e->arena_cap);
+        if (he == hipSuccess) he = hipMalloc((void **)&B.entries_dev, cap_frames * sizeof(EntEntry));
+        if (he == hipSuccess) he = hipMalloc((void **)&B.cursor_dev, sizeof(unsigned long long));
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&B.ev_uploaded, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&B.ev_done, hipEventDisableTiming);
+    }
+    if (he == hipSuccess) he = hipMalloc((void **)&e->coef, nmb * 512);
+    if (he == hipSuccess) he = hipMalloc((void **)&e->mv, nmb * 2);
+    if (he == hipSuccess) he = hipMalloc((void **)&e->has, nmb);
+    if (he == hipSuccess) he = hipHostMalloc((void **)&e->cursor_host, sizeof(unsigned long long), hipHostMallocDefault);
+    if (he != hipSuccess) {
+        rc = hip_fail(ctx, he, "pfv_gop_encoder_create");
+        pfv_gop_encoder_destroy(e);
+        return rc;
+    }
+    rc = pfv_enc_entropy_enable(hot, 0);
+    if (!rc && !e->entries_host.resize(cap_frames)) rc = fail(ctx, PFV_ERR_NOMEM, "pinned staging");
+    if (rc) { pfv_gop_encoder_destroy(e); return rc; }
+    gop_put_header(e->out, width, height, framerate, quality);               // write_header (src/enc.rs:190-219)
+    *out = e;
+    return PFV_OK;
+}
+
+// Encoder::encode_iframe / encode_pframe / encode_dropframe (src/enc.rs:75-123, 125-173, 175-180).  The planes may be reused as soon
+// as the call returns; the packet appears (pfv_gop_encoder_drain) when its batch is complete -- pfv_gop_encoder_flush forces that.
+PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v) { return gop_enc_frame(e, 1, y, u, v); }
+PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v) { return gop_enc_frame(e, 2, y, u, v); }
+PFV_API int pfv_gop_encoder_encode_dropframe(pfv_gop_encoder *e)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    if (e->finished) return fail(e->ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:176)");
+    if (e->failed) return fail(e->ctx, PFV_ERR_STATE, "an earlier batch failed: the stream is incomplete");
+    e->batch[e->cur].order.push_back(GopPacket{3, 0, 0});
+    return PFV_OK;
+}
+// every frame handed over so far becomes packets now (both batches, in stream order)
+PFV_API int pfv_gop_encoder_flush(pfv_gop_encoder *e)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    if (e->failed) return fail(e->ctx, PFV_ERR_STATE, "an earlier batch failed: the stream is incomplete");
+    pfv_ctx *ctx = e->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = gop_enc_collect(e, e->batch[e->cur ^ 1]);       // the older batch first
+    if (!rc) rc = gop_enc_submit(e, e->batch[e->cur]);
+    if (!rc) rc = gop_enc_collect(e, e->batch[e->cur]);
+    if (rc) e->failed = true;
+    return rc;
+}
+// Encoder::finish (src/enc.rs:182-188)
+PFV_API int pfv_gop_encoder_finish(pfv_gop_encoder *e)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    if (e->finished) return fail(e->ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:183)");
+    int rc = pfv_gop_encoder_flush(e);
+    if (rc) return rc;
+    e->finished = true;
+    put_packet(e->out, 0, nullptr);
+    return PFV_OK;
+}
+PFV_API int pfv_gop_encoder_bytes(pfv_gop_encoder *e, const uint8_t **data, size_t *len)
+{
+    if (!e || !data || !len) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_bytes: bad argument");
+    *data = e->out.data();
+    *len = e->out.size();
+    return PFV_OK;
+}
+PFV_API int pfv_gop_encoder_drain(pfv_gop_encoder *e, const uint8_t **data, size_t *len)
+{
+    if (!e || !data || !len) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_drain: bad argument");
+    e->drained.swap(e->out);
+    e->out.clear();
+    *data = e->drained.data();
+    *len = e->drained.size();
+    return PFV_OK;
+}
+/* launches of the frame-encode kernel so far would be frames_in for the serial object; here: */
+PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e) { return e ? e->batches : 0; }
+
+}  // extern "C"
+
+// ================================================================== GOP-batched decoder
+namespace {
+
+struct GopDecEvent {
+    enum Kind { FRAME, DROP, END, ERROR } kind = END;
+    int rc = 0;                          // ERROR: status; FRAME: parse / decode status (set while the batch is decoded)
+    const char *msg = "";
+    uint8_t type = 0;                    // FRAME: 1 / 2
+    int slot = 0, t = 0;
+    const uint8_t *payload = nullptr;
+    uint32_t plen = 0;
+    size_t pos_after = 0;
+};
+
+struct GopDecSet {   // host staging of one frame step (two alternate: the parse of step t + 1 runs under the device work of step t)
+    PinnedBuf<uint32_t> idx;
+    PinnedBuf<int16_t> val;
+    PinnedBuf<uint32_t> counts;
+    PinnedBuf<int8_t> mv;
+    PinnedBuf<uint8_t> has;
+    PinnedBuf<int> flags;                // bad-motion-vector flags of the step, one per slot
+    std::vector<int> rc;                 // per slot: parse status (kSinkFull: dense fallback)
+    std::vector<uint8_t> qidx;           // per slot x 3
+    std::vector<GopDecEvent *> ev;       // per slot: the packet of this step, or null
+    hipEvent_t done = nullptr;           // the device has finished reading this set
+    bool used = false;
+};
+
+}  // namespace
+
+struct pfv_gop_decoder {
+    pfv_ctx *ctx = nullptr;
+    pfv_dec_session *hot = nullptr;
+    const uint8_t *data = nullptr;
+    size_t len = 0, pos = 0, reset_pos = 0;
+    int width = 0, height = 0, framerate = 0, n_qtables = 0, max_gops = 0, max_len = 0;
+    size_t total_blocks = 0, frame_bytes = 0, cap = 0;
+    bool eof = false;
+    double delta_accum = 0.0;
+    // the current batch
+    std::vector<GopDecEvent> events;     // stream order
+    size_t next_event = 0;
+    std::vector<int> glen;               // frames per group
+    std::vector<uint8_t> gfirst;         // type of the group's first frame
+    bool cont_valid = false;
+    int cont_buf = 0, cont_slot = 0;     // where the framebuffer of the previous batch's last group lives (buffer, slot)
+    GopDecSet set[2];
+    PinnedBuf<int16_t> dense;            // one slot's coefficients when its list overflowed
+    PinnedBuf<uint8_t> frames_host;      // [max_gop_frames][max_gops][frame_bytes]: the decoded frames of the batch
+    uint8_t *frames_dev = nullptr;       // [max_gops][frame_bytes]
+    long batches = 0, dense_packets = 0;
+    // worker pool: the packets of a step are parsed in parallel (one task per slot)
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    GopDecSet *job = nullptr;
+    int next = 0, done = 0, n_tasks = 0, generation = 0;
+    bool quit = false;
+};
+
+static void gopd_parse_one(pfv_gop_decoder *d, GopDecSet *s, int k)
+{
+    GopDecEvent *e = s->ev[(size_t)k];
+    s->counts.data()[k] = 0;
+    if (!e) { s->rc[(size_t)k] = 0; return; }
+    const size_t tb = d->total_blocks;
+    SparseSink sink{s->idx.data() + (size_t)k * d->cap, s->val.data() + (size_t)k * d->cap, d->cap};
+    sink.offset = (size_t)k * tb * 256;
+    uint8_t *q = &s->qidx[(size_t)k * 3];
+    const int rc = e->type == 2 ? parse_pframe_to(e->payload, e->plen, (int)tb, d->n_qtables, s->mv.data() + (size_t)k * tb * 2,
+                                                  s->has.data() + (size_t)k * tb, sink, q)
+                                : parse_iframe_to(e->payload, e->plen, (int)tb, d->n_qtables, sink, q);
+    s->counts.data()[k] = rc == 0 ? (uint32_t)sink.n : 0u;
+    s->rc[(size_t)k] = rc;
+}
+static void gopd_worker(pfv_gop_decoder *d)
+{
+    std::unique_lock<std::mutex> lk(d->m);
+    int seen = 0;
+    for (;;) {
+        d->cv_work.wait(lk, [&] { return d->quit || d->generation != seen; });
+        if (d->quit) return;
+        seen = d->generation;
+        GopDecSet *s = d->job;
+        while (s && d->job == s && d->next < d->n_tasks) {
+            const int k = d->next++;
+            lk.unlock();
+            gopd_parse_one(d, s, k);
+            lk.lock();
+            if (++d->done == d->n_tasks) d->cv_done.notify_all();
+        }
+    }
+}
+static void gopd_start_parse(pfv_gop_decoder *d, GopDecSet *s, int n_tasks)
+{
+    std::lock_guard<std::mutex> lk(d->m);
+    d->job = s; d->next = 0; d->done = 0; d->n_tasks = n_tasks; d->generation++;
+    d->cv_work.notify_all();
+}
+static void gopd_join_parse(pfv_gop_decoder *d, GopDecSet *s)
+{
+    std::unique_lock<std::mutex> lk(d->m);
+    while (d->job == s && d->next < d->n_tasks) {     // the caller helps (and is the whole pool when there are no workers)
+        const int k = d->next++;
+        lk.unlock();
+        gopd_parse_one(d, s, k);
+        lk.lock();
+        ++d->done;
+    }
+    d->cv_done.wait(lk, [&] { return d->done >= d->n_tasks; });
+    d->job = nullptr;
+}
+
+// Walks the packet headers from d->pos exactly as the reference's loop does (src/dec.rs:174-222) and cuts the next batch: up to
+// max_gops groups of up to max_gop_frames frame packets, a group per i-frame.
+static void gopd_scan_batch(pfv_gop_decoder *d)
+{
+    d->events.clear(); d->next_event = 0; d->glen.clear(); d->gfirst.clear();
+    size_t pos = d->pos;
+    auto push = [&](GopDecEvent::Kind kind, size_t pos_after) -> GopDecEvent & {
+        d->events.emplace_back();
+        GopDecEvent &e = d->events.back();
+        e.kind = kind; e.pos_after = pos_after;
+        return e;
+    };
+    for (;;) {
+        if (pos + 5 > d->len) {
+            GopDecEvent &e = push(GopDecEvent::ERROR, pos);
+            e.rc = PFV_ERR_IO; e.msg = "unexpected end of stream in a packet header";
+            break;
+        }
+        const uint8_t type = d->data[pos];
+        const uint32_t plen = (uint32_t)d->data[pos + 1] | ((uint32_t)d->data[pos + 2] << 8) | ((uint32_t)d->data[pos + 3] << 16) |
+                              ((uint32_t)d->data[pos + 4] << 24);
+        if (type == 0) { push(GopDecEvent::END, pos + 5); break; }                  // EOF marker (:183-187)
+        if (pos + 5 + (size_t)plen > d->len) {
+            GopDecEvent &e = push(GopDecEvent::ERROR, pos + 5);
+            e.rc = PFV_ERR_IO; e.msg = "packet payload runs past the end of the stream";
+            break;
+        }
+        const size_t after = pos + 5 + (size_t)plen;
+        if (type != 1 && type != 2) { pos = after; continue; }                      // unknown packet: skipped (:216-219)
+        if (type == 1 && plen == 0) { push(GopDecEvent::DROP, after); pos = after; continue; }   // drop frame (:190)
+        if (type == 1) {
+            if ((int)d->glen.size() == d->max_gops) break;                          // the next batch starts here
+            d->glen.push_back(0); d->gfirst.push_back(1);
+        } else if (d->glen.empty() || d->glen.back() == d->max_len) {
+            if (!d->glen.empty()) break;                                            // a run longer than a batch holds: it continues in the next one
+            d->glen.push_back(0); d->gfirst.push_back(2);
+        }
+        GopDecEvent &e = push(GopDecEvent::FRAME, after);
+        e.type = type; e.payload = d->data + pos + 5; e.plen = plen;
+        e.slot = (int)d->glen.size() - 1; e.t = d->glen.back()++;
+        pos = after;
+    }
+}
+
+// decode every frame packet of the scanned batch; the frames land in frames_host[step][slot]
+static int gopd_decode_batch(pfv_gop_decoder *d)
+{
+    pfv_ctx *ctx = d->ctx;
+    pfv_dec_session *hot = d->hot;
+    const int G = (int)d->glen.size();
+    if (G == 0) return PFV_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t tb = d->total_blocks, pad = (size_t)hot->geom.pad_frame_bytes, fbytes = d->frame_bytes;
+    static const char *kBadPayload = "malformed packet payload", *kBadMv = "motion vector points outside the reference plane (src/common.rs:258-259)";
+
+    // chains: the frame packets a slot decodes one after the other.  To begin with, chain k = group k.
+    std::vector<std::vector<GopDecEvent *>> chain((size_t)G);
+    for (GopDecEvent &e : d->events)
+        if (e.kind == GopDecEvent::FRAME) { e.rc = 0; chain[(size_t)e.slot].push_back(&e); }
+    auto wait_set = [&](GopDecSet &s) -> int {   // the device may still be reading the set's lists; then attribute the step's flags
+        if (!s.used) return PFV_OK;
+        HIP_TRY(ctx, hipEventSynchronize(s.done));
+        for (int k = 0; k < G; k++)
+            if (s.flags.data()[k] && s.ev[(size_t)k] && !s.ev[(size_t)k]->rc) { s.ev[(size_t)k]->rc = PFV_ERR_BAD_MV; s.ev[(size_t)k]->msg = kBadMv; }
+        s.used = false;
+        return PFV_OK;
+    };
+    auto fill = [&](GopDecSet &s, int t) {
+        for (int k = 0; k < G; k++) s.ev[(size_t)k] = (int)chain[(size_t)k].size() > t ? chain[(size_t)k][(size_t)t] : nullptr;
+    };
+    // status of a parsed packet: 0 (kSinkFull counts: it is parsed again into the dense form) or the error it is delivered with
+    auto status = [&](const GopDecSet &s, int k) -> int {
+        int prc = s.rc[(size_t)k];
+        if (prc == kSinkFull) prc = 0;
+        const uint8_t *q = &s.qidx[(size_t)k * 3];
+        if (!prc)
+            for (int i = 0; i < 3; i++)
+                if (q[i] >= hot->n_qtables) prc = PFV_ERR_FORMAT;              // the reference panics (src/dec.rs:249-251)
+        return prc;
+    };
+    int rc = wait_set(d->set[0]);
+    if (!rc) rc = wait_set(d->set[1]);
+    if (rc) return rc;
+
+    // step 0 is parsed before anything runs: a group whose i-frame does not parse is no independent run -- the sequential loop
+    // leaves the framebuffer alone and applies the group's p-frames to what the PREVIOUS group left (src/dec.rs:188-214).  Such a
+    // group is appended to the chain of the slot before it (slot 0: it continues the run of the previous batch).
+    fill(d->set[0], 0);
+    gopd_start_parse(d, &d->set[0], G);
+    gopd_join_parse(d, &d->set[0]);
+    bool reparse = false, head_continues = d->gfirst[0] == 2;
+    int last_root = G - 1;
+    {
+        std::vector<int> root((size_t)G);
+        for (int k = 0; k < G; k++) {
+            root[(size_t)k] = k;
+            GopDecEvent *e0 = chain[(size_t)k].empty() ? nullptr : chain[(size_t)k][0];
+            if (!e0 || e0->type != 1) continue;
+            const int prc = status(d->set[0], k);
+            if (!prc) continue;
+            e0->rc = prc; e0->msg = kBadPayload;
+            reparse = true;
+            const int r = k == 0 ? 0 : root[(size_t)k - 1];
+            root[(size_t)k] = r;
+            std::vector<GopDecEvent *> rest(chain[(size_t)k].begin() + 1, chain[(size_t)k].end());
+            if (k == 0) { chain[0] = rest; head_continues = true; }
+            else { chain[(size_t)k].clear(); chain[(size_t)r].insert(chain[(size_t)r].end(), rest.begin(), rest.end()); }
+        }
+        last_root = root[(size_t)G - 1];
+    }
+    int steps = 0;
+    for (int k = 0; k < G; k++) {
+        steps = std::max(steps, (int)chain[(size_t)k].size());
+        for (size_t t = 0; t < chain[(size_t)k].size(); t++) { chain[(size_t)k][t]->slot = k; chain[(size_t)k][t]->t = (int)t; }
+    }
+    if (head_continues && d->cont_valid) {   // slot 0 continues the run the previous batch left open
+        const uint8_t *src = hot->fb[d->cont_buf] + (size_t)d->cont_slot * pad;
+        uint8_t *dst = hot->fb[hot->cur];
+        if (src != dst) HIP_TRY(ctx, hipMemcpyAsync(dst, src, pad, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // merged chains may be longer than a group
+    if (!d->frames_host.resize((size_t)std::max(steps, 1) * (size_t)d->max_gops * fbytes)) return fail(ctx, PFV_ERR_NOMEM, "pinned frame staging");
+    const int cur0 = hot->cur;
+    if (reparse && steps > 0) {              // the chains moved: step 0 is something else now
+        fill(d->set[0], 0);
+        gopd_start_parse(d, &d->set[0], G);
+    }
+    std::vector<int> key((size_t)G);
+    std::vector<uint32_t> combos;            // distinct (frame type, q-table indices) of a step -> launch key
+    for (int t = 0; t < steps; t++) {
+        GopDecSet &s = d->set[t & 1];
+        if (t > 0 || reparse) gopd_join_parse(d, &s);
+        if (t + 1 < steps) {                      // parse of step t + 1 under the device work of step t
+            GopDecSet &n = d->set[(t + 1) & 1];
+            if ((rc = wait_set(n))) return rc;
+            fill(n, t + 1);
+            gopd_start_parse(d, &n, G);
+        }
+        // what runs: the packets that parsed.  A failed packet changes nothing (its error surfaces when the frame is delivered), but its
+        // slot's framebuffer has to follow the ping-pong for the frames behind it.
+        bool any_dense = false;
+        combos.clear();
+        for (int k = 0; k < G; k++) {
+            GopDecEvent *e = s.ev[(size_t)k];
+            key[(size_t)k] = -1;
+            if (!e) continue;
+            const int prc = status(s, k);
+            if (prc) {
+                e->rc = prc; e->msg = kBadPayload;
+                HIP_TRY(ctx, hipMemcpyAsync(hot->fb[hot->cur ^ 1] + (size_t)k * pad, hot->fb[hot->cur] + (size_t)k * pad, pad, hipMemcpyDeviceToDevice, ctx->stream));
+                continue;
+            }
+            any_dense = any_dense || s.rc[(size_t)k] == kSinkFull;
+            const uint8_t *q = &s.qidx[(size_t)k * 3];
+            const uint32_t c = (uint32_t)e->type | ((uint32_t)q[0] << 8) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 24);
+            size_t ci = 0;
+            while (ci < combos.size() && combos[ci] != c) ci++;
+            if (ci == combos.size()) combos.push_back(c);
+            key[(size_t)k] = (int)ci;
+        }
+        const size_t total = tb * (size_t)G * 256;
+        HIP_TRY(ctx, hipMemsetAsync(hot->st_coef, 0, total * 2, ctx->stream));
+        hipLaunchKernelGGL(k_scatter_coef_seg, dim3(64, (unsigned)G), dim3(kThreads), 0, ctx->stream, s.idx.data(), s.val.data(), s.counts.data(),
+                           (uint32_t)d->cap, (uint32_t)total, hot->st_coef);
+        if ((rc = launch_check(ctx, "k_scatter_coef_seg"))) return rc;
+        if (any_dense) {   // a list overflowed (denser than 1 non-zero in 4): that packet again, into the dense form, on this thread
+            for (int k = 0; k < G; k++) {
+                GopDecEvent *e = s.ev[(size_t)k];
+                if (!e || s.rc[(size_t)k] != kSinkFull || key[(size_t)k] < 0) continue;
+                d->dense_packets++;
+                if (!d->dense.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));        // the previous user of the dense buffer
+                memset(d->dense.data(), 0, tb * 512);
+                DenseSink sink{d->dense.data()};
+                uint8_t q[3];
+                const int prc = e->type == 2 ? parse_pframe_to(e->payload, e->plen, (int)tb, d->n_qtables, s.mv.data() + (size_t)k * tb * 2,
+                                                               s.has.data() + (size_t)k * tb, sink, q)
+                                             : parse_iframe_to(e->payload, e->plen, (int)tb, d->n_qtables, sink, q);
+                if (prc) {
+                    e->rc = prc; e->msg = kBadPayload; key[(size_t)k] = -1;
+                    HIP_TRY(ctx, hipMemcpyAsync(hot->fb[hot->cur ^ 1] + (size_t)k * pad, hot->fb[hot->cur] + (size_t)k * pad, pad, hipMemcpyDeviceToDevice, ctx->stream));
+                    continue;
+                }
+                HIP_TRY(ctx, hipMemcpyAsync(hot->st_coef + (size_t)k * tb * 256, d->dense.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_mv, s.mv.data(), (size_t)G * tb * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_has, s.has.data(), (size_t)G * tb, hipMemcpyHostToDevice, ctx->stream));
+        rc = PFV_OK;
+        gop_runs(key, [&](int first, int count, int ci) {
+            if (rc) return;
+            const uint32_t c = combos[(size_t)ci];
+            const uint8_t q[3] = {(uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24)};
+            rc = dec_launch(hot, (c & 0xffu) == 2, first, count, hot->st_mv, hot->st_has, hot->st_coef, q);
+            if (!rc && !fused_output_ok(hot)) {        // geometries without 16-byte rows: the separate crop pass, on the buffer just written
+                hot->cur ^= 1;
+                rc = dec_crop_win(hot, first, count, d->frames_dev, 0);
+                hot->cur ^= 1;
+            }
+            if (!rc && hipMemcpyAsync(d->frames_host.data() + ((size_t)t * (size_t)d->max_gops + (size_t)first) * fbytes, d->frames_dev + (size_t)first * fbytes,
+                                      (size_t)count * fbytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                rc = fail(ctx, PFV_ERR_HIP, "retframe download");
+        });
+        if (rc) return rc;
+        hot->cur ^= 1;
+        HIP_TRY(ctx, hipMemcpyAsync(s.flags.data(), hot->flag_dev, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(hot->flag_dev, 0, (size_t)G * sizeof(int), ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
+        s.used = true;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = wait_set(d->set[0])) || (rc = wait_set(d->set[1]))) return rc;
+    // the run of the last group may go on in the next batch: its framebuffer is in the buffer its chain's last step wrote
+    d->cont_valid = true;
+    d->cont_slot = last_root;
+    d->cont_buf = (cur0 + (int)chain[(size_t)last_root].size()) & 1;
+    d->batches++;
+    return PFV_OK;
+}
+
+extern "C" {
+
+PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d)
+{
+    if (!d) return;
+    {
+        std::lock_guard<std::mutex> lk(d->m);
+        d->quit = true;
+        d->cv_work.notify_all();
+    }
+    for (auto &t : d->workers) t.join();
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    for (GopDecSet &s : d->set)
+        if (s.done) (void)hipEventDestroy(s.done);
+    if (d->frames_dev) (void)hipFree(d->frames_dev);
+    pfv_dec_session_destroy(d->hot);
+    delete d;
+}
+
+// Decoder::new (src/dec.rs:38-134) + the batch shape (see pfv_gop_encoder_create); n_threads: packet parsers besides the calling thread.
+PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, int max_gops, int max_gop_frames, int n_threads,
+                                   pfv_gop_decoder **out)
+{
+    if (!ctx || !data || !out) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_gop_decoder_create: bad argument");
+    *out = nullptr;
+    if (max_gops <= 0 || max_gop_frames <= 0 || max_gops > 4096 || max_gop_frames > 4096 || n_threads < 0 || n_threads > 256)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_gop_decoder_create: max_gops and max_gop_frames must be in 1..4096, n_threads in 0..256");
+    static const char magic[8] = {'P', 'F', 'V', 'I', 'D', 'E', 'O', 0};
+    if (len < 8) return fail(ctx, PFV_ERR_IO, "stream shorter than the magic (DecodeError::IOError)");
+    if (memcmp(data, magic, 8) != 0) return fail(ctx, PFV_ERR_FORMAT, "bad magic (DecodeError::FormatError, src/dec.rs:50-52)");
+    if (len < 12) return fail(ctx, PFV_ERR_IO, "truncated header");
+    const uint32_t ver = (uint32_t)data[8] | ((uint32_t)data[9] << 8) | ((uint32_t)data[10] << 16) | ((uint32_t)data[11] << 24);
+    if (ver != 211) return fail(ctx, PFV_ERR_VERSION, "codec version is not 2.1.1 (DecodeError::VersionError, src/dec.rs:57-59)");
+    if (len < 20) return fail(ctx, PFV_ERR_IO, "truncated header");
+    auto u16 = [&](size_t o) { return (int)data[o] | ((int)data[o + 1] << 8); };
+    const int w = u16(12), h = u16(14), fps = u16(16), nq = u16(18);
+    if (len < 20 + (size_t)nq * 128) return fail(ctx, PFV_ERR_IO, "truncated q-tables");
+    std::vector<int32_t> q((size_t)std::max(nq, 1) * 64, 1);
+    for (int i = 0; i < nq * 64; i++) q[(size_t)i] = u16(20 + 2 * (size_t)i);
+    if (w > 0 && h > 0 && !(w & 1) && !(h & 1) && (uint64_t)max_gops * (uint64_t)pfv_total_blocks(w, h) * 256u > 0xffffffffull)
+        return fail(ctx, PFV_ERR_BAD_ARG, "pfv_gop_decoder_create: max_gops x macroblocks x 256 exceeds the 32-bit coefficient index");
+    pfv_dec_session *hot = nullptr;
+    int rc = pfv_dec_session_create(ctx, w, h, q.data(), nq, max_gops, &hot);
+    if (rc) return rc;
+    pfv_gop_decoder *d = new pfv_gop_decoder();
+    d->ctx = ctx; d->hot = hot; d->data = data; d->len = len;
+    d->pos = d->reset_pos = 20 + (size_t)nq * 128;
+    d->width = w; d->height = h; d->framerate = fps; d->n_qtables = nq; d->max_gops = max_gops; d->max_len = max_gop_frames;
+    d->total_blocks = (size_t)pfv_total_blocks(w, h);
+    d->frame_bytes = pfv_frame_bytes(w, h);
+    d->cap = d->total_blocks * 256 / 4;                        // per slot: denser than 1 non-zero in 4 -> dense fallback
+    const size_t S = (size_t)max_gops, tb = d->total_blocks;
+    bool ok = true;
+    hipError_t he = hipSuccess;
+    for (GopDecSet &s : d->set) {
+        ok = ok && s.idx.resize(S * d->cap) && s.val.resize(S * d->cap) && s.counts.resize(S) && s.mv.resize(S * tb * 2) && s.has.resize(S * tb) &&
+             s.flags.resize(S);
+        s.rc.assign(S, 0); s.qidx.assign(S * 3, 0); s.ev.assign(S, nullptr);
+        if (ok) { memset(s.mv.data(), 0, S * tb * 2); memset(s.has.data(), 0, S * tb); memset(s.flags.data(), 0, S * sizeof(int)); }
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    }
+    ok = ok && d->frames_host.resize(S * (size_t)max_gop_frames * d->frame_bytes);
+    if (ok && he == hipSuccess) he = hipMalloc((void **)&d->frames_dev, S * d->frame_bytes);
+    if (!ok) rc = fail(ctx, PFV_ERR_NOMEM, "pfv_gop_decoder_create: host staging");
+    else if (he != hipSuccess) rc = hip_fail(ctx, he, "pfv_gop_decoder_create");
+    if (!rc) rc = dec_staging(hot);
+    if (!rc) rc = pfv_dec_set_output_dev(hot, d->frames_dev);
+    if (rc) { pfv_gop_decoder_destroy(d); return rc; }
+    for (int t = 0; t < n_threads; t++) d->workers.emplace_back(gopd_worker, d);
+    *out = d;
+    return PFV_OK;
+}
+PFV_API int pfv_gop_decoder_width(const pfv_gop_decoder *d) { return d ? d->width : 0; }
+PFV_API int pfv_gop_decoder_height(const pfv_gop_decoder *d) { return d ? d->height : 0; }
+PFV_API int pfv_gop_decoder_framerate(const pfv_gop_decoder *d) { return d ? d->framerate : 0; }
+PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d) { return d ? d->batches : 0; }
+
+// Decoder::reset (src/dec.rs:148-152).  The framebuffer is NOT rewound (neither is the reference's); unlike the frame-by-frame decoder
+// this one has decoded ahead of the frames it delivered, so a stream whose first packet after the reset is a p-frame sees the state of
+// the last DECODED frame, not of the last delivered one.  Streams start with an i-frame.
+PFV_API int pfv_gop_decoder_reset(pfv_gop_decoder *d)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    d->eof = false;
+    d->events.clear(); d->next_event = 0;
+    d->pos = d->reset_pos;
+    d->cont_valid = false;
+    return PFV_OK;
+}
+
+// Decoder::advance_frame (src/dec.rs:169-224): 1 = Ok(true), 0 = Ok(false) (EOF), negative = error -- the same sequence of results, frames
+// and callbacks as pfv_decoder_advance_frame on the same bytes.  y / u / v stay valid until the call that starts the next batch.
+PFV_API int pfv_gop_decoder_advance_frame(pfv_gop_decoder *d, pfv_video_cb onvideo, void *user)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    if (d->eof) return 0;
+    if (d->next_event >= d->events.size()) {
+        gopd_scan_batch(d);
+        int rc = gopd_decode_batch(d);
+        if (rc) { d->events.clear(); d->next_event = 0; return rc; }
+    }
+    GopDecEvent &e = d->events[d->next_event];
+    if (e.kind == GopDecEvent::END) { d->pos = e.pos_after; d->eof = true; return 0; }
+    if (e.kind == GopDecEvent::ERROR) {   // the next call scans on from where the sequential loop would (src/dec.rs:174-182: the bytes read are gone)
+        const int rc = e.rc;
+        const char *msg = e.msg;
+        d->pos = e.pos_after;
+        d->events.clear(); d->next_event = 0;
+        return fail(d->ctx, rc, msg);
+    }
+    d->next_event++;
+    d->pos = e.pos_after;
+    if (e.kind == GopDecEvent::DROP) return 1;
+    if (e.rc) return fail(d->ctx, e.rc, e.msg);
+    if (onvideo) {
+        const uint8_t *f = d->frames_host.data() + ((size_t)e.t * (size_t)d->max_gops + (size_t)e.slot) * d->frame_bytes;
+        const size_t ny = (size_t)d->width * d->height, nc = (size_t)(d->width / 2) * (d->height / 2);
+        onvideo(user, f, f + ny, f + ny + nc, d->width, d->height);
+    }
+    return 1;
+}
+
+// Decoder::advance_delta (src/dec.rs:154-167)
+PFV_API int pfv_gop_decoder_advance_delta(pfv_gop_decoder *d, double delta, pfv_video_cb onvideo, void *user)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    d->delta_accum += delta;
+    const double delta_per_frame = 1.0 / (double)d->framerate;
+    while (d->delta_accum >= delta_per_frame) {
+        int rc = pfv_gop_decoder_advance_frame(d, onvideo, user);
+        if (rc <= 0) return rc;
+        d->delta_accum -= delta_per_frame;
+    }
+    return 1;
+}
+
+}  // extern "C"

@@ -84,6 +84,71 @@ class Decoder:
             pass
 
 
+class GopDecoder(Decoder):
+    """:class:`Decoder` for one stream with the independent GOPs of the stream as the slots of every kernel launch
+    (``pfv_gop_decoder``, include/pfv_hip.h): same calls, frames, order and errors; ``threads`` packet parsers work beside the caller.
+    ``raw=True`` hands ``onvideo`` the three planes as zero-copy uint8 views (valid until the next batch starts) instead of a
+    :class:`VideoFrame` copy."""
+
+    def __init__(self, reader, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15, threads: int = 8, raw: bool = False):
+        data = reader.read() if hasattr(reader, "read") else bytes(reader)
+        self._data = np.frombuffer(data, dtype=np.uint8).copy()     # must outlive the native decoder
+        self.ctx, self.raw = ctx, raw
+        h = ctypes.c_void_p()
+        rc = ctx._lib.pfv_gop_decoder_create(ctx.handle, self._data.ctypes.data_as(ctypes.c_void_p), self._data.size, int(max_gops), int(max_gop_frames),
+                                             int(threads), ctypes.byref(h))
+        if rc != _lib.PFV_OK:
+            msg = ctx._lib.pfv_last_error(ctx.handle)
+            raise DecodeError(rc, msg.decode() if msg else "")
+        self.handle = h
+        ctx._sessions.add(self)
+
+    def width(self) -> int:
+        return self.ctx._lib.pfv_gop_decoder_width(self.handle)
+
+    def height(self) -> int:
+        return self.ctx._lib.pfv_gop_decoder_height(self.handle)
+
+    def framerate(self) -> int:
+        return self.ctx._lib.pfv_gop_decoder_framerate(self.handle)
+
+    @property
+    def batches(self) -> int:
+        return int(self.ctx._lib.pfv_gop_decoder_batches(self.handle))
+
+    def reset(self):
+        self.ctx.check(self.ctx._lib.pfv_gop_decoder_reset(self.handle))
+
+    def _callback(self, onvideo):
+        if not self.raw:
+            return super()._callback(onvideo)
+
+        def cb(_user, y, u, v, w, h):
+            def arr(p, n):
+                return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,))
+            onvideo(arr(y, w * h), arr(u, (w // 2) * (h // 2)), arr(v, (w // 2) * (h // 2)))
+        return _CB(cb)
+
+    def advance_frame(self, onvideo) -> bool:
+        cb = self._callback(onvideo)
+        rc = self.ctx._lib.pfv_gop_decoder_advance_frame(self.handle, cb, None)
+        if rc < 0:
+            self.ctx.check(rc)
+        return rc == 1
+
+    def advance_delta(self, delta: float, onvideo) -> bool:
+        cb = self._callback(onvideo)
+        rc = self.ctx._lib.pfv_gop_decoder_advance_delta(self.handle, float(delta), cb, None)
+        if rc < 0:
+            self.ctx.check(rc)
+        return rc == 1
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx._lib.pfv_gop_decoder_destroy(self.handle)
+        self.handle = None
+
+
 class BatchDecoder:
     """``n`` ``.pfv`` streams of one geometry and one frame-type pattern (e.g. the outputs of :class:`BatchEncoder`)
     decoded together by the C++ ``pfv_batch_decoder``: the packets of a step are bit-parsed on a worker pool (one task per

@@ -169,3 +169,74 @@ class BatchEncoder:
             self.close()
         except Exception:
             pass
+
+
+class GopEncoder(Encoder):
+    """:class:`Encoder` for one stream with the independent GOPs of the stream as the slots of every kernel launch
+    (``pfv_gop_encoder``, include/pfv_hip.h): same calls, same ``.pfv`` bytes; a packet reaches the writer when its batch of
+    ``max_gops`` groups is complete (or on ``flush()`` / ``finish()``).  ``encode_*frame`` also accept the three planes as flat
+    uint8 arrays ``(y, u, v)`` -- e.g. views into page-locked memory (``Context.host_array``), which upload at PCIe rate."""
+
+    def __init__(self, writer, width: int, height: int, framerate: int, quality: int, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15,
+                 payload_budget: int = 0):
+        assert 0 <= quality <= 10                                   # src/enc.rs:38
+        self.ctx, self.writer = ctx, writer
+        self.width, self.height = int(width), int(height)
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.pfv_gop_encoder_create(ctx.handle, self.width, self.height, int(framerate), int(quality), int(max_gops), int(max_gop_frames),
+                                                  int(payload_budget), ctypes.byref(h)))
+        self.handle = h
+        self.finished = False
+        ctx._sessions.add(self)
+        self._flush()                                               # header (src/enc.rs:70)
+
+    def _flush(self):
+        data, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_drain(self.handle, ctypes.byref(data), ctypes.byref(n)))
+        if n.value:
+            self.writer.write(ctypes.string_at(data.value, n.value))
+
+    def _planes(self, frame):
+        if isinstance(frame, VideoFrame):
+            self._check_frame(frame)
+            return ptr(frame.plane_y.pixels), ptr(frame.plane_u.pixels), ptr(frame.plane_v.pixels)
+        y, u, v = frame
+        assert not self.finished and y.size == self.width * self.height and u.size == v.size == (self.width // 2) * (self.height // 2)
+        return ptr(y), ptr(u), ptr(v)
+
+    def encode_iframe(self, frame):
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_iframe(self.handle, *self._planes(frame)))
+        self._flush()
+
+    def encode_pframe(self, frame):
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_pframe(self.handle, *self._planes(frame)))
+        self._flush()
+
+    def encode_dropframe(self):
+        assert not self.finished
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_dropframe(self.handle))
+
+    def flush(self):
+        """every frame handed over so far becomes packets at the writer now"""
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_flush(self.handle))
+        self._flush()
+
+    def finish(self):
+        assert not self.finished                                    # src/enc.rs:183
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_finish(self.handle))
+        self.finished = True
+        self._flush()
+
+    @property
+    def batches(self) -> int:
+        return int(self.ctx._lib.pfv_gop_encoder_batches(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            if not self.finished:                                   # impl Drop (src/enc.rs:28-34)
+                try:
+                    self.finish()
+                except _lib.PfvError:
+                    pass                                            # a failed stream stays incomplete
+            self.ctx._lib.pfv_gop_encoder_destroy(self.handle)
+        self.handle = None

@@ -331,3 +331,150 @@ def check_empty_pframe_packet(pkg, ctx, oracle, w=48, h=32):
         bd.advance_frames()
     assert e.value.code == pkg._lib.PFV_ERR_IO
     bd.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- GOP-batched objects
+def _outcomes(make_decoder, pkg, n_calls=96, stop_at_error=True):
+    """one entry per advance_frame call of any decoder object: ('frame', bytes) / ('none',) / ('eof',) / ('err', code)"""
+    out = []
+    try:
+        dec = make_decoder()
+    except pkg.PfvError as e:
+        return [("open-err", e.code)]
+    try:
+        for _ in range(n_calls):
+            got = []
+            try:
+                more = dec.advance_frame(lambda fr: got.append(fr.packed()))
+            except pkg.PfvError as e:
+                out.append(("err", e.code))
+                if stop_at_error:
+                    break
+                continue
+            out.append(("frame", got[0].tobytes()) if got else ("none",))
+            if not more:
+                out.append(("eof",))
+                break
+    finally:
+        dec.close()
+    return out
+
+
+def encode_pattern(pkg, ctx, oracle, w, h, quality, pattern, make_encoder, frame_src=None, threads=1, with_oracle=True):
+    """pattern: a string of 'I' / 'P' / 'D' (drop frame), one per packet.  Returns (product bytes, oracle bytes or None)."""
+    if frame_src is None:
+        frame_src = pkg.SyntheticStream(w, h).frame
+    buf = io.BytesIO()
+    enc = make_encoder(buf)
+    oenc = OracleStreamEncoder(oracle, w, h, 30, quality, threads=threads) if with_oracle else None
+    t = 0
+    for c in pattern:
+        if c == "D":
+            enc.encode_dropframe()
+            if oenc: oenc.encode_dropframe()
+            continue
+        f = frame_src(t)
+        t += 1
+        if c == "I":
+            enc.encode_iframe(frame_of(pkg, w, h, f))
+            if oenc: oenc.encode_iframe(f)
+        else:
+            enc.encode_pframe(frame_of(pkg, w, h, f))
+            if oenc: oenc.encode_pframe(f)
+    enc.finish()
+    if oenc: oenc.finish()
+    enc.close()
+    return buf.getvalue(), (oenc.bytes() if oenc else None)
+
+
+def check_gop_objects(pkg, ctx, oracle, w, h, quality, pattern, shapes, frame_src=None, threads=1, dec_threads=2):
+    """pfv_gop_encoder / pfv_gop_decoder against the frame-by-frame objects and the oracle on one packet pattern:
+    for every batch shape (max_gops, max_gop_frames) the .pfv bytes equal the serial product Encoder's and the oracle's, and the
+    GOP-batched decoder delivers, call by call, what the serial Decoder and the oracle's decoder deliver."""
+    serial, odata = encode_pattern(pkg, ctx, oracle, w, h, quality, pattern, lambda buf: pkg.Encoder(buf, w, h, 30, quality, ctx), frame_src, threads)
+    assert serial == odata, "serial product stream differs from the oracle's"
+    want = _outcomes_oracle(oracle, serial)
+    assert [x[0] for x in want].count("frame") == sum(c != "D" for c in pattern)
+    for max_gops, max_len in shapes:
+        data, _ = encode_pattern(pkg, ctx, oracle, w, h, quality, pattern,
+                                 lambda buf: pkg.GopEncoder(buf, w, h, 30, quality, ctx, max_gops=max_gops, max_gop_frames=max_len), frame_src, with_oracle=False)
+        assert data == serial, f"GOP-batched encoder (max_gops {max_gops}, max_gop_frames {max_len}) wrote a different .pfv stream"
+        got = _outcomes(lambda: pkg.GopDecoder(serial, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=dec_threads), pkg)
+        assert len(got) == len(want), (max_gops, max_len, [x[0] for x in got], [x[0] for x in want])
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert a == b, f"GOP-batched decoder (max_gops {max_gops}, max_gop_frames {max_len}): call {k} gives {a[0]}, the oracle {b[0]}"
+    return serial
+
+
+def check_gop_encoder_flush_and_errors(pkg, ctx, oracle, w=64, h=48):
+    """flush() in mid-GOP (the run continues in the next batch from the carried reference frame), packets only appear when a batch
+    completes, finish twice / encode after finish are state errors, a payload budget too small is PFV_ERR_NOMEM and sticks"""
+    import pytest
+    st = pkg.SyntheticStream(w, h)
+    pattern = "IPPPPIPP"
+    serial, _ = encode_pattern(pkg, ctx, oracle, w, h, 5, pattern, lambda buf: pkg.Encoder(buf, w, h, 30, 5, ctx), with_oracle=False)
+    buf = io.BytesIO()
+    enc = pkg.GopEncoder(buf, w, h, 30, 5, ctx, max_gops=4, max_gop_frames=15)
+    head = len(buf.getvalue())
+    for t, c in enumerate(pattern):
+        (enc.encode_iframe if c == "I" else enc.encode_pframe)(frame_of(pkg, w, h, st.frame(t)))
+        if t == 2:
+            assert len(buf.getvalue()) == head, "a packet left before its batch was complete"
+            enc.flush()                                   # mid-GOP
+            assert len(buf.getvalue()) > head
+    enc.finish()
+    with pytest.raises(AssertionError):
+        enc.finish()
+    rc = ctx._lib.pfv_gop_encoder_finish(enc.handle)
+    assert rc == pkg._lib.PFV_ERR_STATE
+    enc.close()
+    assert buf.getvalue() == serial, "flush in mid-GOP changed the stream"
+    # payload budget: 64 bytes cannot hold an i-frame
+    enc = pkg.GopEncoder(io.BytesIO(), w, h, 30, 5, ctx, max_gops=2, max_gop_frames=4, payload_budget=64)
+    enc.encode_iframe(frame_of(pkg, w, h, st.frame(0)))
+    with pytest.raises(pkg.PfvError) as e:
+        enc.flush()
+    assert e.value.code == pkg._lib.PFV_ERR_NOMEM
+    with pytest.raises(pkg.PfvError) as e:
+        enc.encode_iframe(frame_of(pkg, w, h, st.frame(1)))
+    assert e.value.code == pkg._lib.PFV_ERR_STATE
+    enc.finished = True
+    enc.close()
+
+
+def check_gop_decoder_corrupted(pkg, ctx, oracle, data, n_trials, seed, shapes=((3, 15), (2, 2), (8, 4))):
+    """Byte-flip fuzz: the GOP-batched decoder agrees with the oracle's decoder call by call up to the first error (same frames, same
+    error code on the same packet) and with the product's frame-by-frame Decoder on EVERY call, errors included and beyond them --
+    a packet that fails leaves the framebuffer alone; the p-frames behind a failed i-frame decode against the previous run's last
+    frame, exactly as in the sequential loop."""
+    rng = np.random.default_rng(seed)
+    hdr = 20 + 4 * 128
+    stats = {"trials": 0, "errors": 0, "frames": 0, "frames_after_an_error": 0}
+    for _ in range(n_trials):
+        bad = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(hdr, len(bad)))
+            bad[pos] = int(rng.integers(0, 256))
+        if rng.random() < 0.25:
+            bad = bad[: int(rng.integers(hdr, len(bad)))]
+        bad = bytes(bad)
+        max_gops, max_len = shapes[stats["trials"] % len(shapes)]
+        mk = lambda: pkg.GopDecoder(bad, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=stats["trials"] % 3)
+        a = _outcomes(mk, pkg)
+        b = _outcomes_oracle(oracle, bad)
+        assert len(a) == len(b), ([x[0] for x in a], [x[0] for x in b])
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert x == y, (k, x[0], y[0], x[1:] if x[0] == "err" else None, y[1:] if y[0] == "err" else None)
+        # beyond the first error: against the product's sequential decoder (the truncated tail of a stream errors forever: cap the calls)
+        a2 = _outcomes(mk, pkg, n_calls=40, stop_at_error=False)
+        b2 = _outcomes(lambda: pkg.Decoder(bad, ctx, lookahead=0), pkg, n_calls=40, stop_at_error=False)
+        assert len(a2) == len(b2), ([x[0] for x in a2], [x[0] for x in b2])
+        seen_err = False
+        for k, (x, y) in enumerate(zip(a2, b2)):
+            assert x == y, (max_gops, max_len, k, [v[0] for v in a2], [v[0] for v in b2])
+            seen_err = seen_err or x[0] == "err"
+            stats["frames_after_an_error"] += seen_err and x[0] == "frame"
+        stats["trials"] += 1
+        stats["errors"] += any(x[0] == "err" for x in a2)
+        stats["frames"] += sum(x[0] == "frame" for x in a2)
+    return stats

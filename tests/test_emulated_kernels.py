@@ -217,3 +217,23 @@ def test_emu_batch_decoder(pkg, emu_ctx, oracle):
 def test_emu_batch_decoder_dense_fallback(pkg, emu_ctx, oracle):
     """quality 10 on small frames: more than 1 coefficient in 4 is non-zero, the step is parsed into the dense form"""
     sc.check_batch_decoder(pkg, emu_ctx, oracle, 48, 32, 10, n_streams=2, n_frames=3, gop=2, noise=True)
+
+
+def test_emu_gop_objects(pkg, emu_ctx, oracle):
+    """pfv_gop_encoder / pfv_gop_decoder: same bytes / frames as the frame-by-frame objects and the oracle, whatever the batch shape"""
+    # three GOPs of 4 + drop frames; shapes: everything in one batch / batches of 2 groups / groups cut after 3 frames (runs continue
+    # across batches) / one slot (degenerates to the serial order)
+    data = sc.check_gop_objects(pkg, emu_ctx, oracle, 64, 48, 5, "IPPPIPDPPIPPP", shapes=((8, 15), (2, 3)))
+    assert data[-5:] == bytes(5)
+    # a stream that starts with p-frames (prev_frame = new_padded, src/enc.rs:46) and has GOPs of unequal length
+    sc.check_gop_objects(pkg, emu_ctx, oracle, 50, 38, 3, "PPIPIPPPDIP", shapes=((2, 15), (1, 2)))
+
+
+def test_emu_gop_encoder_flush_and_errors(pkg, emu_ctx, oracle):
+    sc.check_gop_encoder_flush_and_errors(pkg, emu_ctx, oracle)
+
+
+def test_emu_gop_decoder_corrupted_streams(pkg, emu_ctx, oracle):
+    data, _ = sc.encode_pattern(pkg, emu_ctx, oracle, 48, 32, 5, "IPPIPPPIP", lambda buf: pkg.Encoder(buf, 48, 32, 30, 5, emu_ctx), with_oracle=False)
+    stats = sc.check_gop_decoder_corrupted(pkg, emu_ctx, oracle, data, n_trials=12, seed=4)
+    assert stats["trials"] == 12 and stats["errors"] > 2 and stats["frames_after_an_error"] > 0

@@ -437,6 +437,45 @@ def test_fuzz_plane_operators(pkg, gpu_ctx, oracle, seed):
     pc.fuzz_plane_ops(pkg, gpu_ctx, oracle, n_cases=40, seed=seed)
 
 
+def test_gop_objects_patterns(pkg, gpu_ctx, oracle):
+    """pfv_gop_encoder / pfv_gop_decoder on packet patterns with drop frames, leading p-frames, unequal GOPs, at batch shapes that cut
+    runs in the middle: same .pfv bytes as the serial Encoder and the oracle, same frames / results call by call"""
+    sc.check_gop_objects(pkg, gpu_ctx, oracle, 64, 48, 5, "IPPPIPDPPIPPP", shapes=((8, 15), (2, 15), (2, 3), (1, 2)))
+    sc.check_gop_objects(pkg, gpu_ctx, oracle, 50, 38, 3, "PPIPIPPPPDIP", shapes=((3, 15), (2, 2)))
+    sc.check_gop_objects(pkg, gpu_ctx, oracle, 640, 360, 8, "IPPPPPPIPPPPPPIPP" + "D" + "IPPPP", shapes=((4, 7), (3, 4)), threads=8, dec_threads=4)
+    sc.check_gop_encoder_flush_and_errors(pkg, gpu_ctx, oracle)
+
+
+@pytest.mark.parametrize("geom", [(3840, 2160, 31, 8), (1920, 1080, 61, 3)])
+def test_gop_objects_config4_vs_serial_and_oracle(pkg, gpu_ctx, oracle, geom):
+    """BASELINE config #4's stream through the GOP-batched objects: 4K x 31 frames (i-frames at 0, 15, 30) in one batch of 3 groups and
+    1080p x 61 frames (5 GOPs) in batches of 3 groups: .pfv bytes == the serial product Encoder's == the oracle's, every decoded frame
+    == the oracle's decoder, in order."""
+    w, h, n, max_gops = geom
+    fb = int(pkg._lib.load().pfv_frame_bytes(w, h))
+    dev = gpu_ctx.alloc(fb)
+    frames = []
+    for t in range(n):
+        gpu_ctx.synth_frames_dev(w, h, [pkg.synth.SEED], t, dev)
+        a = np.empty(fb, np.uint8)
+        gpu_ctx.download(a, dev)
+        frames.append(a)
+    gpu_ctx.free(dev)
+    pattern = "".join("I" if t % 15 == 0 else "P" for t in range(n))
+    threads = min(32, len(os.sched_getaffinity(0)))
+    data = sc.check_gop_objects(pkg, gpu_ctx, oracle, w, h, 5, pattern, shapes=((max_gops, 15),), frame_src=lambda t: frames[t], threads=threads, dec_threads=8)
+    oracle.L.pfvo_pool_shutdown()
+    assert len(data) > 1000
+
+
+@pytest.mark.parametrize("geom", [(48, 32), (130, 70), (320, 240)])
+def test_gop_decoder_corrupted_streams(pkg, gpu_ctx, oracle, geom):
+    w, h = geom
+    data, _ = sc.encode_pattern(pkg, gpu_ctx, oracle, w, h, 5, "IPPIPPPIPDPIP", lambda buf: pkg.Encoder(buf, w, h, 30, 5, gpu_ctx), with_oracle=False)
+    stats = sc.check_gop_decoder_corrupted(pkg, gpu_ctx, oracle, data, n_trials=60, seed=w + h)
+    assert stats["trials"] == 60 and stats["errors"] > 10 and stats["frames_after_an_error"] > 0
+
+
 def test_config4_4k_gop15_stream_vs_oracle(pkg, gpu_ctx, oracle):
     """BASELINE config #4 at its stated geometry and GOP pattern, under the driver's eyes: 3840x2160, 31 frames (i-frames at
     0, 15 and 30 -> two full GOP boundaries, README.md:34-41), quality 5, product Encoder -> .pfv bytes -> product Decoder
