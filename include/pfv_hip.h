@@ -447,6 +447,12 @@ PFV_API int pfv_gop_encoder_finish(pfv_gop_encoder *e);
 PFV_API int pfv_gop_encoder_drain(pfv_gop_encoder *e, const uint8_t **data, size_t *len);
 PFV_API int pfv_gop_encoder_bytes(pfv_gop_encoder *e, const uint8_t **data, size_t *len);
 PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e);
+/* where the object's host time went, in seconds since creation (returns the number of entries written, <= n).
+ * encoder: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,
+ *          [4] packet assembly
+ * decoder: [0] header scan, [1] waiting for the packet parsers, [2] waiting for the device before a staging set is reused,
+ *          [3] enqueueing, [4] waiting for a batch's last frames */
+PFV_API int pfv_gop_encoder_stats(const pfv_gop_encoder *e, double *out, int n);
 PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e);
 PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, int max_gops, int max_gop_frames, int n_threads,
                                    pfv_gop_decoder **out);
@@ -454,6 +460,7 @@ PFV_API int pfv_gop_decoder_width(const pfv_gop_decoder *d);
 PFV_API int pfv_gop_decoder_height(const pfv_gop_decoder *d);
 PFV_API int pfv_gop_decoder_framerate(const pfv_gop_decoder *d);
 PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d);
+PFV_API int pfv_gop_decoder_stats(const pfv_gop_decoder *d, double *out, int n);
 /* Decoder::reset (src/dec.rs:148-152).  Like the reference's, it does not rewind the framebuffer; this decoder has decoded ahead of
  * the frames it delivered, so a stream whose first packet is a p-frame continues from the last DECODED frame after a reset. */
 PFV_API int pfv_gop_decoder_reset(pfv_gop_decoder *d);

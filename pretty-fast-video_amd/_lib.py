@@ -164,12 +164,14 @@ SIGNATURES = [
     ("pfv_gop_encoder_drain", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_gop_encoder_bytes", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_gop_encoder_batches", ctypes.c_long, [_P]),
+    ("pfv_gop_encoder_stats", c_int, [_P, _P, c_int]),
     ("pfv_gop_encoder_destroy", None, [_P]),
     ("pfv_gop_decoder_create", c_int, [_P, _P, c_size_t, c_int, c_int, c_int, POINTER(_P)]),
     ("pfv_gop_decoder_width", c_int, [_P]),
     ("pfv_gop_decoder_height", c_int, [_P]),
     ("pfv_gop_decoder_framerate", c_int, [_P]),
     ("pfv_gop_decoder_batches", ctypes.c_long, [_P]),
+    ("pfv_gop_decoder_stats", c_int, [_P, _P, c_int]),
     ("pfv_gop_decoder_reset", c_int, [_P]),
     ("pfv_gop_decoder_advance_frame", c_int, [_P, _P, _P]),
     ("pfv_gop_decoder_advance_delta", c_int, [_P, ctypes.c_double, _P, _P]),

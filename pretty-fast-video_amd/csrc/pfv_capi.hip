@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>

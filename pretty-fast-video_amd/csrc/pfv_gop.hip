@@ -17,7 +17,17 @@
 //                state is copied explicitly: failed packets on the decoder side).
 #pragma once
 
-namespace {
+// wall-clock accounting of where a GOP-batched object spends its host time (pfv_gop_*_stats): cheap (two clock reads per section)
+struct GopClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap()
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        const double s = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        return s;
+    }
+};
 
 struct GopPacket {
     uint8_t type;     // 1 i-frame, 2 p-frame, 3 drop frame (src/enc.rs:175-180)
@@ -39,8 +49,6 @@ struct GopEncBatch {
     int frames() const { int n = 0; for (int l : len) n += l; return n; }
 };
 
-}  // namespace
-
 struct pfv_gop_encoder {
     pfv_ctx *ctx = nullptr;
     pfv_enc_session *hot = nullptr;
@@ -60,6 +68,9 @@ struct pfv_gop_encoder {
     std::vector<uint8_t> out, drained;
     bool finished = false, failed = false;
     long frames_in = 0, batches = 0;
+    // seconds: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,
+    // [4] packet assembly
+    double stats[5] = {0, 0, 0, 0, 0};
 };
 
 // ---- helpers of both objects
@@ -96,6 +107,7 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
     pfv_enc_session *s = e->hot;
     const int G = (int)B.len.size();
     if (G == 0 || B.in_flight) return PFV_OK;
+    GopClock clk;
     HIP_TRY(ctx, hipEventRecord(B.ev_uploaded, e->copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, B.ev_uploaded, 0));
     const size_t pad = (size_t)s->geom.pad_frame_bytes;
@@ -139,6 +151,7 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
     B.steps = steps;
     B.in_flight = true;
     e->batches++;
+    e->stats[1] += clk.lap();
     return PFV_OK;
 }
 
@@ -155,7 +168,9 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
     const size_t n_ent = (size_t)B.steps * (size_t)e->max_gops;
     // the batch is complete on the device; its results come over on the copy stream (idle: every upload was waited for), NOT behind
     // the kernels of the next batch, which may already be queued on the context's stream
+    GopClock clk;
     HIP_TRY(ctx, hipEventSynchronize(B.ev_done));
+    e->stats[2] += clk.lap();
     HIP_TRY(ctx, hipMemcpyAsync(e->entries_host.data(), B.entries_dev, n_ent * sizeof(EntEntry), hipMemcpyDeviceToHost, e->copy_stream));
     HIP_TRY(ctx, hipMemcpyAsync(e->cursor_host, B.cursor_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
     HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
@@ -172,11 +187,14 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
         return fail(ctx, rc, rc == PFV_ERR_FORMAT ? "coefficient needs more than 15 size bits (src/rle.rs:44)"
                                                   : "the batch's packet payloads exceed the payload budget given to pfv_gop_encoder_create");
     }
-    if (!e->payload_host.resize(std::max<size_t>(used, 1 << 20))) { e->failed = true; return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging"); }
+    // page-locking is slow (tens of milliseconds per 100 MB): grow the landing zone in big steps, not batch by batch
+    if (used > e->payload_host.size() && !e->payload_host.resize(used + used / 2 + ((size_t)4 << 20))) { e->failed = true; return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging"); }
     if (used) {
         HIP_TRY(ctx, hipMemcpyAsync(e->payload_host.data(), B.arena, used, hipMemcpyDeviceToHost, e->copy_stream));
         HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
     }
+    e->stats[3] += clk.lap();
+    e->out.reserve(e->out.size() + used + B.order.size() * 5);
     for (const GopPacket &p : B.order) {
         if (p.type == 3) { put_packet(e->out, 1, nullptr); continue; }   // src/enc.rs:175-180
         const EntEntry &en = e->entries_host.data()[(size_t)p.t * (size_t)e->max_gops + (size_t)p.slot];
@@ -184,6 +202,7 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
         put_u32(e->out, en.size);
         e->out.insert(e->out.end(), e->payload_host.data() + en.offset, e->payload_host.data() + en.offset + en.size);
     }
+    e->stats[4] += clk.lap();
     B.clear();
     return PFV_OK;
 }
@@ -234,7 +253,9 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
     e->frames_in++;
     // the caller's planes are free again when the call returns (they are being read by the copy engine until then; the kernels of the
     // previous batch run underneath)
+    GopClock clk;
     HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
+    e->stats[0] += clk.lap();
     return PFV_OK;
 }
 
@@ -365,12 +386,19 @@ PFV_API int pfv_gop_encoder_drain(pfv_gop_encoder *e, const uint8_t **data, size
 }
 /* launches of the frame-encode kernel so far would be frames_in for the serial object; here: */
 PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e) { return e ? e->batches : 0; }
+/* host seconds so far: out[0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device ->
+ * host, [4] packet assembly; returns the number of entries written (<= n) */
+PFV_API int pfv_gop_encoder_stats(const pfv_gop_encoder *e, double *out, int n)
+{
+    if (!e || !out) return 0;
+    const int k = std::min(n, 5);
+    for (int i = 0; i < k; i++) out[i] = e->stats[i];
+    return k;
+}
 
 }  // extern "C"
 
 // ================================================================== GOP-batched decoder
-namespace {
-
 struct GopDecEvent {
     enum Kind { FRAME, DROP, END, ERROR } kind = END;
     int rc = 0;                          // ERROR: status; FRAME: parse / decode status (set while the batch is decoded)
@@ -396,8 +424,6 @@ struct GopDecSet {   // host staging of one frame step (two alternate: the parse
     bool used = false;
 };
 
-}  // namespace
-
 struct pfv_gop_decoder {
     pfv_ctx *ctx = nullptr;
     pfv_dec_session *hot = nullptr;
@@ -419,6 +445,9 @@ struct pfv_gop_decoder {
     PinnedBuf<uint8_t> frames_host;      // [max_gop_frames][max_gops][frame_bytes]: the decoded frames of the batch
     uint8_t *frames_dev = nullptr;       // [max_gops][frame_bytes]
     long batches = 0, dense_packets = 0;
+    // seconds: [0] header scan, [1] waiting for packet parsers (the caller parses too), [2] waiting for the device before a staging set
+    // can be reused, [3] enqueueing, [4] waiting for the batch's last frames
+    double stats[5] = {0, 0, 0, 0, 0};
     // worker pool: the packets of a step are parsed in parallel (one task per slot)
     std::vector<std::thread> workers;
     std::mutex m;
@@ -542,7 +571,9 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
         if (e.kind == GopDecEvent::FRAME) { e.rc = 0; chain[(size_t)e.slot].push_back(&e); }
     auto wait_set = [&](GopDecSet &s) -> int {   // the device may still be reading the set's lists; then attribute the step's flags
         if (!s.used) return PFV_OK;
+        GopClock wclk;
         HIP_TRY(ctx, hipEventSynchronize(s.done));
+        d->stats[2] += wclk.lap();
         for (int k = 0; k < G; k++)
             if (s.flags.data()[k] && s.ev[(size_t)k] && !s.ev[(size_t)k]->rc) { s.ev[(size_t)k]->rc = PFV_ERR_BAD_MV; s.ev[(size_t)k]->msg = kBadMv; }
         s.used = false;
@@ -568,9 +599,11 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     // step 0 is parsed before anything runs: a group whose i-frame does not parse is no independent run -- the sequential loop
     // leaves the framebuffer alone and applies the group's p-frames to what the PREVIOUS group left (src/dec.rs:188-214).  Such a
     // group is appended to the chain of the slot before it (slot 0: it continues the run of the previous batch).
+    GopClock clk;
     fill(d->set[0], 0);
     gopd_start_parse(d, &d->set[0], G);
     gopd_join_parse(d, &d->set[0]);
+    d->stats[1] += clk.lap();
     bool reparse = false, head_continues = d->gfirst[0] == 2;
     int last_root = G - 1;
     {
@@ -612,7 +645,9 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     std::vector<uint32_t> combos;            // distinct (frame type, q-table indices) of a step -> launch key
     for (int t = 0; t < steps; t++) {
         GopDecSet &s = d->set[t & 1];
+        clk.lap();
         if (t > 0 || reparse) gopd_join_parse(d, &s);
+        d->stats[1] += clk.lap();
         if (t + 1 < steps) {                      // parse of step t + 1 under the device work of step t
             GopDecSet &n = d->set[(t + 1) & 1];
             if ((rc = wait_set(n))) return rc;
@@ -690,8 +725,11 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
         HIP_TRY(ctx, hipMemsetAsync(hot->flag_dev, 0, (size_t)G * sizeof(int), ctx->stream));
         HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
         s.used = true;
+        d->stats[3] += clk.lap();
     }
+    clk.lap();
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    d->stats[4] += clk.lap();
     if ((rc = wait_set(d->set[0])) || (rc = wait_set(d->set[1]))) return rc;
     // the run of the last group may go on in the next batch: its framebuffer is in the buffer its chain's last step wrote
     d->cont_valid = true;
@@ -778,6 +816,15 @@ PFV_API int pfv_gop_decoder_width(const pfv_gop_decoder *d) { return d ? d->widt
 PFV_API int pfv_gop_decoder_height(const pfv_gop_decoder *d) { return d ? d->height : 0; }
 PFV_API int pfv_gop_decoder_framerate(const pfv_gop_decoder *d) { return d ? d->framerate : 0; }
 PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d) { return d ? d->batches : 0; }
+/* host seconds so far: out[0] header scan, [1] waiting for packet parsers, [2] waiting for the device before a staging set can be reused,
+ * [3] enqueueing (incl. the time since the previous measurement point), [4] waiting for a batch's last frames; returns entries written */
+PFV_API int pfv_gop_decoder_stats(const pfv_gop_decoder *d, double *out, int n)
+{
+    if (!d || !out) return 0;
+    const int k = std::min(n, 5);
+    for (int i = 0; i < k; i++) out[i] = d->stats[i];
+    return k;
+}
 
 // Decoder::reset (src/dec.rs:148-152).  The framebuffer is NOT rewound (neither is the reference's); unlike the frame-by-frame decoder
 // this one has decoded ahead of the frames it delivered, so a stream whose first packet after the reset is a p-frame sees the state of
@@ -799,7 +846,9 @@ PFV_API int pfv_gop_decoder_advance_frame(pfv_gop_decoder *d, pfv_video_cb onvid
     if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
     if (d->eof) return 0;
     if (d->next_event >= d->events.size()) {
+        GopClock clk;
         gopd_scan_batch(d);
+        d->stats[0] += clk.lap();
         int rc = gopd_decode_batch(d);
         if (rc) { d->events.clear(); d->next_event = 0; return rc; }
     }

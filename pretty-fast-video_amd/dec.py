@@ -116,6 +116,12 @@ class GopDecoder(Decoder):
     def batches(self) -> int:
         return int(self.ctx._lib.pfv_gop_decoder_batches(self.handle))
 
+    def stats(self) -> dict:
+        """host seconds so far, by what the object was waiting for (pfv_gop_decoder_stats)"""
+        a = (ctypes.c_double * 5)()
+        n = self.ctx._lib.pfv_gop_decoder_stats(self.handle, a, 5)
+        return dict(zip(("scan_s", "parse_wait_s", "device_wait_s", "enqueue_s", "final_wait_s"), list(a)[:n]))
+
     def reset(self):
         self.ctx.check(self.ctx._lib.pfv_gop_decoder_reset(self.handle))
 

@@ -231,6 +231,12 @@ class GopEncoder(Encoder):
     def batches(self) -> int:
         return int(self.ctx._lib.pfv_gop_encoder_batches(self.handle))
 
+    def stats(self) -> dict:
+        """host seconds so far, by what the object was waiting for (pfv_gop_encoder_stats)"""
+        a = (ctypes.c_double * 5)()
+        n = self.ctx._lib.pfv_gop_encoder_stats(self.handle, a, 5)
+        return dict(zip(("upload_wait_s", "enqueue_s", "kernel_wait_s", "payload_download_s", "packet_assembly_s"), list(a)[:n]))
+
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:
             if not self.finished:                                   # impl Drop (src/enc.rs:28-34)
