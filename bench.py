@@ -756,29 +756,37 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop
 
     # (iii) end to end, ALL frames, through the GOP-batched objects: page-locked planes -> copy stream -> k_enc_* + device entropy stage
     # for frame t of every GOP of a batch -> .pfv bytes; .pfv bytes -> GOP-parallel packet parse -> k_dec_* -> frames in page-locked memory
-    class Chunks:                                          # the writer: keeps what it is handed (joined outside the timed region)
+    class Chunks:                                          # a writer that keeps what it is handed (joined outside the timed region)
         def __init__(self):
-            self.parts = []
+            self.parts, self.n = [], 0
 
         def write(self, b):
-            self.parts.append(b)
+            self.parts.append(bytes(b))
+            self.n += len(b)
 
-    def run_objects(make_enc, make_dec, raw):
-        buf = Chunks()
-        e = make_enc(buf)
+    class Count:                                           # a writer that consumes (a socket, a file): the bytes are checked in the run beside it
+        def __init__(self):
+            self.n = 0
+
+        def write(self, b):
+            self.n += len(b)
+
+    def run_encoder(make_enc, raw, sink):
+        e = make_enc(sink)
         t0 = time.perf_counter()
         for t in range(n_frames):
             f = host_all[t]
-            planes = (f[:ny], f[ny:ny + nc], f[ny + nc:])
             if raw:
-                (e.encode_iframe if t % GOP == 0 else e.encode_pframe)(planes)
+                (e.encode_iframe if t % GOP == 0 else e.encode_pframe)((f[:ny], f[ny:ny + nc], f[ny + nc:]))
             else:
                 (e.encode_iframe if t % GOP == 0 else e.encode_pframe)(pkg.VideoFrame.from_packed(W, H, f))
         e.finish()
-        t_enc = time.perf_counter() - t0
-        st_e = e.stats() if hasattr(e, "stats") else None
+        el = time.perf_counter() - t0
+        st = e.stats() if hasattr(e, "stats") else None
         e.close()
-        data = b"".join(buf.parts)
+        return el, st
+
+    def run_decoder(make_dec, data, raw):
         d = make_dec(data)
         n, ok = [0], [None]
 
@@ -790,25 +798,36 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop
         t0 = time.perf_counter()
         while d.advance_frame(onvideo):
             pass
-        t_dec = time.perf_counter() - t0
-        st_d = d.stats() if hasattr(d, "stats") else None
+        el = time.perf_counter() - t0
+        st = d.stats() if hasattr(d, "stats") else None
         d.close()
         assert n[0] == n_frames and ok[0], "decoded .pfv frame != encoder reconstruction"
-        return data, t_enc, t_dec, st_e, st_d
+        return el, st
 
     gops = 10
-    data, t_enc, t_dec, st_e, st_d = run_objects(lambda buf: pkg.GopEncoder(buf, W, H, 30, Q, ctx, max_gops=gops, max_gop_frames=GOP),
-                                     lambda data: pkg.GopDecoder(data, ctx, max_gops=2 * gops, max_gop_frames=GOP, threads=parse_threads, raw=True), True)
+    mk_gop = lambda sink, zc: pkg.GopEncoder(sink, W, H, 30, Q, ctx, max_gops=gops, max_gop_frames=GOP, zero_copy=zc)
+    counted = Count()
+    t_enc, st_e = run_encoder(lambda sink: mk_gop(sink, True), True, counted)       # the timed pass: the writer consumes the segments in place
+    kept = Chunks()
+    run_encoder(lambda sink: mk_gop(sink, False), True, kept)                        # the same again with a writer that keeps the bytes, to check them
+    data = b"".join(kept.parts)
+    assert counted.n == len(data)
+    t_dec, st_d = run_decoder(lambda data: pkg.GopDecoder(data, ctx, max_gops=2 * gops, max_gop_frames=GOP, threads=parse_threads, raw=True), data, True)
     res["end_to_end"] = {"frames": n_frames, "stream_bytes": len(data), "bits_per_pixel": round(len(data) * 8 / (n_frames * W * H), 3),
                          "encode_value": n_frames * n_mb / t_enc, "decode_value": n_frames * n_mb / t_dec,
                          "value": n_frames * n_mb / (t_enc + t_dec), "gops_per_batch": {"encoder": gops, "decoder": 2 * gops}, "parse_threads": parse_threads,
                          "upload_GBps_equivalent": n_frames * fbytes / t_enc / 1e9, "encode_s": t_enc, "decode_s": t_dec,
                          "encoder_host_seconds": st_e, "decoder_host_seconds": st_d,
                          "note": "GopEncoder -> .pfv bytes -> GopDecoder (pfv_gop_encoder / pfv_gop_decoder: frame t of every GOP of a batch per launch), every "
-                                 "frame of the stream, producer frames in page-locked memory, decoded frames delivered from page-locked memory; a decoded frame "
-                                 "checked against the encoder's reconstruction"}
-    sdata, s_enc, s_dec, _, _ = run_objects(lambda buf: pkg.Encoder(buf, W, H, 30, Q, ctx), lambda data: pkg.Decoder(data, ctx), False)
+                                 "frame of the stream; producer frames in page-locked memory (uploaded on a copy stream under the previous batch's kernels), "
+                                 "packets handed to the writer as segments where they lie (pfv_gop_encoder_drain_iov); packets parsed GOP-parallel, decoded "
+                                 "frames delivered from page-locked memory; stream bytes == the serial Encoder's, a decoded frame checked against the "
+                                 "encoder's reconstruction"}
+    skept = Chunks()
+    s_enc, _ = run_encoder(lambda sink: pkg.Encoder(sink, W, H, 30, Q, ctx), False, skept)
+    sdata = b"".join(skept.parts)
     assert sdata == data, "GOP-batched and serial encoder objects wrote different .pfv streams"
+    s_dec, _ = run_decoder(lambda data: pkg.Decoder(data, ctx), sdata, False)
     res["end_to_end"]["serial_objects"] = {"encode_value": n_frames * n_mb / s_enc, "decode_value": n_frames * n_mb / s_dec,
                                            "note": "Encoder -> .pfv -> Decoder, one frame per call and per launch (the same bytes: checked)"}
     ctx.host_free(host_all.reshape(-1))

@@ -437,6 +437,7 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
  * y / u / v of the callback stay valid until the call that starts the next batch. */
 typedef struct pfv_gop_encoder pfv_gop_encoder;
 typedef struct pfv_gop_decoder pfv_gop_decoder;
+typedef struct pfv_iovec { const uint8_t *data; size_t len; } pfv_iovec;
 PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int max_gops, int max_gop_frames,
                                    size_t payload_budget, pfv_gop_encoder **out);
 PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
@@ -446,6 +447,10 @@ PFV_API int pfv_gop_encoder_flush(pfv_gop_encoder *e);
 PFV_API int pfv_gop_encoder_finish(pfv_gop_encoder *e);
 PFV_API int pfv_gop_encoder_drain(pfv_gop_encoder *e, const uint8_t **data, size_t *len);
 PFV_API int pfv_gop_encoder_bytes(pfv_gop_encoder *e, const uint8_t **data, size_t *len);
+/* the writer side without a copy: the bytes produced since the last drain as `count` segments in stream order (packet headers, and
+ * payloads where the device-to-host copy put them, in page-locked memory) -- one write_all per segment, as the reference's W: Write
+ * receives them (src/enc.rs:190-235).  Valid until the next call on this encoder. */
+PFV_API int pfv_gop_encoder_drain_iov(pfv_gop_encoder *e, const pfv_iovec **iov, size_t *count);
 PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e);
 /* where the object's host time went, in seconds since creation (returns the number of entries written, <= n).
  * encoder: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,

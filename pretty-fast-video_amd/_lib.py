@@ -163,6 +163,7 @@ SIGNATURES = [
     ("pfv_gop_encoder_finish", c_int, [_P]),
     ("pfv_gop_encoder_drain", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_gop_encoder_bytes", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
+    ("pfv_gop_encoder_drain_iov", c_int, [_P, POINTER(_P), POINTER(c_size_t)]),
     ("pfv_gop_encoder_batches", ctypes.c_long, [_P]),
     ("pfv_gop_encoder_stats", c_int, [_P, _P, c_int]),
     ("pfv_gop_encoder_destroy", None, [_P]),

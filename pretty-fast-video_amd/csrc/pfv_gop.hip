@@ -45,6 +45,8 @@ struct GopEncBatch {
     EntEntry *entries_dev = nullptr;   // [max_gop_frames][max_gops]
     unsigned long long *cursor_dev = nullptr;
     hipEvent_t ev_uploaded = nullptr, ev_done = nullptr;
+    PinnedBuf<uint8_t> payload_host;   // the batch's payloads on the host (page-locked): the pending segments point into it
+    std::vector<uint8_t> heads;        // 5 bytes per packet of the batch
     void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; steps = 0; }
     int frames() const { int n = 0; for (int l : len) n += l; return n; }
 };
@@ -63,9 +65,12 @@ struct pfv_gop_encoder {
     bool cont_valid = false;               // a group is open across the batch boundary: where its prev_frame lives
     int cont_buf = 0, cont_slot = 0;
     PinnedBuf<EntEntry> entries_host;
-    PinnedBuf<uint8_t> payload_host;
     unsigned long long *cursor_host = nullptr;   // page-locked
+    // the writer side: bytes produced and not yet handed over = `out` (contiguous) followed by `segs` (packet headers and payloads where
+    // they lie: a batch's payloads stay in its page-locked landing zone until the batch slot is collected again)
     std::vector<uint8_t> out, drained;
+    std::vector<pfv_iovec> segs, segs_drained;
+    unsigned segs_in = 0;                  // bit b: pending segments point into batch[b]'s landing zone / header bytes
     bool finished = false, failed = false;
     long frames_in = 0, batches = 0;
     // seconds: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,
@@ -155,11 +160,27 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
     return PFV_OK;
 }
 
+// pending segments -> the contiguous byte vector (callers that did not take them before their buffers are needed again, and the
+// contiguous drain / bytes calls)
+static void gop_enc_materialize(pfv_gop_encoder *e)
+{
+    size_t n = 0;
+    for (const pfv_iovec &v : e->segs) n += v.len;
+    e->out.reserve(e->out.size() + n);
+    for (const pfv_iovec &v : e->segs) e->out.insert(e->out.end(), v.data, v.data + v.len);
+    e->segs.clear();
+    e->segs_in = 0;
+}
+
 // wait for a batch, bring its payloads over and write its packets in stream order
 static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
 {
     pfv_ctx *ctx = e->ctx;
+    const unsigned slot_bit = 1u << (unsigned)(&B - e->batch);
+    if (e->segs_in & slot_bit) gop_enc_materialize(e);   // this slot's landing zone is about to be overwritten: segments nobody took yet
+    //                                                     are copied out first
     if (!B.in_flight) {   // nothing was encoded: only drop frames can be pending
+        gop_enc_materialize(e);
         for (const GopPacket &p : B.order)
             if (p.type == 3) put_packet(e->out, 1, nullptr);
         B.clear();
@@ -187,20 +208,29 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
         return fail(ctx, rc, rc == PFV_ERR_FORMAT ? "coefficient needs more than 15 size bits (src/rle.rs:44)"
                                                   : "the batch's packet payloads exceed the payload budget given to pfv_gop_encoder_create");
     }
-    // page-locking is slow (tens of milliseconds per 100 MB): grow the landing zone in big steps, not batch by batch
-    if (used > e->payload_host.size() && !e->payload_host.resize(used + used / 2 + ((size_t)4 << 20))) { e->failed = true; return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging"); }
+    // page-locking is slow (tens of milliseconds per 100 MB): the landing zone grows in big steps, not batch by batch
+    if (used > B.payload_host.size() && !B.payload_host.resize(used + used / 2 + ((size_t)4 << 20))) { e->failed = true; return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging"); }
     if (used) {
-        HIP_TRY(ctx, hipMemcpyAsync(e->payload_host.data(), B.arena, used, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(B.payload_host.data(), B.arena, used, hipMemcpyDeviceToHost, e->copy_stream));
         HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
     }
     e->stats[3] += clk.lap();
-    e->out.reserve(e->out.size() + used + B.order.size() * 5);
+    // packets in stream order as segments: 5 header bytes (src/enc.rs:301-305, :453-457), then the payload where it lies
+    B.heads.resize(B.order.size() * 5);
+    e->segs_in |= slot_bit;
+    size_t hi = 0;
     for (const GopPacket &p : B.order) {
-        if (p.type == 3) { put_packet(e->out, 1, nullptr); continue; }   // src/enc.rs:175-180
+        uint8_t *h = &B.heads[hi];
+        hi += 5;
+        if (p.type == 3) {                                                // drop frame: an empty i-frame packet (src/enc.rs:175-180)
+            h[0] = 1; h[1] = h[2] = h[3] = h[4] = 0;
+            e->segs.push_back(pfv_iovec{h, 5});
+            continue;
+        }
         const EntEntry &en = e->entries_host.data()[(size_t)p.t * (size_t)e->max_gops + (size_t)p.slot];
-        e->out.push_back(p.type);                                         // packet header (src/enc.rs:301-305, :453-457)
-        put_u32(e->out, en.size);
-        e->out.insert(e->out.end(), e->payload_host.data() + en.offset, e->payload_host.data() + en.offset + en.size);
+        h[0] = p.type; h[1] = (uint8_t)en.size; h[2] = (uint8_t)(en.size >> 8); h[3] = (uint8_t)(en.size >> 16); h[4] = (uint8_t)(en.size >> 24);
+        e->segs.push_back(pfv_iovec{h, 5});
+        if (en.size) e->segs.push_back(pfv_iovec{B.payload_host.data() + en.offset, (size_t)en.size});
     }
     e->stats[4] += clk.lap();
     B.clear();
@@ -326,6 +356,10 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
     }
     rc = pfv_enc_entropy_enable(hot, 0);
     if (!rc && !e->entries_host.resize(cap_frames)) rc = fail(ctx, PFV_ERR_NOMEM, "pinned staging");
+    // landing zones for the payloads of a batch: a sixth of its raw bytes to begin with (quality-5 p-frames of noisy content reach a
+    // tenth); they grow on demand
+    for (GopEncBatch &B : e->batch)
+        if (!rc && !B.payload_host.resize(std::min(e->arena_cap, cap_frames * e->frame_bytes / 6 + ((size_t)4 << 20)))) rc = fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
     if (rc) { pfv_gop_encoder_destroy(e); return rc; }
     gop_put_header(e->out, width, height, framerate, quality);               // write_header (src/enc.rs:190-219)
     *out = e;
@@ -365,12 +399,14 @@ PFV_API int pfv_gop_encoder_finish(pfv_gop_encoder *e)
     int rc = pfv_gop_encoder_flush(e);
     if (rc) return rc;
     e->finished = true;
-    put_packet(e->out, 0, nullptr);
+    static const uint8_t eof[5] = {0, 0, 0, 0, 0};                               // src/enc.rs:221-227
+    e->segs.push_back(pfv_iovec{eof, 5});
     return PFV_OK;
 }
 PFV_API int pfv_gop_encoder_bytes(pfv_gop_encoder *e, const uint8_t **data, size_t *len)
 {
     if (!e || !data || !len) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_bytes: bad argument");
+    gop_enc_materialize(e);
     *data = e->out.data();
     *len = e->out.size();
     return PFV_OK;
@@ -378,13 +414,31 @@ PFV_API int pfv_gop_encoder_bytes(pfv_gop_encoder *e, const uint8_t **data, size
 PFV_API int pfv_gop_encoder_drain(pfv_gop_encoder *e, const uint8_t **data, size_t *len)
 {
     if (!e || !data || !len) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_drain: bad argument");
+    gop_enc_materialize(e);
     e->drained.swap(e->out);
     e->out.clear();
     *data = e->drained.data();
     *len = e->drained.size();
     return PFV_OK;
 }
-/* launches of the frame-encode kernel so far would be frames_in for the serial object; here: */
+// The writer side without a copy (the reference's W: Write takes the packets one write_all at a time, src/enc.rs:190-235): the bytes
+// produced since the last drain as `count` segments in stream order -- packet headers, and payloads where the device-to-host copy put
+// them (page-locked memory).  Valid until the next call on this encoder.
+PFV_API int pfv_gop_encoder_drain_iov(pfv_gop_encoder *e, const pfv_iovec **iov, size_t *count)
+{
+    if (!e || !iov || !count) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_drain_iov: bad argument");
+    e->segs_drained.clear();
+    e->drained.swap(e->out);
+    e->out.clear();
+    if (!e->drained.empty()) e->segs_drained.push_back(pfv_iovec{e->drained.data(), e->drained.size()});
+    e->segs_drained.insert(e->segs_drained.end(), e->segs.begin(), e->segs.end());
+    e->segs.clear();
+    e->segs_in = 0;
+    *iov = e->segs_drained.data();
+    *count = e->segs_drained.size();
+    return PFV_OK;
+}
+
 PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e) { return e ? e->batches : 0; }
 /* host seconds so far: out[0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device ->
  * host, [4] packet assembly; returns the number of entries written (<= n) */
@@ -422,7 +476,13 @@ struct GopDecSet {   // host staging of one frame step (two alternate: the parse
     std::vector<GopDecEvent *> ev;       // per slot: the packet of this step, or null
     hipEvent_t done = nullptr;           // the device has finished reading this set
     bool used = false;
+    int pending = 0;                     // parse tasks of this set not yet finished (under the pool's mutex)
 };
+
+// staging sets in rotation: the packets of up to kGopDecSets - 1 frame steps are being parsed while the device works on a step, so the
+// parser pool always has a few dozen packets to choose from (one step of a 4K stream is 20 packets of ~6 ms: too few for 16 cores
+// to stay busy across the step boundaries)
+constexpr int kGopDecSets = 4;
 
 struct pfv_gop_decoder {
     pfv_ctx *ctx = nullptr;
@@ -440,7 +500,7 @@ struct pfv_gop_decoder {
     std::vector<uint8_t> gfirst;         // type of the group's first frame
     bool cont_valid = false;
     int cont_buf = 0, cont_slot = 0;     // where the framebuffer of the previous batch's last group lives (buffer, slot)
-    GopDecSet set[2];
+    GopDecSet set[kGopDecSets];
     PinnedBuf<int16_t> dense;            // one slot's coefficients when its list overflowed
     PinnedBuf<uint8_t> frames_host;      // [max_gop_frames][max_gops][frame_bytes]: the decoded frames of the batch
     uint8_t *frames_dev = nullptr;       // [max_gops][frame_bytes]
@@ -452,8 +512,7 @@ struct pfv_gop_decoder {
     std::vector<std::thread> workers;
     std::mutex m;
     std::condition_variable cv_work, cv_done;
-    GopDecSet *job = nullptr;
-    int next = 0, done = 0, n_tasks = 0, generation = 0;
+    std::deque<std::pair<GopDecSet *, int>> tasks;   // (staging set, slot) packets waiting for a parser
     bool quit = false;
 };
 
@@ -475,39 +534,54 @@ static void gopd_parse_one(pfv_gop_decoder *d, GopDecSet *s, int k)
 static void gopd_worker(pfv_gop_decoder *d)
 {
     std::unique_lock<std::mutex> lk(d->m);
-    int seen = 0;
     for (;;) {
-        d->cv_work.wait(lk, [&] { return d->quit || d->generation != seen; });
+        d->cv_work.wait(lk, [&] { return d->quit || !d->tasks.empty(); });
         if (d->quit) return;
-        seen = d->generation;
-        GopDecSet *s = d->job;
-        while (s && d->job == s && d->next < d->n_tasks) {
-            const int k = d->next++;
-            lk.unlock();
-            gopd_parse_one(d, s, k);
-            lk.lock();
-            if (++d->done == d->n_tasks) d->cv_done.notify_all();
-        }
+        const auto job = d->tasks.front();
+        d->tasks.pop_front();
+        lk.unlock();
+        gopd_parse_one(d, job.first, job.second);
+        lk.lock();
+        if (--job.first->pending == 0) d->cv_done.notify_all();
     }
 }
-static void gopd_start_parse(pfv_gop_decoder *d, GopDecSet *s, int n_tasks)
+static void gopd_start_parse(pfv_gop_decoder *d, GopDecSet *s, int n_slots)
 {
     std::lock_guard<std::mutex> lk(d->m);
-    d->job = s; d->next = 0; d->done = 0; d->n_tasks = n_tasks; d->generation++;
+    for (int k = 0; k < n_slots; k++) {
+        s->counts.data()[k] = 0;
+        s->rc[(size_t)k] = 0;
+        if (s->ev[(size_t)k]) { d->tasks.emplace_back(s, k); s->pending++; }
+    }
     d->cv_work.notify_all();
 }
 static void gopd_join_parse(pfv_gop_decoder *d, GopDecSet *s)
 {
     std::unique_lock<std::mutex> lk(d->m);
-    while (d->job == s && d->next < d->n_tasks) {     // the caller helps (and is the whole pool when there are no workers)
-        const int k = d->next++;
-        lk.unlock();
-        gopd_parse_one(d, s, k);
-        lk.lock();
-        ++d->done;
+    while (s->pending > 0) {
+        if (!d->tasks.empty()) {     // the caller parses too (and is the whole pool when there are no workers): any packet will do
+            const auto job = d->tasks.front();
+            d->tasks.pop_front();
+            lk.unlock();
+            gopd_parse_one(d, job.first, job.second);
+            lk.lock();
+            if (--job.first->pending == 0) d->cv_done.notify_all();
+        } else {
+            d->cv_done.wait(lk);
+        }
     }
-    d->cv_done.wait(lk, [&] { return d->done >= d->n_tasks; });
-    d->job = nullptr;
+}
+// nothing of an abandoned batch may stay queued (reset, errors): wait for the parsers to let go of the sets
+static void gopd_drain_pool(pfv_gop_decoder *d)
+{
+    std::unique_lock<std::mutex> lk(d->m);
+    for (const auto &job : d->tasks) job.first->pending--;
+    d->tasks.clear();
+    d->cv_done.wait(lk, [&] {
+        for (const GopDecSet &s : d->set)
+            if (s.pending > 0) return false;
+        return true;
+    });
 }
 
 // Walks the packet headers from d->pos exactly as the reference's loop does (src/dec.rs:174-222) and cuts the next batch: up to
@@ -592,8 +666,9 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
                 if (q[i] >= hot->n_qtables) prc = PFV_ERR_FORMAT;              // the reference panics (src/dec.rs:249-251)
         return prc;
     };
-    int rc = wait_set(d->set[0]);
-    if (!rc) rc = wait_set(d->set[1]);
+    int rc = PFV_OK;
+    for (GopDecSet &s : d->set)
+        if (!rc) rc = wait_set(s);
     if (rc) return rc;
 
     // step 0 is parsed before anything runs: a group whose i-frame does not parse is no independent run -- the sequential loop
@@ -637,23 +712,30 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     // merged chains may be longer than a group
     if (!d->frames_host.resize((size_t)std::max(steps, 1) * (size_t)d->max_gops * fbytes)) return fail(ctx, PFV_ERR_NOMEM, "pinned frame staging");
     const int cur0 = hot->cur;
-    if (reparse && steps > 0) {              // the chains moved: step 0 is something else now
-        fill(d->set[0], 0);
-        gopd_start_parse(d, &d->set[0], G);
-    }
+    // steps [t, next_fill) are parsed or being parsed; step s uses staging set s % kGopDecSets.  A set is refilled as soon as the device
+    // has finished with the step that used it last.
+    int next_fill = reparse ? 0 : 1;         // the chains moved: step 0 is something else now
+    auto top_up = [&](int t, bool must_have_t) -> int {
+        while (next_fill < steps && next_fill < t + kGopDecSets) {
+            GopDecSet &n = d->set[next_fill % kGopDecSets];
+            if (n.used && !(must_have_t && next_fill <= t) && hipEventQuery(n.done) != hipSuccess) { (void)hipGetLastError(); break; }
+            const int wrc = wait_set(n);
+            if (wrc) return wrc;
+            fill(n, next_fill);
+            gopd_start_parse(d, &n, G);
+            next_fill++;
+        }
+        return PFV_OK;
+    };
     std::vector<int> key((size_t)G);
     std::vector<uint32_t> combos;            // distinct (frame type, q-table indices) of a step -> launch key
     for (int t = 0; t < steps; t++) {
-        GopDecSet &s = d->set[t & 1];
+        GopDecSet &s = d->set[t % kGopDecSets];
         clk.lap();
-        if (t > 0 || reparse) gopd_join_parse(d, &s);
+        if ((rc = top_up(t, true))) return rc;
+        d->stats[3] += clk.lap();
+        gopd_join_parse(d, &s);
         d->stats[1] += clk.lap();
-        if (t + 1 < steps) {                      // parse of step t + 1 under the device work of step t
-            GopDecSet &n = d->set[(t + 1) & 1];
-            if ((rc = wait_set(n))) return rc;
-            fill(n, t + 1);
-            gopd_start_parse(d, &n, G);
-        }
         // what runs: the packets that parsed.  A failed packet changes nothing (its error surfaces when the frame is delivered), but its
         // slot's framebuffer has to follow the ping-pong for the frames behind it.
         bool any_dense = false;
@@ -725,12 +807,14 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
         HIP_TRY(ctx, hipMemsetAsync(hot->flag_dev, 0, (size_t)G * sizeof(int), ctx->stream));
         HIP_TRY(ctx, hipEventRecord(s.done, ctx->stream));
         s.used = true;
+        if ((rc = top_up(t + 1, false))) return rc;
         d->stats[3] += clk.lap();
     }
     clk.lap();
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     d->stats[4] += clk.lap();
-    if ((rc = wait_set(d->set[0])) || (rc = wait_set(d->set[1]))) return rc;
+    for (GopDecSet &s : d->set)
+        if ((rc = wait_set(s))) return rc;
     // the run of the last group may go on in the next batch: its framebuffer is in the buffer its chain's last step wrote
     d->cont_valid = true;
     d->cont_slot = last_root;
@@ -850,7 +934,7 @@ PFV_API int pfv_gop_decoder_advance_frame(pfv_gop_decoder *d, pfv_video_cb onvid
         gopd_scan_batch(d);
         d->stats[0] += clk.lap();
         int rc = gopd_decode_batch(d);
-        if (rc) { d->events.clear(); d->next_event = 0; return rc; }
+        if (rc) { gopd_drain_pool(d); d->events.clear(); d->next_event = 0; return rc; }
     }
     GopDecEvent &e = d->events[d->next_event];
     if (e.kind == GopDecEvent::END) { d->pos = e.pos_after; d->eof = true; return 0; }

@@ -171,6 +171,10 @@ class BatchEncoder:
             pass
 
 
+class _IoVec(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("len", ctypes.c_size_t)]
+
+
 class GopEncoder(Encoder):
     """:class:`Encoder` for one stream with the independent GOPs of the stream as the slots of every kernel launch
     (``pfv_gop_encoder``, include/pfv_hip.h): same calls, same ``.pfv`` bytes; a packet reaches the writer when its batch of
@@ -178,9 +182,11 @@ class GopEncoder(Encoder):
     uint8 arrays ``(y, u, v)`` -- e.g. views into page-locked memory (``Context.host_array``), which upload at PCIe rate."""
 
     def __init__(self, writer, width: int, height: int, framerate: int, quality: int, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15,
-                 payload_budget: int = 0):
+                 payload_budget: int = 0, zero_copy: bool = False):
+        """zero_copy: the writer receives memoryviews into the library's page-locked buffers (valid during the write() call only, which
+        is all a file or a socket needs) instead of bytes copies"""
         assert 0 <= quality <= 10                                   # src/enc.rs:38
-        self.ctx, self.writer = ctx, writer
+        self.ctx, self.writer, self.zero_copy = ctx, writer, zero_copy
         self.width, self.height = int(width), int(height)
         h = ctypes.c_void_p()
         ctx.check(ctx._lib.pfv_gop_encoder_create(ctx.handle, self.width, self.height, int(framerate), int(quality), int(max_gops), int(max_gop_frames),
@@ -191,10 +197,18 @@ class GopEncoder(Encoder):
         self._flush()                                               # header (src/enc.rs:70)
 
     def _flush(self):
-        data, n = ctypes.c_void_p(), ctypes.c_size_t()
-        self.ctx.check(self.ctx._lib.pfv_gop_encoder_drain(self.handle, ctypes.byref(data), ctypes.byref(n)))
-        if n.value:
-            self.writer.write(ctypes.string_at(data.value, n.value))
+        # packet headers and payloads where they lie (pfv_gop_encoder_drain_iov): one write per segment, like the reference's W: Write
+        iov, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_drain_iov(self.handle, ctypes.byref(iov), ctypes.byref(n)))
+        if not n.value:
+            return
+        segs = ctypes.cast(iov, ctypes.POINTER(_IoVec))
+        for i in range(n.value):
+            p, ln = segs[i].data, segs[i].len
+            if self.zero_copy:      # a view into the library's page-locked memory, valid during this write() only
+                self.writer.write(memoryview((ctypes.c_ubyte * ln).from_address(p)))
+            else:
+                self.writer.write(ctypes.string_at(p, ln))
 
     def _planes(self, frame):
         if isinstance(frame, VideoFrame):

@@ -177,6 +177,7 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 typedef void *hipEvent_t;
 enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // the emulator runs everything synchronously
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (void *)1; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

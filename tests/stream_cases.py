@@ -429,6 +429,23 @@ def check_gop_encoder_flush_and_errors(pkg, ctx, oracle, w=64, h=48):
     assert rc == pkg._lib.PFV_ERR_STATE
     enc.close()
     assert buf.getvalue() == serial, "flush in mid-GOP changed the stream"
+    # a caller that never drains: the library keeps everything (segments are copied out before their landing zone is reused) and
+    # pfv_gop_encoder_bytes hands the whole stream over at the end
+    import ctypes
+    from pretty_fast_video_amd.context import ptr
+    L = ctx._lib
+    hnd = ctypes.c_void_p()
+    ctx.check(L.pfv_gop_encoder_create(ctx.handle, w, h, 30, 5, 1, 2, 0, ctypes.byref(hnd)))
+    for t, c in enumerate(pattern):
+        fr = frame_of(pkg, w, h, st.frame(t))
+        fn = L.pfv_gop_encoder_encode_iframe if c == "I" else L.pfv_gop_encoder_encode_pframe
+        ctx.check(fn(hnd, ptr(fr.plane_y.pixels), ptr(fr.plane_u.pixels), ptr(fr.plane_v.pixels)))
+    ctx.check(L.pfv_gop_encoder_finish(hnd))
+    data, n = ctypes.c_void_p(), ctypes.c_size_t()
+    ctx.check(L.pfv_gop_encoder_bytes(hnd, ctypes.byref(data), ctypes.byref(n)))
+    assert ctypes.string_at(data.value, n.value) == serial, "undrained GOP encoder lost or reordered bytes"
+    assert L.pfv_gop_encoder_batches(hnd) >= 4
+    L.pfv_gop_encoder_destroy(hnd)
     # payload budget: 64 bytes cannot hold an i-frame
     enc = pkg.GopEncoder(io.BytesIO(), w, h, 30, 5, ctx, max_gops=2, max_gop_frames=4, payload_budget=64)
     enc.encode_iframe(frame_of(pkg, w, h, st.frame(0)))
