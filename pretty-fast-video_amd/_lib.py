@@ -1,9 +1,9 @@
 """ctypes loader for libpfv_hip.so (the C ABI declared in include/pfv_hip.h).
 
 The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
-There is no fallback: if the shared object is missing or no GPU is visible, the calls fail
-loudly.  ``PFV_HIP_LIB`` may point at another build of the same C ABI (the test-suite uses
-this for the CPU emulator build of the *same sources*, tests/hipemu).
+There is no fallback and no redirection: the in-tree ``libpfv_hip.so`` is what loads; if it is
+missing or no GPU is visible, the calls fail loudly.  (The non-GPU test suite and the A/B scripts
+swap other builds of the same C ABI in from the outside: tests/libswitch.py.)
 """
 from __future__ import annotations
 
@@ -198,7 +198,7 @@ _lib_path = None
 
 
 def lib_path() -> str:
-    return os.environ.get("PFV_HIP_LIB", DEFAULT_LIB)
+    return DEFAULT_LIB
 
 
 def load():
@@ -211,14 +211,8 @@ def load():
         raise PfvError(PFV_ERR_NO_DEVICE, f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = ctypes.CDLL(path)
-    older = path != DEFAULT_LIB and os.environ.get("PFV_HIP_LIB_OLDER") == "1"   # A/B runs against a build of an earlier commit (tools/ab_prev.sh)
     for name, restype, argtypes in SIGNATURES:
-        try:
-            fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
-        except AttributeError:
-            if older:
-                continue
-            raise
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
     _lib, _lib_path = lib, path

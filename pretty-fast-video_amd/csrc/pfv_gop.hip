@@ -385,8 +385,8 @@ PFV_API int pfv_gop_encoder_flush(pfv_gop_encoder *e)
     if (e->failed) return fail(e->ctx, PFV_ERR_STATE, "an earlier batch failed: the stream is incomplete");
     pfv_ctx *ctx = e->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = gop_enc_collect(e, e->batch[e->cur ^ 1]);       // the older batch first
-    if (!rc) rc = gop_enc_submit(e, e->batch[e->cur]);
+    int rc = gop_enc_submit(e, e->batch[e->cur]);            // its kernels run while the older batch's payloads come over
+    if (!rc) rc = gop_enc_collect(e, e->batch[e->cur ^ 1]);  // packets of the older batch first
     if (!rc) rc = gop_enc_collect(e, e->batch[e->cur]);
     if (rc) e->failed = true;
     return rc;

@@ -4,9 +4,8 @@ Streams (separate Encoder / Decoder instances, src/enc.rs:12-26, src/dec.rs:15-2
 nothing, so stream s simply runs on rank ``s % world``.  No pixel or coefficient ever crosses
 GPUs; the only exchanges are control-plane: one broadcast of the assignment table and one
 reduction of the per-rank counters.  On the GPU node they run on RCCL through the library
-(comm.py / csrc/pfv_comm.hip, no torch in the process); ``broadcast_table`` / ``gather_counters``
-below are the same two exchanges over a torch.distributed group -- gloo in the CPU tests
-(tests/test_sharding.py).
+(comm.py / csrc/pfv_comm.hip, no torch in the process); the gloo world-2 CPU tests run the same two
+exchanges over torch.distributed with helpers of their own (tests/libswitch.py).
 """
 from __future__ import annotations
 
@@ -61,27 +60,3 @@ def splice_stream(header: bytes, gop_packets) -> bytes:
     """header + the GOPs' packets in order + EOF packet (src/enc.rs:221-227)"""
     body = b"".join(p for _, p in sorted(gop_packets))
     return header + body + bytes([0, 0, 0, 0, 0])
-
-
-def broadcast_table(table, rank: int, dist, device=None) -> np.ndarray:
-    """rank 0's table to everyone (a few hundred bytes)"""
-    import torch
-    t = torch.as_tensor(np.asarray(table, dtype=np.int64) if rank == 0 else np.zeros_like(np.asarray(table, dtype=np.int64)))
-    if device is not None:
-        t = t.to(device)
-    dist.broadcast(t, src=0)
-    return t.cpu().numpy()
-
-
-def gather_counters(macroblocks: float, seconds: float, checksum: int, dist, device=None):
-    """(sum of macroblocks, max of seconds, xor-free sum of checksums mod 2^62) over all ranks"""
-    import torch
-    a = torch.tensor([float(macroblocks)], dtype=torch.float64)
-    b = torch.tensor([float(seconds)], dtype=torch.float64)
-    c = torch.tensor([int(checksum) % (1 << 40)], dtype=torch.int64)
-    if device is not None:
-        a, b, c = a.to(device), b.to(device), c.to(device)
-    dist.all_reduce(a, op=dist.ReduceOp.SUM)
-    dist.all_reduce(b, op=dist.ReduceOp.MAX)
-    dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    return float(a.item()), float(b.item()), int(c.item())

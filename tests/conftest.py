@@ -52,13 +52,13 @@ def oracle():
 @pytest.fixture(scope="session")
 def gpu_ctx(graft, pkg):
     """context on the real GPU through the in-tree libpfv_hip.so (no emulator, no fallback)"""
+    import libswitch
     if os.environ.get("PFV_TEST_EMU_AS_GPU") == "1":
         # developer dry-run of the -m gpu tests in the GPU-less build container (never set by the driver)
-        os.environ["PFV_HIP_LIB"] = build_emulator()
+        libswitch.use(pkg, build_emulator())
     else:
-        os.environ.pop("PFV_HIP_LIB", None)
+        libswitch.reset(pkg)
         graft.build_hip()
-    pkg._lib._lib = None
     ctx = pkg.Context(0)
     yield ctx
     ctx.close()
@@ -67,14 +67,9 @@ def gpu_ctx(graft, pkg):
 @pytest.fixture(scope="session")
 def emu_ctx(graft, pkg):
     """context on the CPU emulator build of the same kernel sources (logic check only)"""
-    old = os.environ.get("PFV_HIP_LIB")
-    os.environ["PFV_HIP_LIB"] = build_emulator()
-    pkg._lib._lib = None
+    import libswitch
+    libswitch.use(pkg, build_emulator())
     ctx = pkg.Context(0)
     yield ctx
     ctx.close()
-    pkg._lib._lib = None
-    if old is None:
-        os.environ.pop("PFV_HIP_LIB", None)
-    else:
-        os.environ["PFV_HIP_LIB"] = old
+    libswitch.reset(pkg)

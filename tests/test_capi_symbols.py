@@ -15,8 +15,7 @@ def declared_symbols():
 
 def test_header_symbols_are_all_bound_and_exported(graft, pkg):
     graft.build_hip()
-    os.environ.pop("PFV_HIP_LIB", None)
-    pkg._lib._lib = None
+    __import__("libswitch").reset(pkg)
     lib = pkg._lib.load()                       # binds every entry of SIGNATURES; AttributeError if one is missing
     assert pkg._lib._lib_path == pkg._lib.DEFAULT_LIB
     declared = declared_symbols()
@@ -47,8 +46,7 @@ def test_no_gpu_fails_loudly(graft, pkg):
     if torch.cuda.is_available():
         pytest.skip("a GPU is visible")
     graft.build_hip()
-    os.environ.pop("PFV_HIP_LIB", None)
-    pkg._lib._lib = None
+    __import__("libswitch").reset(pkg)
     with pytest.raises(pkg.PfvError) as e:
         pkg.Context(0)
     assert e.value.code in (pkg._lib.PFV_ERR_NO_DEVICE, pkg._lib.PFV_ERR_HIP)
@@ -56,8 +54,7 @@ def test_no_gpu_fails_loudly(graft, pkg):
 
 def test_qtables_entry_point_matches_oracle(graft, pkg, oracle):
     graft.build_hip()
-    os.environ.pop("PFV_HIP_LIB", None)
-    pkg._lib._lib = None
+    __import__("libswitch").reset(pkg)
     import numpy as np
     for quality in range(11):
         got = pkg.qtables_from_quality(quality)

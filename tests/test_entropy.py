@@ -38,8 +38,7 @@ def test_reference_entropy_vector_roundtrip(oracle):
 @pytest.mark.parametrize("density", [0.0, 0.02, 0.3, 1.0])
 def test_payload_serialisers_product_equals_oracle(graft, pkg, oracle, density):
     graft.build_hip()
-    os.environ.pop("PFV_HIP_LIB", None)
-    pkg._lib._lib = None
+    __import__("libswitch").reset(pkg)
     lib = pkg._lib.load()
     L = _oracle_payloads(oracle)
     rng = np.random.default_rng(int(density * 100))
@@ -65,8 +64,7 @@ def test_payload_serialisers_product_equals_oracle(graft, pkg, oracle, density):
 def test_oversized_coefficient_is_rejected(graft, pkg):
     """|v| >= 16384 needs 16 size bits: the reference would index its 16-bin histogram out of range (rle.rs:44)"""
     graft.build_hip()
-    os.environ.pop("PFV_HIP_LIB", None)
-    pkg._lib._lib = None
+    __import__("libswitch").reset(pkg)
     lib = pkg._lib.load()
     coef = np.zeros((1, 256), np.int16)
     coef[0, 0] = 16384
@@ -118,8 +116,7 @@ def test_payload_parsers_invert_the_serialisers(graft, pkg, oracle, density):
     """product parse(serialise(x)) == x, dense and sparse forms, on payloads from the product and from the oracle;
     truncated payloads are reported, never read past"""
     graft.build_hip()
-    os.environ.pop("PFV_HIP_LIB", None)
-    pkg._lib._lib = None
+    __import__("libswitch").reset(pkg)
     lib = pkg._lib.load()
     L = _oracle_payloads(oracle)
     rng = np.random.default_rng(int(density * 1000) + 1)

@@ -36,19 +36,20 @@ def _worker(rank, world, port, n_total, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as g
+    import libswitch
     pkg = g.load_package()
     from importlib import import_module
     shard = import_module("pretty_fast_video_amd.shard")
     from oracle_bind import Oracle
     table = shard.assign_streams(n_total, world, pkg.synth.SEED) if rank == 0 else np.zeros((n_total, 3), np.int64)
-    table = shard.broadcast_table(table, rank, dist)
+    table = libswitch.broadcast_table(table, rank, dist)
     mine = shard.streams_of_rank(table, rank)
     ora = Oracle()
     cs, mbs = 0, 0
     for _, seed, _sid in mine:
         c, m = _encode_stream(pkg, ora, seed, 48, 32, 2)
         cs, mbs = cs + c, mbs + m
-    tot_mb, max_s, tot_cs = shard.gather_counters(mbs, 1.0 + rank, cs, dist)
+    tot_mb, max_s, tot_cs = libswitch.gather_counters(mbs, 1.0 + rank, cs, dist)
     if rank == 0:
         q.put((tot_mb, max_s, tot_cs, [int(x) for x in mine[:, 2]]))
     dist.destroy_process_group()
@@ -86,16 +87,17 @@ def _gop_worker(rank, world, port, emu_lib, geom, q):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["PFV_HIP_LIB"] = emu_lib          # the product's own sources on the CPU emulator (kernels need a GPU)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as g
+    import libswitch
     pkg = g.load_package()
+    libswitch.use(pkg, emu_lib)                 # the product's own sources on the CPU emulator (kernels need a GPU)
     from importlib import import_module
     shard = import_module("pretty_fast_video_amd.shard")
     import stream_cases as sc
     w, h, fps, quality, n_frames, gop = geom
     table = shard.assign_gops(n_frames, gop, world) if rank == 0 else np.zeros(((n_frames + gop - 1) // gop, 4), np.int64)
-    table = shard.broadcast_table(table, rank, dist)          # the only scatter: frame index ranges
+    table = libswitch.broadcast_table(table, rank, dist)          # the only scatter: frame index ranges
     st = pkg.SyntheticStream(w, h)
     with pkg.Context(0) as ctx:
         mine = shard.encode_gops(pkg, ctx, lambda t: sc.frame_of(pkg, w, h, st.frame(t)), w, h, fps, quality, table[table[:, 0] == rank])
@@ -280,4 +282,7 @@ def test_bench_config5_single_rank_fields():
     for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cgroup_cpu_quota", "affinity_cpus", "value_1thread", "value_best",
               "threads_best"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["cores"] == cb["threads_best"] == cb["threads"] and cb["value_best"] > 0 and cb["value_1thread"] > 0
+    assert cb["kind"] == "port" and cb["cores"] == cb["threads_best"] and "threads" not in cb and cb["value_1thread"] > 0
+    # the pool search never reports a best below what one thread does (the best is re-measured; a noisy pass is repeated)
+    assert cb["value_best"] >= 0.75 * cb["value_1thread"]
+    assert set(res["sections_s"]) >= {"setup", "timed", "cpu_baseline"} and res["step_roofline"]["algorithmic_bytes_per_macroblock"] > 2000

@@ -28,6 +28,8 @@ import torch   # device memory plumbing only
 
 g.build_hip()
 pkg = g.load_package()
+__import__("sys").path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))
+__import__("libswitch").apply_from_env(pkg)      # PFV_HIP_LIB=<variant build> (A/B scripts); the product loader itself has no override
 W, H, Q, GOP, N = 3840, 2160, args.quality, 15, args.frames
 st = pkg.SyntheticStream(W, H)
 t0 = time.perf_counter()

@@ -16,6 +16,8 @@ import __graft_entry__ as g   # noqa: E402
 if not os.environ.get("PFV_HIP_LIB"):
     g.build_hip()
 pkg = g.load_package()
+__import__("sys").path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))
+__import__("libswitch").apply_from_env(pkg)      # PFV_HIP_LIB=<variant build> (A/B scripts); the product loader itself has no override
 W, H, S, Q, GOP = 1920, 1080, 32, 5, 15
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)

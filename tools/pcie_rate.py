@@ -15,6 +15,8 @@ import __graft_entry__ as g   # noqa: E402
 
 g.build_hip()
 pkg = g.load_package()
+__import__("sys").path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))
+__import__("libswitch").apply_from_env(pkg)      # PFV_HIP_LIB=<variant build> (A/B scripts); the product loader itself has no override
 W, H, Q, GOP, S = 1920, 1080, 5, 15, 8
 st = pkg.SyntheticStream(W, H)
 frames1 = [st.frame(t) for t in range(GOP)]

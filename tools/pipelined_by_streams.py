@@ -2,6 +2,8 @@ import sys, time
 sys.argv = ["bench.py"]; sys.path.insert(0, ".")
 import bench, __graft_entry__ as graft
 pkg = graft.load_package()
+__import__("sys").path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))
+__import__("libswitch").apply_from_env(pkg)      # PFV_HIP_LIB=<variant build> (A/B scripts); the product loader itself has no override
 ctx = pkg.Context(0); dctx = pkg.Context(0)
 from importlib import import_module
 shard = import_module("pretty_fast_video_amd.shard")

@@ -10,6 +10,8 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 g.build_hip()
 pkg = g.load_package()
+__import__("sys").path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))
+__import__("libswitch").apply_from_env(pkg)      # PFV_HIP_LIB=<variant build> (A/B scripts); the product loader itself has no override
 ctx = pkg.Context(0)
 if os.environ.get("PFV_PROBE_LANES"):      # force a lane mapping (pfv_kernels.hip, "Lane mappings")
     ctx.set_option(pkg._lib.PFV_OPT_LANE_MAPPING, {"8": pkg._lib.PFV_LANES_PER_MB_8, "16": pkg._lib.PFV_LANES_PER_MB_16}[os.environ["PFV_PROBE_LANES"]])

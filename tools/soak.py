@@ -14,6 +14,8 @@ import __graft_entry__ as g   # noqa: E402
 
 g.build()
 pkg = g.load_package()
+__import__("sys").path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))
+__import__("libswitch").apply_from_env(pkg)      # PFV_HIP_LIB=<variant build> (A/B scripts); the product loader itself has no override
 import parity_cases as pc      # noqa: E402
 import stream_cases as sc      # noqa: E402
 from oracle_bind import Oracle  # noqa: E402
