@@ -98,8 +98,10 @@ def self_launch(args) -> int:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]     # MASTER_PORT of the job; the rendezvous derives its own port from it and walks on if that is busy (comm.py)
     procs = []
+    nonce = os.urandom(12).hex()      # the job's token on the rendezvous (comm.py)
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PFV_RDZV_NONCE=nonce)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -1035,12 +1037,18 @@ def main():
     shard = import_module("pretty_fast_video_amd.shard")
     commlib = import_module("pretty_fast_video_amd.comm")
     if world > 1 and not EMU:
+        # rank -> GPU: the LOCAL_RANK-th VISIBLE device (HIP numbers the devices HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES leave, in that
+        # order), one rank per device.  With ONE visible device (developer dry run of the N > 1 control flow on a one-GPU box, or
+        # PFV_BENCH_SHARE_GPU=1) every rank uses it and the control plane stays on the rendezvous sockets: RCCL refuses two ranks on a
+        # device.  Anything in between is a misconfigured launch and says so instead of piling ranks onto some of the GPUs.
         n_dev = int(pkg._lib.load().pfv_device_count())
-        # fewer devices than ranks (developer dry run of the N > 1 control flow on a one-GPU box): every rank on device 0,
-        # control plane on the rendezvous sockets (RCCL refuses two ranks on one device)
-        share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1" or n_dev < world
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        share = os.environ.get("PFV_BENCH_SHARE_GPU") == "1" or n_dev == 1
         if share:
             local_rank = 0
+        elif n_dev < local_world:
+            raise SystemExit(f"bench.py: {local_world} ranks on this node but only {n_dev} HIP devices are visible "
+                             f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}, ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')})")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     use_comm = world > 1 or (args.force_comm and not EMU)
     rdzv = commlib.Rendezvous(rank, world) if use_comm else None
@@ -1112,9 +1120,21 @@ def main():
     sections["entropy"] = time.perf_counter() - t1
 
     total_mb, el_max = float(args.steps) * NF * S * n_mb, el
+    per_rank = None
     if use_comm:
+        mine_mb = total_mb
         total_mb = float(comm.allreduce([total_mb], "sum")[0])        # whole-job macroblocks
         el_max = float(comm.allreduce([el], "max")[0])                # the slowest rank's time
+        # every rank's own figures on rank 0's line (a straggler GPU must be visible): one slot per rank in a vector that is summed
+        bus = "0000:00:00.0" if EMU else ctx.pci_bus_id()
+        dom, b, df = bus.split(":")
+        dv, fn = df.split(".")
+        slot = np.zeros((4, world))
+        slot[:, rank] = (mine_mb / el, el, local_rank, (int(dom, 16) << 16) | (int(b, 16) << 8) | (int(dv, 16) << 3) | int(fn, 16))
+        g = comm.allreduce(slot.reshape(-1), "sum").reshape(4, world)
+        per_rank = [{"rank": r, "macroblocks_per_s": float(g[0, r]), "seconds": float(g[1, r]), "device_ordinal": int(g[2, r]),
+                     "pci_bus_id": "%04x:%02x:%02x.%x" % (int(g[3, r]) >> 16, (int(g[3, r]) >> 8) & 0xff, (int(g[3, r]) >> 3) & 0x1f, int(g[3, r]) & 7)}
+                    for r in range(world)]
 
     if rank == 0:
         launch_mbs = ss.launch_streams * n_mb        # macroblocks of a full launch (GOP-batched: every GOP of the stream)
@@ -1165,7 +1185,7 @@ def main():
             "data": f"synthetic, generated on the device ({S} distinct integer-hash texture streams per GPU, seed per stream; quality {Q})",
             "rccl_ranks": world if comm is not None and comm.backend == "rccl" else 0,
             "control_plane": {"backend": comm.backend if comm is not None else None, "shared_gpu": bool(share and world > 1), "emulated": EMU,
-                              "rccl_error": comm.rccl_error if comm is not None else None,
+                              "rccl_error": comm.rccl_error if comm is not None else None, "ranks": per_rank,
                               "collectives": "assignment-table broadcast + barriers + counter all-reduce only (no data-path collective); "
                                              "RCCL through libpfv_hip.so (pfv_comm_*), no torch in the process"},
             "config": {"workload": name, "streams_per_gpu": S, "frames_per_step": NF, "macroblocks_per_frame": n_mb, "quality": Q,
@@ -1258,11 +1278,17 @@ def main():
 
     ss.close()
     timer.close()
+    stuck = False
     if use_comm:
         comm.barrier()
         comm.close()
+        stuck = comm.stuck           # ncclCommInitRank never came back on this rank: the context stays, the process leaves the hard way
         rdzv.close()
     ctx.close()
+    if stuck:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

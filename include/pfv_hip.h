@@ -65,7 +65,10 @@ PFV_API int pfv_ctx_create(int device, pfv_ctx **out);
  * encoder and a decoder work side by side on two contexts (a transcoder; bench.py's single-stream schedule), the encoder's launches
  * are the critical path and the decoder's fill the gaps: encoder context high, decoder context low. */
 PFV_API int pfv_ctx_create_prio(int device, int priority, pfv_ctx **out);
+/* also destroys the communicators (pfv_comm_init) still alive on the context */
 PFV_API void pfv_ctx_destroy(pfv_ctx *ctx);
+/* PCI address "domain:bus:device.function" of the context's device (len >= 16): which physical GPU a rank sits on */
+PFV_API int pfv_ctx_pci_bus_id(pfv_ctx *ctx, char *out, int len);
 PFV_API int pfv_ctx_sync(pfv_ctx *ctx);
 /* hipDeviceSynchronize on the context's device (all streams) */
 PFV_API int pfv_device_sync(pfv_ctx *ctx);
@@ -178,7 +181,9 @@ PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int wi
  * bytes that do travel -- the assignment table (broadcast) and the per-rank counters (reduction / gather) -- on the context's
  * HIP stream.  Rank 0 creates the id, every rank of the job gets the same 128 bytes over the launcher's own channel
  * (pretty-fast-video_amd/comm.py: TCP on MASTER_ADDR) and calls pfv_comm_init on the context of ITS device.  librccl.so is
- * opened at run time; PFV_ERR_NO_DEVICE when it is missing.  world = 1 is legal (a 1-rank communicator). */
+ * opened at run time; PFV_ERR_NO_DEVICE when it is missing.  world = 1 is legal (a 1-rank communicator).  A communicator
+ * belongs to its context (it enqueues on the context's stream): destroy it first, or leave it to pfv_ctx_destroy, which tears down
+ * the communicators still alive.  PFV_ERR_STATE while the context records a graph (pfv_graph_begin). */
 typedef struct pfv_comm pfv_comm;
 enum { PFV_COMM_SUM = 0, PFV_COMM_MAX = 1 };
 PFV_API int pfv_comm_unique_id(uint8_t id_out[128]);

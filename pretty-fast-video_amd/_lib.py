@@ -47,6 +47,7 @@ SIGNATURES = [
     ("pfv_ctx_create", c_int, [c_int, POINTER(_P)]),
     ("pfv_ctx_create_prio", c_int, [c_int, c_int, POINTER(_P)]),
     ("pfv_ctx_destroy", None, [_P]),
+    ("pfv_ctx_pci_bus_id", c_int, [_P, _P, c_int]),
     ("pfv_ctx_sync", c_int, [_P]),
     ("pfv_device_sync", c_int, [_P]),
     ("pfv_ctx_stream", _P, [_P]),

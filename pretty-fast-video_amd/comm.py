@@ -36,7 +36,10 @@ class Rendezvous:
         self.rank, self.world = int(rank), int(world)
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         base = rendezvous_port(int(port if port is not None else os.environ.get("MASTER_PORT", "29500")))
-        token = _MAGIC + struct.pack("<ii", base, self.world)
+        # the job's token: the launcher's per-job nonce when there is one (bench.py's self-launcher sets PFV_RDZV_NONCE, torchrun a run id),
+        # so that a process of another job on the node cannot take a rank's place
+        nonce = (os.environ.get("PFV_RDZV_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or "").encode()[:32].ljust(32, b"\0")
+        token = _MAGIC + struct.pack("<ii", base, self.world) + nonce
         self.peers = {}           # rank 0: {rank: socket}
         self.sock = None          # other ranks: socket to rank 0
         self.listener = None
@@ -71,6 +74,9 @@ class Rendezvous:
                     c.close()
                     continue
                 r = struct.unpack("<i", hello[len(token):])[0]
+                if not 1 <= r < self.world:            # not a rank of this job
+                    c.close()
+                    continue
                 try:
                     c.sendall(b"OK")
                     if self._recv_exact(c, 2) != b"GO":   # the rank confirms it is still there (it may have given up on this
@@ -79,12 +85,13 @@ class Rendezvous:
                     c.close()
                     continue
                 c.settimeout(timeout)
-                if r in self.peers:
-                    self.peers[r].close()
+                if r in self.peers:                    # the rank came back on a new connection after giving up on one that sat in the
+                    self.peers[r].close()              # backlog (it only ever completes the GO step on the connection it keeps)
                 self.peers[r] = c
         else:
             while True:
                 for k in range(16):
+                    c = None
                     try:
                         c = socket.create_connection((addr, base + k), timeout=2.0)
                         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
@@ -97,6 +104,8 @@ class Rendezvous:
                             break
                         c.close()
                     except (OSError, ConnectionError):
+                        if c is not None:
+                            c.close()
                         continue
                 if self.sock is not None:
                     break
@@ -174,6 +183,7 @@ class Comm:
         self.handle = None
         self.backend = "tcp"
         self.rccl_error = None        # why RCCL is not in use although it was asked for
+        self._init_thread, self._init_box = None, None   # a pfv_comm_init that did not come back in time (see close())
         if use_rccl:
             self._init_rccl(init_timeout)
 
@@ -202,6 +212,9 @@ class Comm:
             t.join(timeout)
             if t.is_alive():
                 err = f"pfv_comm_init did not return within {timeout:.0f} s"
+                # the thread is still INSIDE the library with this context: the context must outlive it (close() below)
+                self._init_thread, self._init_box = t, box
+                ctx.keep_alive = True
             elif box["rc"] != 0:
                 err = f"pfv_comm_init: {box['rc']} {(lib.pfv_last_error(ctx.handle) or b'').decode()}"
         elif err is None:
@@ -249,7 +262,21 @@ class Comm:
         else:
             self.ctx.check(self.ctx._lib.pfv_comm_barrier(self.handle))
 
+    @property
+    def stuck(self) -> bool:
+        """a pfv_comm_init call is still inside the library (ncclCommInitRank never returned): the context cannot be destroyed under it
+        and the process should leave through os._exit once its output is written"""
+        return self._init_thread is not None and self._init_thread.is_alive()
+
     def close(self):
+        if self._init_thread is not None:
+            self._init_thread.join(1.0)           # it may have come back late
+            if not self._init_thread.is_alive():
+                h = self._init_box.get("h")
+                if self._init_box.get("rc") == 0 and h is not None and h.value and self.ctx.handle:
+                    self.ctx._lib.pfv_comm_destroy(h)   # the late communicator and its scratch buffer
+                self._init_thread, self._init_box = None, None
+                self.ctx.keep_alive = False
         if self.handle is not None and self.ctx.handle:
             self.ctx._lib.pfv_comm_destroy(self.handle)
         self.handle = None

@@ -28,10 +28,20 @@ class Context:
         self.device = int(device)
         self._sessions = weakref.WeakSet()   # sessions die with their context (they hold device buffers of it)
         self._pinned = []                    # page-locked host blocks handed out by host_array()
+        self.keep_alive = False              # a library call is stuck inside this context on another thread (comm.py's init watchdog):
+        #                                      destroying it would pull the context from under that call
+
+    def pci_bus_id(self) -> str:
+        """PCI address of the context's device ("domain:bus:device.function")"""
+        buf = ctypes.create_string_buffer(32)
+        self.check(self._lib.pfv_ctx_pci_bus_id(self.handle, buf, 32))
+        return buf.value.decode()
 
     # -- lifetime
     def close(self):
         if getattr(self, "handle", None):
+            if self.keep_alive:
+                return                       # leaked on purpose; the process is expected to leave through os._exit
             for s in list(self._sessions):
                 s.close()
             for p in self._pinned:

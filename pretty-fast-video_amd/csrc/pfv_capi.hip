@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -65,7 +66,9 @@ struct pfv_ctx {
     int opt_enc_transform = PFV_ENC_TRANSFORM_AUTO;   // pfv_ctx_set_option(PFV_OPT_ENC_TRANSFORM)
     int opt_tile_compaction = 1;                      // pfv_ctx_set_option(PFV_OPT_TILE_COMPACTION)
     int opt_lane_mapping = PFV_LANES_AUTO;            // pfv_ctx_set_option(PFV_OPT_LANE_MAPPING)
+    std::vector<struct pfv_comm *> comms;             // live communicators on this context (pfv_comm.hip): torn down with it
 };
+static void comm_teardown(struct pfv_comm *c);
 
 static thread_local std::string g_tls_err;
 
@@ -183,6 +186,8 @@ PFV_API void pfv_ctx_destroy(pfv_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (pfv_comm *c : ctx->comms) comm_teardown(c);   // communicators the caller did not destroy: they use this context's stream
+    ctx->comms.clear();
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->qtab_dev) (void)hipFree(ctx->qtab_dev);
@@ -190,6 +195,14 @@ PFV_API void pfv_ctx_destroy(pfv_ctx *ctx)
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// "domain:bus:device.function" of the context's device (hipDeviceGetPCIBusId): which physical GPU a rank of a sharded job sits on
+PFV_API int pfv_ctx_pci_bus_id(pfv_ctx *ctx, char *out, int len)
+{
+    if (!ctx || !out || len < 16) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_pci_bus_id: bad argument");
+    HIP_TRY(ctx, hipDeviceGetPCIBusId(out, len, ctx->device));
+    return PFV_OK;
 }
 
 PFV_API int pfv_ctx_sync(pfv_ctx *ctx)

@@ -7,24 +7,23 @@
 // over xGMI.  librccl.so is opened at run time: single-GPU users of libpfv_hip.so need no RCCL, and the process stays free of
 // a second HIP runtime (torch.distributed would bring torch's own, which doubles the host cost of small launches).
 #include <dlfcn.h>
+#include <rccl/rccl.h>   // types, enums and prototypes only: the library itself is opened with dlopen below, nothing links against it
 
 namespace pfv {
 
-// the slice of rccl.h this file needs (ROCm 7.2 librccl.so.1; the ABI of these entry points is NCCL 2's)
-struct RcclUniqueId { char internal[128]; };
-typedef void *RcclComm;
-enum { kRcclUint8 = 1, kRcclInt64 = 4, kRcclFloat64 = 8, kRcclSum = 0, kRcclMax = 2 };
+// the entry points this file calls, typed by the header's own prototypes
 struct RcclApi {
     void *lib = nullptr;
-    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
-    int (*CommInitRank)(RcclComm *, int, RcclUniqueId, int) = nullptr;
-    int (*CommDestroy)(RcclComm) = nullptr;
-    int (*Broadcast)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, RcclComm, hipStream_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string why;     // why it could not be loaded
 };
+static_assert(sizeof(ncclUniqueId) == 128, "pfv_comm_unique_id / pfv_comm_init carry the id as 128 bytes");
 static const RcclApi &rccl_api()
 {
     static const RcclApi api = [] {
@@ -52,15 +51,32 @@ static const RcclApi &rccl_api()
 
 struct pfv_comm {
     pfv_ctx *ctx = nullptr;
-    pfv::RcclComm comm = nullptr;
+    ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     double *scratch = nullptr;      // device staging for the host-value reductions
 };
 
-static int rccl_fail(pfv_ctx *ctx, int rc, const char *what)
+static int rccl_fail(pfv_ctx *ctx, ncclResult_t rc, const char *what)
 {
     const pfv::RcclApi &a = pfv::rccl_api();
     return fail(ctx, PFV_ERR_HIP, std::string(what) + ": " + (a.GetErrorString ? a.GetErrorString(rc) : "RCCL error"));
+}
+// a collective enqueued while the context's stream is being captured (pfv_graph_begin) would either end up inside the graph or break
+// the capture with its synchronisation: refuse
+static int comm_usable(pfv_comm *c, const char *what)
+{
+    if (c->ctx->capturing) return fail(c->ctx, PFV_ERR_STATE, std::string(what) + ": the context is recording a graph (pfv_graph_begin)");
+    return PFV_OK;
+}
+
+// also called by pfv_ctx_destroy for communicators the caller left behind
+static void comm_teardown(pfv_comm *c)
+{
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) pfv::rccl_api().CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    delete c;
 }
 
 extern "C" {
@@ -70,9 +86,9 @@ PFV_API int pfv_comm_unique_id(uint8_t id_out[128])
     if (!id_out) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_comm_unique_id: null");
     const pfv::RcclApi &a = pfv::rccl_api();
     if (!a.why.empty()) return fail(nullptr, PFV_ERR_NO_DEVICE, a.why);
-    pfv::RcclUniqueId id;
-    const int rc = a.GetUniqueId(&id);
-    if (rc) return rccl_fail(nullptr, rc, "ncclGetUniqueId");
+    ncclUniqueId id;
+    const ncclResult_t rc = a.GetUniqueId(&id);
+    if (rc != ncclSuccess) return rccl_fail(nullptr, rc, "ncclGetUniqueId");
     memcpy(id_out, id.internal, 128);
     return PFV_OK;
 }
@@ -84,14 +100,16 @@ PFV_API int pfv_comm_init(pfv_ctx *ctx, int rank, int world, const uint8_t id[12
     const pfv::RcclApi &a = pfv::rccl_api();
     if (!a.why.empty()) return fail(ctx, PFV_ERR_NO_DEVICE, a.why);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    pfv::RcclUniqueId uid;
+    if (ctx->capturing) return fail(ctx, PFV_ERR_STATE, "pfv_comm_init: the context is recording a graph (pfv_graph_begin)");
+    ncclUniqueId uid;
     memcpy(uid.internal, id, 128);
     pfv_comm *c = new pfv_comm();
     c->ctx = ctx; c->rank = rank; c->world = world;
-    int rc = a.CommInitRank(&c->comm, world, uid, rank);
-    if (rc) { delete c; return rccl_fail(ctx, rc, "ncclCommInitRank"); }
+    const ncclResult_t rc = a.CommInitRank(&c->comm, world, uid, rank);
+    if (rc != ncclSuccess) { delete c; return rccl_fail(ctx, rc, "ncclCommInitRank"); }
     hipError_t e = hipMalloc((void **)&c->scratch, 64 * sizeof(double));
     if (e != hipSuccess) { a.CommDestroy(c->comm); delete c; return hip_fail(ctx, e, "pfv_comm_init"); }
+    ctx->comms.push_back(c);      // a communicator does not outlive its context: pfv_ctx_destroy tears down what is still here
     *out = c;
     return PFV_OK;
 }
@@ -102,25 +120,28 @@ PFV_API int pfv_comm_world(const pfv_comm *c) { return c ? c->world : 0; }
 PFV_API int pfv_comm_broadcast_dev(pfv_comm *c, void *buf_dev, size_t bytes, int root)
 {
     if (!c || !buf_dev || root < 0 || root >= c->world) return fail(c ? c->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_comm_broadcast_dev: bad argument");
+    if (comm_usable(c, "pfv_comm_broadcast_dev")) return PFV_ERR_STATE;
     HIP_TRY(c->ctx, hipSetDevice(c->ctx->device));
-    const int rc = pfv::rccl_api().Broadcast(buf_dev, buf_dev, bytes, pfv::kRcclUint8, root, c->comm, c->ctx->stream);
-    return rc ? rccl_fail(c->ctx, rc, "ncclBroadcast") : PFV_OK;
+    const ncclResult_t rc = pfv::rccl_api().Broadcast(buf_dev, buf_dev, bytes, ncclUint8, root, c->comm, c->ctx->stream);
+    return rc != ncclSuccess ? rccl_fail(c->ctx, rc, "ncclBroadcast") : PFV_OK;
 }
 
 PFV_API int pfv_comm_allreduce_f64_dev(pfv_comm *c, double *buf_dev, size_t count, int op)
 {
     if (!c || !buf_dev || (op != PFV_COMM_SUM && op != PFV_COMM_MAX)) return fail(c ? c->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_comm_allreduce_f64_dev: bad argument");
+    if (comm_usable(c, "pfv_comm_allreduce_f64_dev")) return PFV_ERR_STATE;
     HIP_TRY(c->ctx, hipSetDevice(c->ctx->device));
-    const int rc = pfv::rccl_api().AllReduce(buf_dev, buf_dev, count, pfv::kRcclFloat64, op == PFV_COMM_SUM ? pfv::kRcclSum : pfv::kRcclMax, c->comm, c->ctx->stream);
-    return rc ? rccl_fail(c->ctx, rc, "ncclAllReduce") : PFV_OK;
+    const ncclResult_t rc = pfv::rccl_api().AllReduce(buf_dev, buf_dev, count, ncclFloat64, op == PFV_COMM_SUM ? ncclSum : ncclMax, c->comm, c->ctx->stream);
+    return rc != ncclSuccess ? rccl_fail(c->ctx, rc, "ncclAllReduce") : PFV_OK;
 }
 
 PFV_API int pfv_comm_allgather_dev(pfv_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank)
 {
     if (!c || !send_dev || !recv_dev) return fail(c ? c->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_comm_allgather_dev: bad argument");
+    if (comm_usable(c, "pfv_comm_allgather_dev")) return PFV_ERR_STATE;
     HIP_TRY(c->ctx, hipSetDevice(c->ctx->device));
-    const int rc = pfv::rccl_api().AllGather(send_dev, recv_dev, bytes_per_rank, pfv::kRcclUint8, c->comm, c->ctx->stream);
-    return rc ? rccl_fail(c->ctx, rc, "ncclAllGather") : PFV_OK;
+    const ncclResult_t rc = pfv::rccl_api().AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, c->comm, c->ctx->stream);
+    return rc != ncclSuccess ? rccl_fail(c->ctx, rc, "ncclAllGather") : PFV_OK;
 }
 
 // host-value convenience forms: stage through the communicator's device scratch, run the collective on the context's
@@ -129,6 +150,7 @@ PFV_API int pfv_comm_allreduce_f64(pfv_comm *c, double *values, size_t count, in
 {
     if (!c || !values || count == 0 || count > 64) return fail(c ? c->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_comm_allreduce_f64: bad argument");
     pfv_ctx *ctx = c->ctx;
+    if (comm_usable(c, "pfv_comm_allreduce_f64")) return PFV_ERR_STATE;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(c->scratch, values, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     int rc = pfv_comm_allreduce_f64_dev(c, c->scratch, count, op);
@@ -148,11 +170,9 @@ PFV_API int pfv_comm_barrier(pfv_comm *c)
 PFV_API void pfv_comm_destroy(pfv_comm *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->comm) pfv::rccl_api().CommDestroy(c->comm);
-    if (c->scratch) (void)hipFree(c->scratch);
-    delete c;
+    auto &live = c->ctx->comms;
+    live.erase(std::remove(live.begin(), live.end(), c), live.end());
+    comm_teardown(c);
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <ucontext.h>
 
+#include <cstdio>
 #include <functional>
 #include <vector>
 
@@ -177,6 +178,7 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 typedef void *hipEvent_t;
 enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipDeviceGetPCIBusId(char *out, int len, int) { snprintf(out, (size_t)len, "0000:00:00.0"); return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // the emulator runs everything synchronously
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (void *)1; return hipSuccess; }

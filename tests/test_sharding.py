@@ -243,6 +243,49 @@ def test_rccl_init_failure_on_one_rank_sends_every_rank_to_the_socket_backend():
         assert destroyed == (1 if rank == 0 else 0)
 
 
+def test_rccl_init_that_hangs_keeps_the_context_alive_under_it():
+    """the init watchdog gives up on a pfv_comm_init that does not come back, but the thread is still INSIDE the library
+    with the context: the context must not be destroyed under it (Context.close() becomes a no-op, the process is expected to leave
+    through os._exit), and a call that returns late leaves a communicator that close() destroys"""
+    import ctypes
+    import time
+    import __graft_entry__ as g
+    g.load_package()
+    from importlib import import_module
+    commlib = import_module("pretty_fast_video_amd.comm")
+
+    class FakeLib:
+        destroyed = 0
+
+        def pfv_comm_unique_id(self, p):
+            ctypes.memset(p, 7, 128)
+            return 0
+
+        def pfv_comm_init(self, ctx, r, w, uid, out):
+            time.sleep(0.8)                                  # ncclCommInitRank stuck on a dead peer
+            ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = ctypes.c_void_p(0x1234)
+            return 0
+
+        def pfv_last_error(self, ctx):
+            return b""
+
+        def pfv_comm_destroy(self, h):
+            FakeLib.destroyed += 1
+
+    class FakeCtx:
+        handle = ctypes.c_void_p(1)
+        _lib = FakeLib()
+        keep_alive = False
+
+    ctx = FakeCtx()
+    comm = commlib.Comm(ctx, commlib.Rendezvous(0, 1), use_rccl=True, init_timeout=0.1)
+    assert comm.backend == "tcp" and "did not return" in comm.rccl_error
+    assert comm.stuck and ctx.keep_alive is True             # the context stays while the call is in it
+    time.sleep(1.0)
+    comm.close()                                             # the call came back late: its communicator is destroyed, the context is free again
+    assert not comm.stuck and ctx.keep_alive is False and FakeLib.destroyed == 1
+
+
 def _run_bench(extra_args, env_extra=None):
     import json
     import subprocess
@@ -268,6 +311,10 @@ def test_bench_self_launch_two_ranks():
     # whole-job count: 2 ranks x 2 streams x 3 frames x 20 macroblocks per step
     assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 2 * 2 * 3 * 20) < 1e-6
     assert res["cpu_baseline"] is None and "roofline" in res and res["config"]["streams_per_gpu"] == 2
+    # every rank's own rate, device and PCI address on rank 0's line (a straggler must be visible)
+    ranks = res["control_plane"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["macroblocks_per_s"] > 0 and r["seconds"] > 0 and r["pci_bus_id"] for r in ranks)
+    assert abs(sum(r["macroblocks_per_s"] * r["seconds"] for r in ranks) - 2 * 2 * 3 * 20) < 1e-6
 
 
 def test_bench_config5_single_rank_fields():
