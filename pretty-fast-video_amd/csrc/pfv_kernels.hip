@@ -38,6 +38,7 @@
 #include "pfv_device.h"
 #include "pfv_prof.h"   // KMARK: phase timestamps of the experiment builds, empty otherwise
 
+
 namespace pfv {
 
 // reference src/dct.rs:4-13 (data)

@@ -6,7 +6,17 @@
 
 namespace pfv {
 
-#ifdef PFV_KPROF
+#if defined(PFV_KPROF) && PFV_KPROF >= 2
+// -DPFV_KPROF=2: one row per WAVEFRONT (row = workgroup * 4 + wavefront), written by the wavefront's first lane -- what each SIMD's
+// resident wavefronts were doing at any time can then be reconstructed (tools/kprof_simd.py: when could NO resident wavefront issue?)
+constexpr int kProfRows = 1 << 18;
+__device__ unsigned long long pfv_kprof[kProfRows][16];
+#define KPROF_ROW() ((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)))
+#define KMARK(i) do { if ((threadIdx.x & 63) == 0 && KPROF_ROW() < kProfRows) pfv_kprof[KPROF_ROW()][i] = clock64(); } while (0)
+#define KMARK_WHERE() do { if ((threadIdx.x & 63) == 0 && KPROF_ROW() < kProfRows) { \
+        pfv_kprof[KPROF_ROW()][12] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+        pfv_kprof[KPROF_ROW()][13] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } } while (0)
+#elif defined(PFV_KPROF)
 constexpr int kProfRows = 1 << 16;
 __device__ unsigned long long pfv_kprof[kProfRows][16];
 #define KMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < kProfRows) pfv_kprof[blockIdx.x][i] = clock64(); } while (0)
