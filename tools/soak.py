@@ -57,6 +57,16 @@ with pkg.Context(0) as ctx:
         sc.check_batch_decoder(pkg, ctx, oracle, w, h, q, n_streams=S, n_frames=4, gop=3)
         stats["batch"] += 1
         pc.check_sparse_decode(pkg, ctx, w, h, n_streams=S, seed=s)
+        # round 4: the GOP-batched paths -- the slots of one session / one batch hold the GOPs of ONE stream
+        g_gop, g_frames = int(r.integers(1, 6)), int(r.integers(2, 14))
+        pc.check_gop_batched_session(pkg, ctx, oracle, w, h, q, n_frames=g_frames, gop=g_gop, seed=s, kind=kind)
+        pattern = "".join("IPPPD"[int(k)] for k in r.integers(0, 5, int(r.integers(3, 14))))     # any packet order the API allows, leading p-frames included
+        shapes = ((int(r.integers(1, 6)), int(r.integers(1, 6))), (8, 15))
+        gdata = sc.check_gop_objects(pkg, ctx, oracle, w, h, q, pattern, shapes=shapes, dec_threads=int(r.integers(0, 4)))
+        stats["gop_batched"] = stats.get("gop_batched", 0) + 1
+        if pattern.count("I") + pattern.count("P") >= 2:
+            stats["gop_corrupted_trials"] = stats.get("gop_corrupted_trials", 0) + sc.check_gop_decoder_corrupted(
+                pkg, ctx, oracle, gdata, n_trials=12, seed=s, shapes=shapes)["trials"]
         if w % 32 == 0:     # the fused retframe crop needs 16-byte rows in every plane
             pc.check_gop_graph(pkg, ctx, oracle, w, h, n_streams=S, n_frames=int(r.integers(2, 5)), quality=q)
             stats["graphs"] = stats.get("graphs", 0) + 1
