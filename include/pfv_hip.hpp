@@ -3,6 +3,8 @@
 //   pfv::VideoFrame  (src/frame.rs:3-59)     width, height, plane_y / plane_u / plane_v
 //   pfv::Encoder     (src/enc.rs:12-188)     new(writer, w, h, framerate, quality, num_threads) -> Encoder(writer, ..., Context&)
 //   pfv::Decoder     (src/dec.rs:15-224)     new(reader, num_threads)                            -> Decoder(reader, Context&)
+//   pfv::GopEncoder / pfv::GopDecoder        the same two objects with the independent GOPs of the stream as the slots of every launch
+//                                            (pfv_gop_encoder / pfv_gop_decoder): same bytes, same frames, same results call by call
 // The reference's `num_threads` slot (its rayon pool) is the pfv::Context: one device + one HIP stream.  Writers are
 // std::ostream, readers std::istream (read to the end on construction; the reference needs Read + Seek).  Errors of the
 // C ABI become pfv::Error (what() = pfv_last_error); DecodeError::{FormatError, VersionError, IOError} keep their codes.
@@ -209,6 +211,130 @@ class Decoder {
     std::string data_;              // the whole stream: the native decoder reads from it for its lifetime
     pfv_decoder *h_ = nullptr;
     VideoFrame frame_;              // retframe (src/dec.rs:22)
+    const OnVideo *cb_ = nullptr;
+};
+
+// Encoder with the GOPs of the stream batched per launch (pfv_gop_encoder, pfv_hip.h): same calls, same .pfv bytes; a packet reaches the
+// writer when its batch of max_gops groups is complete, on flush() or on finish().  Packets are written segment by segment from where
+// they lie (pfv_gop_encoder_drain_iov): no copy on the way to the writer.
+class GopEncoder {
+  public:
+    GopEncoder(std::ostream &writer, size_t width, size_t height, uint32_t framerate, int quality, Context &ctx, int max_gops = 8, int max_gop_frames = 15,
+               size_t payload_budget = 0)
+        : ctx_(ctx), out_(writer), width_(width), height_(height)
+    {
+        ctx_.check(pfv_gop_encoder_create(ctx.handle(), (int)width, (int)height, (int)framerate, quality, max_gops, max_gop_frames, payload_budget, &h_));
+        drain();   // the header (src/enc.rs:70)
+    }
+    ~GopEncoder()   // impl Drop (src/enc.rs:28-34)
+    {
+        if (h_) {
+            if (!finished_ && pfv_gop_encoder_finish(h_) == PFV_OK) {
+                try { drain(); } catch (...) {}
+            }
+            pfv_gop_encoder_destroy(h_);
+        }
+    }
+    GopEncoder(const GopEncoder &) = delete;
+    GopEncoder &operator=(const GopEncoder &) = delete;
+    void encode_iframe(const VideoFrame &f)   // src/enc.rs:75-123
+    {
+        check_frame(f);
+        ctx_.check(pfv_gop_encoder_encode_iframe(h_, f.plane_y.pixels.data(), f.plane_u.pixels.data(), f.plane_v.pixels.data()));
+        drain();
+    }
+    void encode_pframe(const VideoFrame &f)   // src/enc.rs:125-173
+    {
+        check_frame(f);
+        ctx_.check(pfv_gop_encoder_encode_pframe(h_, f.plane_y.pixels.data(), f.plane_u.pixels.data(), f.plane_v.pixels.data()));
+        drain();
+    }
+    void encode_dropframe() { ctx_.check(pfv_gop_encoder_encode_dropframe(h_)); }   // src/enc.rs:175-180
+    void flush()                              // every frame handed over so far becomes packets at the writer now
+    {
+        ctx_.check(pfv_gop_encoder_flush(h_));
+        drain();
+    }
+    void finish()                             // src/enc.rs:182-188
+    {
+        ctx_.check(pfv_gop_encoder_finish(h_));
+        finished_ = true;
+        drain();
+    }
+    long batches() const { return pfv_gop_encoder_batches(h_); }
+
+  private:
+    void check_frame(const VideoFrame &f) const   // the asserts of src/enc.rs:76-80
+    {
+        if (f.width != width_ || f.height != height_ || f.plane_y.pixels.size() != width_ * height_ ||
+            f.plane_u.pixels.size() != (width_ / 2) * (height_ / 2) || f.plane_v.pixels.size() != (width_ / 2) * (height_ / 2))
+            throw std::invalid_argument("GopEncoder: frame geometry does not match the encoder (src/enc.rs:76-79)");
+    }
+    void drain()
+    {
+        const pfv_iovec *iov = nullptr;
+        size_t n = 0;
+        ctx_.check(pfv_gop_encoder_drain_iov(h_, &iov, &n));
+        for (size_t i = 0; i < n; i++) out_.write(reinterpret_cast<const char *>(iov[i].data), (std::streamsize)iov[i].len);
+        if (!out_) throw Error(PFV_ERR_IO, "GopEncoder: the writer failed (the reference propagates io::Error, src/enc.rs:190-235)");
+    }
+    Context &ctx_;
+    std::ostream &out_;
+    size_t width_, height_;
+    bool finished_ = false;
+    pfv_gop_encoder *h_ = nullptr;
+};
+
+// Decoder with the GOPs of the stream batched per launch (pfv_gop_decoder): the frames, their order and the result of every call are
+// those of pfv::Decoder; n_threads packet parsers work beside the caller.
+class GopDecoder {
+  public:
+    using OnVideo = std::function<void(const VideoFrame &)>;
+    GopDecoder(std::istream &reader, Context &ctx, int max_gops = 8, int max_gop_frames = 15, int n_threads = 4)
+        : ctx_(ctx), data_((std::istreambuf_iterator<char>(reader)), std::istreambuf_iterator<char>())
+    {
+        int rc = pfv_gop_decoder_create(ctx.handle(), reinterpret_cast<const uint8_t *>(data_.data()), data_.size(), max_gops, max_gop_frames, n_threads, &h_);
+        if (rc != PFV_OK) ctx_.check(rc);
+        frame_ = VideoFrame((size_t)width(), (size_t)height());
+    }
+    ~GopDecoder() { pfv_gop_decoder_destroy(h_); }
+    GopDecoder(const GopDecoder &) = delete;
+    GopDecoder &operator=(const GopDecoder &) = delete;
+    uint32_t width() const { return (uint32_t)pfv_gop_decoder_width(h_); }
+    uint32_t height() const { return (uint32_t)pfv_gop_decoder_height(h_); }
+    uint32_t framerate() const { return (uint32_t)pfv_gop_decoder_framerate(h_); }
+    void reset() { ctx_.check(pfv_gop_decoder_reset(h_)); }
+    bool advance_delta(double delta, const OnVideo &onvideo)
+    {
+        cb_ = &onvideo;
+        return result(pfv_gop_decoder_advance_delta(h_, delta, &GopDecoder::trampoline, this));
+    }
+    bool advance_frame(const OnVideo &onvideo)
+    {
+        cb_ = &onvideo;
+        return result(pfv_gop_decoder_advance_frame(h_, &GopDecoder::trampoline, this));
+    }
+
+  private:
+    bool result(int rc)
+    {
+        cb_ = nullptr;
+        if (rc < 0) ctx_.check(rc);
+        return rc == 1;
+    }
+    static void trampoline(void *user, const uint8_t *y, const uint8_t *u, const uint8_t *v, int w, int h)
+    {
+        GopDecoder *d = static_cast<GopDecoder *>(user);
+        const size_t ny = (size_t)w * h, nc = (size_t)(w / 2) * (h / 2);
+        d->frame_.plane_y.pixels.assign(y, y + ny);
+        d->frame_.plane_u.pixels.assign(u, u + nc);
+        d->frame_.plane_v.pixels.assign(v, v + nc);
+        if (d->cb_ && *d->cb_) (*d->cb_)(d->frame_);
+    }
+    Context &ctx_;
+    std::string data_;
+    pfv_gop_decoder *h_ = nullptr;
+    VideoFrame frame_;
     const OnVideo *cb_ = nullptr;
 };
 

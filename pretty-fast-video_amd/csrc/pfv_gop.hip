@@ -678,6 +678,16 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     fill(d->set[0], 0);
     gopd_start_parse(d, &d->set[0], G);
     gopd_join_parse(d, &d->set[0]);
+    // An i-frame whose list overflowed (denser than 1 non-zero in 4) was not read to its end: whether it parses is only known after a
+    // full pass, and the chains below depend on it -- read it once more with a sink that keeps nothing (dense i-frames only: rare)
+    for (int k = 0; k < G; k++) {
+        GopDecEvent *e0 = d->set[0].ev[(size_t)k];
+        if (!e0 || e0->type != 1 || d->set[0].rc[(size_t)k] != kSinkFull) continue;
+        struct { bool put(size_t, int16_t) { return true; } } none;
+        uint8_t q[3];
+        const int vrc = parse_iframe_to(e0->payload, e0->plen, (int)tb, d->n_qtables, none, q);
+        if (vrc) d->set[0].rc[(size_t)k] = vrc;
+    }
     d->stats[1] += clk.lap();
     bool reparse = false, head_continues = d->gfirst[0] == 2;
     int last_root = G - 1;

@@ -60,6 +60,42 @@ int main(int argc, char **argv)
         } catch (const pfv::Error &e) {
             if (e.code() != PFV_ERR_FORMAT) { std::fprintf(stderr, "wrong error code %d\n", e.code()); return 1; }
         }
+        // the GOP-batched objects on the same clip: same bytes, same frames (batches of 2 groups of at most 2 frames: runs are cut)
+        {
+            std::ifstream in3(argv[7], std::ios::binary);
+            std::stringstream gs(std::ios::in | std::ios::out | std::ios::binary);
+            {
+                pfv::GopEncoder ge(gs, w, h, fps, quality, ctx, 2, 2);
+                pfv::VideoFrame f(w, h);
+                for (int t = 0; t < n_in; t++) {
+                    in3.read(reinterpret_cast<char *>(f.plane_y.pixels.data()), (std::streamsize)f.plane_y.pixels.size());
+                    in3.read(reinterpret_cast<char *>(f.plane_u.pixels.data()), (std::streamsize)f.plane_u.pixels.size());
+                    in3.read(reinterpret_cast<char *>(f.plane_v.pixels.data()), (std::streamsize)f.plane_v.pixels.size());
+                    if (t == drop_at) ge.encode_dropframe();
+                    else if (t % gop == 0) ge.encode_iframe(f);
+                    else ge.encode_pframe(f);
+                }
+            }   // ~GopEncoder flushes the open batch and writes the EOF packet
+            if (gs.str() != bytes) { std::fprintf(stderr, "GopEncoder bytes differ from Encoder bytes\n"); return 1; }
+            std::istringstream greader(bytes, std::ios::binary);
+            pfv::GopDecoder gd(greader, ctx, 3, 2, 2);
+            out.flush();
+            std::ifstream ref(argv[9], std::ios::binary);
+            const size_t ny = w * h, nc = (w / 2) * (h / 2);
+            std::vector<char> want(ny + 2 * nc);
+            int n_gop = 0;
+            bool same = true;
+            auto cmp = [&](const pfv::VideoFrame &fr) {
+                ref.read(want.data(), (std::streamsize)want.size());
+                same = same && ref && std::equal(fr.plane_y.pixels.begin(), fr.plane_y.pixels.end(), reinterpret_cast<const uint8_t *>(want.data())) &&
+                       std::equal(fr.plane_u.pixels.begin(), fr.plane_u.pixels.end(), reinterpret_cast<const uint8_t *>(want.data()) + ny) &&
+                       std::equal(fr.plane_v.pixels.begin(), fr.plane_v.pixels.end(), reinterpret_cast<const uint8_t *>(want.data()) + ny + nc);
+                n_gop++;
+            };
+            while (gd.advance_frame(cmp)) {}
+            if (!same || n_gop != n_out) { std::fprintf(stderr, "GopDecoder frames differ from Decoder's (%d of %d)\n", n_gop, n_out); return 1; }
+            std::printf("gop: %d frames identical to the frame-by-frame objects\n", n_gop);
+        }
         // the batch classes on the same clip: both streams carry the clip itself, so each writer must receive `bytes`
         // and every decoded step must equal the frames the single Decoder wrote (when no drop frame was asked for)
         if (drop_at < 0) {

@@ -495,3 +495,33 @@ def check_gop_decoder_corrupted(pkg, ctx, oracle, data, n_trials, seed, shapes=(
         stats["errors"] += any(x[0] == "err" for x in a2)
         stats["frames"] += sum(x[0] == "frame" for x in a2)
     return stats
+
+
+def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quality=1):
+    """Found by tools/soak.py (round 4): at a fine quantiser an i-frame is denser than 1 non-zero in 4, its coefficient LIST overflows
+    before the parser reaches a corrupted byte further on, and the GOP-batched decoder took the frame for good when it cut its chains --
+    the p-frames behind it then decoded against the slot's stale framebuffer instead of the previous run's last frame.  P P I P with the
+    i-frame damaged in its second half: every call of the GOP-batched decoder must match the sequential Decoder's."""
+    data, _ = encode_pattern(pkg, ctx, oracle, w, h, quality, "PPIP", lambda buf: pkg.Encoder(buf, w, h, 30, quality, ctx), with_oracle=False)
+    hdr = 20 + 4 * 128
+    pos, pk = hdr, []
+    while pos + 5 <= len(data):
+        n = int.from_bytes(data[pos + 1:pos + 5], "little")
+        pk.append((data[pos], pos, n))
+        pos += 5 + n
+    assert [t for t, _, _ in pk] == [2, 2, 1, 2, 0]
+    _, p, n = pk[2]
+    hit = 0
+    for frac in (0.55, 0.7, 0.8, 0.9, 0.97):
+        bad = bytearray(data)
+        bad[p + 5 + int(n * frac)] ^= 0xFF
+        bad = bytes(bad)
+        want = _outcomes(lambda: pkg.Decoder(bad, ctx, lookahead=0), pkg, n_calls=12, stop_at_error=False)
+        if [x[0] for x in want][:4] != ["frame", "frame", "err", "frame"]:
+            continue                                                   # this flip happened to leave the packet parseable
+        hit += 1
+        for shape in ((8, 15), (2, 2), (1, 15)):
+            got = _outcomes(lambda: pkg.GopDecoder(bad, ctx, max_gops=shape[0], max_gop_frames=shape[1], threads=1), pkg, n_calls=12, stop_at_error=False)
+            assert got == want, (frac, shape, [x[0] for x in got], [x == y for x, y in zip(got, want)])
+    assert hit >= 1, "no flip produced the failing i-frame this case is about"
+    return hit

@@ -49,6 +49,7 @@ def _run(pkg, oracle, exe, tmp_path, w, h, quality, n_frames, gop, drop_at):
     got = np.fromfile(yuv_out, dtype=np.uint8)
     assert got.size == sum(d.size for d in decoded) and np.array_equal(got, np.concatenate(decoded))
     assert f"decoded {len(decoded)}" in r.stdout
+    assert f"gop: {len(decoded)} frames identical" in r.stdout     # pfv::GopEncoder / pfv::GopDecoder: same bytes, same frames
     if drop_at < 0:                      # the program also ran pfv::BatchEncoder / BatchDecoder on two copies of the clip
         assert "batch: 2 streams" in r.stdout
 

@@ -237,3 +237,7 @@ def test_emu_gop_decoder_corrupted_streams(pkg, emu_ctx, oracle):
     data, _ = sc.encode_pattern(pkg, emu_ctx, oracle, 48, 32, 5, "IPPIPPPIP", lambda buf: pkg.Encoder(buf, 48, 32, 30, 5, emu_ctx), with_oracle=False)
     stats = sc.check_gop_decoder_corrupted(pkg, emu_ctx, oracle, data, n_trials=12, seed=4)
     assert stats["trials"] == 12 and stats["errors"] > 2 and stats["frames_after_an_error"] > 0
+
+
+def test_emu_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle):
+    assert sc.check_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle) >= 1

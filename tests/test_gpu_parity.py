@@ -476,6 +476,11 @@ def test_gop_decoder_corrupted_streams(pkg, gpu_ctx, oracle, geom):
     assert stats["trials"] == 60 and stats["errors"] > 10 and stats["frames_after_an_error"] > 0
 
 
+def test_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle):
+    assert sc.check_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle) >= 1
+    assert sc.check_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle, 320, 240, 0) >= 1
+
+
 def test_config4_4k_gop15_stream_vs_oracle(pkg, gpu_ctx, oracle):
     """BASELINE config #4 at its stated geometry and GOP pattern, under the driver's eyes: 3840x2160, 31 frames (i-frames at
     0, 15 and 30 -> two full GOP boundaries, README.md:34-41), quality 5, product Encoder -> .pfv bytes -> product Decoder
