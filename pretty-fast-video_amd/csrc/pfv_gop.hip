@@ -895,9 +895,13 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
         if (ok) { memset(s.mv.data(), 0, S * tb * 2); memset(s.has.data(), 0, S * tb); memset(s.flags.data(), 0, S * sizeof(int)); }
         if (he == hipSuccess) he = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
     }
+    // the scatter kernel reads the coefficient lists where the parsers wrote them: that memory must be page-locked (= mapped to the device)
+    bool lists_pinned = true;
+    for (GopDecSet &s : d->set) lists_pinned = lists_pinned && s.idx.pinned && s.val.pinned && s.counts.pinned;
     ok = ok && d->frames_host.resize(S * (size_t)max_gop_frames * d->frame_bytes);
     if (ok && he == hipSuccess) he = hipMalloc((void **)&d->frames_dev, S * d->frame_bytes);
     if (!ok) rc = fail(ctx, PFV_ERR_NOMEM, "pfv_gop_decoder_create: host staging");
+    else if (!lists_pinned) rc = fail(ctx, PFV_ERR_NOMEM, "pfv_gop_decoder_create: the coefficient-list staging could not be page-locked (locked-memory limit): use a smaller max_gops");
     else if (he != hipSuccess) rc = hip_fail(ctx, he, "pfv_gop_decoder_create");
     if (!rc) rc = dec_staging(hot);
     if (!rc) rc = pfv_dec_set_output_dev(hot, d->frames_dev);
