@@ -497,7 +497,7 @@ def check_gop_decoder_corrupted(pkg, ctx, oracle, data, n_trials, seed, shapes=(
     return stats
 
 
-def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quality=1):
+def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quality=1, require_hit=True):
     """Found by tools/soak.py (round 4): at a fine quantiser an i-frame is denser than 1 non-zero in 4, its coefficient LIST overflows
     before the parser reaches a corrupted byte further on, and the GOP-batched decoder took the frame for good when it cut its chains --
     the p-frames behind it then decoded against the slot's stale framebuffer instead of the previous run's last frame.  P P I P with the
@@ -514,7 +514,9 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
     hit = 0
     for frac in (0.55, 0.7, 0.8, 0.9, 0.97):
         bad = bytearray(data)
-        bad[p + 5 + int(n * frac)] ^= 0xFF
+        at = p + 5 + int(n * frac)
+        bad[at:at + 4] = bytes(4)                                      # a hole of zero bits: a long run the frame has no room for
+        bad[at + 4] ^= 0xFF
         bad = bytes(bad)
         want = _outcomes(lambda: pkg.Decoder(bad, ctx, lookahead=0), pkg, n_calls=12, stop_at_error=False)
         if [x[0] for x in want][:4] != ["frame", "frame", "err", "frame"]:
@@ -523,5 +525,5 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
         for shape in ((8, 15), (2, 2), (1, 15)):
             got = _outcomes(lambda: pkg.GopDecoder(bad, ctx, max_gops=shape[0], max_gop_frames=shape[1], threads=1), pkg, n_calls=12, stop_at_error=False)
             assert got == want, (frac, shape, [x[0] for x in got], [x == y for x, y in zip(got, want)])
-    assert hit >= 1, "no flip produced the failing i-frame this case is about"
+    assert hit >= 1 or not require_hit, "no flip produced the failing i-frame this case is about"
     return hit
