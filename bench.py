@@ -688,6 +688,12 @@ def single_stream_side(pkg, ctx, Q, reps=6):
         ss.close()
     dctx.close()
     ectx.close()
+    # one 1080p stream of 300 frames with its 20 GOPs as the slots of each launch (GopBatchSet; round 4): what the reference's own
+    # usage -- one Encoder, one stream -- gets when the caller has more than one GOP in hand
+    gb = GopBatchSet(pkg, ctx, 1920, 1080, Q, [pkg.synth.SEED], 20 * GOP)
+    out["streams_1"]["gop_batched_20_gops_per_launch"] = gb.wall(reps)
+    gb.verify()
+    gb.close()
     out["unit"] = "macroblocks/s (encode+decode, 1080p GOP-15, kernel scope, host clock incl. launch overhead)"
     return out
 
