@@ -683,7 +683,7 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     for (int k = 0; k < G; k++) {
         GopDecEvent *e0 = d->set[0].ev[(size_t)k];
         if (!e0 || e0->type != 1 || d->set[0].rc[(size_t)k] != kSinkFull) continue;
-        struct { bool put(size_t, int16_t) { return true; } } none;
+        struct { bool put(size_t, int16_t) { return true; } bool put_if(bool, size_t, int16_t) { return true; } } none;
         uint8_t q[3];
         const int vrc = parse_iframe_to(e0->payload, e0->plen, (int)tb, d->n_qtables, none, q);
         if (vrc) d->set[0].rc[(size_t)k] = vrc;

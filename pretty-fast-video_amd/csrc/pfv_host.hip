@@ -78,6 +78,8 @@ class BitSource {
     BitSource(const uint8_t *p, size_t n) : p_(p), total_((uint64_t)n * 8) {}
     uint64_t total_bits() const { return total_; }
     uint64_t position() const { return pos_; }
+    void set_position(uint64_t pos) { pos_ = pos; }
+    const uint8_t *data() const { return p_; }
     void seek(int64_t delta) { pos_ = (uint64_t)((int64_t)pos_ + delta); }
     bool ok() const { return ok_; }
     uint32_t get(unsigned nbits)   // BitRead::read (nbits <= 32)
@@ -165,6 +167,7 @@ class HuffmanTree {
     // two codes is longer than 8 bits or the pair longer than 12 -- take the one-at-a-time path)
     struct PairEntry { uint8_t used, zeros, size; };
     const PairEntry &pair(uint32_t low12) const { return pair_[low12 & 4095]; }
+    uint32_t pair32(uint32_t low12) const { return pair32_[low12 & 4095]; }   // the same entry in one word: used | zeros << 8 | size << 16
     void build_pair_table()   // once per packet that is worth it (the run parser of whole frames)
     {
         for (uint32_t v = 0; v < 4096; v++) {
@@ -175,6 +178,7 @@ class HuffmanTree {
                 if (b.len && a.len + b.len <= 12) e = PairEntry{(uint8_t)(a.len + b.len), a.symbol, b.symbol};
             }
             pair_[v] = e;
+            pair32_[v] = (uint32_t)e.used | ((uint32_t)e.zeros << 8) | ((uint32_t)e.size << 16);
         }
     }
 
@@ -226,6 +230,7 @@ class HuffmanTree {
     std::array<HuffCode, 16> codes_{};
     std::array<HuffCode, 256> fast_{};
     std::array<PairEntry, 4096> pair_{};
+    std::array<uint32_t, 4096> pair32_{};
     std::vector<Node> nodes_;
     int root_ = -1;
 };
@@ -375,6 +380,7 @@ inline int parse_head(BitSource &r, PacketHead &h, int n_qtables)
 struct DenseSink {
     int16_t *out;
     bool put(size_t i, int16_t v) { out[i] = v; return true; }
+    bool put_if(size_t c, size_t i, int16_t v) { if (c) out[i] = v; return true; }
 };
 struct SparseSink {
     uint32_t *idx;
@@ -388,33 +394,79 @@ struct SparseSink {
         val[n++] = v;
         return true;
     }
+    // put(i, v) when c, nothing otherwise -- without a branch on c: the slot is written either way and only claimed when c
+    bool put_if(size_t c, size_t i, int16_t v)
+    {
+        if (__builtin_expect(n >= cap, 0)) return !c;
+        idx[n] = (uint32_t)(i + offset);
+        val[n] = v;
+        n += c;
+        return true;
+    }
 };
 constexpr int kSinkFull = 1;   // SparseSink ran out of room: the caller falls back to the dense form
 
-// reads run symbols until `count` coefficients are covered, handing values to sink.put(base + index, value)
+// reads run symbols until `count` coefficients are covered, handing values to the sink (base + index, value).
+// Fast section (while at least kFastTailBits of stream lie behind the read position): a 64-bit bit buffer refilled without a branch
+// and OFF the decode's dependency chain (buf |= load(ptr) << have; ptr += (63 - have) >> 3; have |= 56 -- the bytes that overlap the
+// buffer's top are the same bits again), two symbols per refill (a symbol is at most 12 code bits, the pair table, + 15 value bits),
+// value / no value handled without a branch: half of all symbols carry no value (fillers, closing runs), unpredictably mixed with those
+// that do, and those mispredictions were a third of the parser's time.  What the reference does per symbol is unchanged
+// (huffman.rs:156-197, dec.rs:261-296, 378-417); the last bytes of a packet and codes longer than the table go the one-field-at-a-time way.
+constexpr uint64_t kFastTailBits = 192;
 template <class Sink>
 inline int read_runs(BitSource &r, const HuffmanTree &tree, Sink &sink, size_t base, size_t count)
 {
     size_t idx = 0;
+    const uint64_t total = r.total_bits();
     while (idx < count) {
-        if (r.can_peek()) {
-            // whole symbol from one 64-bit window when both codes hit the 8-bit table (the same lookups
-            // HuffmanTree::read makes, huffman.rs:156-197, minus the per-field refills)
-            const uint64_t win = r.peek();
-            const HuffmanTree::PairEntry &pe = tree.pair((uint32_t)win);
-            if (pe.used) {
-                unsigned used = pe.used;
-                idx += pe.zeros;
-                if (const unsigned nb = pe.size) {
-                    if (idx >= count) return -6;
-                    const uint32_t raw = (uint32_t)(win >> used) & ((1u << nb) - 1u);
-                    const int16_t v = (int16_t)(int32_t)((raw ^ (1u << (nb - 1))) - (1u << (nb - 1)));   // sign-extend nb bits
-                    if (!sink.put(base + idx++, v)) return kSinkFull;
-                    used += nb;
+        const uint64_t pos = r.position();
+        if (pos + kFastTailBits <= total) {
+            const uint8_t *const data = r.data();
+            const uint8_t *ptr = data + (pos >> 3);
+            uint64_t buf;
+            std::memcpy(&buf, ptr, 8);
+            ptr += 7;
+            unsigned have = 56 - (unsigned)(pos & 7);          // valid bits claimed in buf (the byte above them is re-read by the refill)
+            buf >>= (pos & 7);
+            const uint64_t stop = total - kFastTailBits;
+            bool slow = false;
+            for (;;) {
+                uint64_t w;
+                std::memcpy(&w, ptr, 8);
+                buf |= w << have;
+                ptr += (63 - have) >> 3;
+                have |= 56;                                    // 56..63 valid bits: two symbols of at most 27 each
+#define PFV_RUN_SYMBOL()                                                                                                  \
+                {                                                                                                         \
+                    const uint32_t pe = tree.pair32((uint32_t)buf);          /* used | zeros << 8 | size << 16 */        \
+                    if (!(pe & 0xffu)) { slow = true; break; }                                                            \
+                    const unsigned pused = pe & 0xffu, nb = pe >> 16;                                                     \
+                    idx += (pe >> 8) & 0xffu;                                                                             \
+                    if (idx >= count) {             /* the run closes the macroblock, or the stream is damaged */         \
+                        if (nb) return -6;          /* the reference would index out of bounds here */                    \
+                        buf >>= pused;                                                                                    \
+                        have -= pused;                                                                                    \
+                        break;                                                                                            \
+                    }                                                                                                     \
+                    const uint32_t sign = (1u << nb) >> 1;                                  /* 0 for nb == 0 */           \
+                    const uint32_t raw = (uint32_t)(buf >> pused) & ((1u << nb) - 1u);                                    \
+                    const int16_t v = (int16_t)(int32_t)((raw ^ sign) - sign);              /* sign-extend nb bits */     \
+                    const size_t has_value = nb != 0;                                                                     \
+                    if (!sink.put_if(has_value, base + idx, v)) return kSinkFull;                                         \
+                    idx += has_value;                                                                                     \
+                    const unsigned used = pused + nb;                                                                     \
+                    buf >>= used;                                                                                         \
+                    have -= used;                                                                                         \
+                    if (idx >= count) break;                                                                              \
                 }
-                r.skip(used);
-                continue;
+                PFV_RUN_SYMBOL()
+                PFV_RUN_SYMBOL()
+#undef PFV_RUN_SYMBOL
+                if ((uint64_t)(ptr - data) * 8 - have > stop) break;
             }
+            r.set_position((uint64_t)(ptr - data) * 8 - have);
+            if (!slow) continue;
         }
         int z = tree.read(r, r.total_bits());
         if (z < 0) return z == -2 ? -8 : -6;
