@@ -677,6 +677,19 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     GopClock clk;
     fill(d->set[0], 0);
     gopd_start_parse(d, &d->set[0], G);
+    // The steps behind it go to the parsers at the same time, on the assumption that every group's first frame is sound (the i-frames of
+    // step 0 are several times the size of a p-frame: without this the pool idles while the slowest of them is read).  If one is not,
+    // the chains change and these steps are parsed again.
+    int prefilled = 1;
+    {
+        int steps0 = 0;
+        for (int k = 0; k < G; k++) steps0 = std::max(steps0, (int)chain[(size_t)k].size());
+        for (int t = 1; t < kGopDecSets && t < steps0; t++) {
+            fill(d->set[t], t);
+            gopd_start_parse(d, &d->set[t], G);
+            prefilled = t + 1;
+        }
+    }
     gopd_join_parse(d, &d->set[0]);
     // An i-frame whose list overflowed (denser than 1 non-zero in 4) was not read to its end: whether it parses is only known after a
     // full pass, and the chains below depend on it -- read it once more with a sink that keeps nothing (dense i-frames only: rare)
@@ -724,7 +737,8 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     const int cur0 = hot->cur;
     // steps [t, next_fill) are parsed or being parsed; step s uses staging set s % kGopDecSets.  A set is refilled as soon as the device
     // has finished with the step that used it last.
-    int next_fill = reparse ? 0 : 1;         // the chains moved: step 0 is something else now
+    if (reparse) gopd_drain_pool(d);         // the chains moved: what was parsed ahead belongs to other (slot, step) places now
+    int next_fill = reparse ? 0 : prefilled;
     auto top_up = [&](int t, bool must_have_t) -> int {
         while (next_fill < steps && next_fill < t + kGopDecSets) {
             GopDecSet &n = d->set[next_fill % kGopDecSets];
