@@ -253,7 +253,9 @@ class Comm:
             parts = [np.frombuffer(p, np.float64) for p in self.rdzv.allgather(v.tobytes())]
             return np.sum(parts, axis=0) if op == "sum" else np.max(parts, axis=0)
         out = v.copy()
-        self.ctx.check(self.ctx._lib.pfv_comm_allreduce_f64(self.handle, out.ctypes.data_as(ctypes.c_void_p), out.size, 0 if op == "sum" else 1))
+        for at in range(0, out.size, 64):       # the host-value form stages at most 64 values per call
+            part = out[at:at + 64]
+            self.ctx.check(self.ctx._lib.pfv_comm_allreduce_f64(self.handle, part.ctypes.data_as(ctypes.c_void_p), part.size, 0 if op == "sum" else 1))
         return out
 
     def barrier(self):
