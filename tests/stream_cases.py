@@ -403,6 +403,21 @@ def check_gop_objects(pkg, ctx, oracle, w, h, quality, pattern, shapes, frame_sr
         assert len(got) == len(want), (max_gops, max_len, [x[0] for x in got], [x[0] for x in want])
         for k, (a, b) in enumerate(zip(got, want)):
             assert a == b, f"GOP-batched decoder (max_gops {max_gops}, max_gop_frames {max_len}): call {k} gives {a[0]}, the oracle {b[0]}"
+    # reset() (dec.rs:148-152) in mid-batch and real-time pacing (advance_delta, dec.rs:154-167): as the frame-by-frame Decoder behaves
+    if pattern[:1] == "I" and len(pattern) >= 3:
+        max_gops, max_len = shapes[0]
+        gd, sd = pkg.GopDecoder(serial, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=1), pkg.Decoder(serial, ctx, lookahead=0)
+        ga, sa = [], []
+        for dec, acc in ((gd, ga), (sd, sa)):
+            assert (dec.width(), dec.height(), dec.framerate()) == (w, h, 30)
+            dec.advance_frame(lambda fr: acc.append(fr.packed().tobytes()))
+            dec.advance_frame(lambda fr: acc.append(fr.packed().tobytes()))
+            dec.reset()
+            acc.append(dec.advance_delta(2.5 / 30, lambda fr: acc.append(fr.packed().tobytes())))    # two packets, half a period carried over
+            acc.append(dec.advance_delta(0.6 / 30, lambda fr: acc.append(fr.packed().tobytes())))    # one more
+            acc.append(dec.advance_delta(100.0, lambda fr: acc.append(fr.packed().tobytes())))       # runs into the end of the stream
+            dec.close()
+        assert ga == sa, "GOP-batched decoder: reset / advance_delta deliver something else than the frame-by-frame Decoder"
     return serial
 
 

@@ -231,6 +231,12 @@ def test_gop_batched_session_vs_serial_oracle(pkg, gpu_ctx, oracle, geom):
     assert r["gops"] == (n + 14) // 15 and r["launches_per_operation"] == 15 and r["frames"] == n
 
 
+def test_gop_batched_session_low_motion_and_static(pkg, gpu_ctx, oracle):
+    """the same with content that takes the skip-aware paths inside the batch (tile compaction, wavefronts with nothing coded)"""
+    pc.check_gop_batched_session(pkg, gpu_ctx, oracle, 640, 368, 5, n_frames=22, gop=5, kind="low_motion", threads=8)
+    pc.check_gop_batched_session(pkg, gpu_ctx, oracle, 336, 256, 8, n_frames=9, gop=4, kind="static", threads=8)
+
+
 def test_session_4k_roundtrip_property(pkg, gpu_ctx):
     """BASELINE config #4 geometry (3840x2160, 48 720 MB/frame): size-independent property --
     the decoder's framebuffer equals the encoder's closed-loop reconstruction for every frame
