@@ -265,6 +265,30 @@ def test_session_4k_roundtrip_property(pkg, gpu_ctx):
     dec.close()
 
 
+def test_rccl_world_of_every_visible_gpu(pkg, gpu_ctx):
+    """the real world > 1 RCCL path (ncclCommInitRank over xGMI, the table broadcast, barriers and the counter reduction of
+    bench.py) wherever at least two GPUs are visible -- one rank per visible device, self-launched like `python bench.py --gpus N`.
+    The build pool's boxes have ONE MI355X: there this test is skipped, and says so."""
+    import json
+    import subprocess
+    import sys
+    n = int(gpu_ctx._lib.pfv_device_count())
+    if n < 2:
+        pytest.skip(f"{n} GPU visible: the multi-rank RCCL path needs at least two (the 1-rank communicator test below runs here)")
+    n = min(n, 8)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--streams", "8", "--no-entropy"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    res = json.loads(line[0])
+    assert res["n_gpus"] == n and res["rccl_ranks"] == n and res["control_plane"]["backend"] == "rccl", res["control_plane"]
+    ranks = res["control_plane"]["ranks"]
+    assert sorted(x["device_ordinal"] for x in ranks) == list(range(n)) and len({x["pci_bus_id"] for x in ranks}) == n
+    assert abs(sum(x["macroblocks_per_s"] * x["seconds"] for x in ranks) - n * 8 * 15 * 12240 * 2) < 1.0
+
+
 def test_rccl_one_rank_communicator(pkg, gpu_ctx):
     """the control plane of the multi-GPU path on the real RCCL: a 1-rank communicator on the MI355X box runs the very entry
     points the 8-GPU job uses (pfv_comm_*: ncclCommInitRank, ncclBroadcast, ncclAllReduce, ncclAllGather on the context's
