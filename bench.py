@@ -1073,7 +1073,8 @@ def main():
     else:
         table = shard.assign_streams(n_streams_total=S * world, world=world, base_seed=pkg.synth.SEED)
     ctx = pkg.Context(local_rank)
-    comm = commlib.Comm(ctx, rdzv, use_rccl=not share) if use_comm else None
+    # ncclCommInitRank of 8 ranks on one node takes seconds; past 90 s every rank falls back to the socket backend together (comm.py)
+    comm = commlib.Comm(ctx, rdzv, use_rccl=not share, init_timeout=float(os.environ.get("PFV_RCCL_INIT_TIMEOUT", "90"))) if use_comm else None
     if use_comm:
         table = comm.broadcast_array(np.asarray(table, dtype=np.int64) if rank == 0 else np.zeros_like(np.asarray(table, dtype=np.int64)))
     mine = shard.streams_of_rank(table, rank)
