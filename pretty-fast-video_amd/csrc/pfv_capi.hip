@@ -3,7 +3,16 @@
 //
 // There is NO CPU fallback here: every entry point either runs the HIP kernels or returns
 // a negative status.
+#define PFV_CAPI_TU
 #include "pfv_kernels.hip"
+#ifdef PFV_SPLIT_PENC    // product build: the p-frame encode kernels are compiled on their own, with their own scheduling strategy (pfv_penc.hip)
+namespace pfv {
+void launch_enc_pframe_kernels(hipStream_t stream, bool flt, bool small, int compact_max, const FrameGeom &g, unsigned blocks, const uint8_t *src,
+                               const uint8_t *ref, int8_t *mv, uint8_t *has, int16_t *coef, uint8_t *recon, const QTab *qt, float min_err);
+}
+#else
+#include "pfv_penc.hip"
+#endif
 #include "pfv_entropy_kernels.hip"
 #include "pfv_synth_kernels.hip"
 #include "pfv_host.hip"
@@ -491,14 +500,7 @@ static void launch_enc_iframe(pfv_ctx *ctx, bool flt, bool small, const FrameGeo
 static void launch_enc_pframe(pfv_ctx *ctx, bool flt, bool small, bool compaction, const FrameGeom &g, const uint8_t *src, const uint8_t *ref, int8_t *mv,
                               uint8_t *has, int16_t *coef, uint8_t *recon, const QTab *qt, float min_err)
 {
-    if (small) {
-        if (flt) hipLaunchKernelGGL(k_enc_pframe16<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads16), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic);
-        else hipLaunchKernelGGL(k_enc_pframe16<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads16), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic);
-    } else {
-        const int cmax = compaction ? kPencCompactMax : 0;
-        if (flt) hipLaunchKernelGGL(k_enc_pframe<true>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic, cmax);
-        else hipLaunchKernelGGL(k_enc_pframe<false>, dim3(penc_blocks(ctx, g)), dim3(kThreads), 0, ctx->stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic, cmax);
-    }
+    launch_enc_pframe_kernels(ctx->stream, flt, small, compaction ? kPencCompactMax : 0, g, penc_blocks(ctx, g), src, ref, mv, has, coef, recon, qt, min_err);
 }
 static void launch_dec_iframe(pfv_ctx *ctx, bool small, const FrameGeom &g, const int16_t *coef, uint8_t *out, const QTab *qt, uint8_t *frames_out)
 {

@@ -41,7 +41,9 @@
 
 namespace pfv {
 
-// reference src/dct.rs:4-13 (data)
+// reference src/dct.rs:4-13 (data).  Internal linkage: the p-frame encoder is its own translation unit in the product build
+// (pfv_penc.hip) and carries its own copy of the two tables
+namespace {
 __constant__ int kScale[64] = {
     32, 37, 34, 26, 32, 26, 34, 37, 37, 43, 39, 31, 37, 31, 39, 43, 34, 39, 35, 28, 34, 28, 35, 39, 26, 31, 28, 22, 26, 22,
     28, 31, 32, 37, 34, 26, 32, 26, 34, 37, 26, 31, 28, 22, 26, 22, 28, 31, 34, 39, 35, 28, 34, 28, 35, 39, 37, 43, 39, 31,
@@ -53,6 +55,7 @@ __constant__ int kInvZigzag[64] = {
     44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49,
     57, 58, 62, 63,
 };
+}  // namespace
 
 // ------------------------------------------------------------------ LDS layout
 constexpr int kWinRows = 16 * kStripsPerWG + 30;   // reference window of a 128 x 64 tile: +-15 rows
@@ -1810,6 +1813,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     }
 }
 
+#ifndef PFV_PENC_TU   // the non-template kernels exist once: in the main translation unit
 // ================================================================== plane blits
 // reference: VideoPlane::blit (src/plane.rs:20-29), byte-granular rectangle copy.
 __global__ __launch_bounds__(kThreads) void k_blit(uint8_t *__restrict__ dst, int dst_w, const uint8_t *__restrict__ src,
@@ -1952,5 +1956,7 @@ __global__ void __launch_bounds__(kThreads) k_scatter_coef_seg(const uint32_t *i
         if (at < limit) coef[at] = vk[i];
     }
 }
+
+#endif  // PFV_PENC_TU
 
 }  // namespace pfv

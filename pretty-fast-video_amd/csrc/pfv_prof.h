@@ -6,7 +6,11 @@
 
 namespace pfv {
 
-#if defined(PFV_KPROF) && PFV_KPROF >= 2
+#if defined(PFV_KPROF) && defined(PFV_SPLIT_PENC) && !defined(PFV_PENC_TU)
+// split build: the marks (and the array they write) belong to the p-frame encoder's own translation unit
+#define KMARK(i) do {} while (0)
+#define KMARK_WHERE() do {} while (0)
+#elif defined(PFV_KPROF) && PFV_KPROF >= 2
 // -DPFV_KPROF=2: one row per WAVEFRONT (row = workgroup * 4 + wavefront), written by the wavefront's first lane -- what each SIMD's
 // resident wavefronts were doing at any time can then be reconstructed (tools/kprof_simd.py: when could NO resident wavefront issue?)
 constexpr int kProfRows = 1 << 18;

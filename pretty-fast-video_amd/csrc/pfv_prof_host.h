@@ -10,10 +10,4 @@ extern "C" __attribute__((visibility("default"))) int pfv_debug_ent_profile(int 
     return 0;
 }
 #endif
-#ifdef PFV_KPROF         // tools/kprof.py: the rows of the last k_enc_pframe launch
-extern "C" __attribute__((visibility("default"))) int pfv_debug_kprof(unsigned long long *out, int n_rows)
-{
-    hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pfv::pfv_kprof), sizeof(unsigned long long) * 16 * (size_t)n_rows) == hipSuccess ? 0 : -1;
-}
-#endif
+// (pfv_debug_kprof, the k_enc_pframe stamp rows, is in pfv_penc.hip: the array lives in the translation unit that holds the kernel)

@@ -9,7 +9,7 @@ cd $R
 names=()
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  (cd pretty-fast-video_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -DPFV_BUILD_ID="\"ab-$name\"" $flags -o /tmp/libpfv_$name.so pfv_capi.hip) 2>$OUT/$name.build.err || { echo "$name: build failed"; tail -3 $OUT/$name.build.err; continue; }
+  bash tools/build_lib.sh /tmp/libpfv_$name.so -DPFV_BUILD_ID="\"ab-$name\"" $flags 2>$OUT/$name.build.err || { echo "$name: build failed"; tail -3 $OUT/$name.build.err; continue; }
   names+=($name)
 done
 for r in $(seq 1 $ROUNDS); do

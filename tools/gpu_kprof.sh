@@ -3,5 +3,5 @@
 TAG=${1:-kprof}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-cd $R/pretty-fast-video_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -DPFV_KPROF "$@" -o /tmp/libpfv_kprof.so pfv_capi.hip 2>$OUT/build.err || { tail -5 $OUT/build.err; exit 1; }
+bash $R/tools/build_lib.sh /tmp/libpfv_kprof.so -DPFV_KPROF "$@" 2>$OUT/build.err || { tail -5 $OUT/build.err; exit 1; }
 cd $R && PFV_HIP_LIB=/tmp/libpfv_kprof.so timeout 600 python tools/kprof.py 2>&1 | tee $OUT/kprof.txt

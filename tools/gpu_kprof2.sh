@@ -3,5 +3,5 @@
 TAG=${1:-kprof2}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-cd $R/pretty-fast-video_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -DPFV_KPROF=2 "$@" -o /tmp/libpfv_kprof2.so pfv_capi.hip 2>$OUT/build.err || { tail -5 $OUT/build.err; exit 1; }
+bash $R/tools/build_lib.sh /tmp/libpfv_kprof2.so -DPFV_KPROF=2 "$@" 2>$OUT/build.err || { tail -5 $OUT/build.err; exit 1; }
 cd $R && PFV_HIP_LIB=/tmp/libpfv_kprof2.so timeout 600 python tools/kprof_simd.py 2>&1 | tee $OUT/kprof_simd.txt

@@ -7,7 +7,7 @@ cd $R
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   lib=/tmp/libpfv_$name.so
-  (cd pretty-fast-video_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden $flags -o $lib pfv_capi.hip) 2>$OUT/$name.build.err || { echo "$name: build failed"; tail -3 $OUT/$name.build.err; continue; }
+  bash tools/build_lib.sh $lib $flags 2>$OUT/$name.build.err || { echo "$name: build failed"; tail -3 $OUT/$name.build.err; continue; }
   PFV_HIP_LIB=$lib timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra > $OUT/$name.json 2>$OUT/$name.err
   cd /tmp; export TMPDIR=/tmp
   PFV_HIP_LIB=$lib timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$name -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-entropy > /dev/null 2>&1
