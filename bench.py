@@ -845,12 +845,17 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop
     run_encoder(lambda sink: mk_gop(sink, False), True, kept)                        # the same again with a writer that keeps the bytes, to check them
     data = b"".join(kept.parts)
     assert counted.n == len(data)
-    t_dec, st_d = run_decoder(lambda data: pkg.GopDecoder(data, ctx, max_gops=2 * gops, max_gop_frames=GOP, threads=parse_threads, raw=True), data, True)
+    mk_dec = lambda mode: (lambda data: pkg.GopDecoder(data, ctx, max_gops=2 * gops, max_gop_frames=GOP, threads=parse_threads, raw=True, entropy=mode))
+    t_dec_host, st_d_host = run_decoder(mk_dec("host"), data, True)
+    run_decoder(mk_dec("device"), data, True)                                       # first use: allocations, code objects
+    t_dec, st_d = run_decoder(mk_dec("device"), data, True)
     res["end_to_end"] = {"frames": n_frames, "stream_bytes": len(data), "bits_per_pixel": round(len(data) * 8 / (n_frames * W * H), 3),
                          "encode_value": n_frames * n_mb / t_enc, "decode_value": n_frames * n_mb / t_dec,
                          "value": n_frames * n_mb / (t_enc + t_dec), "gops_per_batch": {"encoder": gops, "decoder": 2 * gops}, "parse_threads": parse_threads,
                          "upload_GBps_equivalent": n_frames * fbytes / t_enc / 1e9, "encode_s": t_enc, "decode_s": t_dec,
                          "encoder_host_seconds": st_e, "decoder_host_seconds": st_d,
+                         "decode_payloads_read_on_host": {"decode_value": n_frames * n_mb / t_dec_host, "decode_s": t_dec_host, "decoder_host_seconds": st_d_host,
+                                                          "note": "PFV_ENTROPY_DECODE_HOST: the packets of a step parsed by the host pool (round 4's first form)"},
                          "note": "GopEncoder -> .pfv bytes -> GopDecoder (pfv_gop_encoder / pfv_gop_decoder: frame t of every GOP of a batch per launch), every "
                                  "frame of the stream; producer frames in page-locked memory (uploaded on a copy stream under the previous batch's kernels), "
                                  "packets handed to the writer as segments where they lie (pfv_gop_encoder_drain_iov); packets parsed GOP-parallel, decoded "

@@ -94,8 +94,16 @@ PFV_API const char *pfv_version(void);
  *                                  fill the device, 16 (a wavefront = 4 macroblocks, half as long) for launches of fewer than
  *                                  4 096 strips -- one or two 1080p streams per launch, the reference's own usage
  *                                  (src/enc.rs:125-173)
- *       PFV_LANES_PER_MB_8 / PFV_LANES_PER_MB_16   force one of them */
-typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2, PFV_OPT_LANE_MAPPING = 3 } pfv_option;
+ *       PFV_LANES_PER_MB_8 / PFV_LANES_PER_MB_16   force one of them
+ *   PFV_OPT_ENTROPY_DECODE  where pfv_gop_decoder turns packet payloads into coefficients (src/dec.rs:258-296, 378-417):
+ *       PFV_ENTROPY_DECODE_AUTO (default)  on the device (k_entd_*: self-synchronising parallel read of the run streams) when the
+ *                                          batch's coefficient arrays fit the device's free memory, on the host otherwise
+ *       PFV_ENTROPY_DECODE_HOST            the host parser pool (n_threads of pfv_gop_decoder_create)
+ *       PFV_ENTROPY_DECODE_DEVICE          the device, or PFV_ERR_NOMEM from pfv_gop_decoder_create
+ *     Either way a payload the device stage is not sure about (damaged, degenerate code table, periodic content whose read does
+ *     not settle) is parsed by the host code, which alone decides about errors. */
+typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2, PFV_OPT_LANE_MAPPING = 3, PFV_OPT_ENTROPY_DECODE = 4 } pfv_option;
+enum { PFV_ENTROPY_DECODE_AUTO = 0, PFV_ENTROPY_DECODE_HOST = 1, PFV_ENTROPY_DECODE_DEVICE = 2 };
 enum { PFV_LANES_AUTO = 0, PFV_LANES_PER_MB_8 = 1, PFV_LANES_PER_MB_16 = 2 };
 enum { PFV_ENC_TRANSFORM_AUTO = 0, PFV_ENC_TRANSFORM_INT = 1 };
 PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value);
@@ -461,7 +469,8 @@ PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e);
  * encoder: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,
  *          [4] packet assembly
  * decoder: [0] header scan, [1] waiting for the packet parsers, [2] waiting for the device before a staging set is reused,
- *          [3] enqueueing, [4] waiting for a batch's last frames */
+ *          [3] enqueueing, [4] waiting for a batch's last frames, [5] waiting for the device's entropy stage (PFV_OPT_ENTROPY_DECODE);
+ *          counts: [6] packets whose payload the device read, [7] packets of such batches that were left to the host parser */
 PFV_API int pfv_gop_encoder_stats(const pfv_gop_encoder *e, double *out, int n);
 PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e);
 PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, int max_gops, int max_gop_frames, int n_threads,
@@ -471,6 +480,10 @@ PFV_API int pfv_gop_decoder_height(const pfv_gop_decoder *d);
 PFV_API int pfv_gop_decoder_framerate(const pfv_gop_decoder *d);
 PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d);
 PFV_API int pfv_gop_decoder_stats(const pfv_gop_decoder *d, double *out, int n);
+/* on != 0: decoded frames stay in device memory and the callback's y / u / v are DEVICE pointers (valid until the call that starts the
+ * next batch; the context's stream is idle when the callback runs) -- for consumers on the GPU (the reference README's texture-out
+ * wish, README.md:20): the download of the frames, the whole PCIe cost of decoding, is not paid.  Between batches only (PFV_ERR_STATE). */
+PFV_API int pfv_gop_decoder_set_output_device(pfv_gop_decoder *d, int on);
 /* Decoder::reset (src/dec.rs:148-152).  Like the reference's, it does not rewind the framebuffer; this decoder has decoded ahead of
  * the frames it delivered, so a stream whose first packet is a p-frame continues from the last DECODED frame after a reset. */
 PFV_API int pfv_gop_decoder_reset(pfv_gop_decoder *d);

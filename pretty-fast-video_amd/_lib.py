@@ -31,6 +31,8 @@ PFV_OPT_ENC_TRANSFORM = 1
 PFV_OPT_TILE_COMPACTION = 2
 PFV_OPT_LANE_MAPPING = 3
 PFV_LANES_AUTO, PFV_LANES_PER_MB_8, PFV_LANES_PER_MB_16 = 0, 1, 2
+PFV_OPT_ENTROPY_DECODE = 4
+PFV_ENTROPY_DECODE_AUTO, PFV_ENTROPY_DECODE_HOST, PFV_ENTROPY_DECODE_DEVICE = 0, 1, 2
 PFV_ENC_TRANSFORM_AUTO, PFV_ENC_TRANSFORM_INT = 0, 1
 
 
@@ -174,6 +176,7 @@ SIGNATURES = [
     ("pfv_gop_decoder_framerate", c_int, [_P]),
     ("pfv_gop_decoder_batches", ctypes.c_long, [_P]),
     ("pfv_gop_decoder_stats", c_int, [_P, _P, c_int]),
+    ("pfv_gop_decoder_set_output_device", c_int, [_P, c_int]),
     ("pfv_gop_decoder_reset", c_int, [_P]),
     ("pfv_gop_decoder_advance_frame", c_int, [_P, _P, _P]),
     ("pfv_gop_decoder_advance_delta", c_int, [_P, ctypes.c_double, _P, _P]),

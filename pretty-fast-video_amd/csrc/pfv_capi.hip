@@ -14,6 +14,7 @@ void launch_enc_pframe_kernels(hipStream_t stream, bool flt, bool small, int com
 #include "pfv_penc.hip"
 #endif
 #include "pfv_entropy_kernels.hip"
+#include "pfv_entdec_kernels.hip"
 #include "pfv_synth_kernels.hip"
 #include "pfv_host.hip"
 #include "pfv_selfcheck.hip"
@@ -75,6 +76,7 @@ struct pfv_ctx {
     int opt_enc_transform = PFV_ENC_TRANSFORM_AUTO;   // pfv_ctx_set_option(PFV_OPT_ENC_TRANSFORM)
     int opt_tile_compaction = 1;                      // pfv_ctx_set_option(PFV_OPT_TILE_COMPACTION)
     int opt_lane_mapping = PFV_LANES_AUTO;            // pfv_ctx_set_option(PFV_OPT_LANE_MAPPING)
+    int opt_entropy_decode = PFV_ENTROPY_DECODE_AUTO; // pfv_ctx_set_option(PFV_OPT_ENTROPY_DECODE)
     std::vector<struct pfv_comm *> comms;             // live communicators on this context (pfv_comm.hip): torn down with it
 };
 static void comm_teardown(struct pfv_comm *c);
@@ -128,6 +130,10 @@ PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value)
         if (value != PFV_LANES_AUTO && value != PFV_LANES_PER_MB_8 && value != PFV_LANES_PER_MB_16) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_LANE_MAPPING: unknown value");
         ctx->opt_lane_mapping = value;
         return PFV_OK;
+    case PFV_OPT_ENTROPY_DECODE:
+        if (value != PFV_ENTROPY_DECODE_AUTO && value != PFV_ENTROPY_DECODE_HOST && value != PFV_ENTROPY_DECODE_DEVICE) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENTROPY_DECODE: unknown value");
+        ctx->opt_entropy_decode = value;
+        return PFV_OK;
     default:
         return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_set_option: unknown option");
     }
@@ -139,6 +145,7 @@ PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value)
     case PFV_OPT_ENC_TRANSFORM: *value = ctx->opt_enc_transform; return PFV_OK;
     case PFV_OPT_TILE_COMPACTION: *value = ctx->opt_tile_compaction; return PFV_OK;
     case PFV_OPT_LANE_MAPPING: *value = ctx->opt_lane_mapping; return PFV_OK;
+    case PFV_OPT_ENTROPY_DECODE: *value = ctx->opt_entropy_decode; return PFV_OK;
     default: return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_get_option: unknown option");
     }
 }

@@ -484,9 +484,47 @@ struct GopDecSet {   // host staging of one frame step (two alternate: the parse
 // to stay busy across the step boundaries)
 constexpr int kGopDecSets = 4;
 
+// one packet of a batch on the device-entropy path
+struct GopDevPacket {
+    GopDecEvent *ev = nullptr;
+    int rc = 0;                          // status the frame is delivered with (0: decoded)
+    bool host_parse = false;             // the host parser reads it (degenerate table, oversize, or the device stage was not sure)
+    uint8_t qidx[3] = {0, 0, 0};
+    size_t frame = 0;                    // t * max_gops + slot: its place in the batch-wide arrays
+};
+
+// device-entropy path of the decoder (PFV_OPT_ENTROPY_DECODE): the whole batch's payloads are read by the k_entd_* kernels
+struct GopDecDev {
+    bool on = false;
+    size_t frames_cap = 0;               // max_gops * max_gop_frames
+    uint8_t *bytes_dev = nullptr; size_t bytes_cap = 0;
+    EdPacket *pk_dev = nullptr; uint32_t *status_dev = nullptr; size_t pk_cap = 0;
+    uint2 *groups_dev = nullptr; size_t groups_cap = 0;
+    uint32_t *sub_dev = nullptr; size_t sub_cap = 0;     // end | used | cnt | vstart
+    uint32_t *coded_dev = nullptr;
+    int16_t *coef_dev = nullptr;
+    int8_t *mv_dev = nullptr;
+    uint8_t *has_dev = nullptr;
+    PinnedBuf<uint8_t> bytes_host, has_host;
+    PinnedBuf<int8_t> mv_host;
+    PinnedBuf<EdPacket> pk_host;
+    PinnedBuf<uint2> groups_host;
+    PinnedBuf<uint32_t> status_host;
+    PinnedBuf<int> flags_host;           // [step][max_gops]
+    PinnedBuf<int16_t> dense_host;       // kGopDevDense frames: packets the host parser reads
+    std::vector<GopDevPacket> pk;
+    std::vector<int> todo;               // phase 2: the packets the host parser reads, kGopDevDense at a time
+    int phase = 0, todo_first = 0;
+    int pending = 0;                     // tasks of the current phase not yet finished (under the pool's mutex)
+    long packets_dev = 0, packets_host = 0, batches_dev = 0, batches_host = 0;
+};
+constexpr int kGopDevDense = 8;
+constexpr int kGopDevRounds = 6;         // k_entd_sync launches before the verifying one
+
 struct pfv_gop_decoder {
     pfv_ctx *ctx = nullptr;
     pfv_dec_session *hot = nullptr;
+    GopDecDev dev;
     const uint8_t *data = nullptr;
     size_t len = 0, pos = 0, reset_pos = 0;
     int width = 0, height = 0, framerate = 0, n_qtables = 0, max_gops = 0, max_len = 0;
@@ -504,10 +542,13 @@ struct pfv_gop_decoder {
     PinnedBuf<int16_t> dense;            // one slot's coefficients when its list overflowed
     PinnedBuf<uint8_t> frames_host;      // [max_gop_frames][max_gops][frame_bytes]: the decoded frames of the batch
     uint8_t *frames_dev = nullptr;       // [max_gops][frame_bytes]
+    bool out_dev = false;                // pfv_gop_decoder_set_output_device: frames stay in HBM, the callback gets device pointers
+    uint8_t *frames_all_dev = nullptr;   // [steps][max_gops][frame_bytes] then
+    size_t frames_all_cap = 0;           // bytes
     long batches = 0, dense_packets = 0;
     // seconds: [0] header scan, [1] waiting for packet parsers (the caller parses too), [2] waiting for the device before a staging set
     // can be reused, [3] enqueueing, [4] waiting for the batch's last frames
-    double stats[5] = {0, 0, 0, 0, 0};
+    double stats[6] = {0, 0, 0, 0, 0, 0};   // [5]: waiting for the device's entropy stage (device-entropy path)
     // worker pool: the packets of a step are parsed in parallel (one task per slot)
     std::vector<std::thread> workers;
     std::mutex m;
@@ -531,6 +572,14 @@ static void gopd_parse_one(pfv_gop_decoder *d, GopDecSet *s, int k)
     s->counts.data()[k] = rc == 0 ? (uint32_t)sink.n : 0u;
     s->rc[(size_t)k] = rc;
 }
+static void gopd_dev_task(pfv_gop_decoder *d, int j);
+// a queued task: (staging set, slot) = parse that packet into the set's lists; (null, j) = task j of the device-entropy path's current phase
+static void gopd_run_task(pfv_gop_decoder *d, const std::pair<GopDecSet *, int> &job)
+{
+    if (job.first) gopd_parse_one(d, job.first, job.second);
+    else gopd_dev_task(d, job.second);
+}
+static int &gopd_pending_of(pfv_gop_decoder *d, const std::pair<GopDecSet *, int> &job) { return job.first ? job.first->pending : d->dev.pending; }
 static void gopd_worker(pfv_gop_decoder *d)
 {
     std::unique_lock<std::mutex> lk(d->m);
@@ -540,9 +589,9 @@ static void gopd_worker(pfv_gop_decoder *d)
         const auto job = d->tasks.front();
         d->tasks.pop_front();
         lk.unlock();
-        gopd_parse_one(d, job.first, job.second);
+        gopd_run_task(d, job);
         lk.lock();
-        if (--job.first->pending == 0) d->cv_done.notify_all();
+        if (--gopd_pending_of(d, job) == 0) d->cv_done.notify_all();
     }
 }
 static void gopd_start_parse(pfv_gop_decoder *d, GopDecSet *s, int n_slots)
@@ -555,32 +604,33 @@ static void gopd_start_parse(pfv_gop_decoder *d, GopDecSet *s, int n_slots)
     }
     d->cv_work.notify_all();
 }
-static void gopd_join_parse(pfv_gop_decoder *d, GopDecSet *s)
+static void gopd_join(pfv_gop_decoder *d, int *pending)
 {
     std::unique_lock<std::mutex> lk(d->m);
-    while (s->pending > 0) {
+    while (*pending > 0) {
         if (!d->tasks.empty()) {     // the caller parses too (and is the whole pool when there are no workers): any packet will do
             const auto job = d->tasks.front();
             d->tasks.pop_front();
             lk.unlock();
-            gopd_parse_one(d, job.first, job.second);
+            gopd_run_task(d, job);
             lk.lock();
-            if (--job.first->pending == 0) d->cv_done.notify_all();
+            if (--gopd_pending_of(d, job) == 0) d->cv_done.notify_all();
         } else {
             d->cv_done.wait(lk);
         }
     }
 }
+static void gopd_join_parse(pfv_gop_decoder *d, GopDecSet *s) { gopd_join(d, &s->pending); }
 // nothing of an abandoned batch may stay queued (reset, errors): wait for the parsers to let go of the sets
 static void gopd_drain_pool(pfv_gop_decoder *d)
 {
     std::unique_lock<std::mutex> lk(d->m);
-    for (const auto &job : d->tasks) job.first->pending--;
+    for (const auto &job : d->tasks) gopd_pending_of(d, job)--;
     d->tasks.clear();
     d->cv_done.wait(lk, [&] {
         for (const GopDecSet &s : d->set)
             if (s.pending > 0) return false;
-        return true;
+        return d->dev.pending <= 0;
     });
 }
 
@@ -628,6 +678,41 @@ static void gopd_scan_batch(pfv_gop_decoder *d)
     }
 }
 
+// where a batch's frames go: page-locked host memory [step][slot] (the default), or a device array of the same shape
+static int gopd_out_room(pfv_gop_decoder *d, int steps)
+{
+    pfv_ctx *ctx = d->ctx;
+    const size_t need = (size_t)std::max(steps, 1) * (size_t)d->max_gops * d->frame_bytes;
+    if (!d->out_dev) return d->frames_host.resize(need) ? PFV_OK : fail(ctx, PFV_ERR_NOMEM, "pinned frame staging");
+    if (need <= d->frames_all_cap) return PFV_OK;
+    if (d->frames_all_dev) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(d->frames_all_dev); d->frames_all_dev = nullptr; d->frames_all_cap = 0; }
+    HIP_TRY(ctx, hipMalloc((void **)&d->frames_all_dev, need));
+    d->frames_all_cap = need;
+    return PFV_OK;
+}
+// the retframes of step t, slots [first, first + count), after dec_launch: the separate crop pass where the fused one does not apply, and
+// the way to the host
+static int gopd_step_out(pfv_gop_decoder *d, int t, int first, int count)
+{
+    pfv_ctx *ctx = d->ctx;
+    pfv_dec_session *hot = d->hot;
+    int rc = PFV_OK;
+    if (!fused_output_ok(hot)) {             // geometries without 16-byte rows: on the buffer just written
+        hot->cur ^= 1;
+        rc = dec_crop_win(hot, first, count, hot->frames_out, 0);
+        hot->cur ^= 1;
+    }
+    if (!rc && !d->out_dev &&
+        hipMemcpyAsync(d->frames_host.data() + ((size_t)t * (size_t)d->max_gops + (size_t)first) * d->frame_bytes, d->frames_dev + (size_t)first * d->frame_bytes,
+                       (size_t)count * d->frame_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = fail(ctx, PFV_ERR_HIP, "retframe download");
+    return rc;
+}
+static void gopd_step_target(pfv_gop_decoder *d, int t)
+{
+    d->hot->frames_out = d->out_dev ? d->frames_all_dev + (size_t)t * (size_t)d->max_gops * d->frame_bytes : d->frames_dev;
+}
+
 // decode every frame packet of the scanned batch; the frames land in frames_host[step][slot]
 static int gopd_decode_batch(pfv_gop_decoder *d)
 {
@@ -636,7 +721,7 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     const int G = (int)d->glen.size();
     if (G == 0) return PFV_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t tb = d->total_blocks, pad = (size_t)hot->geom.pad_frame_bytes, fbytes = d->frame_bytes;
+    const size_t tb = d->total_blocks, pad = (size_t)hot->geom.pad_frame_bytes;
     static const char *kBadPayload = "malformed packet payload", *kBadMv = "motion vector points outside the reference plane (src/common.rs:258-259)";
 
     // chains: the frame packets a slot decodes one after the other.  To begin with, chain k = group k.
@@ -733,7 +818,7 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
         if (src != dst) HIP_TRY(ctx, hipMemcpyAsync(dst, src, pad, hipMemcpyDeviceToDevice, ctx->stream));
     }
     // merged chains may be longer than a group
-    if (!d->frames_host.resize((size_t)std::max(steps, 1) * (size_t)d->max_gops * fbytes)) return fail(ctx, PFV_ERR_NOMEM, "pinned frame staging");
+    if ((rc = gopd_out_room(d, steps))) return rc;
     const int cur0 = hot->cur;
     // steps [t, next_fill) are parsed or being parsed; step s uses staging set s % kGopDecSets.  A set is refilled as soon as the device
     // has finished with the step that used it last.
@@ -811,19 +896,13 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
         HIP_TRY(ctx, hipMemcpyAsync(hot->st_mv, s.mv.data(), (size_t)G * tb * 2, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(hot->st_has, s.has.data(), (size_t)G * tb, hipMemcpyHostToDevice, ctx->stream));
         rc = PFV_OK;
+        gopd_step_target(d, t);
         gop_runs(key, [&](int first, int count, int ci) {
             if (rc) return;
             const uint32_t c = combos[(size_t)ci];
             const uint8_t q[3] = {(uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24)};
             rc = dec_launch(hot, (c & 0xffu) == 2, first, count, hot->st_mv, hot->st_has, hot->st_coef, q);
-            if (!rc && !fused_output_ok(hot)) {        // geometries without 16-byte rows: the separate crop pass, on the buffer just written
-                hot->cur ^= 1;
-                rc = dec_crop_win(hot, first, count, d->frames_dev, 0);
-                hot->cur ^= 1;
-            }
-            if (!rc && hipMemcpyAsync(d->frames_host.data() + ((size_t)t * (size_t)d->max_gops + (size_t)first) * fbytes, d->frames_dev + (size_t)first * fbytes,
-                                      (size_t)count * fbytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-                rc = fail(ctx, PFV_ERR_HIP, "retframe download");
+            if (!rc) rc = gopd_step_out(d, t, first, count);
         });
         if (rc) return rc;
         hot->cur ^= 1;
@@ -847,6 +926,273 @@ static int gopd_decode_batch(pfv_gop_decoder *d)
     return PFV_OK;
 }
 
+// ---------------------------------------------------------------- device-entropy path (PFV_OPT_ENTROPY_DECODE)
+// phase 1, per packet: what the kernels need that only a serial read can give -- the table (-> the tree's codes), the q indices, a
+// p-frame's block headers (-> motion vectors, has_coeff, the first bit of the run streams); the payload goes to page-locked staging
+static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
+{
+    GopDecDev &v = d->dev;
+    GopDevPacket &p = v.pk[(size_t)j];
+    const GopDecEvent *e = p.ev;
+    EdPacket &k = v.pk_host.data()[j];
+    const size_t tb = d->total_blocks;
+    k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = 0;
+    k.pframe = e->type == 2 ? 1u : 0u;
+    k.total_blocks = (uint32_t)tb;
+    memset(k.code_val, 0, sizeof k.code_val);
+    memset(k.code_len, 0, sizeof k.code_len);
+    BitSource r(e->payload, e->plen);
+    PacketHead h;
+    p.rc = parse_head(r, h, d->n_qtables);
+    if (p.rc) return;
+    memcpy(p.qidx, h.qidx, 3);
+    size_t n_coded = tb;
+    if (e->type == 2) {
+        n_coded = parse_block_headers(r, (int)tb, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb);
+        if (!r.ok()) { p.rc = PFV_ERR_IO; return; }
+    }
+    if (n_coded == 0) return;                                  // no run stream: nothing is read behind the headers (src/dec.rs:378-380)
+    int n_syms = 0;
+    for (uint8_t t : h.table) n_syms += t != 0;
+    const uint64_t bits = (uint64_t)e->plen * 8, bit0 = r.position();
+    if (n_syms < 2 || bits >= (1ull << 32) || bit0 >= bits) { p.host_parse = true; return; }   // zero-length codes / 32-bit positions / no bits left
+    HuffmanTree tree(h.table);
+    for (int s = 0; s < 16; s++) {
+        k.code_val[s] = (uint16_t)tree.code((uint8_t)s).val;
+        k.code_len[s] = (uint8_t)tree.code((uint8_t)s).len;
+    }
+    k.total_bits = (uint32_t)bits;
+    k.bit0 = (uint32_t)bit0;
+    k.total_coefs = (uint32_t)(n_coded * 256);
+    k.n_sub = (uint32_t)((bits - bit0 + kEdSubBits - 1) / kEdSubBits);
+    uint8_t *dst = v.bytes_host.data() + k.byte_off;
+    memcpy(dst, e->payload, e->plen);
+    memset(dst + e->plen, 0, 16);
+}
+// phase 2, per packet the device stage left to the host: the host parser, into a dense frame
+static void gopd_dev_hostparse(pfv_gop_decoder *d, int j)
+{
+    GopDecDev &v = d->dev;
+    GopDevPacket &p = v.pk[(size_t)v.todo[(size_t)(v.todo_first + j)]];
+    const GopDecEvent *e = p.ev;
+    const size_t tb = d->total_blocks;
+    int16_t *coef = v.dense_host.data() + (size_t)j * tb * 256;
+    uint8_t q[3];
+    p.rc = e->type == 2 ? parse_pframe(e->payload, e->plen, (int)tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, coef, q)
+                        : parse_iframe(e->payload, e->plen, (int)tb, d->n_qtables, coef, q);
+}
+static void gopd_dev_task(pfv_gop_decoder *d, int j)
+{
+    if (d->dev.phase == 1) gopd_dev_prepare(d, j);
+    else gopd_dev_hostparse(d, j);
+}
+static void gopd_dev_run_phase(pfv_gop_decoder *d, int phase, int n_tasks)
+{
+    {
+        std::lock_guard<std::mutex> lk(d->m);
+        d->dev.phase = phase;
+        for (int j = 0; j < n_tasks; j++) { d->tasks.emplace_back(nullptr, j); d->dev.pending++; }
+        d->cv_work.notify_all();
+    }
+    gopd_join(d, &d->dev.pending);
+}
+template <class T>
+static int gopd_dev_room(pfv_ctx *ctx, T **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return PFV_OK;
+    if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    need += need / 4;
+    HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(T)));
+    *cap = need;
+    return PFV_OK;
+}
+
+// Decode the scanned batch with the payloads read on the device.  PFV_OK: done (frames in frames_host[step][slot]); 1: this batch needs
+// the host path (a group's i-frame does not parse: the chains change, see gopd_decode_batch) -- nothing has been decoded; negative: error.
+static int gopd_decode_batch_dev(pfv_gop_decoder *d)
+{
+    pfv_ctx *ctx = d->ctx;
+    pfv_dec_session *hot = d->hot;
+    GopDecDev &v = d->dev;
+    const int G = (int)d->glen.size();
+    if (G == 0) return PFV_OK;
+    int steps = 0;
+    for (int k = 0; k < G; k++) steps = std::max(steps, d->glen[(size_t)k]);
+    if (steps > d->max_len || G > d->max_gops) return 1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t tb = d->total_blocks, pad = (size_t)hot->geom.pad_frame_bytes, S = (size_t)d->max_gops;
+    static const char *kBadPayload = "malformed packet payload", *kBadMv = "motion vector points outside the reference plane (src/common.rs:258-259)";
+    GopClock clk;
+
+    v.pk.clear();
+    for (GopDecEvent &e : d->events)
+        if (e.kind == GopDecEvent::FRAME) {
+            GopDevPacket p;
+            p.ev = &e;
+            p.frame = (size_t)e.t * S + (size_t)e.slot;
+            v.pk.push_back(p);
+        }
+    const size_t n = v.pk.size();
+    if (!v.pk_host.resize(n) || !v.status_host.resize(n)) return fail(ctx, PFV_ERR_NOMEM, "device-entropy staging");
+    size_t bytes_total = 0;
+    for (size_t j = 0; j < n; j++) {
+        EdPacket &k = v.pk_host.data()[j];
+        k.byte_off = bytes_total;
+        k.frame_off = v.pk[j].frame;
+        bytes_total += ((size_t)v.pk[j].ev->plen + 16 + 15) & ~(size_t)15;
+    }
+    if (!v.bytes_host.resize(bytes_total + 64)) return fail(ctx, PFV_ERR_NOMEM, "device-entropy payload staging");
+    gopd_dev_run_phase(d, 1, (int)n);
+    d->stats[1] += clk.lap();
+
+    size_t total_sub = 0, n_groups = 0;
+    for (size_t j = 0; j < n; j++) {
+        EdPacket &k = v.pk_host.data()[j];
+        if (v.pk[j].rc || v.pk[j].host_parse) k.n_sub = 0;
+        k.sub_first = (uint32_t)total_sub;
+        total_sub += k.n_sub;
+        n_groups += (k.n_sub + kEdThreads - 1) / kEdThreads;
+    }
+    if (total_sub >= 0xffffffffull) return 1;
+    int rc = PFV_OK;
+    if (!v.groups_host.resize(std::max<size_t>(n_groups, 1))) return fail(ctx, PFV_ERR_NOMEM, "device-entropy staging");
+    {
+        size_t g = 0;
+        for (size_t j = 0; j < n; j++)
+            for (uint32_t b = 0; b * (uint32_t)kEdThreads < v.pk_host.data()[j].n_sub; b++) v.groups_host.data()[g++] = make_uint2((unsigned)j, b);
+    }
+    if ((rc = gopd_dev_room(ctx, &v.bytes_dev, &v.bytes_cap, bytes_total + 64))) return rc;
+    if (n > v.pk_cap) {
+        if (v.pk_dev) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(v.pk_dev); (void)hipFree(v.status_dev); v.pk_dev = nullptr; v.status_dev = nullptr; v.pk_cap = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&v.pk_dev, (n + n / 4) * sizeof(EdPacket)));
+        HIP_TRY(ctx, hipMalloc((void **)&v.status_dev, (n + n / 4) * sizeof(uint32_t)));
+        v.pk_cap = n + n / 4;
+    }
+    if ((rc = gopd_dev_room(ctx, &v.groups_dev, &v.groups_cap, std::max<size_t>(n_groups, 1)))) return rc;
+    if ((rc = gopd_dev_room(ctx, &v.sub_dev, &v.sub_cap, std::max<size_t>(total_sub, 1) * 4))) return rc;
+    const size_t frames_used = (size_t)steps * S;
+    HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev, v.bytes_host.data(), bytes_total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, v.pk_host.data(), n * sizeof(EdPacket), hipMemcpyHostToDevice, ctx->stream));
+    if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, v.groups_host.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev, v.mv_host.data(), frames_used * tb * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(v.has_dev, v.has_host.data(), frames_used * tb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(v.coef_dev, 0, frames_used * tb * 512, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, n * sizeof(uint32_t), ctx->stream));
+    if (n_groups) {
+        const size_t ts = v.sub_cap / 4;
+        EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.has_dev, v.coded_dev, v.coef_dev, v.status_dev};
+        hipLaunchKernelGGL(k_entd_coded, dim3((unsigned)n), dim3(kEdThreads), 0, ctx->stream, b);
+        for (int round = 0; round <= kGopDevRounds; round++)
+            hipLaunchKernelGGL(k_entd_sync, dim3((unsigned)n_groups), dim3(kEdThreads), 0, ctx->stream, b, round == 0 ? 1 : 0, round == kGopDevRounds ? 1 : 0);
+        hipLaunchKernelGGL(k_entd_prefix, dim3((unsigned)n), dim3(kEdThreads), 0, ctx->stream, b);
+        hipLaunchKernelGGL(k_entd_emit, dim3((unsigned)n_groups), dim3(kEdThreads), 0, ctx->stream, b);
+        if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data(), v.status_dev, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    d->stats[3] += clk.lap();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    d->stats[5] += clk.lap();
+
+    // what the device stage was not sure about goes through the host parser, which decides
+    v.todo.clear();
+    for (size_t j = 0; j < n; j++) {
+        GopDevPacket &p = v.pk[j];
+        if (p.rc) continue;
+        if (p.host_parse || v.status_host.data()[j]) { p.host_parse = true; v.todo.push_back((int)j); }
+    }
+    for (size_t first = 0; first < v.todo.size(); first += (size_t)kGopDevDense) {
+        const int cnt = (int)std::min<size_t>((size_t)kGopDevDense, v.todo.size() - first);
+        if (!v.dense_host.resize((size_t)kGopDevDense * tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
+        v.todo_first = (int)first;
+        gopd_dev_run_phase(d, 2, cnt);
+        for (int j = 0; j < cnt; j++) {
+            const GopDevPacket &p = v.pk[(size_t)v.todo[first + (size_t)j]];
+            if (p.rc) continue;
+            HIP_TRY(ctx, hipMemcpyAsync(v.coef_dev + p.frame * tb * 256, v.dense_host.data() + (size_t)j * tb * 256, tb * 512, hipMemcpyHostToDevice, ctx->stream));
+            if (p.ev->type == 2) {   // the host parser wrote the headers again (the same values): keep the device copies in step
+                HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + p.frame * tb * 2, v.mv_host.data() + p.frame * tb * 2, tb * 2, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + p.frame * tb, v.has_host.data() + p.frame * tb, tb, hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    d->stats[1] += clk.lap();
+    std::vector<int> at((size_t)steps * (size_t)G, -1);
+    for (size_t j = 0; j < n; j++) {
+        GopDevPacket &p = v.pk[j];
+        if (!p.rc)
+            for (int i = 0; i < 3; i++)
+                if (p.qidx[i] >= hot->n_qtables) p.rc = PFV_ERR_FORMAT;      // the reference panics (src/dec.rs:249-251)
+        if (p.rc && p.ev->t == 0 && p.ev->type == 1) return 1;              // not an independent run after all: the chains change
+        at[(size_t)p.ev->t * (size_t)G + (size_t)p.ev->slot] = (int)j;
+    }
+    for (size_t j = 0; j < n; j++) {
+        GopDevPacket &p = v.pk[j];
+        p.ev->rc = p.rc;
+        if (p.rc) p.ev->msg = kBadPayload;
+        else if (p.host_parse) v.packets_host++;
+        else v.packets_dev++;
+    }
+
+    if (d->gfirst[0] == 2 && d->cont_valid) {   // slot 0 continues the run the previous batch left open
+        const uint8_t *src = hot->fb[d->cont_buf] + (size_t)d->cont_slot * pad;
+        uint8_t *dst = hot->fb[hot->cur];
+        if (src != dst) HIP_TRY(ctx, hipMemcpyAsync(dst, src, pad, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if ((rc = gopd_out_room(d, steps))) return rc;
+    if (!v.flags_host.resize((size_t)steps * S)) return fail(ctx, PFV_ERR_NOMEM, "pinned flag staging");
+    memset(v.flags_host.data(), 0, (size_t)steps * S * sizeof(int));
+    const int cur0 = hot->cur;
+    std::vector<int> key((size_t)G);
+    std::vector<uint32_t> combos;
+    for (int t = 0; t < steps; t++) {
+        combos.clear();
+        for (int k = 0; k < G; k++) {
+            key[(size_t)k] = -1;
+            const int j = at[(size_t)t * (size_t)G + (size_t)k];
+            if (j < 0) continue;
+            const GopDevPacket &p = v.pk[(size_t)j];
+            if (p.rc) {   // a failed packet changes nothing, but its slot's framebuffer has to follow the ping-pong
+                HIP_TRY(ctx, hipMemcpyAsync(hot->fb[hot->cur ^ 1] + (size_t)k * pad, hot->fb[hot->cur] + (size_t)k * pad, pad, hipMemcpyDeviceToDevice, ctx->stream));
+                continue;
+            }
+            const uint32_t c = (uint32_t)p.ev->type | ((uint32_t)p.qidx[0] << 8) | ((uint32_t)p.qidx[1] << 16) | ((uint32_t)p.qidx[2] << 24);
+            size_t ci = 0;
+            while (ci < combos.size() && combos[ci] != c) ci++;
+            if (ci == combos.size()) combos.push_back(c);
+            key[(size_t)k] = (int)ci;
+        }
+        const size_t f0 = (size_t)t * S;
+        rc = PFV_OK;
+        gopd_step_target(d, t);
+        gop_runs(key, [&](int first, int count, int ci) {
+            if (rc) return;
+            const uint32_t c = combos[(size_t)ci];
+            const uint8_t q[3] = {(uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24)};
+            rc = dec_launch(hot, (c & 0xffu) == 2, first, count, v.mv_dev + f0 * tb * 2, v.has_dev + f0 * tb, v.coef_dev + f0 * tb * 256, q);
+            if (!rc) rc = gopd_step_out(d, t, first, count);
+        });
+        if (rc) return rc;
+        hot->cur ^= 1;
+        HIP_TRY(ctx, hipMemcpyAsync(v.flags_host.data() + f0, hot->flag_dev, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(hot->flag_dev, 0, (size_t)G * sizeof(int), ctx->stream));
+    }
+    d->stats[3] += clk.lap();
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    d->stats[4] += clk.lap();
+    for (int t = 0; t < steps; t++)
+        for (int k = 0; k < G; k++) {
+            const int j = at[(size_t)t * (size_t)G + (size_t)k];
+            if (j >= 0 && v.flags_host.data()[(size_t)t * S + (size_t)k] && !v.pk[(size_t)j].ev->rc) { v.pk[(size_t)j].ev->rc = PFV_ERR_BAD_MV; v.pk[(size_t)j].ev->msg = kBadMv; }
+        }
+    d->cont_valid = true;
+    d->cont_slot = G - 1;
+    d->cont_buf = (cur0 + d->glen[(size_t)G - 1]) & 1;
+    d->batches++;
+    v.batches_dev++;
+    return PFV_OK;
+}
+
 extern "C" {
 
 PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d)
@@ -863,6 +1209,10 @@ PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d)
     for (GopDecSet &s : d->set)
         if (s.done) (void)hipEventDestroy(s.done);
     if (d->frames_dev) (void)hipFree(d->frames_dev);
+    if (d->frames_all_dev) (void)hipFree(d->frames_all_dev);
+    for (void *p : {(void *)d->dev.bytes_dev, (void *)d->dev.pk_dev, (void *)d->dev.status_dev, (void *)d->dev.groups_dev, (void *)d->dev.sub_dev, (void *)d->dev.coded_dev,
+                    (void *)d->dev.coef_dev, (void *)d->dev.mv_dev, (void *)d->dev.has_dev})
+        if (p) (void)hipFree(p);
     pfv_dec_session_destroy(d->hot);
     delete d;
 }
@@ -919,6 +1269,46 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
     else if (he != hipSuccess) rc = hip_fail(ctx, he, "pfv_gop_decoder_create");
     if (!rc) rc = dec_staging(hot);
     if (!rc) rc = pfv_dec_set_output_dev(hot, d->frames_dev);
+    // the device-entropy path keeps the coefficient arrays of a whole batch in HBM (PFV_OPT_ENTROPY_DECODE)
+    if (!rc && ctx->opt_entropy_decode != PFV_ENTROPY_DECODE_HOST && tb > 0) {
+        GopDecDev &v = d->dev;
+        const size_t F = S * (size_t)max_gop_frames;
+        const size_t need = F * tb * (512 + 2 + 1 + 4 + 64);
+        size_t free_b = 0, total_b = 0;
+        bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2;
+        if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
+        if (fits) {
+            hipError_t e2 = hipMalloc((void **)&v.coef_dev, F * tb * 512);
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.mv_dev, F * tb * 2);
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.has_dev, F * tb);
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.coded_dev, F * tb * 4);
+            // a batch's payloads are at most the whole stream: size the staging now, not inside the first batch
+            const size_t bytes_guess = std::min(len + F * 32 + 64, F * (tb * 512 / 8 + 64));
+            const size_t sub_guess = bytes_guess * 8 / kEdSubBits + F;
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.bytes_dev, bytes_guess);
+            if (e2 == hipSuccess) { v.bytes_cap = bytes_guess; e2 = hipMalloc((void **)&v.sub_dev, sub_guess * 4 * sizeof(uint32_t)); }
+            if (e2 == hipSuccess) { v.sub_cap = sub_guess * 4; e2 = hipMalloc((void **)&v.groups_dev, (sub_guess / kEdThreads + F) * sizeof(uint2)); }
+            if (e2 == hipSuccess) { v.groups_cap = sub_guess / kEdThreads + F; e2 = hipMalloc((void **)&v.pk_dev, F * sizeof(EdPacket)); }
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.status_dev, F * sizeof(uint32_t));
+            if (e2 == hipSuccess) v.pk_cap = F;
+            const bool host_ok = e2 == hipSuccess && v.mv_host.resize(F * tb * 2) && v.has_host.resize(F * tb) && v.bytes_host.resize(bytes_guess) &&
+                                 v.pk_host.resize(F) && v.status_host.resize(F) && v.groups_host.resize(sub_guess / kEdThreads + F) && v.flags_host.resize(F);
+            if (host_ok) {
+                memset(v.mv_host.data(), 0, F * tb * 2);
+                memset(v.has_host.data(), 0, F * tb);
+                v.frames_cap = F;
+                v.on = true;
+            } else {
+                (void)hipGetLastError();
+                for (void **p : {(void **)&v.coef_dev, (void **)&v.mv_dev, (void **)&v.has_dev, (void **)&v.coded_dev, (void **)&v.bytes_dev, (void **)&v.sub_dev,
+                                 (void **)&v.groups_dev, (void **)&v.pk_dev, (void **)&v.status_dev})
+                    if (*p) { (void)hipFree(*p); *p = nullptr; }
+                v.bytes_cap = v.sub_cap = v.groups_cap = v.pk_cap = 0;
+                if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE)
+                    rc = fail(ctx, PFV_ERR_NOMEM, "pfv_gop_decoder_create: the batch's coefficient arrays do not fit the device (PFV_ENTROPY_DECODE_DEVICE): use a smaller batch");
+            }
+        }
+    }
     if (rc) { pfv_gop_decoder_destroy(d); return rc; }
     for (int t = 0; t < n_threads; t++) d->workers.emplace_back(gopd_worker, d);
     *out = d;
@@ -929,13 +1319,26 @@ PFV_API int pfv_gop_decoder_height(const pfv_gop_decoder *d) { return d ? d->hei
 PFV_API int pfv_gop_decoder_framerate(const pfv_gop_decoder *d) { return d ? d->framerate : 0; }
 PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d) { return d ? d->batches : 0; }
 /* host seconds so far: out[0] header scan, [1] waiting for packet parsers, [2] waiting for the device before a staging set can be reused,
- * [3] enqueueing (incl. the time since the previous measurement point), [4] waiting for a batch's last frames; returns entries written */
+ * [3] enqueueing (incl. the time since the previous measurement point), [4] waiting for a batch's last frames, [5] waiting for the device's
+ * entropy stage; counts: [6] packets whose payload the device read, [7] packets of device-entropy batches the host parser read; returns
+ * entries written */
 PFV_API int pfv_gop_decoder_stats(const pfv_gop_decoder *d, double *out, int n)
 {
     if (!d || !out) return 0;
-    const int k = std::min(n, 5);
-    for (int i = 0; i < k; i++) out[i] = d->stats[i];
+    const int k = std::min(n, 8);
+    for (int i = 0; i < k; i++) out[i] = i < 6 ? d->stats[i] : i == 6 ? (double)d->dev.packets_dev : (double)d->dev.packets_host;
     return k;
+}
+
+// on != 0: decoded frames stay in device memory and the callback's y / u / v are DEVICE pointers (valid until the call that starts the next
+// batch; ordered on the context's stream, which is idle when the callback runs) -- for consumers on the GPU (the reference README's
+// texture-out wish); the download, the whole PCIe cost of decoding, is then not paid.  Only between batches (PFV_ERR_STATE otherwise).
+PFV_API int pfv_gop_decoder_set_output_device(pfv_gop_decoder *d, int on)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    if (d->next_event < d->events.size()) return fail(d->ctx, PFV_ERR_STATE, "pfv_gop_decoder_set_output_device: a batch is being delivered");
+    d->out_dev = on != 0;
+    return PFV_OK;
 }
 
 // Decoder::reset (src/dec.rs:148-152).  The framebuffer is NOT rewound (neither is the reference's); unlike the frame-by-frame decoder
@@ -961,7 +1364,11 @@ PFV_API int pfv_gop_decoder_advance_frame(pfv_gop_decoder *d, pfv_video_cb onvid
         GopClock clk;
         gopd_scan_batch(d);
         d->stats[0] += clk.lap();
-        int rc = gopd_decode_batch(d);
+        int rc = d->dev.on ? gopd_decode_batch_dev(d) : 1;
+        if (rc == 1) {
+            if (d->dev.on) d->dev.batches_host++;
+            rc = gopd_decode_batch(d);
+        }
         if (rc) { gopd_drain_pool(d); d->events.clear(); d->next_event = 0; return rc; }
     }
     GopDecEvent &e = d->events[d->next_event];
@@ -978,7 +1385,7 @@ PFV_API int pfv_gop_decoder_advance_frame(pfv_gop_decoder *d, pfv_video_cb onvid
     if (e.kind == GopDecEvent::DROP) return 1;
     if (e.rc) return fail(d->ctx, e.rc, e.msg);
     if (onvideo) {
-        const uint8_t *f = d->frames_host.data() + ((size_t)e.t * (size_t)d->max_gops + (size_t)e.slot) * d->frame_bytes;
+        const uint8_t *f = (d->out_dev ? d->frames_all_dev : d->frames_host.data()) + ((size_t)e.t * (size_t)d->max_gops + (size_t)e.slot) * d->frame_bytes;
         const size_t ny = (size_t)d->width * d->height, nc = (size_t)(d->width / 2) * (d->height / 2);
         onvideo(user, f, f + ny, f + ny + nc, d->width, d->height);
     }

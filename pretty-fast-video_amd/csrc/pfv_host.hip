@@ -493,17 +493,11 @@ inline int parse_iframe_to(const uint8_t *payload, size_t n, int total_blocks, i
     std::memcpy(qidx, h.qidx, 3);
     return read_runs(r, tree, sink, 0, (size_t)total_blocks * 256);   // ONE run stream for the whole frame (dec.rs:261)
 }
-template <class Sink>
-inline int parse_pframe_to(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int8_t *mv, uint8_t *has,
-                           Sink &sink, uint8_t qidx[3])
+// the block headers of a p-frame payload (dec.rs:361-372): [has_mvec][has_coeff]([mx:7s][my:7s]); returns the number of coded macroblocks
+inline size_t parse_block_headers(BitSource &r, int total_blocks, int8_t *mv, uint8_t *has)
 {
-    BitSource r(payload, n);
-    PacketHead h;
-    if (int rc = parse_head(r, h, n_qtables)) return rc;
-    HuffmanTree tree(h.table);
-    tree.build_pair_table();
-    std::memcpy(qidx, h.qidx, 3);
-    for (int b = 0; b < total_blocks; b++) {   // dec.rs:361-372
+    size_t n_coded = 0;
+    for (int b = 0; b < total_blocks; b++) {
         if (r.can_peek()) {   // the whole block header (2 or 16 bits) from one window
             const uint32_t w = (uint32_t)r.peek();
             has[b] = (uint8_t)((w >> 1) & 1u);
@@ -515,6 +509,7 @@ inline int parse_pframe_to(const uint8_t *payload, size_t n, int total_blocks, i
                 mv[2 * b] = mv[2 * b + 1] = 0;
                 r.skip(2);
             }
+            n_coded += has[b];
             continue;
         }
         bool has_mvec = r.get(1) != 0;
@@ -524,7 +519,21 @@ inline int parse_pframe_to(const uint8_t *payload, size_t n, int total_blocks, i
             mv[2 * b] = (int8_t)r.get_signed(7);
             mv[2 * b + 1] = (int8_t)r.get_signed(7);
         }
+        n_coded += has[b];
     }
+    return n_coded;
+}
+template <class Sink>
+inline int parse_pframe_to(const uint8_t *payload, size_t n, int total_blocks, int n_qtables, int8_t *mv, uint8_t *has,
+                           Sink &sink, uint8_t qidx[3])
+{
+    BitSource r(payload, n);
+    PacketHead h;
+    if (int rc = parse_head(r, h, n_qtables)) return rc;
+    HuffmanTree tree(h.table);
+    tree.build_pair_table();
+    std::memcpy(qidx, h.qidx, 3);
+    (void)parse_block_headers(r, total_blocks, mv, has);
     if (!r.ok()) return -8;
     for (int b = 0; b < total_blocks; b++)     // dec.rs:378-417: 256 coefficients per coded macroblock
         if (has[b])

@@ -88,20 +88,34 @@ class GopDecoder(Decoder):
     """:class:`Decoder` for one stream with the independent GOPs of the stream as the slots of every kernel launch
     (``pfv_gop_decoder``, include/pfv_hip.h): same calls, frames, order and errors; ``threads`` packet parsers work beside the caller.
     ``raw=True`` hands ``onvideo`` the three planes as zero-copy uint8 views (valid until the next batch starts) instead of a
-    :class:`VideoFrame` copy."""
+    :class:`VideoFrame` copy.  ``entropy``: where packet payloads are read -- ``"auto"`` / ``"host"`` / ``"device"``
+    (PFV_OPT_ENTROPY_DECODE, include/pfv_hip.h), ``None`` = whatever the context is set to.  ``output="device"`` (needs ``raw``): the
+    frames stay in HBM and ``onvideo`` gets the three planes' device addresses (ints) instead (pfv_gop_decoder_set_output_device)."""
 
-    def __init__(self, reader, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15, threads: int = 8, raw: bool = False):
+    ENTROPY = {"auto": _lib.PFV_ENTROPY_DECODE_AUTO, "host": _lib.PFV_ENTROPY_DECODE_HOST, "device": _lib.PFV_ENTROPY_DECODE_DEVICE}
+
+    def __init__(self, reader, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15, threads: int = 8, raw: bool = False, entropy=None, output: str = "host"):
         data = reader.read() if hasattr(reader, "read") else bytes(reader)
         self._data = np.frombuffer(data, dtype=np.uint8).copy()     # must outlive the native decoder
         self.ctx, self.raw = ctx, raw
         h = ctypes.c_void_p()
-        rc = ctx._lib.pfv_gop_decoder_create(ctx.handle, self._data.ctypes.data_as(ctypes.c_void_p), self._data.size, int(max_gops), int(max_gop_frames),
-                                             int(threads), ctypes.byref(h))
+        before = ctx.get_option(_lib.PFV_OPT_ENTROPY_DECODE)
+        if entropy is not None:
+            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, self.ENTROPY[entropy])
+        try:
+            rc = ctx._lib.pfv_gop_decoder_create(ctx.handle, self._data.ctypes.data_as(ctypes.c_void_p), self._data.size, int(max_gops), int(max_gop_frames),
+                                                 int(threads), ctypes.byref(h))
+        finally:
+            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, before)
         if rc != _lib.PFV_OK:
             msg = ctx._lib.pfv_last_error(ctx.handle)
             raise DecodeError(rc, msg.decode() if msg else "")
         self.handle = h
         ctx._sessions.add(self)
+        self.output = output
+        if output == "device":
+            assert raw, "device output hands over addresses: raw=True"
+            ctx.check(ctx._lib.pfv_gop_decoder_set_output_device(h, 1))
 
     def width(self) -> int:
         return self.ctx._lib.pfv_gop_decoder_width(self.handle)
@@ -118,9 +132,14 @@ class GopDecoder(Decoder):
 
     def stats(self) -> dict:
         """host seconds so far, by what the object was waiting for (pfv_gop_decoder_stats)"""
-        a = (ctypes.c_double * 5)()
-        n = self.ctx._lib.pfv_gop_decoder_stats(self.handle, a, 5)
-        return dict(zip(("scan_s", "parse_wait_s", "device_wait_s", "enqueue_s", "final_wait_s"), list(a)[:n]))
+        a = (ctypes.c_double * 8)()
+        n = self.ctx._lib.pfv_gop_decoder_stats(self.handle, a, 8)
+        out = dict(zip(("scan_s", "parse_wait_s", "device_wait_s", "enqueue_s", "final_wait_s", "device_entropy_wait_s", "packets_read_on_device",
+                        "packets_left_to_host_parser"), list(a)[:n]))
+        for k in ("packets_read_on_device", "packets_left_to_host_parser"):
+            if k in out:
+                out[k] = int(out[k])
+        return out
 
     def reset(self):
         self.ctx.check(self.ctx._lib.pfv_gop_decoder_reset(self.handle))
@@ -128,6 +147,11 @@ class GopDecoder(Decoder):
     def _callback(self, onvideo):
         if not self.raw:
             return super()._callback(onvideo)
+
+        if self.output == "device":
+            def cbd(_user, y, u, v, w, h):
+                onvideo(*(int(p or 0) for p in (y, u, v)))
+            return _CB(cbd)
 
         def cb(_user, y, u, v, w, h):
             def arr(p, n):

@@ -334,6 +334,11 @@ def check_empty_pframe_packet(pkg, ctx, oracle, w=48, h=32):
 
 
 # ---------------------------------------------------------------------------------------------------------------- GOP-batched objects
+# where the GOP-batched decoder read its packet payloads, summed over every decoder _outcomes closed (PFV_OPT_ENTROPY_DECODE)
+ENTROPY_COUNTS = {"packets_read_on_device": 0, "packets_left_to_host_parser": 0}
+GOP_ENTROPY_MODES = ("host", "device")
+
+
 def _outcomes(make_decoder, pkg, n_calls=96, stop_at_error=True):
     """one entry per advance_frame call of any decoder object: ('frame', bytes) / ('none',) / ('eof',) / ('err', code)"""
     out = []
@@ -356,6 +361,10 @@ def _outcomes(make_decoder, pkg, n_calls=96, stop_at_error=True):
                 out.append(("eof",))
                 break
     finally:
+        if hasattr(dec, "stats"):
+            for k, v in dec.stats().items():
+                if k in ENTROPY_COUNTS:
+                    ENTROPY_COUNTS[k] += v
         dec.close()
     return out
 
@@ -399,14 +408,34 @@ def check_gop_objects(pkg, ctx, oracle, w, h, quality, pattern, shapes, frame_sr
         data, _ = encode_pattern(pkg, ctx, oracle, w, h, quality, pattern,
                                  lambda buf: pkg.GopEncoder(buf, w, h, 30, quality, ctx, max_gops=max_gops, max_gop_frames=max_len), frame_src, with_oracle=False)
         assert data == serial, f"GOP-batched encoder (max_gops {max_gops}, max_gop_frames {max_len}) wrote a different .pfv stream"
-        got = _outcomes(lambda: pkg.GopDecoder(serial, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=dec_threads), pkg)
-        assert len(got) == len(want), (max_gops, max_len, [x[0] for x in got], [x[0] for x in want])
-        for k, (a, b) in enumerate(zip(got, want)):
-            assert a == b, f"GOP-batched decoder (max_gops {max_gops}, max_gop_frames {max_len}): call {k} gives {a[0]}, the oracle {b[0]}"
+        for mode in GOP_ENTROPY_MODES:
+            got = _outcomes(lambda: pkg.GopDecoder(serial, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=dec_threads, entropy=mode), pkg)
+            assert len(got) == len(want), (max_gops, max_len, mode, [x[0] for x in got], [x[0] for x in want])
+            for k, (a, b) in enumerate(zip(got, want)):
+                assert a == b, f"GOP-batched decoder (max_gops {max_gops}, max_gop_frames {max_len}, payloads read on the {mode}): call {k} gives {a[0]}, the oracle {b[0]}"
+    # frames left in device memory (pfv_gop_decoder_set_output_device): the same bytes, fetched from the addresses the callback gets
+    max_gops, max_len = shapes[-1]
+    fb = w * h + 2 * (w // 2) * (h // 2)
+    dd = pkg.GopDecoder(serial, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=dec_threads, raw=True, entropy="device", output="device")
+    got_dev = []
+
+    def on_dev(y, u, v):
+        assert u == y + w * h and v == u + (w // 2) * (h // 2)
+        a = np.empty(fb, np.uint8)
+        ctx.download(a, y)
+        got_dev.append(a.tobytes())
+    try:
+        while dd.advance_frame(on_dev):
+            pass
+    except pkg.PfvError:
+        pass
+    dd.close()
+    want_frames = [x[1] for x in want if x[0] == "frame"]
+    assert got_dev == want_frames[:len(got_dev)] and len(got_dev) == len(want_frames), "frames delivered in device memory differ"
     # reset() (dec.rs:148-152) in mid-batch and real-time pacing (advance_delta, dec.rs:154-167): as the frame-by-frame Decoder behaves
     if pattern[:1] == "I" and len(pattern) >= 3:
         max_gops, max_len = shapes[0]
-        gd, sd = pkg.GopDecoder(serial, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=1), pkg.Decoder(serial, ctx, lookahead=0)
+        gd, sd = pkg.GopDecoder(serial, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=1, entropy="device"), pkg.Decoder(serial, ctx, lookahead=0)
         ga, sa = [], []
         for dec, acc in ((gd, ga), (sd, sa)):
             assert (dec.width(), dec.height(), dec.framerate()) == (w, h, 30)
@@ -491,7 +520,8 @@ def check_gop_decoder_corrupted(pkg, ctx, oracle, data, n_trials, seed, shapes=(
             bad = bad[: int(rng.integers(hdr, len(bad)))]
         bad = bytes(bad)
         max_gops, max_len = shapes[stats["trials"] % len(shapes)]
-        mk = lambda: pkg.GopDecoder(bad, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=stats["trials"] % 3)
+        mode = GOP_ENTROPY_MODES[(stats["trials"] // len(shapes)) % len(GOP_ENTROPY_MODES)] if stats["trials"] % 4 else "device"
+        mk = lambda: pkg.GopDecoder(bad, ctx, max_gops=max_gops, max_gop_frames=max_len, threads=stats["trials"] % 3, entropy=mode)
         a = _outcomes(mk, pkg)
         b = _outcomes_oracle(oracle, bad)
         assert len(a) == len(b), ([x[0] for x in a], [x[0] for x in b])
@@ -503,7 +533,7 @@ def check_gop_decoder_corrupted(pkg, ctx, oracle, data, n_trials, seed, shapes=(
         assert len(a2) == len(b2), ([x[0] for x in a2], [x[0] for x in b2])
         seen_err = False
         for k, (x, y) in enumerate(zip(a2, b2)):
-            assert x == y, (max_gops, max_len, k, [v[0] for v in a2], [v[0] for v in b2])
+            assert x == y, (max_gops, max_len, mode, k, [v[0] for v in a2], [v[0] for v in b2])
             seen_err = seen_err or x[0] == "err"
             stats["frames_after_an_error"] += seen_err and x[0] == "frame"
         stats["trials"] += 1
@@ -538,7 +568,8 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
             continue                                                   # this flip happened to leave the packet parseable
         hit += 1
         for shape in ((8, 15), (2, 2), (1, 15)):
-            got = _outcomes(lambda: pkg.GopDecoder(bad, ctx, max_gops=shape[0], max_gop_frames=shape[1], threads=1), pkg, n_calls=12, stop_at_error=False)
-            assert got == want, (frac, shape, [x[0] for x in got], [x == y for x, y in zip(got, want)])
+            for mode in GOP_ENTROPY_MODES:
+                got = _outcomes(lambda: pkg.GopDecoder(bad, ctx, max_gops=shape[0], max_gop_frames=shape[1], threads=1, entropy=mode), pkg, n_calls=12, stop_at_error=False)
+                assert got == want, (frac, shape, mode, [x[0] for x in got], [x == y for x, y in zip(got, want)])
     assert hit >= 1 or not require_hit, "no flip produced the failing i-frame this case is about"
     return hit
