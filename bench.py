@@ -869,8 +869,32 @@ def stream_4k_side(pkg, ctx, Q, seed, n_frames=300, pcie_frames=30, ss=None, gop
     res["end_to_end"]["serial_objects"] = {"encode_value": n_frames * n_mb / s_enc, "decode_value": n_frames * n_mb / s_dec,
                                            "note": "Encoder -> .pfv -> Decoder, one frame per call and per launch (the same bytes: checked)"}
     ctx.host_free(host_all.reshape(-1))
+    res["end_to_end"]["native_host"] = native_end_to_end(W, H, n_frames, Q, gops, parse_threads)      # its own context; this one's page-locked frames are gone
     res["unit"] = "macroblocks/s"
     return res
+
+
+def native_end_to_end(W, H, n_frames, Q, gops, parse_threads):
+    """the same end-to-end run from a native host program over the C ABI (tools/e2e_native.cpp, built here with g++): what a compiled
+    caller -- the reference's are Rust -- sees, without the Python mirror's ~0.15 ms of interpreter per delivered frame"""
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.gettempdir(), f"pfv_e2e_native_{os.getpid()}")
+    libdir = os.path.join(ROOT, "pretty-fast-video_amd")
+    try:
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "e2e_native.cpp"), "-L", libdir, "-lpfv_hip",
+                        f"-Wl,-rpath,{libdir}", "-o", exe], check=True, capture_output=True, text=True)
+        r = subprocess.run([exe, str(W), str(H), str(n_frames), str(GOP), str(Q), str(gops), str(2 * gops), str(parse_threads)], check=True, capture_output=True,
+                           text=True, timeout=600)
+        out = json.loads(r.stdout)
+        out["note"] = ("tools/e2e_native.cpp: page-locked producer frames -> pfv_gop_encoder -> .pfv bytes -> pfv_gop_decoder -> the consumer's callback per frame "
+                       "(best of 3 per decoder mode; sampled frames identical in all modes)")
+        return out
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return {"error": f"{type(e).__name__}: {getattr(e, 'stderr', '') or e}"[:400]}
+    finally:
+        if os.path.exists(exe):
+            os.remove(exe)
 
 
 def batch_encoder_side(pkg, ctx, Q, n_streams=32, reps=3):

@@ -314,8 +314,26 @@ class GopDecoder {
         cb_ = &onvideo;
         return result(pfv_gop_decoder_advance_frame(h_, &GopDecoder::trampoline, this));
     }
+    // frames left in device memory (pfv_gop_decoder_set_output_device): the consumer gets the three planes' DEVICE addresses, valid until
+    // the call that starts the next batch -- for consumers on the GPU; no frame crosses PCIe
+    using OnVideoDevice = std::function<void(const uint8_t *y, const uint8_t *u, const uint8_t *v, uint32_t width, uint32_t height)>;
+    void set_output_device(bool on) { ctx_.check(pfv_gop_decoder_set_output_device(h_, on ? 1 : 0)); device_out_ = on; }
+    bool advance_frame_device(const OnVideoDevice &onvideo)
+    {
+        if (!device_out_) throw std::logic_error("GopDecoder::advance_frame_device: set_output_device(true) first");
+        dcb_ = &onvideo;
+        const int rc = pfv_gop_decoder_advance_frame(h_, &GopDecoder::trampoline_device, this);
+        dcb_ = nullptr;
+        if (rc < 0) ctx_.check(rc);
+        return rc == 1;
+    }
 
   private:
+    static void trampoline_device(void *user, const uint8_t *y, const uint8_t *u, const uint8_t *v, int w, int h)
+    {
+        GopDecoder *d = static_cast<GopDecoder *>(user);
+        if (d->dcb_ && *d->dcb_) (*d->dcb_)(y, u, v, (uint32_t)w, (uint32_t)h);
+    }
     bool result(int rc)
     {
         cb_ = nullptr;
@@ -336,6 +354,8 @@ class GopDecoder {
     pfv_gop_decoder *h_ = nullptr;
     VideoFrame frame_;
     const OnVideo *cb_ = nullptr;
+    const OnVideoDevice *dcb_ = nullptr;
+    bool device_out_ = false;
 };
 
 // n Encoders of one geometry stepped together (pfv_batch_encoder): every writer receives exactly the bytes an Encoder of

@@ -7,13 +7,14 @@
 // after a handful of runs and is identical to the true reader from there on.  Hence (after Weissenberger & Schmidt's parallel
 // Huffman decoding):
 //
-//   k_entd_coded  p-frames: the list of coded macroblocks (has_coeff != 0) of every packet, in order (one workgroup per packet).
 //   k_entd_sync   the payload behind the block headers is cut into subsequences of kEdSubBits bits, one lane each.  end[i] = the
 //                 first run boundary at or behind the end of subsequence i when reading from `start` -- round 1 takes the
 //                 subsequence's own first bit for `start` (a guess), every later round takes end[i - 1] and only runs where that
-//                 differs from what the lane used before.  A last launch only verifies that no lane has anything left to do: then
-//                 end[0] is true (the first lane starts at the true first run) and every end[i] follows from a true start.  A packet
-//                 that has not settled (long periodic content can keep a wrong phase) is left to the host parser.
+//                 differs from what the lane used before.  Rounds are cheap inside a workgroup (256 lanes pass their ends along in
+//                 LDS until nothing changes) and are launches between workgroups.  A last launch only verifies that no lane has
+//                 anything left to do: then end[0] is true (the first lane starts at the true first run) and every end[i] follows
+//                 from a true start.  A packet that has not settled (periodic content can keep a wrong phase for ever) is left to
+//                 the host parser.
 //   k_entd_prefix exclusive prefix over the coefficients each subsequence covers: the coefficient index its first run starts at.
 //   k_entd_emit   every lane reads its subsequence once more, from its true start and coefficient index, and stores the values
 //                 (zeros are what the buffer was cleared to).  It also decides whether the host parser would have accepted the
@@ -33,12 +34,13 @@ namespace pfv {
 
 constexpr int kEdThreads = 256;
 #ifndef PFV_ED_SUB_BITS
-#define PFV_ED_SUB_BITS 512
+#define PFV_ED_SUB_BITS 256
 #endif
-constexpr uint32_t kEdSubBits = PFV_ED_SUB_BITS;     // payload bits per lane
+constexpr uint32_t kEdSubBits = PFV_ED_SUB_BITS;     // payload bits per lane (default; EdPacket::sub_bits is what the kernels use)
 constexpr uint32_t kEdIrregular = 1u;               // k_entd_emit: the host parser decides about this packet
 constexpr uint32_t kEdUnsettled = 2u;               // k_entd_sync: the subsequence starts had not settled
 constexpr uint32_t kEdNoStart = 0xffffffffu;
+constexpr int kEdInner = 24;                        // k_entd_sync: rounds inside a workgroup per launch (default)
 
 // one packet of the batch (made by the host from the packet's first 19 bytes and, p-frames, its block headers)
 struct EdPacket {
@@ -46,7 +48,8 @@ struct EdPacket {
     uint32_t total_bits;           // payload size in bits
     uint32_t bit0;                 // first bit of the run streams (behind the table, the q indices and the block headers)
     uint32_t total_coefs;          // coefficients the run streams cover: macroblocks x 256 (i-frame), coded macroblocks x 256 (p-frame)
-    uint32_t n_sub;                // subsequences = ceil((total_bits - bit0) / kEdSubBits); 0: nothing to read
+    uint32_t n_sub;                // subsequences = ceil((total_bits - bit0) / sub_bits); 0: nothing to read
+    uint32_t sub_bits;             // payload bits per lane
     uint32_t sub_first;            // index of subsequence 0 in the per-subsequence arrays
     uint32_t pframe;               // 1: values go through the coded-macroblock list
     uint32_t total_blocks;         // macroblocks per frame
@@ -60,10 +63,10 @@ struct EdBufs {
     const EdPacket *packets;
     const uint2 *groups;           // workgroups of k_entd_sync / k_entd_emit: (packet, which kEdThreads subsequences of it)
     uint32_t *end, *used, *cnt, *vstart;   // per subsequence
-    const uint8_t *has;            // [frame][total_blocks]
-    uint32_t *coded;               // [frame][total_blocks]: the k-th coded macroblock of the frame
+    const uint32_t *coded;         // [frame][total_blocks]: the k-th coded macroblock of the frame (p-frames; from the host's pass over the block headers)
     int16_t *coef;                 // [frame][total_blocks][256], cleared
     uint32_t *status;              // per packet: kEd* bits
+    uint32_t packet0;              // k_entd_prefix: the launch's first packet (one workgroup per packet)
 };
 
 // (used bits | num_zeroes << 4 | coeff_size << 8) of the code pair at the low end of v, 0 when the pair is longer than 12 bits
@@ -146,16 +149,20 @@ __device__ __forceinline__ void ed_run(EdReader &r, const uint16_t *pair, const 
 
 __device__ __forceinline__ uint32_t ed_limit(const EdPacket &pk, uint32_t i)
 {
-    const unsigned long long lim = (unsigned long long)pk.bit0 + (unsigned long long)(i + 1u) * kEdSubBits;
+    const unsigned long long lim = (unsigned long long)pk.bit0 + (unsigned long long)(i + 1u) * pk.sub_bits;
     return lim < pk.total_bits ? (uint32_t)lim : pk.total_bits;
 }
 
-// one workgroup per entry of b.groups.  verify != 0: nothing is read, a lane that still has work marks the packet.
-__global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_round, int verify)
+// one workgroup per entry of b.groups.  Inside a launch the lanes of a workgroup pass their ends along through LDS and repeat until
+// none of them has a new start (a lane whose read had not met the true one by its end changes its neighbour's start, and so on: a few
+// short rounds instead of launches); between workgroups the ends travel through memory, launch to launch.  verify != 0: nothing is
+// read, a lane that still has work marks the packet.
+__global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_round, int verify, int inner)
 {
     __shared__ uint16_t pair[4096];
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
+    __shared__ uint32_t s_end[kEdThreads];
     __shared__ int any_work;
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
@@ -163,36 +170,56 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
     const uint32_t i = grp.y * kEdThreads + (uint32_t)tid;
     const bool mine = i < pk.n_sub;
     const size_t at = (size_t)pk.sub_first + i;
-    uint32_t start = kEdNoStart;
-    bool work = false;
-    if (mine) {
-        start = first_round || i == 0 ? (i == 0 ? pk.bit0 : pk.bit0 + i * kEdSubBits) : b.end[at - 1];
-        work = first_round || b.used[at] != start;
+    uint32_t used = kEdNoStart, end = 0, count = 0, before = 0;
+    if (mine && !first_round) { used = b.used[at]; end = b.end[at]; count = b.cnt[at]; }
+    if (mine && !first_round && tid == 0 && i > 0) before = b.end[at - 1];       // the workgroup in front: as the last launch left it
+    const uint32_t limit = mine ? ed_limit(pk, i) : 0;
+    bool built = false, dirty = false;
+    for (int it = 0; it < inner; it++) {
+        s_end[tid] = end;
+        if (tid == 0) any_work = 0;
+        __syncthreads();
+        uint32_t start = kEdNoStart;
+        bool work = false;
+        if (mine) {
+            if (i == 0) start = pk.bit0;
+            else if (first_round && it == 0) start = pk.bit0 + i * pk.sub_bits;  // a guess: the subsequence's own first bit
+            else if (tid == 0) start = first_round ? used : before;
+            else start = s_end[tid - 1];
+            work = used != start;
+        }
+        if (work) any_work = 1;
+        __syncthreads();
+        if (!any_work) break;
+        if (verify) {
+            if (work) atomicOr(b.status + grp.x, kEdUnsettled);
+            return;
+        }
+        if (!built) {
+            ed_build_pairs(pair, cval, clen, pk, tid);
+            built = true;
+        }
+        if (work) {
+            count = 0;
+            EdReader r;
+            r.open(b.bytes + pk.byte_off, start);
+            while (r.pos < limit) {
+                uint32_t zeros, nb;
+                int value;
+                ed_run(r, pair, cval, clen, zeros, nb, value);
+                count += zeros + (nb ? 1u : 0u);
+            }
+            end = r.pos;
+            used = start;
+            dirty = true;
+        }
+        __syncthreads();
     }
-    if (tid == 0) any_work = 0;
-    __syncthreads();
-    if (work) any_work = 1;
-    __syncthreads();
-    if (!any_work) return;
-    if (verify) {
-        if (work) atomicOr(b.status + grp.x, kEdUnsettled);
-        return;
+    if (dirty) {
+        b.end[at] = end;
+        b.used[at] = used;
+        b.cnt[at] = count;
     }
-    ed_build_pairs(pair, cval, clen, pk, tid);
-    if (!work) return;
-    const uint32_t limit = ed_limit(pk, i);
-    uint32_t count = 0;
-    EdReader r;
-    r.open(b.bytes + pk.byte_off, start);
-    while (r.pos < limit) {
-        uint32_t zeros, nb;
-        int value;
-        ed_run(r, pair, cval, clen, zeros, nb, value);
-        count += zeros + (nb ? 1u : 0u);
-    }
-    b.end[at] = r.pos;
-    b.used[at] = start;
-    b.cnt[at] = count;
 }
 
 // workgroup scan helper: exclusive prefix of one value per lane (kEdThreads lanes), total in *sum
@@ -216,7 +243,7 @@ __device__ __forceinline__ uint32_t ed_block_exclusive(uint32_t v, uint32_t *scr
 __global__ void __launch_bounds__(kEdThreads) k_entd_prefix(EdBufs b)
 {
     __shared__ uint32_t scratch[kEdThreads];
-    const EdPacket &pk = b.packets[blockIdx.x];
+    const EdPacket &pk = b.packets[b.packet0 + blockIdx.x];
     const int tid = (int)threadIdx.x;
     if (pk.n_sub == 0) return;
     const uint32_t per = (pk.n_sub + kEdThreads - 1) / kEdThreads;
@@ -230,24 +257,6 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_prefix(EdBufs b)
         vs[i] = run;
         run += cnt[i];
     }
-}
-
-// one workgroup per packet: coded[k] = index of the k-th macroblock with has_coeff
-__global__ void __launch_bounds__(kEdThreads) k_entd_coded(EdBufs b)
-{
-    __shared__ uint32_t scratch[kEdThreads];
-    const EdPacket &pk = b.packets[blockIdx.x];
-    const int tid = (int)threadIdx.x;
-    if (!pk.pframe) return;
-    const uint32_t tb = pk.total_blocks, per = (tb + kEdThreads - 1) / kEdThreads;
-    const uint32_t lo = min((uint32_t)tid * per, tb), hi = min(lo + per, tb);
-    const uint8_t *has = b.has + pk.frame_off * tb;
-    uint32_t *coded = b.coded + pk.frame_off * tb;
-    uint32_t mine = 0;
-    for (uint32_t m = lo; m < hi; m++) mine += has[m] ? 1u : 0u;
-    uint32_t k = ed_block_exclusive(mine, scratch, tid, nullptr);
-    for (uint32_t m = lo; m < hi; m++)
-        if (has[m]) coded[k++] = m;
 }
 
 // workgroups as k_entd_sync: the values of subsequence i into the coefficient array

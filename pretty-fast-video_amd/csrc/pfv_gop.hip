@@ -493,6 +493,9 @@ struct GopDevPacket {
     size_t frame = 0;                    // t * max_gops + slot: its place in the batch-wide arrays
 };
 
+constexpr int kGopDevDense = 8;
+constexpr int kGopDevRounds = 4;         // k_entd_sync launches before the verifying one
+
 // device-entropy path of the decoder (PFV_OPT_ENTROPY_DECODE): the whole batch's payloads are read by the k_entd_* kernels
 struct GopDecDev {
     bool on = false;
@@ -505,10 +508,18 @@ struct GopDecDev {
     int16_t *coef_dev = nullptr;
     int8_t *mv_dev = nullptr;
     uint8_t *has_dev = nullptr;
+    hipStream_t stream = nullptr;        // the entropy stage's own stream: it works ahead of the decode kernels and their downloads
+    hipStream_t up_stream = nullptr;     // ... and the uploads / clears it needs run ahead of it on a third
+    std::vector<hipEvent_t> window_done; // per step: payloads read, statuses on the host
+    std::vector<hipEvent_t> window_up;   // per step: payloads, headers and cleared coefficient arrays in place
     PinnedBuf<uint8_t> bytes_host, has_host;
     PinnedBuf<int8_t> mv_host;
     PinnedBuf<EdPacket> pk_host;
     PinnedBuf<uint2> groups_host;
+    PinnedBuf<uint32_t> coded_host;      // [frame][total_blocks]
+    uint32_t sub_bits = kEdSubBits;      // payload bits per lane (PFV_ED_SUB_BITS in the environment: experiments)
+    int launches = kGopDevRounds, inner = kEdInner;   // k_entd_sync launches before the verifying one, rounds inside each (PFV_ED_ROUNDS="launches,inner": tests)
+    long unsettled = 0, irregular = 0;   // why packets were left to the host parser
     PinnedBuf<uint32_t> status_host;
     PinnedBuf<int> flags_host;           // [step][max_gops]
     PinnedBuf<int16_t> dense_host;       // kGopDevDense frames: packets the host parser reads
@@ -518,8 +529,6 @@ struct GopDecDev {
     int pending = 0;                     // tasks of the current phase not yet finished (under the pool's mutex)
     long packets_dev = 0, packets_host = 0, batches_dev = 0, batches_host = 0;
 };
-constexpr int kGopDevDense = 8;
-constexpr int kGopDevRounds = 6;         // k_entd_sync launches before the verifying one
 
 struct pfv_gop_decoder {
     pfv_ctx *ctx = nullptr;
@@ -937,6 +946,7 @@ static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
     EdPacket &k = v.pk_host.data()[j];
     const size_t tb = d->total_blocks;
     k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = 0;
+    k.sub_bits = v.sub_bits;
     k.pframe = e->type == 2 ? 1u : 0u;
     k.total_blocks = (uint32_t)tb;
     memset(k.code_val, 0, sizeof k.code_val);
@@ -948,7 +958,7 @@ static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
     memcpy(p.qidx, h.qidx, 3);
     size_t n_coded = tb;
     if (e->type == 2) {
-        n_coded = parse_block_headers(r, (int)tb, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb);
+        n_coded = parse_block_headers(r, (int)tb, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, v.coded_host.data() + p.frame * tb);
         if (!r.ok()) { p.rc = PFV_ERR_IO; return; }
     }
     if (n_coded == 0) return;                                  // no run stream: nothing is read behind the headers (src/dec.rs:378-380)
@@ -964,7 +974,7 @@ static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
     k.total_bits = (uint32_t)bits;
     k.bit0 = (uint32_t)bit0;
     k.total_coefs = (uint32_t)(n_coded * 256);
-    k.n_sub = (uint32_t)((bits - bit0 + kEdSubBits - 1) / kEdSubBits);
+    k.n_sub = (uint32_t)((bits - bit0 + v.sub_bits - 1) / v.sub_bits);
     uint8_t *dst = v.bytes_host.data() + k.byte_off;
     memcpy(dst, e->payload, e->plen);
     memset(dst + e->plen, 0, 16);
@@ -1009,6 +1019,10 @@ static int gopd_dev_room(pfv_ctx *ctx, T **p, size_t *cap, size_t need)
 
 // Decode the scanned batch with the payloads read on the device.  PFV_OK: done (frames in frames_host[step][slot]); 1: this batch needs
 // the host path (a group's i-frame does not parse: the chains change, see gopd_decode_batch) -- nothing has been decoded; negative: error.
+//
+// The entropy stage of step t (payload upload, k_entd_*, status download) runs on a stream of its own, one window per step, all windows
+// enqueued up front: while the context's stream decodes step t and sends its frames to the host -- the PCIe time that bounds the whole
+// decoder -- the device reads the payloads of the steps behind it.
 static int gopd_decode_batch_dev(pfv_gop_decoder *d)
 {
     pfv_ctx *ctx = d->ctx;
@@ -1023,7 +1037,10 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     const size_t tb = d->total_blocks, pad = (size_t)hot->geom.pad_frame_bytes, S = (size_t)d->max_gops;
     static const char *kBadPayload = "malformed packet payload", *kBadMv = "motion vector points outside the reference plane (src/common.rs:258-259)";
     GopClock clk;
+    HIP_TRY(ctx, hipStreamSynchronize(v.up_stream));       // a batch that went to the host path may have left windows behind
+    HIP_TRY(ctx, hipStreamSynchronize(v.stream));
 
+    // packets in (step, slot) order: a step's packets, payload bytes, subsequences and workgroups are contiguous
     v.pk.clear();
     for (GopDecEvent &e : d->events)
         if (e.kind == GopDecEvent::FRAME) {
@@ -1032,15 +1049,22 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             p.frame = (size_t)e.t * S + (size_t)e.slot;
             v.pk.push_back(p);
         }
+    std::sort(v.pk.begin(), v.pk.end(), [](const GopDevPacket &a, const GopDevPacket &b) { return a.frame < b.frame; });
     const size_t n = v.pk.size();
     if (!v.pk_host.resize(n) || !v.status_host.resize(n)) return fail(ctx, PFV_ERR_NOMEM, "device-entropy staging");
+    std::vector<size_t> p0((size_t)steps + 1, n), byte0((size_t)steps + 1, 0), grp0((size_t)steps + 1, 0);
     size_t bytes_total = 0;
     for (size_t j = 0; j < n; j++) {
         EdPacket &k = v.pk_host.data()[j];
+        const size_t t = (size_t)v.pk[j].ev->t;
+        if (p0[t] == n) { p0[t] = j; byte0[t] = bytes_total; }
         k.byte_off = bytes_total;
         k.frame_off = v.pk[j].frame;
         bytes_total += ((size_t)v.pk[j].ev->plen + 16 + 15) & ~(size_t)15;
     }
+    byte0[(size_t)steps] = bytes_total;
+    for (size_t t = (size_t)steps; t-- > 0;)
+        if (p0[t] == n) { p0[t] = p0[t + 1]; byte0[t] = byte0[t + 1]; }
     if (!v.bytes_host.resize(bytes_total + 64)) return fail(ctx, PFV_ERR_NOMEM, "device-entropy payload staging");
     gopd_dev_run_phase(d, 1, (int)n);
     d->stats[1] += clk.lap();
@@ -1057,9 +1081,12 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     int rc = PFV_OK;
     if (!v.groups_host.resize(std::max<size_t>(n_groups, 1))) return fail(ctx, PFV_ERR_NOMEM, "device-entropy staging");
     {
-        size_t g = 0;
-        for (size_t j = 0; j < n; j++)
+        size_t g = 0, t = 0;
+        for (size_t j = 0; j < n; j++) {
+            for (; t <= (size_t)steps && p0[t] <= j; t++) grp0[t] = g;
             for (uint32_t b = 0; b * (uint32_t)kEdThreads < v.pk_host.data()[j].n_sub; b++) v.groups_host.data()[g++] = make_uint2((unsigned)j, b);
+        }
+        for (; t <= (size_t)steps; t++) grp0[t] = g;
     }
     if ((rc = gopd_dev_room(ctx, &v.bytes_dev, &v.bytes_cap, bytes_total + 64))) return rc;
     if (n > v.pk_cap) {
@@ -1070,69 +1097,45 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     }
     if ((rc = gopd_dev_room(ctx, &v.groups_dev, &v.groups_cap, std::max<size_t>(n_groups, 1)))) return rc;
     if ((rc = gopd_dev_room(ctx, &v.sub_dev, &v.sub_cap, std::max<size_t>(total_sub, 1) * 4))) return rc;
-    const size_t frames_used = (size_t)steps * S;
-    HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev, v.bytes_host.data(), bytes_total, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, v.pk_host.data(), n * sizeof(EdPacket), hipMemcpyHostToDevice, ctx->stream));
-    if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, v.groups_host.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev, v.mv_host.data(), frames_used * tb * 2, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(v.has_dev, v.has_host.data(), frames_used * tb, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(v.coef_dev, 0, frames_used * tb * 512, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, n * sizeof(uint32_t), ctx->stream));
-    if (n_groups) {
-        const size_t ts = v.sub_cap / 4;
-        EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.has_dev, v.coded_dev, v.coef_dev, v.status_dev};
-        hipLaunchKernelGGL(k_entd_coded, dim3((unsigned)n), dim3(kEdThreads), 0, ctx->stream, b);
-        for (int round = 0; round <= kGopDevRounds; round++)
-            hipLaunchKernelGGL(k_entd_sync, dim3((unsigned)n_groups), dim3(kEdThreads), 0, ctx->stream, b, round == 0 ? 1 : 0, round == kGopDevRounds ? 1 : 0);
-        hipLaunchKernelGGL(k_entd_prefix, dim3((unsigned)n), dim3(kEdThreads), 0, ctx->stream, b);
-        hipLaunchKernelGGL(k_entd_emit, dim3((unsigned)n_groups), dim3(kEdThreads), 0, ctx->stream, b);
-        if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
+    while (v.window_done.size() < (size_t)steps) {
+        hipEvent_t ev = nullptr, ev2 = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        v.window_done.push_back(ev);
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
+        v.window_up.push_back(ev2);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data(), v.status_dev, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    d->stats[3] += clk.lap();
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    d->stats[5] += clk.lap();
-
-    // what the device stage was not sure about goes through the host parser, which decides
-    v.todo.clear();
-    for (size_t j = 0; j < n; j++) {
-        GopDevPacket &p = v.pk[j];
-        if (p.rc) continue;
-        if (p.host_parse || v.status_host.data()[j]) { p.host_parse = true; v.todo.push_back((int)j); }
+    // every window of the batch: uploads and clears on one stream, the kernels behind them on another
+    HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, v.pk_host.data(), n * sizeof(EdPacket), hipMemcpyHostToDevice, v.up_stream));
+    if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, v.groups_host.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, v.up_stream));
+    HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, n * sizeof(uint32_t), v.up_stream));
+    const size_t ts = v.sub_cap / 4;
+    for (int t = 0; t < steps; t++) {
+        const size_t f0 = (size_t)t * S;
+        const size_t ba = byte0[(size_t)t], bb = byte0[(size_t)t + 1];
+        if (bb > ba) HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev + ba, v.bytes_host.data() + ba, bb - ba, hipMemcpyHostToDevice, v.up_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + f0 * tb * 2, v.mv_host.data() + f0 * tb * 2, S * tb * 2, hipMemcpyHostToDevice, v.up_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + f0 * tb, v.has_host.data() + f0 * tb, S * tb, hipMemcpyHostToDevice, v.up_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev + f0 * tb, v.coded_host.data() + f0 * tb, S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, v.up_stream));
+        HIP_TRY(ctx, hipMemsetAsync(v.coef_dev + f0 * tb * 256, 0, S * tb * 512, v.up_stream));
+        HIP_TRY(ctx, hipEventRecord(v.window_up[(size_t)t], v.up_stream));
     }
-    for (size_t first = 0; first < v.todo.size(); first += (size_t)kGopDevDense) {
-        const int cnt = (int)std::min<size_t>((size_t)kGopDevDense, v.todo.size() - first);
-        if (!v.dense_host.resize((size_t)kGopDevDense * tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
-        v.todo_first = (int)first;
-        gopd_dev_run_phase(d, 2, cnt);
-        for (int j = 0; j < cnt; j++) {
-            const GopDevPacket &p = v.pk[(size_t)v.todo[first + (size_t)j]];
-            if (p.rc) continue;
-            HIP_TRY(ctx, hipMemcpyAsync(v.coef_dev + p.frame * tb * 256, v.dense_host.data() + (size_t)j * tb * 256, tb * 512, hipMemcpyHostToDevice, ctx->stream));
-            if (p.ev->type == 2) {   // the host parser wrote the headers again (the same values): keep the device copies in step
-                HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + p.frame * tb * 2, v.mv_host.data() + p.frame * tb * 2, tb * 2, hipMemcpyHostToDevice, ctx->stream));
-                HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + p.frame * tb, v.has_host.data() + p.frame * tb, tb, hipMemcpyHostToDevice, ctx->stream));
-            }
+    for (int t = 0; t < steps; t++) {
+        const size_t pa = p0[(size_t)t], pb = p0[(size_t)t + 1], ga = grp0[(size_t)t], gb = grp0[(size_t)t + 1];
+        HIP_TRY(ctx, hipStreamWaitEvent(v.stream, v.window_up[(size_t)t], 0));
+        if (gb > ga) {
+            EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, v.coef_dev, v.status_dev,
+                     (uint32_t)pa};
+            const unsigned np = (unsigned)(pb - pa), ng = (unsigned)(gb - ga);
+            for (int round = 0; round <= v.launches; round++)
+                hipLaunchKernelGGL(k_entd_sync, dim3(ng), dim3(kEdThreads), 0, v.stream, b, round == 0 ? 1 : 0, round == v.launches ? 1 : 0, round == v.launches ? 1 : v.inner);
+            hipLaunchKernelGGL(k_entd_prefix, dim3(np), dim3(kEdThreads), 0, v.stream, b);
+            hipLaunchKernelGGL(k_entd_emit, dim3(ng), dim3(kEdThreads), 0, v.stream, b);
+            if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data() + pa, v.status_dev + pa, (pb - pa) * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
+        HIP_TRY(ctx, hipEventRecord(v.window_done[(size_t)t], v.stream));
     }
-    d->stats[1] += clk.lap();
-    std::vector<int> at((size_t)steps * (size_t)G, -1);
-    for (size_t j = 0; j < n; j++) {
-        GopDevPacket &p = v.pk[j];
-        if (!p.rc)
-            for (int i = 0; i < 3; i++)
-                if (p.qidx[i] >= hot->n_qtables) p.rc = PFV_ERR_FORMAT;      // the reference panics (src/dec.rs:249-251)
-        if (p.rc && p.ev->t == 0 && p.ev->type == 1) return 1;              // not an independent run after all: the chains change
-        at[(size_t)p.ev->t * (size_t)G + (size_t)p.ev->slot] = (int)j;
-    }
-    for (size_t j = 0; j < n; j++) {
-        GopDevPacket &p = v.pk[j];
-        p.ev->rc = p.rc;
-        if (p.rc) p.ev->msg = kBadPayload;
-        else if (p.host_parse) v.packets_host++;
-        else v.packets_dev++;
-    }
+    d->stats[3] += clk.lap();
 
     if (d->gfirst[0] == 2 && d->cont_valid) {   // slot 0 continues the run the previous batch left open
         const uint8_t *src = hot->fb[d->cont_buf] + (size_t)d->cont_slot * pad;
@@ -1146,23 +1149,59 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     std::vector<int> key((size_t)G);
     std::vector<uint32_t> combos;
     for (int t = 0; t < steps; t++) {
+        const size_t f0 = (size_t)t * S, pa = p0[(size_t)t], pb = p0[(size_t)t + 1];
+        HIP_TRY(ctx, hipEventSynchronize(v.window_done[(size_t)t]));
+        d->stats[5] += clk.lap();
+        // what the device stage was not sure about goes through the host parser, which decides
+        v.todo.clear();
+        for (size_t j = pa; j < pb; j++) {
+            GopDevPacket &p = v.pk[j];
+            if (p.rc) continue;
+            const uint32_t st = v.status_host.data()[j];
+            if (st & kEdUnsettled) v.unsettled++;
+            else if (st) v.irregular++;
+            if (p.host_parse || st) { p.host_parse = true; v.todo.push_back((int)j); }
+        }
+        for (size_t first = 0; first < v.todo.size(); first += (size_t)kGopDevDense) {
+            const int cnt = (int)std::min<size_t>((size_t)kGopDevDense, v.todo.size() - first);
+            if (!v.dense_host.resize((size_t)kGopDevDense * tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
+            v.todo_first = (int)first;
+            gopd_dev_run_phase(d, 2, cnt);
+            for (int j = 0; j < cnt; j++) {
+                const GopDevPacket &p = v.pk[(size_t)v.todo[first + (size_t)j]];
+                if (p.rc) continue;
+                HIP_TRY(ctx, hipMemcpyAsync(v.coef_dev + p.frame * tb * 256, v.dense_host.data() + (size_t)j * tb * 256, tb * 512, hipMemcpyHostToDevice, ctx->stream));
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the dense staging is used again
+        }
+        if (!v.todo.empty()) d->stats[1] += clk.lap();
         combos.clear();
-        for (int k = 0; k < G; k++) {
-            key[(size_t)k] = -1;
-            const int j = at[(size_t)t * (size_t)G + (size_t)k];
-            if (j < 0) continue;
-            const GopDevPacket &p = v.pk[(size_t)j];
+        for (int k = 0; k < G; k++) key[(size_t)k] = -1;
+        for (size_t j = pa; j < pb; j++) {
+            GopDevPacket &p = v.pk[j];
+            if (!p.rc)
+                for (int i = 0; i < 3; i++)
+                    if (p.qidx[i] >= hot->n_qtables) p.rc = PFV_ERR_FORMAT;      // the reference panics (src/dec.rs:249-251)
+            if (p.rc && t == 0 && p.ev->type == 1) return 1;                    // not an independent run after all: the chains change
+        }
+        for (size_t j = pa; j < pb; j++) {
+            GopDevPacket &p = v.pk[j];
+            const int k = p.ev->slot;
+            p.ev->rc = p.rc;
             if (p.rc) {   // a failed packet changes nothing, but its slot's framebuffer has to follow the ping-pong
+                p.ev->msg = kBadPayload;
                 HIP_TRY(ctx, hipMemcpyAsync(hot->fb[hot->cur ^ 1] + (size_t)k * pad, hot->fb[hot->cur] + (size_t)k * pad, pad, hipMemcpyDeviceToDevice, ctx->stream));
                 continue;
             }
+            if (p.host_parse) v.packets_host++;
+            else v.packets_dev++;
             const uint32_t c = (uint32_t)p.ev->type | ((uint32_t)p.qidx[0] << 8) | ((uint32_t)p.qidx[1] << 16) | ((uint32_t)p.qidx[2] << 24);
             size_t ci = 0;
             while (ci < combos.size() && combos[ci] != c) ci++;
             if (ci == combos.size()) combos.push_back(c);
             key[(size_t)k] = (int)ci;
         }
-        const size_t f0 = (size_t)t * S;
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, v.window_done[(size_t)t], 0));
         rc = PFV_OK;
         gopd_step_target(d, t);
         gop_runs(key, [&](int first, int count, int ci) {
@@ -1176,15 +1215,14 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         hot->cur ^= 1;
         HIP_TRY(ctx, hipMemcpyAsync(v.flags_host.data() + f0, hot->flag_dev, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(hot->flag_dev, 0, (size_t)G * sizeof(int), ctx->stream));
+        d->stats[3] += clk.lap();
     }
-    d->stats[3] += clk.lap();
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     d->stats[4] += clk.lap();
-    for (int t = 0; t < steps; t++)
-        for (int k = 0; k < G; k++) {
-            const int j = at[(size_t)t * (size_t)G + (size_t)k];
-            if (j >= 0 && v.flags_host.data()[(size_t)t * S + (size_t)k] && !v.pk[(size_t)j].ev->rc) { v.pk[(size_t)j].ev->rc = PFV_ERR_BAD_MV; v.pk[(size_t)j].ev->msg = kBadMv; }
-        }
+    for (size_t j = 0; j < n; j++) {
+        GopDecEvent *e = v.pk[j].ev;
+        if (v.flags_host.data()[(size_t)e->t * S + (size_t)e->slot] && !e->rc) { e->rc = PFV_ERR_BAD_MV; e->msg = kBadMv; }
+    }
     d->cont_valid = true;
     d->cont_slot = G - 1;
     d->cont_buf = (cur0 + d->glen[(size_t)G - 1]) & 1;
@@ -1210,6 +1248,10 @@ PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d)
         if (s.done) (void)hipEventDestroy(s.done);
     if (d->frames_dev) (void)hipFree(d->frames_dev);
     if (d->frames_all_dev) (void)hipFree(d->frames_all_dev);
+    if (d->dev.stream) { (void)hipStreamSynchronize(d->dev.stream); (void)hipStreamDestroy(d->dev.stream); }
+    if (d->dev.up_stream) { (void)hipStreamSynchronize(d->dev.up_stream); (void)hipStreamDestroy(d->dev.up_stream); }
+    for (hipEvent_t ev : d->dev.window_done) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : d->dev.window_up) (void)hipEventDestroy(ev);
     for (void *p : {(void *)d->dev.bytes_dev, (void *)d->dev.pk_dev, (void *)d->dev.status_dev, (void *)d->dev.groups_dev, (void *)d->dev.sub_dev, (void *)d->dev.coded_dev,
                     (void *)d->dev.coef_dev, (void *)d->dev.mv_dev, (void *)d->dev.has_dev})
         if (p) (void)hipFree(p);
@@ -1278,20 +1320,27 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
         bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2;
         if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
         if (fits) {
-            hipError_t e2 = hipMalloc((void **)&v.coef_dev, F * tb * 512);
+            hipError_t e2 = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking);
+            if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&v.up_stream, hipStreamNonBlocking);
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.coef_dev, F * tb * 512);
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.mv_dev, F * tb * 2);
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.has_dev, F * tb);
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.coded_dev, F * tb * 4);
             // a batch's payloads are at most the whole stream: size the staging now, not inside the first batch
             const size_t bytes_guess = std::min(len + F * 32 + 64, F * (tb * 512 / 8 + 64));
-            const size_t sub_guess = bytes_guess * 8 / kEdSubBits + F;
+            if (const char *env = getenv("PFV_ED_SUB_BITS")) { const long sb = atol(env); if (sb >= 64 && sb <= (1 << 20)) v.sub_bits = (uint32_t)sb; }
+            if (const char *env = getenv("PFV_ED_ROUNDS")) {
+                int a = 0, b2 = 0;
+                if (sscanf(env, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= 64 && b2 >= 1 && b2 <= 1024) { v.launches = a; v.inner = b2; }
+            }
+            const size_t sub_guess = bytes_guess * 8 / v.sub_bits + F;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.bytes_dev, bytes_guess);
             if (e2 == hipSuccess) { v.bytes_cap = bytes_guess; e2 = hipMalloc((void **)&v.sub_dev, sub_guess * 4 * sizeof(uint32_t)); }
             if (e2 == hipSuccess) { v.sub_cap = sub_guess * 4; e2 = hipMalloc((void **)&v.groups_dev, (sub_guess / kEdThreads + F) * sizeof(uint2)); }
             if (e2 == hipSuccess) { v.groups_cap = sub_guess / kEdThreads + F; e2 = hipMalloc((void **)&v.pk_dev, F * sizeof(EdPacket)); }
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.status_dev, F * sizeof(uint32_t));
             if (e2 == hipSuccess) v.pk_cap = F;
-            const bool host_ok = e2 == hipSuccess && v.mv_host.resize(F * tb * 2) && v.has_host.resize(F * tb) && v.bytes_host.resize(bytes_guess) &&
+            const bool host_ok = e2 == hipSuccess && v.mv_host.resize(F * tb * 2) && v.has_host.resize(F * tb) && v.coded_host.resize(F * tb) && v.bytes_host.resize(bytes_guess) &&
                                  v.pk_host.resize(F) && v.status_host.resize(F) && v.groups_host.resize(sub_guess / kEdThreads + F) && v.flags_host.resize(F);
             if (host_ok) {
                 memset(v.mv_host.data(), 0, F * tb * 2);
@@ -1304,6 +1353,8 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
                                  (void **)&v.groups_dev, (void **)&v.pk_dev, (void **)&v.status_dev})
                     if (*p) { (void)hipFree(*p); *p = nullptr; }
                 v.bytes_cap = v.sub_cap = v.groups_cap = v.pk_cap = 0;
+                if (v.stream) { (void)hipStreamDestroy(v.stream); v.stream = nullptr; }
+                if (v.up_stream) { (void)hipStreamDestroy(v.up_stream); v.up_stream = nullptr; }
                 if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE)
                     rc = fail(ctx, PFV_ERR_NOMEM, "pfv_gop_decoder_create: the batch's coefficient arrays do not fit the device (PFV_ENTROPY_DECODE_DEVICE): use a smaller batch");
             }
@@ -1320,13 +1371,14 @@ PFV_API int pfv_gop_decoder_framerate(const pfv_gop_decoder *d) { return d ? d->
 PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d) { return d ? d->batches : 0; }
 /* host seconds so far: out[0] header scan, [1] waiting for packet parsers, [2] waiting for the device before a staging set can be reused,
  * [3] enqueueing (incl. the time since the previous measurement point), [4] waiting for a batch's last frames, [5] waiting for the device's
- * entropy stage; counts: [6] packets whose payload the device read, [7] packets of device-entropy batches the host parser read; returns
- * entries written */
+ * entropy stage; counts: [6] packets whose payload the device read, [7] packets of device-entropy batches the host parser read, of which
+ * [8] because the device's read had not settled and [9] because it found the payload irregular; returns entries written */
 PFV_API int pfv_gop_decoder_stats(const pfv_gop_decoder *d, double *out, int n)
 {
     if (!d || !out) return 0;
-    const int k = std::min(n, 8);
-    for (int i = 0; i < k; i++) out[i] = i < 6 ? d->stats[i] : i == 6 ? (double)d->dev.packets_dev : (double)d->dev.packets_host;
+    const int k = std::min(n, 10);
+    const double counts[4] = {(double)d->dev.packets_dev, (double)d->dev.packets_host, (double)d->dev.unsettled, (double)d->dev.irregular};
+    for (int i = 0; i < k; i++) out[i] = i < 6 ? d->stats[i] : counts[i - 6];
     return k;
 }
 

@@ -494,9 +494,12 @@ inline int parse_iframe_to(const uint8_t *payload, size_t n, int total_blocks, i
     return read_runs(r, tree, sink, 0, (size_t)total_blocks * 256);   // ONE run stream for the whole frame (dec.rs:261)
 }
 // the block headers of a p-frame payload (dec.rs:361-372): [has_mvec][has_coeff]([mx:7s][my:7s]); returns the number of coded macroblocks
-inline size_t parse_block_headers(BitSource &r, int total_blocks, int8_t *mv, uint8_t *has)
+inline size_t parse_block_headers(BitSource &r, int total_blocks, int8_t *mv, uint8_t *has, uint32_t *coded = nullptr /* [total_blocks]: the coded macroblocks, in order */)
 {
     size_t n_coded = 0;
+    uint32_t scratch = 0;
+    const size_t step = coded ? 1 : 0;
+    if (!coded) coded = &scratch;
     for (int b = 0; b < total_blocks; b++) {
         if (r.can_peek()) {   // the whole block header (2 or 16 bits) from one window
             const uint32_t w = (uint32_t)r.peek();
@@ -509,6 +512,7 @@ inline size_t parse_block_headers(BitSource &r, int total_blocks, int8_t *mv, ui
                 mv[2 * b] = mv[2 * b + 1] = 0;
                 r.skip(2);
             }
+            coded[n_coded * step] = (uint32_t)b;     // claimed only when the macroblock is coded
             n_coded += has[b];
             continue;
         }
@@ -519,6 +523,7 @@ inline size_t parse_block_headers(BitSource &r, int total_blocks, int8_t *mv, ui
             mv[2 * b] = (int8_t)r.get_signed(7);
             mv[2 * b + 1] = (int8_t)r.get_signed(7);
         }
+        coded[n_coded * step] = (uint32_t)b;
         n_coded += has[b];
     }
     return n_coded;

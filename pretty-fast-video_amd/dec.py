@@ -132,11 +132,11 @@ class GopDecoder(Decoder):
 
     def stats(self) -> dict:
         """host seconds so far, by what the object was waiting for (pfv_gop_decoder_stats)"""
-        a = (ctypes.c_double * 8)()
-        n = self.ctx._lib.pfv_gop_decoder_stats(self.handle, a, 8)
+        a = (ctypes.c_double * 10)()
+        n = self.ctx._lib.pfv_gop_decoder_stats(self.handle, a, 10)
         out = dict(zip(("scan_s", "parse_wait_s", "device_wait_s", "enqueue_s", "final_wait_s", "device_entropy_wait_s", "packets_read_on_device",
-                        "packets_left_to_host_parser"), list(a)[:n]))
-        for k in ("packets_read_on_device", "packets_left_to_host_parser"):
+                        "packets_left_to_host_parser", "left_unsettled", "left_irregular"), list(a)[:n]))
+        for k in ("packets_read_on_device", "packets_left_to_host_parser", "left_unsettled", "left_irregular"):
             if k in out:
                 out[k] = int(out[k])
         return out
@@ -159,8 +159,14 @@ class GopDecoder(Decoder):
             onvideo(arr(y, w * h), arr(u, (w // 2) * (h // 2)), arr(v, (w // 2) * (h // 2)))
         return _CB(cb)
 
+    def _cached_callback(self, onvideo):
+        # one ctypes trampoline per consumer, not per call (building one costs more than decoding a frame)
+        if getattr(self, "_cb_for", None) is not onvideo:
+            self._cb, self._cb_for = self._callback(onvideo), onvideo
+        return self._cb
+
     def advance_frame(self, onvideo) -> bool:
-        cb = self._callback(onvideo)
+        cb = self._cached_callback(onvideo)
         rc = self.ctx._lib.pfv_gop_decoder_advance_frame(self.handle, cb, None)
         if rc < 0:
             self.ctx.check(rc)

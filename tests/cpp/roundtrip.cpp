@@ -94,6 +94,22 @@ int main(int argc, char **argv)
             };
             while (gd.advance_frame(cmp)) {}
             if (!same || n_gop != n_out) { std::fprintf(stderr, "GopDecoder frames differ from Decoder's (%d of %d)\n", n_gop, n_out); return 1; }
+            // the same stream with the frames left in device memory: fetched from the addresses the callback gets
+            std::istringstream greader2(bytes, std::ios::binary);
+            pfv::GopDecoder gd2(greader2, ctx, 3, 2, 2);
+            gd2.set_output_device(true);
+            ref.clear();
+            ref.seekg(0);
+            std::vector<uint8_t> got(ny + 2 * nc);
+            int n_dev = 0;
+            auto cmp_dev = [&](const uint8_t *y, const uint8_t *, const uint8_t *, uint32_t, uint32_t) {
+                ref.read(want.data(), (std::streamsize)want.size());
+                same = same && ref && pfv_dev_download(ctx.handle(), got.data(), y, got.size()) == PFV_OK &&
+                       std::equal(got.begin(), got.end(), reinterpret_cast<const uint8_t *>(want.data()));
+                n_dev++;
+            };
+            while (gd2.advance_frame_device(cmp_dev)) {}
+            if (!same || n_dev != n_out) { std::fprintf(stderr, "GopDecoder frames left in device memory differ (%d of %d)\n", n_dev, n_out); return 1; }
             std::printf("gop: %d frames identical to the frame-by-frame objects\n", n_gop);
         }
         // the batch classes on the same clip: both streams carry the clip itself, so each writer must receive `bytes`

@@ -573,3 +573,52 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
                 assert got == want, (frac, shape, mode, [x[0] for x in got], [x == y for x, y in zip(got, want)])
     assert hit >= 1 or not require_hit, "no flip produced the failing i-frame this case is about"
     return hit
+
+
+def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIPPPP", min_device_share=1.0):
+    """The decoder's entropy stage on the device (k_entd_*, PFV_OPT_ENTROPY_DECODE) on VALID streams: (a) the synthetic pan content -- every
+    packet's payload is read on the device and every call matches the oracle's decoder; (b) the same stream with the payload cut into 64-bit
+    subsequences and one single round of reading (PFV_ED_SUB_BITS, PFV_ED_ROUNDS: read when the decoder is created): the starts have not
+    settled, packets go to the host parser by the 'unsettled' road -- same frames; (c) flat frames: every macroblock codes the same runs, the bit stream is periodic (a
+    wrong read phase can persist) -- same frames whichever side reads them; (d) frames of noise at a fine quantiser: long codes and 15-bit
+    values (the pair table's slow path)."""
+    import os
+    out = {}
+    rng = np.random.default_rng(w * 7 + h)
+    fb = w * h + 2 * (w // 2) * (h // 2)
+    st = pkg.SyntheticStream(w, h)
+    flat = [np.full(fb, 16 + 40 * (t // 3), np.uint8) for t in range(len(pattern))]
+    noise = [rng.integers(0, 256, fb, dtype=np.uint8) for _ in range(len(pattern))]
+    cases = (("pan", st.frame, quality, None), ("pan_sub64", st.frame, quality, "64"), ("flat", lambda t: flat[t], quality, None), ("noise", lambda t: noise[t], 0, None))
+    for name, src, q, sub_bits in cases:
+        data, _ = encode_pattern(pkg, ctx, oracle, w, h, q, pattern, lambda buf: pkg.Encoder(buf, w, h, 30, q, ctx), src, with_oracle=False)
+        want = _outcomes_oracle(oracle, data)
+        n_packets = sum(c != "D" for c in pattern)
+        assert [x[0] for x in want].count("frame") == n_packets
+        before = {k: os.environ.get(k) for k in ("PFV_ED_SUB_BITS", "PFV_ED_ROUNDS")}
+        if sub_bits:
+            os.environ.update({"PFV_ED_SUB_BITS": sub_bits, "PFV_ED_ROUNDS": "1,1"})
+        try:
+            dec = pkg.GopDecoder(data, ctx, max_gops=3, max_gop_frames=8, threads=2, entropy="device")
+        finally:
+            for k, val in before.items():
+                os.environ.pop(k, None)
+                if val is not None:
+                    os.environ[k] = val
+        got = []
+        while True:
+            fr = []
+            more = dec.advance_frame(lambda f: fr.append(f.packed().tobytes()))
+            got.append(("frame", fr[0]) if fr else ("none",))
+            if not more:
+                got.append(("eof",))
+                break
+        stats = dec.stats()
+        dec.close()
+        assert got == want, f"{name}: the decoder with the payloads read on the device delivers other frames than the oracle's"
+        assert stats["packets_read_on_device"] + stats["packets_left_to_host_parser"] == n_packets, (name, stats)
+        assert stats["left_unsettled"] + stats["left_irregular"] <= stats["packets_left_to_host_parser"]
+        out[name] = {k: stats[k] for k in ("packets_read_on_device", "packets_left_to_host_parser", "left_unsettled", "left_irregular")}
+    assert out["pan"]["packets_read_on_device"] >= min_device_share * n_packets, out
+    assert out["pan_sub64"]["left_unsettled"] >= 1, out
+    return out

@@ -229,6 +229,12 @@ def test_emu_gop_objects(pkg, emu_ctx, oracle):
     sc.check_gop_objects(pkg, emu_ctx, oracle, 50, 38, 3, "PPIPIPPDIP", shapes=((2, 15), (1, 2)))
 
 
+def test_emu_gop_decoder_device_entropy(pkg, emu_ctx, oracle):
+    """k_entd_*: payloads read by the self-synchronising device stage; unsettled / periodic / long-code content"""
+    out = sc.check_gop_device_entropy(pkg, emu_ctx, oracle, 96, 64, pattern="IPPPIPP")
+    assert out["noise"]["packets_read_on_device"] >= 1, out
+
+
 def test_emu_gop_encoder_flush_and_errors(pkg, emu_ctx, oracle):
     sc.check_gop_encoder_flush_and_errors(pkg, emu_ctx, oracle)
 

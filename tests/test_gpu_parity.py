@@ -506,6 +506,15 @@ def test_gop_decoder_corrupted_streams(pkg, gpu_ctx, oracle, geom):
     assert stats["trials"] == 60 and stats["errors"] > 10 and stats["frames_after_an_error"] > 0
 
 
+@pytest.mark.parametrize("geom", [(96, 64), (640, 360), (1920, 1080)])
+def test_gop_decoder_device_entropy(pkg, gpu_ctx, oracle, geom):
+    """k_entd_*: packet payloads read by the self-synchronising device stage (PFV_OPT_ENTROPY_DECODE): every packet of the synthetic
+    content on the device, unsettled / periodic / long-code content through whichever side, always the oracle's frames"""
+    out = sc.check_gop_device_entropy(pkg, gpu_ctx, oracle, *geom)
+    assert out["noise"]["packets_read_on_device"] >= 1, out
+    oracle.L.pfvo_pool_shutdown()
+
+
 def test_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle):
     assert sc.check_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle) >= 1
     sc.check_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle, 320, 240, 0, require_hit=False)   # another geometry; a flip may leave the packet parseable

@@ -1,0 +1,154 @@
+// e2e_native.cpp -- BASELINE config 4 end to end from a NATIVE host program (the reference's callers are Rust; the Python mirror pays
+// ~0.15 ms of interpreter per delivered frame, more than the device needs for the frame): synthetic frames in page-locked memory ->
+// pfv_gop_encoder -> .pfv bytes -> pfv_gop_decoder -> frames, through the C ABI only (include/pfv_hip.h).
+//   g++ -O2 -std=c++17 -I include tools/e2e_native.cpp -L pretty-fast-video_amd -lpfv_hip -Wl,-rpath,$PWD/pretty-fast-video_amd -o /tmp/e2e_native
+//   /tmp/e2e_native [width height frames gop quality enc_gops dec_gops parse_threads]
+// Prints one JSON object.  Measurement tool (bench.py runs it for extra.config4.end_to_end.native_host); not part of the library.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pfv_hip.h"
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define CHECK(expr)                                                                                                   \
+    do {                                                                                                              \
+        int rc__ = (expr);                                                                                            \
+        if (rc__ < 0) { fprintf(stderr, "%s -> %d: %s\n", #expr, rc__, pfv_last_error(ctx)); return 1; }             \
+    } while (0)
+
+struct Sink {
+    pfv_ctx *ctx;
+    int w, h, every;
+    bool device;
+    long n = 0;
+    uint64_t hash = 1469598103934665603ull, touched = 0;
+    std::vector<uint8_t> tmp;
+};
+static void fnv(uint64_t &h, const uint8_t *p, size_t n)
+{
+    for (size_t i = 0; i + 8 <= n; i += 8 * 61) {   // every 61st 8-byte word: a checksum of the sampled frames, not a benchmark of hashing
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        h = (h ^ v) * 1099511628211ull;
+    }
+}
+static void on_video(void *user, const uint8_t *y, const uint8_t *u, const uint8_t *v, int w, int h)
+{
+    Sink *s = (Sink *)user;
+    const size_t ny = (size_t)w * h, nc = (size_t)(w / 2) * (h / 2);
+    if (s->n % s->every == 0) {
+        if (s->device) {
+            s->tmp.resize(ny + 2 * nc);
+            pfv_dev_download(s->ctx, s->tmp.data(), y, ny + 2 * nc);    // the three planes are contiguous
+            fnv(s->hash, s->tmp.data(), (ny + 2 * nc) & ~(size_t)7);
+        } else {
+            fnv(s->hash, y, ny & ~(size_t)7);
+            fnv(s->hash, u, nc & ~(size_t)7);
+            fnv(s->hash, v, nc & ~(size_t)7);
+        }
+    } else if (!s->device) {
+        s->touched += y[0] + u[0] + v[0] + y[ny - 1];                   // the consumer looks at the frame it is handed
+    }
+    s->n++;
+}
+
+int main(int argc, char **argv)
+{
+    const int W = argc > 1 ? atoi(argv[1]) : 3840, H = argc > 2 ? atoi(argv[2]) : 2160, N = argc > 3 ? atoi(argv[3]) : 300;
+    const int GOP = argc > 4 ? atoi(argv[4]) : 15, Q = argc > 5 ? atoi(argv[5]) : 5, EG = argc > 6 ? atoi(argv[6]) : 10, DG = argc > 7 ? atoi(argv[7]) : 20;
+    const int threads = argc > 8 ? atoi(argv[8]) : 15;
+    pfv_ctx *ctx = nullptr;
+    if (pfv_ctx_create(0, &ctx) != PFV_OK) { fprintf(stderr, "no device: %s\n", pfv_last_error(nullptr)); return 1; }
+    const size_t fb = pfv_frame_bytes(W, H), ny = (size_t)W * H, nc = (size_t)(W / 2) * (H / 2);
+    const long n_mb = pfv_total_blocks(W, H);
+    // the producer's frames, page-locked
+    uint8_t *frames = nullptr;
+    void *dev = nullptr;
+    CHECK(pfv_host_alloc(ctx, fb * (size_t)N, (void **)&frames));
+    CHECK(pfv_dev_alloc(ctx, fb, &dev));
+    const uint64_t seed = 0x50465632ull;
+    for (int t = 0; t < N; t++) {
+        CHECK(pfv_synth_frames_dev(ctx, W, H, 1, &seed, t, (uint8_t *)dev));
+        CHECK(pfv_dev_download(ctx, frames + (size_t)t * fb, dev, fb));
+    }
+    // ---- encode: a timed pass whose writer only counts the segments, then one that keeps the bytes
+    std::vector<uint8_t> stream;
+    double t_enc = 0, enc_stats[5] = {0, 0, 0, 0, 0};
+    for (int pass = 0; pass < 2; pass++) {
+        pfv_gop_encoder *e = nullptr;
+        CHECK(pfv_gop_encoder_create(ctx, W, H, 30, Q, EG, GOP, 0, &e));
+        size_t total = 0;
+        auto drain = [&]() -> int {
+            const pfv_iovec *iov = nullptr;
+            size_t cnt = 0;
+            int rc = pfv_gop_encoder_drain_iov(e, &iov, &cnt);
+            if (rc) return rc;
+            for (size_t i = 0; i < cnt; i++) {
+                total += iov[i].len;
+                if (pass == 1) stream.insert(stream.end(), (const uint8_t *)iov[i].data, (const uint8_t *)iov[i].data + iov[i].len);
+            }
+            return 0;
+        };
+        const double t0 = now();
+        CHECK(drain());
+        for (int t = 0; t < N; t++) {
+            const uint8_t *f = frames + (size_t)t * fb;
+            CHECK(t % GOP == 0 ? pfv_gop_encoder_encode_iframe(e, f, f + ny, f + ny + nc) : pfv_gop_encoder_encode_pframe(e, f, f + ny, f + ny + nc));
+            CHECK(drain());
+        }
+        CHECK(pfv_gop_encoder_finish(e));
+        CHECK(drain());
+        if (pass == 0) { t_enc = now() - t0; pfv_gop_encoder_stats(e, enc_stats, 5); }
+        pfv_gop_encoder_destroy(e);
+        if (pass == 1 && total != stream.size()) return 2;
+    }
+    // ---- decode
+    struct Mode { const char *name; int entropy; bool device_out; };
+    const Mode modes[] = {{"payloads_read_on_host", PFV_ENTROPY_DECODE_HOST, false},
+                          {"payloads_read_on_device", PFV_ENTROPY_DECODE_DEVICE, false},
+                          {"payloads_read_on_device_frames_left_in_hbm", PFV_ENTROPY_DECODE_DEVICE, true}};
+    std::string out = "{";
+    char buf[1024];
+    snprintf(buf, sizeof buf,
+             "\"workload\": \"%dx%d, %d frames, GOP-%d, quality %d\", \"stream_bytes\": %zu, \"encode_value\": %.1f, \"encode_s\": %.5f, "
+             "\"encoder_host_seconds\": {\"upload_wait_s\": %.5f, \"enqueue_s\": %.5f, \"kernel_wait_s\": %.5f, \"payload_download_s\": %.5f, \"packet_assembly_s\": %.5f}, "
+             "\"gops_per_batch\": {\"encoder\": %d, \"decoder\": %d}, \"parse_threads\": %d, \"decode\": {",
+             W, H, N, GOP, Q, stream.size(), (double)N * n_mb / t_enc, t_enc, enc_stats[0], enc_stats[1], enc_stats[2], enc_stats[3], enc_stats[4], EG, DG, threads);
+    out += buf;
+    uint64_t want_hash = 0;
+    for (size_t m = 0; m < sizeof modes / sizeof modes[0]; m++) {
+        double best = 1e30, st[10] = {0};
+        for (int rep = 0; rep < 3; rep++) {   // the first run of a mode pays for code objects and first-touch of its buffers
+            CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTROPY_DECODE, modes[m].entropy));
+            pfv_gop_decoder *d = nullptr;
+            CHECK(pfv_gop_decoder_create(ctx, stream.data(), stream.size(), DG, GOP, threads, &d));
+            CHECK(pfv_gop_decoder_set_output_device(d, modes[m].device_out ? 1 : 0));
+            Sink s{ctx, W, H, 101, modes[m].device_out};
+            const double t0 = now();
+            int rc;
+            while ((rc = pfv_gop_decoder_advance_frame(d, on_video, &s)) == 1) {}
+            const double el = now() - t0;
+            CHECK(rc);
+            if (s.n != N) { fprintf(stderr, "%s: %ld frames of %d\n", modes[m].name, s.n, N); return 3; }
+            if (!want_hash) want_hash = s.hash;
+            if (s.hash != want_hash) { fprintf(stderr, "%s: decoded frames differ between modes\n", modes[m].name); return 4; }
+            if (el < best) { best = el; pfv_gop_decoder_stats(d, st, 10); }
+            pfv_gop_decoder_destroy(d);
+        }
+        snprintf(buf, sizeof buf,
+                 "%s\"%s\": {\"decode_value\": %.1f, \"decode_s\": %.5f, \"decoder_host_seconds\": {\"scan_s\": %.5f, \"parse_wait_s\": %.5f, \"device_wait_s\": %.5f, "
+                 "\"enqueue_s\": %.5f, \"final_wait_s\": %.5f, \"device_entropy_wait_s\": %.5f}, \"packets_read_on_device\": %.0f, \"packets_left_to_host_parser\": %.0f, \"left_unsettled\": %.0f, \"left_irregular\": %.0f}",
+                 m ? ", " : "", modes[m].name, (double)N * n_mb / best, best, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9]);
+        out += buf;
+    }
+    out += "}, \"frames_checked\": \"every 101st frame sampled (every 61st word) in every mode: identical\"}";
+    puts(out.c_str());
+    pfv_host_free(ctx, frames);
+    pfv_ctx_destroy(ctx);
+    return 0;
+}

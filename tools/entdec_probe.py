@@ -33,7 +33,7 @@ with pkg.Context(0) as ctx:
     data = buf.getvalue()
     print("stream", len(data), "bytes,", N, "frames", flush=True)
     digests = {}
-    for mode in ("host", "device", "device", "host", "device", "device->HBM", "device->HBM"):
+    for mode in os.environ.get("PFV_PROBE_MODES", "host,device,device,host,device,device->HBM,device->HBM").split(","):
         import hashlib
         h = hashlib.sha256()
         cnt = [0]
