@@ -15,7 +15,8 @@
 //                 anything left to do: then end[0] is true (the first lane starts at the true first run) and every end[i] follows
 //                 from a true start.  A packet that has not settled (periodic content can keep a wrong phase for ever) is left to
 //                 the host parser.
-//   k_entd_prefix exclusive prefix over the coefficients each subsequence covers: the coefficient index its first run starts at.
+//   k_entd_prefix exclusive prefix over the coefficients each workgroup's subsequences cover (summed by the verifying launch): with a
+//                 workgroup-local prefix in k_entd_emit, the coefficient index every lane's first run starts at.
 //   k_entd_emit   every lane reads its subsequence once more, from its true start and coefficient index, and stores the values
 //                 (zeros are what the buffer was cleared to).  It also decides whether the host parser would have accepted the
 //                 payload and produced the same array: anything it is not sure of -- a field that runs past the payload, a value
@@ -23,8 +24,8 @@
 //                 packet, and a marked packet is parsed by the host code instead (pfv_host.hip: read_runs), which alone
 //                 decides about errors.  The device path therefore never has to reproduce an error case.
 //
-// Code pairs are looked up in a 12-bit table (LDS, built by the workgroup from the packet's 16 codes); longer pairs and codes
-// go through the 16 codes one by one.  Included by pfv_capi.hip.
+// Codes are looked up in a 12-bit table (LDS, built by the workgroup from the packet's 16 codes), longer codes go through the 16 codes
+// one by one; the payload bits a workgroup reads are staged in LDS.  Included by pfv_capi.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,7 +37,7 @@ constexpr int kEdThreads = 256;
 #ifndef PFV_ED_SUB_BITS
 #define PFV_ED_SUB_BITS 256
 #endif
-constexpr uint32_t kEdSubBits = PFV_ED_SUB_BITS;     // payload bits per lane (default; EdPacket::sub_bits is what the kernels use)
+constexpr uint32_t kEdSubBits = PFV_ED_SUB_BITS;     // payload bits per lane (default; EdPacket::sub_bits, a multiple of 32 up to kEdMaxSubBits, is what the kernels use)
 constexpr uint32_t kEdIrregular = 1u;               // k_entd_emit: the host parser decides about this packet
 constexpr uint32_t kEdUnsettled = 2u;               // k_entd_sync: the subsequence starts had not settled
 constexpr uint32_t kEdNoStart = 0xffffffffu;
@@ -44,13 +45,14 @@ constexpr int kEdInner = 24;                        // k_entd_sync: rounds insid
 
 // one packet of the batch (made by the host from the packet's first 19 bytes and, p-frames, its block headers)
 struct EdPacket {
-    unsigned long long byte_off;   // payload position in the device byte buffer (multiple of 4; >= 8 readable bytes behind the payload)
+    unsigned long long byte_off;   // payload position in the device byte buffer (multiple of 4; >= 16 readable bytes behind the payload)
     uint32_t total_bits;           // payload size in bits
     uint32_t bit0;                 // first bit of the run streams (behind the table, the q indices and the block headers)
     uint32_t total_coefs;          // coefficients the run streams cover: macroblocks x 256 (i-frame), coded macroblocks x 256 (p-frame)
     uint32_t n_sub;                // subsequences = ceil((total_bits - bit0) / sub_bits); 0: nothing to read
     uint32_t sub_bits;             // payload bits per lane
     uint32_t sub_first;            // index of subsequence 0 in the per-subsequence arrays
+    uint32_t grp_first;            // index of its first workgroup in the per-workgroup array
     uint32_t pframe;               // 1: values go through the coded-macroblock list
     uint32_t total_blocks;         // macroblocks per frame
     unsigned long long frame_off;  // which frame of the has / coded-list / coefficient arrays this packet fills
@@ -62,89 +64,87 @@ struct EdBufs {
     const uint8_t *bytes;          // payloads
     const EdPacket *packets;
     const uint2 *groups;           // workgroups of k_entd_sync / k_entd_emit: (packet, which kEdThreads subsequences of it)
-    uint32_t *end, *used, *cnt, *vstart;   // per subsequence
+    uint32_t *end, *used, *cnt;    // per subsequence
+    uint32_t *wgsum;               // per workgroup of k_entd_sync: the coefficients its subsequences cover, then (k_entd_prefix) those before it
     const uint32_t *coded;         // [frame][total_blocks]: the k-th coded macroblock of the frame (p-frames; from the host's pass over the block headers)
     int16_t *coef;                 // [frame][total_blocks][256], cleared
     uint32_t *status;              // per packet: kEd* bits
     uint32_t packet0;              // k_entd_prefix: the launch's first packet (one workgroup per packet)
+    uint32_t group0;               // index of b.groups[0] among all workgroups of the batch (EdPacket::grp_first counts from there too)
 };
 
-// (used bits | num_zeroes << 4 | coeff_size << 8) of the code pair at the low end of v, 0 when the pair is longer than 12 bits
-__device__ __forceinline__ void ed_build_pairs(uint16_t *pair, uint16_t *cval, uint8_t *clen, const EdPacket &pk, int tid)
+// tab[v] = (code length | symbol << 4) of the tree code at the low end of the 12 bits v, 0 when that code is longer than 12 bits.
+// One lookup per code and no (num_zeroes, coeff_size) pair table: a pair table needs a second path for the pairs it cannot hold, and with
+// 64 lanes per wavefront nearly every step had SOME lane on that path -- the wavefront then pays for both.
+__device__ __forceinline__ void ed_build_table(uint8_t *tab, uint16_t *cval, uint8_t *clen, const EdPacket &pk, int tid)
 {
     if (tid < 16) { cval[tid] = pk.code_val[tid]; clen[tid] = pk.code_len[tid]; }
     __syncthreads();
     for (uint32_t v = (uint32_t)tid; v < 4096u; v += kEdThreads) {
-        uint32_t e = 0, la = 0, za = 0;
+        uint32_t e = 0;
         for (uint32_t s = 0; s < 16; s++) {
             const uint32_t l = clen[s];
-            if (l && l <= 11 && (v & ((1u << l) - 1u)) == cval[s]) { la = l; za = s; }
+            if (l && l <= 12 && (v & ((1u << l) - 1u)) == cval[s]) e = l | (s << 4);
         }
-        if (la) {
-            const uint32_t r = v >> la;
-            for (uint32_t s = 0; s < 16; s++) {
-                const uint32_t l = clen[s];
-                if (l && la + l <= 12 && (r & ((1u << l) - 1u)) == cval[s]) e = (la + l) | (za << 4) | (s << 8);
-            }
-        }
-        pair[v] = (uint16_t)e;
+        tab[v] = (uint8_t)e;
     }
     __syncthreads();
 }
 
+// The bits a workgroup reads -- its 256 subsequences and what the last run of a lane hangs over -- are staged in LDS once (coalesced);
+// a lane then takes 32-bit windows at any bit position with one two-word read and one v_alignbit, and keeps no bit-buffer state.
+constexpr uint32_t kEdMaxSubBits = 512;                                    // the staging area is sized for this
+constexpr uint32_t kEdStageWords = kEdThreads * kEdMaxSubBits / 32 + 8;    // + 256 bits: a run starts < 45 bits behind a lane's limit, a window reads 64 behind its position
 struct EdReader {
-    const uint32_t *words;
-    uint64_t buf;
-    uint32_t have, wi, pos;
-    __device__ __forceinline__ void open(const uint8_t *payload, uint32_t at)
+    const uint32_t *lw;    // LDS: the payload from bit `base` on
+    uint32_t base, pos;
+    __device__ __forceinline__ uint32_t window() const   // the 32 payload bits from pos on
     {
-        words = (const uint32_t *)payload;
-        pos = at;
-        wi = at >> 5;
-        buf = (uint64_t)words[wi++] >> (at & 31u);
-        have = 32u - (at & 31u);
+        const uint32_t rel = pos - base, k = rel >> 5;
+        return __builtin_amdgcn_alignbit(lw[k + 1], lw[k], rel & 31u);
     }
-    __device__ __forceinline__ void refill()   // >= 33 valid bits behind this
-    {
-        if (have <= 32u) {
-            buf |= (uint64_t)words[wi++] << have;
-            have += 32u;
-        }
-    }
-    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; have -= n; pos += n; }
 };
-
-// one tree code through the 16 codes (a tree of >= 2 symbols is full: exactly one code matches any bit pattern)
-__device__ __forceinline__ uint32_t ed_code(EdReader &r, const uint16_t *cval, const uint8_t *clen)
+// stage the workgroup's bits: words [first_bit / 32, ...) of the payload; beyond the payload's own words (+ 3: the slack the host left) zeros
+__device__ __forceinline__ uint32_t ed_stage(uint32_t *lw, const uint8_t *bytes, const EdPacket &pk, uint32_t wg, int tid)
 {
-    r.refill();
-    const uint32_t w = (uint32_t)r.buf;
-    uint32_t sym = 0, len = 1;
+    const unsigned long long first_bit = (unsigned long long)pk.bit0 + (unsigned long long)wg * kEdThreads * pk.sub_bits;
+    const uint32_t w0 = (uint32_t)(first_bit >> 5), n = kEdThreads * pk.sub_bits / 32u + 8u, have = (pk.total_bits + 31u) / 32u + 3u;
+    const uint32_t *src = (const uint32_t *)(bytes + pk.byte_off);
+    for (uint32_t k = (uint32_t)tid; k < n; k += kEdThreads) lw[k] = w0 + k < have ? src[w0 + k] : 0u;
+    return w0 * 32u;
+}
+
+// a tree code longer than 12 bits, through the 16 codes (a tree of >= 2 symbols is full: exactly one code matches any bit pattern)
+__device__ __forceinline__ uint32_t ed_long_code(uint32_t w, const uint16_t *cval, const uint8_t *clen)
+{
+    uint32_t e = 1u;
     for (uint32_t s = 0; s < 16; s++) {
         const uint32_t l = clen[s];
-        if (l && (w & ((1u << l) - 1u)) == cval[s]) { sym = s; len = l; }
+        if (l && (w & ((1u << l) - 1u)) == cval[s]) e = l | (s << 4);
     }
-    r.drop(len);
-    return sym;
+    return e;
 }
 
 // one run: num_zeroes, coeff_size, the value bits (sign-extended); the reader ends up on the next run
-__device__ __forceinline__ void ed_run(EdReader &r, const uint16_t *pair, const uint16_t *cval, const uint8_t *clen, uint32_t &zeros, uint32_t &nb, int &value)
+__device__ __forceinline__ void ed_run(EdReader &r, const uint8_t *tab, const uint16_t *cval, const uint8_t *clen, uint32_t &zeros, uint32_t &nb, int &value)
 {
-    r.refill();
-    const uint32_t e = pair[(uint32_t)r.buf & 4095u];
-    if (e) {
-        zeros = (e >> 4) & 15u;
-        nb = e >> 8;
-        r.drop(e & 15u);           // <= 12 of >= 33: the value's <= 15 bits are there
-    } else {
-        zeros = ed_code(r, cval, clen);
-        nb = ed_code(r, cval, clen);
-        r.refill();
-    }
-    const uint32_t raw = (uint32_t)r.buf & ((1u << nb) - 1u), sign = (1u << nb) >> 1;
+    uint32_t w = r.window();
+    uint32_t e = tab[w & 4095u];
+    if (__builtin_expect(e == 0, 0)) e = ed_long_code(w, cval, clen);
+    uint32_t used = e & 15u;
+    zeros = e >> 4;
+    if (__builtin_expect(used > 12, 0)) { r.pos += used; used = 0; w = r.window(); }       // keep >= 20 bits in the window
+    else w >>= used;
+    e = tab[w & 4095u];
+    if (__builtin_expect(e == 0, 0)) e = ed_long_code(w, cval, clen);
+    const uint32_t l2 = e & 15u;
+    nb = e >> 4;
+    used += l2;
+    w >>= l2;
+    if (__builtin_expect(used + nb > 32, 0)) { r.pos += used; used = 0; w = r.window(); }  // the value's bits are not all in this window
+    const uint32_t raw = w & ((1u << nb) - 1u), sign = (1u << nb) >> 1;
     value = (int)((raw ^ sign) - sign);
-    r.drop(nb);
+    r.pos += used + nb;
 }
 
 __device__ __forceinline__ uint32_t ed_limit(const EdPacket &pk, uint32_t i)
@@ -153,16 +153,34 @@ __device__ __forceinline__ uint32_t ed_limit(const EdPacket &pk, uint32_t i)
     return lim < pk.total_bits ? (uint32_t)lim : pk.total_bits;
 }
 
+// workgroup scan helper: exclusive prefix of one value per lane (kEdThreads lanes), total in *sum
+__device__ __forceinline__ uint32_t ed_block_exclusive(uint32_t v, uint32_t *scratch, int tid, uint32_t *sum)
+{
+    scratch[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < kEdThreads; d <<= 1) {
+        const uint32_t add = tid >= d ? scratch[tid - d] : 0u;
+        __syncthreads();
+        scratch[tid] += add;
+        __syncthreads();
+    }
+    const uint32_t incl = scratch[tid];
+    if (sum) *sum = scratch[kEdThreads - 1];
+    __syncthreads();
+    return incl - v;
+}
+
 // one workgroup per entry of b.groups.  Inside a launch the lanes of a workgroup pass their ends along through LDS and repeat until
 // none of them has a new start (a lane whose read had not met the true one by its end changes its neighbour's start, and so on: a few
 // short rounds instead of launches); between workgroups the ends travel through memory, launch to launch.  verify != 0: nothing is
 // read, a lane that still has work marks the packet.
 __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_round, int verify, int inner)
 {
-    __shared__ uint16_t pair[4096];
+    __shared__ uint8_t tab[4096];
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
     __shared__ uint32_t s_end[kEdThreads];
+    __shared__ uint32_t lw[kEdStageWords];
     __shared__ int any_work;
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
@@ -175,6 +193,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
     if (mine && !first_round && tid == 0 && i > 0) before = b.end[at - 1];       // the workgroup in front: as the last launch left it
     const uint32_t limit = mine ? ed_limit(pk, i) : 0;
     bool built = false, dirty = false;
+    uint32_t base = 0;
     for (int it = 0; it < inner; it++) {
         s_end[tid] = end;
         if (tid == 0) any_work = 0;
@@ -196,17 +215,17 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
             return;
         }
         if (!built) {
-            ed_build_pairs(pair, cval, clen, pk, tid);
+            base = ed_stage(lw, b.bytes, pk, grp.y, tid);
+            ed_build_table(tab, cval, clen, pk, tid);
             built = true;
         }
         if (work) {
             count = 0;
-            EdReader r;
-            r.open(b.bytes + pk.byte_off, start);
+            EdReader r{lw, base, start};
             while (r.pos < limit) {
                 uint32_t zeros, nb;
                 int value;
-                ed_run(r, pair, cval, clen, zeros, nb, value);
+                ed_run(r, tab, cval, clen, zeros, nb, value);
                 count += zeros + (nb ? 1u : 0u);
             }
             end = r.pos;
@@ -220,85 +239,87 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
         b.used[at] = used;
         b.cnt[at] = count;
     }
-}
-
-// workgroup scan helper: exclusive prefix of one value per lane (kEdThreads lanes), total in *sum
-__device__ __forceinline__ uint32_t ed_block_exclusive(uint32_t v, uint32_t *scratch, int tid, uint32_t *sum)
-{
-    scratch[tid] = v;
-    __syncthreads();
-    for (int d = 1; d < kEdThreads; d <<= 1) {
-        const uint32_t add = tid >= d ? scratch[tid - d] : 0u;
-        __syncthreads();
-        scratch[tid] += add;
-        __syncthreads();
+    if (verify) {   // settled (otherwise the launch has returned above): what the workgroup's subsequences cover, for k_entd_prefix
+        uint32_t sum = 0;
+        (void)ed_block_exclusive(mine ? count : 0u, s_end, tid, &sum);
+        if (tid == 0) b.wgsum[b.group0 + blockIdx.x] = sum;
     }
-    const uint32_t incl = scratch[tid];
-    if (sum) *sum = scratch[kEdThreads - 1];
-    __syncthreads();
-    return incl - v;
 }
 
-// one workgroup per packet: vstart[i] = coefficients covered by the subsequences before i
+// one workgroup per packet: wgsum[g] = coefficients covered by the packet's workgroups before g
 __global__ void __launch_bounds__(kEdThreads) k_entd_prefix(EdBufs b)
 {
     __shared__ uint32_t scratch[kEdThreads];
     const EdPacket &pk = b.packets[b.packet0 + blockIdx.x];
     const int tid = (int)threadIdx.x;
-    if (pk.n_sub == 0) return;
-    const uint32_t per = (pk.n_sub + kEdThreads - 1) / kEdThreads;
-    const uint32_t lo = min((uint32_t)tid * per, pk.n_sub), hi = min(lo + per, pk.n_sub);
-    const uint32_t *cnt = b.cnt + pk.sub_first;
-    uint32_t *vs = b.vstart + pk.sub_first;
-    uint32_t mine = 0;
-    for (uint32_t i = lo; i < hi; i++) mine += cnt[i];
-    uint32_t run = ed_block_exclusive(mine, scratch, tid, nullptr);
-    for (uint32_t i = lo; i < hi; i++) {
-        vs[i] = run;
-        run += cnt[i];
+    if (pk.n_sub == 0 || (b.status[b.packet0 + blockIdx.x] & kEdUnsettled)) return;
+    const uint32_t n = (pk.n_sub + kEdThreads - 1) / kEdThreads;
+    uint32_t *w = b.wgsum + pk.grp_first;
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < n; g0 += kEdThreads) {
+        const uint32_t g = g0 + (uint32_t)tid, v = g < n ? w[g] : 0u;
+        uint32_t sum = 0;
+        const uint32_t ex = ed_block_exclusive(v, scratch, tid, &sum);
+        if (g < n) w[g] = carry + ex;
+        carry += sum;
     }
 }
 
 // workgroups as k_entd_sync: the values of subsequence i into the coefficient array
 __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
 {
-    __shared__ uint16_t pair[4096];
+    __shared__ uint8_t tab[4096];
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
+    __shared__ uint32_t lw[kEdStageWords];
+    __shared__ uint32_t scratch[kEdThreads];
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
     if (b.status[grp.x] & kEdUnsettled) return;           // set by an earlier launch
     const int tid = (int)threadIdx.x;
     const uint32_t i = grp.y * kEdThreads + (uint32_t)tid;
-    ed_build_pairs(pair, cval, clen, pk, tid);
-    if (i >= pk.n_sub) return;
+    const uint32_t base = ed_stage(lw, b.bytes, pk, grp.y, tid);
+    ed_build_table(tab, cval, clen, pk, tid);
+    const bool mine = i < pk.n_sub;
     const size_t at = (size_t)pk.sub_first + i;
+    const uint32_t vlocal = ed_block_exclusive(mine ? b.cnt[at] : 0u, scratch, tid, nullptr);   // coefficients covered by the workgroup's lanes before this one
+    if (!mine) return;
     const uint32_t start = i == 0 ? pk.bit0 : b.end[at - 1];
     const uint32_t limit = ed_limit(pk, i), total = pk.total_coefs;
-    uint32_t V = b.vstart[at];
+    uint32_t V = b.wgsum[b.group0 + blockIdx.x] + vlocal;
     const uint32_t *coded = b.coded + pk.frame_off * pk.total_blocks;
     int16_t *coef = b.coef + pk.frame_off * pk.total_blocks * 256u;
     bool odd = false;
-    EdReader r;
-    r.open(b.bytes + pk.byte_off, start);
-    while (r.pos < limit && V < total) {
-        uint32_t zeros, nb;
-        int value;
-        ed_run(r, pair, cval, clen, zeros, nb, value);
-        if (r.pos > pk.total_bits) { odd = true; break; }            // the run's fields run past the payload
-        if (pk.pframe) {
+    EdReader r{lw, base, start};
+    if (pk.pframe) {
+        uint32_t cur = kEdNoStart;       // which coded macroblock mb_coef belongs to: the list is read when the macroblock changes, not per value
+        int16_t *mb_coef = coef;
+        while (r.pos < limit && V < total) {
+            uint32_t zeros, nb;
+            int value;
+            ed_run(r, tab, cval, clen, zeros, nb, value);
+            if (r.pos > pk.total_bits) { odd = true; break; }        // the run's fields run past the payload
             const uint32_t local = (V & 255u) + zeros;
+            V += zeros;
             if (local >= 256u) {                                       // the run closes the macroblock: exactly, and without a value
                 if (local != 256u || nb) { odd = true; break; }
-                V += zeros;
                 continue;
             }
-            V += zeros;
             if (nb) {
-                coef[(size_t)coded[V >> 8] * 256u + (V & 255u)] = (int16_t)value;
+                if ((V >> 8) != cur) {
+                    cur = V >> 8;
+                    mb_coef = coef + (size_t)coded[cur] * 256u;
+                }
+                mb_coef[local] = (int16_t)value;
                 V++;
             }
-        } else {
+        }
+    } else {
+        while (r.pos < limit && V < total) {
+            uint32_t zeros, nb;
+            int value;
+            ed_run(r, tab, cval, clen, zeros, nb, value);
+            if (r.pos > pk.total_bits) { odd = true; break; }
             V += zeros;
             if (V >= total) {                                          // the closing run of the frame
                 if (nb) odd = true;

@@ -945,7 +945,7 @@ static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
     const GopDecEvent *e = p.ev;
     EdPacket &k = v.pk_host.data()[j];
     const size_t tb = d->total_blocks;
-    k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = 0;
+    k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = k.grp_first = 0;
     k.sub_bits = v.sub_bits;
     k.pframe = e->type == 2 ? 1u : 0u;
     k.total_blocks = (uint32_t)tb;
@@ -1074,6 +1074,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         EdPacket &k = v.pk_host.data()[j];
         if (v.pk[j].rc || v.pk[j].host_parse) k.n_sub = 0;
         k.sub_first = (uint32_t)total_sub;
+        k.grp_first = (uint32_t)n_groups;
         total_sub += k.n_sub;
         n_groups += (k.n_sub + kEdThreads - 1) / kEdThreads;
     }
@@ -1124,7 +1125,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         HIP_TRY(ctx, hipStreamWaitEvent(v.stream, v.window_up[(size_t)t], 0));
         if (gb > ga) {
             EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, v.coef_dev, v.status_dev,
-                     (uint32_t)pa};
+                     (uint32_t)pa, (uint32_t)ga};
             const unsigned np = (unsigned)(pb - pa), ng = (unsigned)(gb - ga);
             for (int round = 0; round <= v.launches; round++)
                 hipLaunchKernelGGL(k_entd_sync, dim3(ng), dim3(kEdThreads), 0, v.stream, b, round == 0 ? 1 : 0, round == v.launches ? 1 : 0, round == v.launches ? 1 : v.inner);
@@ -1328,7 +1329,7 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.coded_dev, F * tb * 4);
             // a batch's payloads are at most the whole stream: size the staging now, not inside the first batch
             const size_t bytes_guess = std::min(len + F * 32 + 64, F * (tb * 512 / 8 + 64));
-            if (const char *env = getenv("PFV_ED_SUB_BITS")) { const long sb = atol(env); if (sb >= 64 && sb <= (1 << 20)) v.sub_bits = (uint32_t)sb; }
+            if (const char *env = getenv("PFV_ED_SUB_BITS")) { const long sb = atol(env); if (sb >= 32 && sb <= (long)kEdMaxSubBits && sb % 32 == 0) v.sub_bits = (uint32_t)sb; }
             if (const char *env = getenv("PFV_ED_ROUNDS")) {
                 int a = 0, b2 = 0;
                 if (sscanf(env, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= 64 && b2 >= 1 && b2 <= 1024) { v.launches = a; v.inner = b2; }

@@ -117,6 +117,12 @@ static inline unsigned hipemu_alignbyte(unsigned hi, unsigned lo, unsigned sh)
     return (unsigned)(v >> (8 * (sh & 3)));
 }
 #define __builtin_amdgcn_alignbyte hipemu_alignbyte
+static inline unsigned hipemu_alignbit(unsigned hi, unsigned lo, unsigned sh)
+{
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (unsigned)(v >> (sh & 31));
+}
+#define __builtin_amdgcn_alignbit hipemu_alignbit
 static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int, bool bound_ctrl)
 {
     int lane = (int)(threadIdx.x & 63), from = lane;

@@ -45,7 +45,9 @@ static void on_video(void *user, const uint8_t *y, const uint8_t *u, const uint8
         if (s->device) {
             s->tmp.resize(ny + 2 * nc);
             pfv_dev_download(s->ctx, s->tmp.data(), y, ny + 2 * nc);    // the three planes are contiguous
-            fnv(s->hash, s->tmp.data(), (ny + 2 * nc) & ~(size_t)7);
+            fnv(s->hash, s->tmp.data(), ny & ~(size_t)7);
+            fnv(s->hash, s->tmp.data() + ny, nc & ~(size_t)7);
+            fnv(s->hash, s->tmp.data() + ny + nc, nc & ~(size_t)7);
         } else {
             fnv(s->hash, y, ny & ~(size_t)7);
             fnv(s->hash, u, nc & ~(size_t)7);
