@@ -443,11 +443,15 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
  * Encoder: the planes may be reused when an encode call returns; frames are uploaded on a copy stream while the kernels of the
  * previous batch run.  A packet reaches pfv_gop_encoder_drain when its batch is complete (max_gops groups seen, flush, finish);
  * the byte stream is the one pfv_encoder writes.  After an error the stream is incomplete and every call returns PFV_ERR_STATE.
- * Decoder: one scan of the packet headers (type:u8, len:u32, src/dec.rs:179-180) cuts a batch, the packets of a frame step are
- * bit-parsed in parallel on n_threads workers + the caller (step t + 1 under the device work of step t), frames are delivered in
+ * Decoder: one scan of the packet headers (type:u8, len:u32, src/dec.rs:179-180) cuts a batch.  The packet payloads are read
+ * either on the DEVICE (PFV_OPT_ENTROPY_DECODE, the default when the batch's coefficient arrays fit: the host only reads each
+ * packet's table, q indices and block headers -- n_threads workers + the caller -- and the run streams are read by the k_entd_*
+ * kernels, step t + 1 on streams of their own while step t is decoded and its frames travel to the host) or by the host parser
+ * pool (the packets of a frame step bit-parsed in parallel, step t + 1 under the device work of step t).  Frames are delivered in
  * stream order, with the results (1 / 0 / error) the sequential loop gives call by call -- a packet that does not parse leaves
  * the framebuffer alone, and the frames behind a failed i-frame decode against the previous run's last frame, as they do there.
- * y / u / v of the callback stay valid until the call that starts the next batch. */
+ * y / u / v of the callback are one packed frame (u == y + w*h, v == u + (w/2)*(h/2)) and stay valid until the call that starts
+ * the next batch. */
 typedef struct pfv_gop_encoder pfv_gop_encoder;
 typedef struct pfv_gop_decoder pfv_gop_decoder;
 typedef struct pfv_iovec { const uint8_t *data; size_t len; } pfv_iovec;

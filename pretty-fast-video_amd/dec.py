@@ -154,9 +154,10 @@ class GopDecoder(Decoder):
             return _CB(cbd)
 
         def cb(_user, y, u, v, w, h):
-            def arr(p, n):
-                return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,))
-            onvideo(arr(y, w * h), arr(u, (w // 2) * (h // 2)), arr(v, (w // 2) * (h // 2)))
+            # the three planes of a frame lie back to back in the decoder's staging (include/pfv_hip.h): one view, three slices
+            ny, nc = w * h, (w // 2) * (h // 2)
+            a = np.frombuffer((ctypes.c_uint8 * (ny + 2 * nc)).from_address(y), dtype=np.uint8)
+            onvideo(a[:ny], a[ny:ny + nc], a[ny + nc:])
         return _CB(cb)
 
     def _cached_callback(self, onvideo):

@@ -575,7 +575,7 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
     return hit
 
 
-def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIPPPP", min_device_share=1.0):
+def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIPPPP", min_device_share=1.0, expect_unsettled=True):
     """The decoder's entropy stage on the device (k_entd_*, PFV_OPT_ENTROPY_DECODE) on VALID streams: (a) the synthetic pan content -- every
     packet's payload is read on the device and every call matches the oracle's decoder; (b) the same stream with the payload cut into 64-bit
     subsequences and one single round of reading (PFV_ED_SUB_BITS, PFV_ED_ROUNDS: read when the decoder is created): the starts have not
@@ -620,5 +620,5 @@ def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIP
         assert stats["left_unsettled"] + stats["left_irregular"] <= stats["packets_left_to_host_parser"]
         out[name] = {k: stats[k] for k in ("packets_read_on_device", "packets_left_to_host_parser", "left_unsettled", "left_irregular")}
     assert out["pan"]["packets_read_on_device"] >= min_device_share * n_packets, out
-    assert out["pan_sub64"]["left_unsettled"] >= 1, out
+    assert out["pan_sub64"]["left_unsettled"] >= 1 or not expect_unsettled, out
     return out

@@ -14,7 +14,6 @@ import __graft_entry__ as g   # noqa: E402
 
 g.build()
 pkg = g.load_package()
-__import__("sys").path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))
 __import__("libswitch").apply_from_env(pkg)      # PFV_HIP_LIB=<variant build> (A/B scripts); the product loader itself has no override
 import parity_cases as pc      # noqa: E402
 import stream_cases as sc      # noqa: E402
@@ -67,6 +66,14 @@ with pkg.Context(0) as ctx:
         if pattern.count("I") + pattern.count("P") >= 2:
             stats["gop_corrupted_trials"] = stats.get("gop_corrupted_trials", 0) + sc.check_gop_decoder_corrupted(
                 pkg, ctx, oracle, gdata, n_trials=12, seed=s, shapes=shapes)["trials"]
+        # round 4: the decoder's entropy stage on the device (k_entd_*): unsettled / periodic / long-code content on valid streams, and the
+        # counters of every GOP-batched decoder the checks above ran (half of them read their payloads on the device)
+        if it % 3 == 0:
+            ed = sc.check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=q, pattern="".join("IPPP"[int(k)] for k in r.integers(0, 4, int(r.integers(2, 9)))),
+                                             min_device_share=0.0, expect_unsettled=False)
+            stats["device_entropy_cases"] = stats.get("device_entropy_cases", 0) + 1
+            stats["device_entropy_noise_on_device"] = stats.get("device_entropy_noise_on_device", 0) + ed["noise"]["packets_read_on_device"]
+        stats.update({"gop_dec_" + k: v for k, v in sc.ENTROPY_COUNTS.items()})
         if w % 32 == 0:     # the fused retframe crop needs 16-byte rows in every plane
             pc.check_gop_graph(pkg, ctx, oracle, w, h, n_streams=S, n_frames=int(r.integers(2, 5)), quality=q)
             stats["graphs"] = stats.get("graphs", 0) + 1
