@@ -101,8 +101,14 @@ PFV_API const char *pfv_version(void);
  *       PFV_ENTROPY_DECODE_HOST            the host parser pool (n_threads of pfv_gop_decoder_create)
  *       PFV_ENTROPY_DECODE_DEVICE          the device, or PFV_ERR_NOMEM from pfv_gop_decoder_create
  *     Either way a payload the device stage is not sure about (damaged, degenerate code table, periodic content whose read does
- *     not settle) is parsed by the host code, which alone decides about errors. */
-typedef enum pfv_option { PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2, PFV_OPT_LANE_MAPPING = 3, PFV_OPT_ENTROPY_DECODE = 4 } pfv_option;
+ *     not settle) is parsed by the host code, which alone decides about errors.
+ *   PFV_OPT_ENTDEC_LANE_BITS / _LAUNCHES / _INNER_ROUNDS  shape of the device stage (measurements, and tests that force the "not settled"
+ *       road): payload bits per lane (a multiple of 32 in 32..512, default 256), k_entd_sync launches before the verifying one (1..64,
+ *       default 4), settling rounds inside a workgroup per launch (1..1024, default 24) */
+typedef enum pfv_option {
+    PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2, PFV_OPT_LANE_MAPPING = 3, PFV_OPT_ENTROPY_DECODE = 4,
+    PFV_OPT_ENTDEC_LANE_BITS = 5, PFV_OPT_ENTDEC_LAUNCHES = 6, PFV_OPT_ENTDEC_INNER_ROUNDS = 7
+} pfv_option;
 enum { PFV_ENTROPY_DECODE_AUTO = 0, PFV_ENTROPY_DECODE_HOST = 1, PFV_ENTROPY_DECODE_DEVICE = 2 };
 enum { PFV_LANES_AUTO = 0, PFV_LANES_PER_MB_8 = 1, PFV_LANES_PER_MB_16 = 2 };
 enum { PFV_ENC_TRANSFORM_AUTO = 0, PFV_ENC_TRANSFORM_INT = 1 };

@@ -32,6 +32,7 @@ PFV_OPT_TILE_COMPACTION = 2
 PFV_OPT_LANE_MAPPING = 3
 PFV_LANES_AUTO, PFV_LANES_PER_MB_8, PFV_LANES_PER_MB_16 = 0, 1, 2
 PFV_OPT_ENTROPY_DECODE = 4
+PFV_OPT_ENTDEC_LANE_BITS, PFV_OPT_ENTDEC_LAUNCHES, PFV_OPT_ENTDEC_INNER_ROUNDS = 5, 6, 7
 PFV_ENTROPY_DECODE_AUTO, PFV_ENTROPY_DECODE_HOST, PFV_ENTROPY_DECODE_DEVICE = 0, 1, 2
 PFV_ENC_TRANSFORM_AUTO, PFV_ENC_TRANSFORM_INT = 0, 1
 

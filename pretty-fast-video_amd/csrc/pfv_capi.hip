@@ -77,6 +77,7 @@ struct pfv_ctx {
     int opt_tile_compaction = 1;                      // pfv_ctx_set_option(PFV_OPT_TILE_COMPACTION)
     int opt_lane_mapping = PFV_LANES_AUTO;            // pfv_ctx_set_option(PFV_OPT_LANE_MAPPING)
     int opt_entropy_decode = PFV_ENTROPY_DECODE_AUTO; // pfv_ctx_set_option(PFV_OPT_ENTROPY_DECODE)
+    int opt_entdec_lane_bits = (int)kEdSubBits, opt_entdec_launches = 4, opt_entdec_inner = kEdInner;   // PFV_OPT_ENTDEC_*
     std::vector<struct pfv_comm *> comms;             // live communicators on this context (pfv_comm.hip): torn down with it
 };
 static void comm_teardown(struct pfv_comm *c);
@@ -134,6 +135,18 @@ PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value)
         if (value != PFV_ENTROPY_DECODE_AUTO && value != PFV_ENTROPY_DECODE_HOST && value != PFV_ENTROPY_DECODE_DEVICE) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENTROPY_DECODE: unknown value");
         ctx->opt_entropy_decode = value;
         return PFV_OK;
+    case PFV_OPT_ENTDEC_LANE_BITS:
+        if (value < 32 || value > (int)kEdMaxSubBits || value % 32) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENTDEC_LANE_BITS: a multiple of 32 in 32..512");
+        ctx->opt_entdec_lane_bits = value;
+        return PFV_OK;
+    case PFV_OPT_ENTDEC_LAUNCHES:
+        if (value < 1 || value > 64) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENTDEC_LAUNCHES: 1..64");
+        ctx->opt_entdec_launches = value;
+        return PFV_OK;
+    case PFV_OPT_ENTDEC_INNER_ROUNDS:
+        if (value < 1 || value > 1024) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENTDEC_INNER_ROUNDS: 1..1024");
+        ctx->opt_entdec_inner = value;
+        return PFV_OK;
     default:
         return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_set_option: unknown option");
     }
@@ -146,6 +159,9 @@ PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value)
     case PFV_OPT_TILE_COMPACTION: *value = ctx->opt_tile_compaction; return PFV_OK;
     case PFV_OPT_LANE_MAPPING: *value = ctx->opt_lane_mapping; return PFV_OK;
     case PFV_OPT_ENTROPY_DECODE: *value = ctx->opt_entropy_decode; return PFV_OK;
+    case PFV_OPT_ENTDEC_LANE_BITS: *value = ctx->opt_entdec_lane_bits; return PFV_OK;
+    case PFV_OPT_ENTDEC_LAUNCHES: *value = ctx->opt_entdec_launches; return PFV_OK;
+    case PFV_OPT_ENTDEC_INNER_ROUNDS: *value = ctx->opt_entdec_inner; return PFV_OK;
     default: return fail(ctx, PFV_ERR_BAD_ARG, "pfv_ctx_get_option: unknown option");
     }
 }

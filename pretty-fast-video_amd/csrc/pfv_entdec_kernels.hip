@@ -34,10 +34,7 @@
 namespace pfv {
 
 constexpr int kEdThreads = 256;
-#ifndef PFV_ED_SUB_BITS
-#define PFV_ED_SUB_BITS 256
-#endif
-constexpr uint32_t kEdSubBits = PFV_ED_SUB_BITS;     // payload bits per lane (default; EdPacket::sub_bits, a multiple of 32 up to kEdMaxSubBits, is what the kernels use)
+constexpr uint32_t kEdSubBits = 256;                // payload bits per lane (default; EdPacket::sub_bits, a multiple of 32 up to kEdMaxSubBits, is what the kernels use)
 constexpr uint32_t kEdIrregular = 1u;               // k_entd_emit: the host parser decides about this packet
 constexpr uint32_t kEdUnsettled = 2u;               // k_entd_sync: the subsequence starts had not settled
 constexpr uint32_t kEdNoStart = 0xffffffffu;
@@ -79,14 +76,16 @@ struct EdBufs {
 __device__ __forceinline__ void ed_build_table(uint8_t *tab, uint16_t *cval, uint8_t *clen, const EdPacket &pk, int tid)
 {
     if (tid < 16) { cval[tid] = pk.code_val[tid]; clen[tid] = pk.code_len[tid]; }
+    uint32_t *tab32 = (uint32_t *)tab;
+    for (int k = tid; k < 1024; k += kEdThreads) tab32[k] = 0u;           // what no code of <= 12 bits claims stays 0
     __syncthreads();
-    for (uint32_t v = (uint32_t)tid; v < 4096u; v += kEdThreads) {
-        uint32_t e = 0;
-        for (uint32_t s = 0; s < 16; s++) {
-            const uint32_t l = clen[s];
-            if (l && l <= 12 && (v & ((1u << l) - 1u)) == cval[s]) e = l | (s << 4);
-        }
-        tab[v] = (uint8_t)e;
+    // a code of l bits owns the 2^(12 - l) entries whose low l bits are the code: 4 096 stores in all (the codes are prefix-free), not
+    // 4 096 x 16 comparisons -- the table is rebuilt by every workgroup of every launch that reads, and was half of k_entd_emit's VALU work
+    for (uint32_t s = 0; s < 16; s++) {
+        const uint32_t l = clen[s];
+        if (l == 0 || l > 12) continue;
+        const uint32_t e = l | (s << 4), base = cval[s], n = 4096u >> l;
+        for (uint32_t k = (uint32_t)tid; k < n; k += kEdThreads) tab[base | (k << l)] = (uint8_t)e;
     }
     __syncthreads();
 }
@@ -176,7 +175,7 @@ __device__ __forceinline__ uint32_t ed_block_exclusive(uint32_t v, uint32_t *scr
 // read, a lane that still has work marks the packet.
 __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_round, int verify, int inner)
 {
-    __shared__ uint8_t tab[4096];
+    __shared__ __attribute__((aligned(16))) uint8_t tab[4096];
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
     __shared__ uint32_t s_end[kEdThreads];
@@ -268,7 +267,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_prefix(EdBufs b)
 // workgroups as k_entd_sync: the values of subsequence i into the coefficient array
 __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
 {
-    __shared__ uint8_t tab[4096];
+    __shared__ __attribute__((aligned(16))) uint8_t tab[4096];
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
     __shared__ uint32_t lw[kEdStageWords];

@@ -494,7 +494,6 @@ struct GopDevPacket {
 };
 
 constexpr int kGopDevDense = 8;
-constexpr int kGopDevRounds = 4;         // k_entd_sync launches before the verifying one
 
 // device-entropy path of the decoder (PFV_OPT_ENTROPY_DECODE): the whole batch's payloads are read by the k_entd_* kernels
 struct GopDecDev {
@@ -517,8 +516,8 @@ struct GopDecDev {
     PinnedBuf<EdPacket> pk_host;
     PinnedBuf<uint2> groups_host;
     PinnedBuf<uint32_t> coded_host;      // [frame][total_blocks]
-    uint32_t sub_bits = kEdSubBits;      // payload bits per lane (PFV_ED_SUB_BITS in the environment: experiments)
-    int launches = kGopDevRounds, inner = kEdInner;   // k_entd_sync launches before the verifying one, rounds inside each (PFV_ED_ROUNDS="launches,inner": tests)
+    uint32_t sub_bits = kEdSubBits;      // payload bits per lane (PFV_OPT_ENTDEC_LANE_BITS)
+    int launches = 4, inner = kEdInner;  // k_entd_sync launches before the verifying one, rounds inside each (PFV_OPT_ENTDEC_LAUNCHES / _INNER_ROUNDS)
     long unsettled = 0, irregular = 0;   // why packets were left to the host parser
     PinnedBuf<uint32_t> status_host;
     PinnedBuf<int> flags_host;           // [step][max_gops]
@@ -1329,11 +1328,7 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.coded_dev, F * tb * 4);
             // a batch's payloads are at most the whole stream: size the staging now, not inside the first batch
             const size_t bytes_guess = std::min(len + F * 32 + 64, F * (tb * 512 / 8 + 64));
-            if (const char *env = getenv("PFV_ED_SUB_BITS")) { const long sb = atol(env); if (sb >= 32 && sb <= (long)kEdMaxSubBits && sb % 32 == 0) v.sub_bits = (uint32_t)sb; }
-            if (const char *env = getenv("PFV_ED_ROUNDS")) {
-                int a = 0, b2 = 0;
-                if (sscanf(env, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= 64 && b2 >= 1 && b2 <= 1024) { v.launches = a; v.inner = b2; }
-            }
+            v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;   // PFV_OPT_ENTDEC_*
             const size_t sub_guess = bytes_guess * 8 / v.sub_bits + F;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.bytes_dev, bytes_guess);
             if (e2 == hipSuccess) { v.bytes_cap = bytes_guess; e2 = hipMalloc((void **)&v.sub_dev, sub_guess * 4 * sizeof(uint32_t)); }

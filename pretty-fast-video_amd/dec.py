@@ -94,19 +94,24 @@ class GopDecoder(Decoder):
 
     ENTROPY = {"auto": _lib.PFV_ENTROPY_DECODE_AUTO, "host": _lib.PFV_ENTROPY_DECODE_HOST, "device": _lib.PFV_ENTROPY_DECODE_DEVICE}
 
-    def __init__(self, reader, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15, threads: int = 8, raw: bool = False, entropy=None, output: str = "host"):
+    def __init__(self, reader, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15, threads: int = 8, raw: bool = False, entropy=None, output: str = "host", entropy_shape=None):
         data = reader.read() if hasattr(reader, "read") else bytes(reader)
         self._data = np.frombuffer(data, dtype=np.uint8).copy()     # must outlive the native decoder
         self.ctx, self.raw = ctx, raw
         h = ctypes.c_void_p()
-        before = ctx.get_option(_lib.PFV_OPT_ENTROPY_DECODE)
-        if entropy is not None:
-            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, self.ENTROPY[entropy])
+        # entropy_shape: (lane bits, launches, inner rounds) of the device stage, None entries = as the context has them (PFV_OPT_ENTDEC_*)
+        opts = [_lib.PFV_OPT_ENTROPY_DECODE, _lib.PFV_OPT_ENTDEC_LANE_BITS, _lib.PFV_OPT_ENTDEC_LAUNCHES, _lib.PFV_OPT_ENTDEC_INNER_ROUNDS]
+        before = [ctx.get_option(o) for o in opts]
+        wanted = [None if entropy is None else self.ENTROPY[entropy]] + list(entropy_shape or (None, None, None))
         try:
+            for o, v in zip(opts, wanted):
+                if v is not None:
+                    ctx.set_option(o, v)
             rc = ctx._lib.pfv_gop_decoder_create(ctx.handle, self._data.ctypes.data_as(ctypes.c_void_p), self._data.size, int(max_gops), int(max_gop_frames),
                                                  int(threads), ctypes.byref(h))
         finally:
-            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, before)
+            for o, v in zip(opts, before):
+                ctx.set_option(o, v)
         if rc != _lib.PFV_OK:
             msg = ctx._lib.pfv_last_error(ctx.handle)
             raise DecodeError(rc, msg.decode() if msg else "")

@@ -578,11 +578,10 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
 def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIPPPP", min_device_share=1.0, expect_unsettled=True):
     """The decoder's entropy stage on the device (k_entd_*, PFV_OPT_ENTROPY_DECODE) on VALID streams: (a) the synthetic pan content -- every
     packet's payload is read on the device and every call matches the oracle's decoder; (b) the same stream with the payload cut into 64-bit
-    subsequences and one single round of reading (PFV_ED_SUB_BITS, PFV_ED_ROUNDS: read when the decoder is created): the starts have not
+    subsequences and one single round of reading (PFV_OPT_ENTDEC_*): the starts have not
     settled, packets go to the host parser by the 'unsettled' road -- same frames; (c) flat frames: every macroblock codes the same runs, the bit stream is periodic (a
     wrong read phase can persist) -- same frames whichever side reads them; (d) frames of noise at a fine quantiser: long codes and 15-bit
     values (the pair table's slow path)."""
-    import os
     out = {}
     rng = np.random.default_rng(w * 7 + h)
     fb = w * h + 2 * (w // 2) * (h // 2)
@@ -595,16 +594,7 @@ def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIP
         want = _outcomes_oracle(oracle, data)
         n_packets = sum(c != "D" for c in pattern)
         assert [x[0] for x in want].count("frame") == n_packets
-        before = {k: os.environ.get(k) for k in ("PFV_ED_SUB_BITS", "PFV_ED_ROUNDS")}
-        if sub_bits:
-            os.environ.update({"PFV_ED_SUB_BITS": sub_bits, "PFV_ED_ROUNDS": "1,1"})
-        try:
-            dec = pkg.GopDecoder(data, ctx, max_gops=3, max_gop_frames=8, threads=2, entropy="device")
-        finally:
-            for k, val in before.items():
-                os.environ.pop(k, None)
-                if val is not None:
-                    os.environ[k] = val
+        dec = pkg.GopDecoder(data, ctx, max_gops=3, max_gop_frames=8, threads=2, entropy="device", entropy_shape=(64, 1, 1) if sub_bits else None)
         got = []
         while True:
             fr = []

@@ -2,7 +2,7 @@
 // ~0.15 ms of interpreter per delivered frame, more than the device needs for the frame): synthetic frames in page-locked memory ->
 // pfv_gop_encoder -> .pfv bytes -> pfv_gop_decoder -> frames, through the C ABI only (include/pfv_hip.h).
 //   g++ -O2 -std=c++17 -I include tools/e2e_native.cpp -L pretty-fast-video_amd -lpfv_hip -Wl,-rpath,$PWD/pretty-fast-video_amd -o /tmp/e2e_native
-//   /tmp/e2e_native [width height frames gop quality enc_gops dec_gops parse_threads]
+//   /tmp/e2e_native [width height frames gop quality enc_gops dec_gops parse_threads [lane_bits]]
 // Prints one JSON object.  Measurement tool (bench.py runs it for extra.config4.end_to_end.native_host); not part of the library.
 #include <chrono>
 #include <cstdint>
@@ -63,9 +63,10 @@ int main(int argc, char **argv)
 {
     const int W = argc > 1 ? atoi(argv[1]) : 3840, H = argc > 2 ? atoi(argv[2]) : 2160, N = argc > 3 ? atoi(argv[3]) : 300;
     const int GOP = argc > 4 ? atoi(argv[4]) : 15, Q = argc > 5 ? atoi(argv[5]) : 5, EG = argc > 6 ? atoi(argv[6]) : 10, DG = argc > 7 ? atoi(argv[7]) : 20;
-    const int threads = argc > 8 ? atoi(argv[8]) : 15;
+    const int threads = argc > 8 ? atoi(argv[8]) : 15, lane_bits = argc > 9 ? atoi(argv[9]) : 0;
     pfv_ctx *ctx = nullptr;
     if (pfv_ctx_create(0, &ctx) != PFV_OK) { fprintf(stderr, "no device: %s\n", pfv_last_error(nullptr)); return 1; }
+    if (lane_bits) CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTDEC_LANE_BITS, lane_bits));
     const size_t fb = pfv_frame_bytes(W, H), ny = (size_t)W * H, nc = (size_t)(W / 2) * (H / 2);
     const long n_mb = pfv_total_blocks(W, H);
     // the producer's frames, page-locked
