@@ -527,6 +527,11 @@ PFV_API void pfv_decoder_destroy(pfv_decoder *d);
  * one being decoded, on worker threads; 0 = parse inline.  Default min(4, hardware threads - 1).  Frames, their order
  * and the error returned by each advance call are those of the sequential loop (src/dec.rs:169-224). */
 PFV_API int pfv_decoder_set_lookahead(pfv_decoder *d, int n_threads);
+/* The run streams of a packet are read on the DEVICE (k_entd_*, see PFV_OPT_ENTROPY_DECODE: taken from the context when the decoder is
+ * created) for payloads of 64 KiB and more -- every payload under PFV_ENTROPY_DECODE_DEVICE, none under _HOST; the look-ahead threads
+ * then only read tables and block headers.  counts_out[0]: packets the device read so far, [1]: packets its stage was not certain
+ * about and left to the host parser.  Same frames and results either way. */
+PFV_API void pfv_decoder_entropy_counts(const pfv_decoder *d, long counts_out[2]);
 PFV_API int pfv_decoder_width(const pfv_decoder *d);
 PFV_API int pfv_decoder_height(const pfv_decoder *d);
 PFV_API int pfv_decoder_framerate(const pfv_decoder *d);

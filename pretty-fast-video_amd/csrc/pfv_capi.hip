@@ -1806,6 +1806,62 @@ struct pfv_encoder {
 // One step of Decoder::advance_frame's packet loop (src/dec.rs:169-224), found by the header scanner.  FRAME events are
 // parsed (bits -> coefficients / block headers, dec.rs:226-296, 328-417) ahead of their turn by worker threads: packets
 // are independent bit streams, only the device decode behind them is sequential.
+// ------------------------------------------------------------------ the decoders' entropy stage on the device: host half
+// What only a serial read of a packet can give the k_entd_* kernels (pfv_entdec_kernels.hip): the table (-> the tree's codes), the q
+// indices, a p-frame's block headers (-> motion vectors, has_coeff, the list of coded macroblocks, the first bit of the run streams).
+// The payload is copied to `bytes_dst` (page-locked staging, >= plen + 16 bytes).  The caller has set k.byte_off / k.frame_off.
+struct EntdPrep {
+    int rc = 0;                  // a status the host parser would have returned before it read any run (header, q index, truncated block headers)
+    bool host_parse = false;     // the host parser has to read this packet (degenerate code table, 512 MiB or more, no bits behind the headers)
+    uint8_t qidx[3] = {0, 0, 0};
+};
+static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, size_t tb, int n_qtables, uint32_t sub_bits, int8_t *mv, uint8_t *has,
+                             uint32_t *coded, EdPacket &k, uint8_t *bytes_dst)
+{
+    EntdPrep p;
+    k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = k.grp_first = 0;
+    k.sub_bits = sub_bits;
+    k.pframe = type == 2 ? 1u : 0u;
+    k.total_blocks = (uint32_t)tb;
+    memset(k.code_val, 0, sizeof k.code_val);
+    memset(k.code_len, 0, sizeof k.code_len);
+    BitSource r(payload, plen);
+    PacketHead h;
+    p.rc = parse_head(r, h, n_qtables);
+    if (p.rc) return p;
+    memcpy(p.qidx, h.qidx, 3);
+    size_t n_coded = tb;
+    if (type == 2) {
+        n_coded = parse_block_headers(r, (int)tb, mv, has, coded);
+        if (!r.ok()) { p.rc = PFV_ERR_IO; return p; }
+    }
+    if (n_coded == 0) return p;                                // no run stream: nothing is read behind the headers (src/dec.rs:378-380)
+    int n_syms = 0;
+    for (uint8_t t : h.table) n_syms += t != 0;
+    const uint64_t bits = (uint64_t)plen * 8, bit0 = r.position();
+    if (n_syms < 2 || bits >= (1ull << 32) || bit0 >= bits) { p.host_parse = true; return p; }   // zero-length codes / 32-bit positions / no bits left
+    HuffmanTree tree(h.table);
+    for (int s = 0; s < 16; s++) {
+        k.code_val[s] = (uint16_t)tree.code((uint8_t)s).val;
+        k.code_len[s] = (uint8_t)tree.code((uint8_t)s).len;
+    }
+    k.total_bits = (uint32_t)bits;
+    k.bit0 = (uint32_t)bit0;
+    k.total_coefs = (uint32_t)(n_coded * 256);
+    k.n_sub = (uint32_t)((bits - bit0 + sub_bits - 1) / sub_bits);
+    memcpy(bytes_dst, payload, plen);
+    memset(bytes_dst + plen, 0, 16);
+    return p;
+}
+// the launches of one window: np packets from b.packet0 on, ng workgroups from b.group0 on (b.groups already points at the first of them)
+static void entd_launch(hipStream_t stream, const EdBufs &b, unsigned np, unsigned ng, int launches, int inner)
+{
+    for (int round = 0; round <= launches; round++)
+        hipLaunchKernelGGL(k_entd_sync, dim3(ng), dim3(kEdThreads), 0, stream, b, round == 0 ? 1 : 0, round == launches ? 1 : 0, round == launches ? 1 : inner);
+    hipLaunchKernelGGL(k_entd_prefix, dim3(np), dim3(kEdThreads), 0, stream, b);
+    hipLaunchKernelGGL(k_entd_emit, dim3(ng), dim3(kEdThreads), 0, stream, b);
+}
+
 struct DecEvent {
     enum Kind { FRAME, DROP, END, ERROR } kind = END;
     enum State { FREE, QUEUED, RUNNING, DONE } state = FREE;
@@ -1823,9 +1879,31 @@ struct DecEvent {
     PinnedBuf<int16_t> val;
     size_t n_sparse = 0;
     bool dense = false;
+    // device-entropy form (PFV_OPT_ENTROPY_DECODE): what entd_prepare left for the k_entd_* kernels instead of a parsed packet
+    bool dev_form = false, host_parse = false;
+    PinnedBuf<uint8_t> bytes;            // the payload (+ 16)
+    PinnedBuf<uint32_t> coded;           // p-frames: the coded macroblocks, in order
+    PinnedBuf<EdPacket> pk;              // 1
+    PinnedBuf<uint2> groups;             // workgroups of the packet
 };
 
+// the frame-by-frame decoder's device-entropy state: one packet per call through the k_entd_* kernels
+struct DecEntd {
+    bool on = false, force = false;      // force: every packet (PFV_ENTROPY_DECODE_DEVICE); otherwise payloads of kDecEntdMinBytes and more
+    uint32_t sub_bits = kEdSubBits;
+    int launches = 4, inner = kEdInner;
+    uint8_t *bytes_dev = nullptr; size_t bytes_cap = 0;
+    EdPacket *pk_dev = nullptr;
+    uint32_t *status_dev = nullptr, *coded_dev = nullptr;
+    uint2 *groups_dev = nullptr; size_t groups_cap = 0;
+    uint32_t *sub_dev = nullptr; size_t sub_cap = 0;
+    PinnedBuf<uint32_t> status_host;
+    long packets_dev = 0, packets_host = 0;
+};
+constexpr uint32_t kDecEntdMinBytes = 64 * 1024;   // below this the launches cost more than the host parser needs for the packet
+
 struct pfv_decoder {
+    DecEntd entd;
     pfv_ctx *ctx = nullptr;
     pfv_dec_session *hot = nullptr;
     const uint8_t *data = nullptr;
@@ -2575,6 +2653,20 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
     }
     memset(d->retframe.data(), 0, (size_t)w * h);                              // VideoFrame::new (frame.rs:12-26): Y 0, U/V 128
     memset(d->retframe.data() + (size_t)w * h, 128, d->retframe.size() - (size_t)w * h);
+    if (ctx->opt_entropy_decode != PFV_ENTROPY_DECODE_HOST && d->total_blocks > 0) {   // the run streams of big packets are read on the device
+        DecEntd &v = d->entd;
+        v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
+        v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
+        hipError_t he = hipMalloc((void **)&v.pk_dev, sizeof(EdPacket));
+        if (he == hipSuccess) he = hipMalloc((void **)&v.status_dev, sizeof(uint32_t));
+        if (he == hipSuccess) he = hipMalloc((void **)&v.coded_dev, (size_t)d->total_blocks * sizeof(uint32_t));
+        v.on = he == hipSuccess && v.status_host.resize(1);
+        if (!v.on) (void)hipGetLastError();
+        if (!v.on && v.force) {
+            pfv_decoder_destroy(d);
+            return fail(ctx, PFV_ERR_NOMEM, "pfv_decoder_create: device entropy stage (PFV_ENTROPY_DECODE_DEVICE)");
+        }
+    }
     const unsigned hw = std::thread::hardware_concurrency();
     if ((rc = pfv_decoder_set_lookahead(d, hw > 1 ? (int)std::min(4u, hw - 1) : 0))) {
         pfv_decoder_destroy(d);
@@ -2591,6 +2683,33 @@ static void dec_parse(pfv_decoder *d, DecEvent *e)   // any thread; touches only
     const size_t tb = (size_t)d->total_blocks, cap = tb * 256 / 4;   // denser than 1 in 4: not worth a list
     e->dense = false;
     e->n_sparse = 0;
+    e->dev_form = e->host_parse = false;
+    if (d->entd.on && (d->entd.force || e->plen >= kDecEntdMinBytes)) {   // the device reads the run streams: only the headers here
+        const uint32_t max_sub = (uint32_t)(((uint64_t)e->plen * 8 + d->entd.sub_bits - 1) / d->entd.sub_bits);
+        if (!e->bytes.resize((size_t)e->plen + 32) || !e->pk.resize(1) || !e->groups.resize((size_t)max_sub / kEdThreads + 1) ||
+            (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb) || !e->coded.resize(tb)))) {
+            e->rc = PFV_ERR_NOMEM;
+            return;
+        }
+        EdPacket &k = *e->pk.data();
+        k.byte_off = 0; k.frame_off = 0;
+        const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, d->entd.sub_bits, e->mv.data(), e->has.data(), e->coded.data(), k, e->bytes.data());
+        e->rc = r.rc;
+        memcpy(e->qidx, r.qidx, 3);
+        e->dev_form = true;
+        e->host_parse = r.host_parse;
+        if (r.rc || r.host_parse) k.n_sub = 0;
+        const uint32_t ng = (k.n_sub + kEdThreads - 1) / kEdThreads;
+        for (uint32_t g = 0; g < ng; g++) e->groups.data()[g] = make_uint2(0u, g);
+        if (!e->rc && e->host_parse) {   // the host parser decides about this one, here, on this thread
+            if (!e->coef.resize(tb * 256)) { e->rc = PFV_ERR_NOMEM; return; }
+            e->rc = e->type == 1 ? parse_iframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->coef.data(), e->qidx)
+                                 : parse_pframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
+            e->dev_form = false;
+            e->dense = true;
+        }
+        return;
+    }
     if (!e->idx.resize(cap) || !e->val.resize(cap) || (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb)))) {
         e->rc = PFV_ERR_NOMEM;
         return;
@@ -2724,8 +2843,18 @@ PFV_API void pfv_decoder_destroy(pfv_decoder *d)
 {
     if (!d) return;
     dec_stop_workers(d);
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    for (void *p : {(void *)d->entd.bytes_dev, (void *)d->entd.pk_dev, (void *)d->entd.status_dev, (void *)d->entd.coded_dev, (void *)d->entd.groups_dev, (void *)d->entd.sub_dev})
+        if (p) (void)hipFree(p);
     pfv_dec_session_destroy(d->hot);
     delete d;
+}
+PFV_API void pfv_decoder_entropy_counts(const pfv_decoder *d, long counts_out[2])
+{
+    if (!d || !counts_out) return;
+    counts_out[0] = d->entd.packets_dev;
+    counts_out[1] = d->entd.packets_host;
 }
 PFV_API int pfv_decoder_width(const pfv_decoder *d) { return d ? d->width : 0; }          // dec.rs:136-138
 PFV_API int pfv_decoder_height(const pfv_decoder *d) { return d ? d->height : 0; }        // dec.rs:140-142
@@ -2740,6 +2869,65 @@ PFV_API int pfv_decoder_reset(pfv_decoder *d)
     return PFV_OK;
 }
 
+}  // extern "C"
+
+// One packet through the device's entropy stage, then the decode launch: coefficients in the session's staging array.
+static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
+{
+    pfv_ctx *ctx = d->ctx;
+    pfv_dec_session *hot = d->hot;
+    DecEntd &v = d->entd;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = dec_staging(hot);
+    if (rc) return rc;
+    const size_t tb = (size_t)d->total_blocks;
+    const EdPacket &k = *e->pk.data();
+    const uint32_t ng = (k.n_sub + kEdThreads - 1) / kEdThreads;
+    auto room = [&](auto **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return PFV_OK;
+        if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+        need += need / 2;
+        HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(**p)));
+        *cap = need;
+        return PFV_OK;
+    };
+    if ((rc = room(&v.bytes_dev, &v.bytes_cap, (size_t)e->plen + 64))) return rc;
+    if ((rc = room(&v.groups_dev, &v.groups_cap, (size_t)ng + 1))) return rc;
+    if ((rc = room(&v.sub_dev, &v.sub_cap, ((size_t)k.n_sub + 1) * 4))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev, e->bytes.data(), (size_t)e->plen + 16, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, e->pk.data(), sizeof(EdPacket), hipMemcpyHostToDevice, ctx->stream));
+    if (ng) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, e->groups.data(), ng * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    if (e->type == 2) {
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_mv, e->mv.data(), tb * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_has, e->has.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev, e->coded.data(), tb * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(hot->st_coef, 0, tb * 512, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, sizeof(uint32_t), ctx->stream));
+    if (ng) {
+        const size_t ts = v.sub_cap / 4;
+        EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, hot->st_coef, v.status_dev, 0u, 0u};
+        entd_launch(ctx->stream, b, 1u, ng, v.launches, v.inner);
+        if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data(), v.status_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*v.status_host.data()) {   // the device stage is not certain about this payload: the host parser reads it and decides
+        v.packets_host++;
+        if (!e->coef.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging for a parsed packet");
+        const int prc = e->type == 1 ? parse_iframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->coef.data(), e->qidx)
+                                     : parse_pframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
+        if (prc) return fail(ctx, prc, "malformed packet payload");
+        HIP_TRY(ctx, hipMemcpyAsync(hot->st_coef, e->coef.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        v.packets_dev++;
+    }
+    rc = e->type == 1 ? pfv_dec_iframe_dev(hot, hot->st_coef, e->qidx) : pfv_dec_pframe_dev(hot, hot->st_mv, hot->st_has, hot->st_coef, e->qidx);
+    if (rc) return rc;
+    return pfv_dec_check(hot);
+}
+
+extern "C" {
 // Decoder::advance_frame (src/dec.rs:169-224).  Returns 1 = Ok(true), 0 = Ok(false) (EOF), negative = error.
 // onvideo(user, y, u, v, width, height) is called for every decoded frame (not for drop frames).
 PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void *user)
@@ -2778,7 +2966,9 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
         lk.unlock();   // workers keep parsing the packets behind this one while the device decodes it
         rc = e->rc;
         if (rc) rc = fail(d->ctx, rc, rc == PFV_ERR_NOMEM ? "pinned staging for a parsed packet" : "malformed packet payload");
-        if (!rc && e->dense)
+        if (!rc && e->dev_form)
+            rc = dec_consume_entd(d, e);
+        else if (!rc && e->dense)
             rc = e->type == 1 ? pfv_dec_iframe(d->hot, e->coef.data(), e->qidx)
                               : pfv_dec_pframe(d->hot, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
         else if (!rc)

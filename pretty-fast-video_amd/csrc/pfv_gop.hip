@@ -944,39 +944,11 @@ static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
     const GopDecEvent *e = p.ev;
     EdPacket &k = v.pk_host.data()[j];
     const size_t tb = d->total_blocks;
-    k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = k.grp_first = 0;
-    k.sub_bits = v.sub_bits;
-    k.pframe = e->type == 2 ? 1u : 0u;
-    k.total_blocks = (uint32_t)tb;
-    memset(k.code_val, 0, sizeof k.code_val);
-    memset(k.code_len, 0, sizeof k.code_len);
-    BitSource r(e->payload, e->plen);
-    PacketHead h;
-    p.rc = parse_head(r, h, d->n_qtables);
-    if (p.rc) return;
-    memcpy(p.qidx, h.qidx, 3);
-    size_t n_coded = tb;
-    if (e->type == 2) {
-        n_coded = parse_block_headers(r, (int)tb, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, v.coded_host.data() + p.frame * tb);
-        if (!r.ok()) { p.rc = PFV_ERR_IO; return; }
-    }
-    if (n_coded == 0) return;                                  // no run stream: nothing is read behind the headers (src/dec.rs:378-380)
-    int n_syms = 0;
-    for (uint8_t t : h.table) n_syms += t != 0;
-    const uint64_t bits = (uint64_t)e->plen * 8, bit0 = r.position();
-    if (n_syms < 2 || bits >= (1ull << 32) || bit0 >= bits) { p.host_parse = true; return; }   // zero-length codes / 32-bit positions / no bits left
-    HuffmanTree tree(h.table);
-    for (int s = 0; s < 16; s++) {
-        k.code_val[s] = (uint16_t)tree.code((uint8_t)s).val;
-        k.code_len[s] = (uint8_t)tree.code((uint8_t)s).len;
-    }
-    k.total_bits = (uint32_t)bits;
-    k.bit0 = (uint32_t)bit0;
-    k.total_coefs = (uint32_t)(n_coded * 256);
-    k.n_sub = (uint32_t)((bits - bit0 + v.sub_bits - 1) / v.sub_bits);
-    uint8_t *dst = v.bytes_host.data() + k.byte_off;
-    memcpy(dst, e->payload, e->plen);
-    memset(dst + e->plen, 0, 16);
+    const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, v.sub_bits, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb,
+                                    v.coded_host.data() + p.frame * tb, k, v.bytes_host.data() + k.byte_off);
+    p.rc = r.rc;
+    p.host_parse = r.host_parse;
+    memcpy(p.qidx, r.qidx, 3);
 }
 // phase 2, per packet the device stage left to the host: the host parser, into a dense frame
 static void gopd_dev_hostparse(pfv_gop_decoder *d, int j)
@@ -1126,10 +1098,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, v.coef_dev, v.status_dev,
                      (uint32_t)pa, (uint32_t)ga};
             const unsigned np = (unsigned)(pb - pa), ng = (unsigned)(gb - ga);
-            for (int round = 0; round <= v.launches; round++)
-                hipLaunchKernelGGL(k_entd_sync, dim3(ng), dim3(kEdThreads), 0, v.stream, b, round == 0 ? 1 : 0, round == v.launches ? 1 : 0, round == v.launches ? 1 : v.inner);
-            hipLaunchKernelGGL(k_entd_prefix, dim3(np), dim3(kEdThreads), 0, v.stream, b);
-            hipLaunchKernelGGL(k_entd_emit, dim3(ng), dim3(kEdThreads), 0, v.stream, b);
+            entd_launch(v.stream, b, np, ng, v.launches, v.inner);
             if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
         }
         if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data() + pa, v.status_dev + pa, (pb - pa) * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));

@@ -22,12 +22,22 @@ class DecodeError(_lib.PfvError):
 
 
 class Decoder:
-    def __init__(self, reader, ctx: Context, lookahead: int | None = None):
+    """dec::Decoder (src/dec.rs:15-224) over ``pfv_decoder``.  ``entropy``: where the run streams of a packet are read -- ``"auto"`` (on the
+    device for payloads of 64 KiB and more), ``"host"``, ``"device"`` (every packet) -- ``None`` = as the context is set (PFV_OPT_ENTROPY_DECODE)."""
+    ENTROPY = {"auto": _lib.PFV_ENTROPY_DECODE_AUTO, "host": _lib.PFV_ENTROPY_DECODE_HOST, "device": _lib.PFV_ENTROPY_DECODE_DEVICE}
+
+    def __init__(self, reader, ctx: Context, lookahead: int | None = None, entropy=None):
         data = reader.read() if hasattr(reader, "read") else bytes(reader)
         self._data = np.frombuffer(data, dtype=np.uint8).copy()     # must outlive the native decoder
         self.ctx = ctx
         h = ctypes.c_void_p()
-        rc = ctx._lib.pfv_decoder_create(ctx.handle, self._data.ctypes.data_as(ctypes.c_void_p), self._data.size, ctypes.byref(h))
+        before = ctx.get_option(_lib.PFV_OPT_ENTROPY_DECODE)
+        if entropy is not None:
+            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, self.ENTROPY[entropy])
+        try:
+            rc = ctx._lib.pfv_decoder_create(ctx.handle, self._data.ctypes.data_as(ctypes.c_void_p), self._data.size, ctypes.byref(h))
+        finally:
+            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, before)
         if rc != _lib.PFV_OK:
             msg = ctx._lib.pfv_last_error(ctx.handle)
             raise DecodeError(rc, msg.decode() if msg else "")
@@ -35,6 +45,12 @@ class Decoder:
         ctx._sessions.add(self)
         if lookahead is not None:                                   # packets parsed ahead on this many worker threads
             ctx.check(ctx._lib.pfv_decoder_set_lookahead(h, int(lookahead)))
+
+    def entropy_counts(self) -> dict:
+        """packets whose run streams the device read / that its stage left to the host parser (pfv_decoder_entropy_counts)"""
+        a = (ctypes.c_long * 2)()
+        self.ctx._lib.pfv_decoder_entropy_counts(self.handle, a)
+        return {"packets_read_on_device": int(a[0]), "packets_left_to_host_parser": int(a[1])}
 
     def width(self) -> int:
         return self.ctx._lib.pfv_decoder_width(self.handle)
@@ -91,8 +107,6 @@ class GopDecoder(Decoder):
     :class:`VideoFrame` copy.  ``entropy``: where packet payloads are read -- ``"auto"`` / ``"host"`` / ``"device"``
     (PFV_OPT_ENTROPY_DECODE, include/pfv_hip.h), ``None`` = whatever the context is set to.  ``output="device"`` (needs ``raw``): the
     frames stay in HBM and ``onvideo`` gets the three planes' device addresses (ints) instead (pfv_gop_decoder_set_output_device)."""
-
-    ENTROPY = {"auto": _lib.PFV_ENTROPY_DECODE_AUTO, "host": _lib.PFV_ENTROPY_DECODE_HOST, "device": _lib.PFV_ENTROPY_DECODE_DEVICE}
 
     def __init__(self, reader, ctx: Context, max_gops: int = 8, max_gop_frames: int = 15, threads: int = 8, raw: bool = False, entropy=None, output: str = "host", entropy_shape=None):
         data = reader.read() if hasattr(reader, "read") else bytes(reader)

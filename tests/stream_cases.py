@@ -38,8 +38,15 @@ def check_stream_roundtrip(pkg, ctx, oracle, w, h, quality, n_frames, gop, drop_
     assert data[:8] == b"PFVIDEO\x00" and int.from_bytes(data[8:12], "little") == 211      # common.rs:1-2
     assert data[-5:] == b"\x00\x00\x00\x00\x00"                                              # EOF packet (enc.rs:221-227)
     assert data == odata, "product .pfv stream differs from the oracle's"
-    # decode with the product and with the oracle: same frames, same count, both hit EOF
-    dec = pkg.Decoder(io.BytesIO(data), ctx)
+    # decode with the product and with the oracle: same frames, same count, both hit EOF; the product with the run streams read by the
+    # host parser and by the device stage (every packet: PFV_ENTROPY_DECODE_DEVICE), which must hand over the same frames
+    hdec = pkg.Decoder(io.BytesIO(data), ctx, entropy="host")
+    hframes = []
+    while hdec.advance_frame(lambda fr: hframes.append(fr.packed())):
+        pass
+    assert hdec.entropy_counts() == {"packets_read_on_device": 0, "packets_left_to_host_parser": 0}
+    hdec.close()
+    dec = pkg.Decoder(io.BytesIO(data), ctx, entropy="device")
     assert (dec.width(), dec.height(), dec.framerate()) == (w, h, 30)
     odec = OracleStreamDecoder(oracle, data, threads=threads)
     frames = []
@@ -49,6 +56,9 @@ def check_stream_roundtrip(pkg, ctx, oracle, w, h, quality, n_frames, gop, drop_
         n_calls += 1
         if not more:
             break
+    counts = dec.entropy_counts()
+    assert counts["packets_read_on_device"] + counts["packets_left_to_host_parser"] >= 1 or n_frames == len(drop_at), counts
+    assert len(hframes) == len(frames) and all(np.array_equal(a, b) for a, b in zip(hframes, frames)), "host-parsed and device-read frames differ"
     oframes = []
     while True:
         rc, fr = odec.advance_frame()
@@ -116,11 +126,11 @@ def check_header_errors(pkg, ctx, data):
     dec.close()
 
 
-def _outcomes_product(pkg, ctx, data, lookahead=None):
+def _outcomes_product(pkg, ctx, data, lookahead=None, entropy=None):
     """one entry per advance_frame call: ('frame', bytes) / ('none',) / ('eof',) / ('err', code)"""
     out = []
     try:
-        dec = pkg.Decoder(data, ctx, lookahead=lookahead)
+        dec = pkg.Decoder(data, ctx, lookahead=lookahead, entropy=entropy)
     except pkg.PfvError as e:
         return [("open-err", e.code)]
     try:
@@ -170,7 +180,8 @@ def check_corrupted_streams(pkg, ctx, oracle, data, n_trials, seed):
             bad[pos] = int(rng.integers(0, 256))
         if rng.random() < 0.25:
             bad = bad[: int(rng.integers(hdr, len(bad)))]
-        a = _outcomes_product(pkg, ctx, bytes(bad), lookahead=(None, 0, 3)[stats["trials"] % 3])   # default / inline / 3 workers
+        a = _outcomes_product(pkg, ctx, bytes(bad), lookahead=(None, 0, 3)[stats["trials"] % 3],   # default / inline / 3 workers
+                              entropy=("device", "host")[(stats["trials"] // 3) % 2])                  # run streams read by the device stage / the host parser
         b = _outcomes_oracle(oracle, bytes(bad))
         assert len(a) == len(b), (a[-1][:1], b[-1][:1], [x[0] for x in a], [x[0] for x in b])
         for k, (x, y) in enumerate(zip(a, b)):
@@ -542,7 +553,7 @@ def check_gop_decoder_corrupted(pkg, ctx, oracle, data, n_trials, seed, shapes=(
     return stats
 
 
-def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quality=1, require_hit=True):
+def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quality=1, require_hit=True, shapes=((8, 15), (2, 2), (1, 15))):
     """Found by tools/soak.py (round 4): at a fine quantiser an i-frame is denser than 1 non-zero in 4, its coefficient LIST overflows
     before the parser reaches a corrupted byte further on, and the GOP-batched decoder took the frame for good when it cut its chains --
     the p-frames behind it then decoded against the slot's stale framebuffer instead of the previous run's last frame.  P P I P with the
@@ -567,7 +578,7 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
         if [x[0] for x in want][:4] != ["frame", "frame", "err", "frame"]:
             continue                                                   # this flip happened to leave the packet parseable
         hit += 1
-        for shape in ((8, 15), (2, 2), (1, 15)):
+        for shape in shapes:
             for mode in GOP_ENTROPY_MODES:
                 got = _outcomes(lambda: pkg.GopDecoder(bad, ctx, max_gops=shape[0], max_gop_frames=shape[1], threads=1, entropy=mode), pkg, n_calls=12, stop_at_error=False)
                 assert got == want, (frac, shape, mode, [x[0] for x in got], [x == y for x, y in zip(got, want)])

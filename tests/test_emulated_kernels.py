@@ -246,4 +246,4 @@ def test_emu_gop_decoder_corrupted_streams(pkg, emu_ctx, oracle):
 
 
 def test_emu_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle):
-    assert sc.check_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle) >= 1
+    assert sc.check_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle, shapes=((8, 15), (1, 15))) >= 1
