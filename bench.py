@@ -939,21 +939,26 @@ def batch_encoder_side(pkg, ctx, Q, n_streams=32, reps=3):
         (be.encode_iframes if t % GOP == 0 else be.encode_pframes)(host[t % GOP])
     be.close()
     data = [b.getvalue() for b in bufs]
-    dec = {}
-    for th in (8, 16, 32):
-        bd = pkg.BatchDecoder(data, ctx, threads=th)
-        t0 = time.perf_counter()
-        steps = 0
-        while bd.advance_frames() is not False:
-            steps += 1
-        el = time.perf_counter() - t0
-        assert steps == 2 * GOP and bd.dense_steps == 0
-        bd.close()
-        dec[str(th)] = steps * n_streams * 12240 / el
-    res["batch_decoder"] = {"value": max(dec.values()), "unit": "macroblocks/s", "by_parse_threads": dec,
-                            "note": ".pfv bytes in host memory -> host bit parser on a worker pool (step t+1 under the device work of "
-                                    "step t) -> coefficient lists read by the scatter kernel from page-locked memory -> k_dec_* -> "
-                                    "frames back in page-locked host memory"}
+    dec, dec_dev = {}, {}
+    for mode, ths, out in (("host", (8, 16, 32), dec), ("device", (4, 8), dec_dev)):
+        for th in ths:
+            bd = pkg.BatchDecoder(data, ctx, threads=th, entropy=mode)
+            t0 = time.perf_counter()
+            steps = 0
+            while bd.advance_frames() is not False:
+                steps += 1
+            el = time.perf_counter() - t0
+            assert steps == 2 * GOP and bd.dense_steps == 0
+            counts = bd.entropy_counts()
+            assert mode == "host" or counts["packets_read_on_device"] == steps * n_streams, counts
+            bd.close()
+            out[str(th)] = steps * n_streams * 12240 / el
+    res["batch_decoder"] = {"value": max(dec_dev.values()), "unit": "macroblocks/s", "by_threads": dec_dev,
+                            "payloads_read_on_host": {"value": max(dec.values()), "by_parse_threads": dec},
+                            "note": ".pfv bytes in host memory -> tables and block headers read on a worker pool (step t+1 under the device work "
+                                    "of step t), run streams read by the device's entropy stage (k_entd_*) -> k_dec_* -> frames back in "
+                                    "page-locked host memory; payloads_read_on_host: the host bit parser on the pool -> coefficient lists "
+                                    "read by the scatter kernel (round 3's form)"}
     return res
 
 

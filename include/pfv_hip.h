@@ -430,6 +430,9 @@ PFV_API int pfv_batch_decoder_height(const pfv_batch_decoder *b);
 PFV_API int pfv_batch_decoder_framerate(const pfv_batch_decoder *b);
 /* steps so far whose coefficient lists overflowed (more than 1 non-zero in 4) and were parsed / uploaded in the dense form */
 PFV_API long pfv_batch_decoder_dense_steps(const pfv_batch_decoder *b);
+/* as pfv_decoder_entropy_counts: a step whose payloads reach 64 KiB (every step under PFV_ENTROPY_DECODE_DEVICE) goes through the device's
+ * entropy stage, the pool then only reads tables and block headers */
+PFV_API void pfv_batch_decoder_entropy_counts(const pfv_batch_decoder *b, long counts_out[2]);
 /* 1: *frames_out = [n_streams][pfv_frame_bytes] decoded frames (page-locked, valid until the call after next); 2: a step of drop
  * frames; 0: end of the streams; negative: error (PFV_ERR_FORMAT also when packet types or q-table indices diverge between streams) */
 PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **frames_out);

@@ -2318,8 +2318,17 @@ struct BdSet {   // host staging of one step (two sets alternate)
     std::vector<const uint8_t *> payload;
     std::vector<size_t> len;
     int type = 0;                      // 0 EOF, 1 i-frames, 2 p-frames, 3 drop frames; negative: error found by the scanner
+    // device-entropy form of the step (PFV_OPT_ENTROPY_DECODE): what entd_prepare leaves for the k_entd_* kernels, per stream
+    bool dev_form = false;
+    PinnedBuf<uint8_t> bytes;          // the payloads, 16-byte aligned starts
+    PinnedBuf<EdPacket> pk;            // [n]
+    PinnedBuf<uint32_t> coded;         // [n][total_blocks]
+    PinnedBuf<uint2> groups;
+    std::vector<uint8_t> host_parse;   // per stream: the host parser reads this packet
+    size_t bytes_total = 0;
 };
 struct pfv_batch_decoder {
+    DecEntd entd;                      // device buffers of the entropy stage (coded_dev: [n][total_blocks]; pk_dev / status_dev: [n])
     pfv_ctx *ctx = nullptr;
     pfv_dec_session *hot = nullptr;
     int n = 0, width = 0, height = 0, framerate = 0, n_qtables = 0;
@@ -2344,6 +2353,16 @@ struct pfv_batch_decoder {
 static void bd_parse_one(pfv_batch_decoder *b, BdSet *s, int k)
 {
     const size_t tb = b->total_blocks;
+    if (s->dev_form) {   // the device reads the run streams: table, q indices, block headers and the payload's copy here
+        EdPacket &pk = s->pk.data()[k];
+        const EntdPrep r = entd_prepare(s->payload[(size_t)k], (uint32_t)s->len[(size_t)k], s->type, tb, b->n_qtables, b->entd.sub_bits, s->mv.data() + (size_t)k * tb * 2,
+                                        s->has.data() + (size_t)k * tb, s->coded.data() + (size_t)k * tb, pk, s->bytes.data() + pk.byte_off);
+        s->rc[(size_t)k] = r.rc;
+        s->host_parse[(size_t)k] = r.host_parse;
+        memcpy(&s->qidx[(size_t)k * 3], r.qidx, 3);
+        s->counts.data()[k] = 0;
+        return;
+    }
     SparseSink sink{s->idx.data() + (size_t)k * b->cap, s->val.data() + (size_t)k * b->cap, b->cap};
     sink.offset = (size_t)k * tb * 256;
     uint8_t *q = &s->qidx[(size_t)k * 3];
@@ -2403,6 +2422,19 @@ static void bd_scan_and_start(pfv_batch_decoder *b, BdSet *s)
     if (first == 1 && all_empty) { s->type = 3; return; }                 // drop frames (src/dec.rs:188-202)
     if (any_empty) { s->type = first == 2 ? PFV_ERR_IO : PFV_ERR_FORMAT; return; }   // empty p-frame packet: truncated read (:204-214)
     s->type = first;
+    s->dev_form = false;
+    if (b->entd.on) {
+        size_t total = 0;
+        bool big = b->entd.force;
+        for (int k = 0; k < b->n; k++) {
+            s->pk.data()[k].byte_off = total;
+            s->pk.data()[k].frame_off = (unsigned long long)k;
+            total += (s->len[(size_t)k] + 16 + 15) & ~(size_t)15;
+            big = big || s->len[(size_t)k] >= kDecEntdMinBytes;
+        }
+        s->bytes_total = total;
+        s->dev_form = big && total < (1ull << 32) && s->bytes.resize(total + 64 > s->bytes.size() ? total + total / 2 + 64 : total + 64);
+    }
     std::lock_guard<std::mutex> lk(b->m);
     b->job = s; b->next = 0; b->done = 0; b->generation++;
     b->cv_work.notify_all();
@@ -2434,6 +2466,8 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     if (b->frames_dev) (void)hipFree(b->frames_dev);
+    for (void *p : {(void *)b->entd.bytes_dev, (void *)b->entd.pk_dev, (void *)b->entd.status_dev, (void *)b->entd.coded_dev, (void *)b->entd.groups_dev, (void *)b->entd.sub_dev})
+        if (p) (void)hipFree(p);
     pfv_dec_session_destroy(b->hot);
     delete b;
 }
@@ -2480,6 +2514,22 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
         s.rc.assign(S, 0); s.qidx.assign(S * 3, 0); s.payload.assign(S, nullptr); s.len.assign(S, 0);
     }
     ok = ok && b->frames[0].resize(S * b->frame_bytes) && b->frames[1].resize(S * b->frame_bytes);
+    if (ok && ctx->opt_entropy_decode != PFV_ENTROPY_DECODE_HOST && tb > 0) {   // the steps' run streams are read on the device (big payloads; every step under _DEVICE)
+        DecEntd &v = b->entd;
+        v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
+        v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
+        hipError_t he = hipMalloc((void **)&v.pk_dev, S * sizeof(EdPacket));
+        if (he == hipSuccess) he = hipMalloc((void **)&v.status_dev, S * sizeof(uint32_t));
+        if (he == hipSuccess) he = hipMalloc((void **)&v.coded_dev, S * tb * sizeof(uint32_t));
+        bool host_ok = he == hipSuccess && v.status_host.resize(S);
+        for (auto &s : b->set) {
+            host_ok = host_ok && s.pk.resize(S) && s.coded.resize(S * tb);
+            s.host_parse.assign(S, 0);
+        }
+        v.on = host_ok;
+        if (!v.on) (void)hipGetLastError();
+        if (!v.on && v.force) ok = false;
+    }
     hipError_t e = ok ? hipMalloc((void **)&b->frames_dev, S * b->frame_bytes) : hipErrorOutOfMemory;
     if (e == hipSuccess && (rc = dec_staging(hot)) == PFV_OK) rc = pfv_dec_set_output_dev(hot, b->frames_dev);
     if (e != hipSuccess) rc = hip_fail(ctx, e, "pfv_batch_decoder_create");
@@ -2494,6 +2544,12 @@ PFV_API int pfv_batch_decoder_height(const pfv_batch_decoder *b) { return b ? b-
 PFV_API int pfv_batch_decoder_framerate(const pfv_batch_decoder *b) { return b ? b->framerate : 0; }
 // steps so far whose coefficient lists overflowed (denser than 1 non-zero in 4) and went up in the dense form
 PFV_API long pfv_batch_decoder_dense_steps(const pfv_batch_decoder *b) { return b ? b->dense_steps : 0; }
+PFV_API void pfv_batch_decoder_entropy_counts(const pfv_batch_decoder *b, long counts_out[2])
+{
+    if (!b || !counts_out) return;
+    counts_out[0] = b->entd.packets_dev;
+    counts_out[1] = b->entd.packets_host;
+}
 
 // One step for all streams: 1 = *frames_out points at [n_streams][frame_bytes] decoded frames (page-locked, valid until the
 // call after next), 2 = a step of drop frames (no frames), 0 = end of the streams, negative = error (PFV_ERR_FORMAT also when
@@ -2529,6 +2585,61 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
     pfv_dec_session *hot = b->hot;
     const size_t total = tb * S * 256;
     int rc = PFV_OK;
+    if (s->dev_form) {   // the step's payloads through the device's entropy stage, the host parser for what it will not take
+        DecEntd &v = b->entd;
+        size_t total_sub = 0, n_groups = 0;
+        for (size_t k = 0; k < S; k++) {
+            EdPacket &pk = s->pk.data()[k];
+            if (s->host_parse[k]) pk.n_sub = 0;
+            pk.sub_first = (uint32_t)total_sub;
+            pk.grp_first = (uint32_t)n_groups;
+            total_sub += pk.n_sub;
+            n_groups += (pk.n_sub + kEdThreads - 1) / kEdThreads;
+        }
+        if (total_sub >= 0xffffffffull) return fail(ctx, PFV_ERR_NOMEM, "batch decoder: payloads too large for one step of the device entropy stage");
+        if (!s->groups.resize(n_groups + 1)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging");
+        {
+            size_t g = 0;
+            for (size_t k = 0; k < S; k++)
+                for (uint32_t blk = 0; blk * (uint32_t)kEdThreads < s->pk.data()[k].n_sub; blk++) s->groups.data()[g++] = make_uint2((unsigned)k, blk);
+        }
+        auto room = [&](auto **p, size_t *cap, size_t need) -> int {
+            if (need <= *cap) return PFV_OK;
+            if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+            need += need / 2;
+            HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(**p)));
+            *cap = need;
+            return PFV_OK;
+        };
+        if ((rc = room(&v.bytes_dev, &v.bytes_cap, s->bytes_total + 64))) return rc;
+        if ((rc = room(&v.groups_dev, &v.groups_cap, n_groups + 1))) return rc;
+        if ((rc = room(&v.sub_dev, &v.sub_cap, (total_sub + 1) * 4))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev, s->bytes.data(), s->bytes_total, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, s->pk.data(), S * sizeof(EdPacket), hipMemcpyHostToDevice, ctx->stream));
+        if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, s->groups.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+        if (s->type == 2) HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev, s->coded.data(), S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(hot->st_coef, 0, total * 2, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, S * sizeof(uint32_t), ctx->stream));
+        if (n_groups) {
+            const size_t ts = v.sub_cap / 4;
+            EdBufs eb{v.bytes_dev, v.pk_dev, v.groups_dev, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, hot->st_coef, v.status_dev, 0u, 0u};
+            entd_launch(ctx->stream, eb, (unsigned)S, (unsigned)n_groups, v.launches, v.inner);
+            if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data(), v.status_dev, S * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t k = 0; k < S; k++) {
+            if (!s->host_parse[k] && !v.status_host.data()[k]) { v.packets_dev++; continue; }
+            v.packets_host++;
+            if (!b->dense.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
+            uint8_t q[3];
+            const int prc = s->type == 2 ? parse_pframe(s->payload[k], s->len[k], (int)tb, b->n_qtables, s->mv.data() + k * tb * 2, s->has.data() + k * tb, b->dense.data(), q)
+                                         : parse_iframe(s->payload[k], s->len[k], (int)tb, b->n_qtables, b->dense.data(), q);
+            if (prc) { b->eof = true; return fail(ctx, prc, "malformed packet payload"); }
+            HIP_TRY(ctx, hipMemcpyAsync(hot->st_coef + k * tb * 256, b->dense.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // the one dense staging frame is used again
+        }
+    } else {
     const bool lists_on_device_bus = s->idx.pinned && s->val.pinned && s->counts.pinned;   // page-locked: the kernel can read them
     if (!dense && !lists_on_device_bus) {   // pageable staging (locked-memory limit): expand the lists on the host instead
         if (!b->dense.resize(total)) return fail(ctx, PFV_ERR_NOMEM, "dense staging");
@@ -2553,6 +2664,7 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
         hipLaunchKernelGGL(k_scatter_coef_seg, dim3(64, (unsigned)S), dim3(kThreads), 0, ctx->stream, s->idx.data(), s->val.data(),
                            s->counts.data(), (uint32_t)b->cap, (uint32_t)total, hot->st_coef);
         if ((rc = launch_check(ctx, "k_scatter_coef_seg"))) return rc;
+    }
     }
     if (s->type == 2) {
         HIP_TRY(ctx, hipMemcpyAsync(hot->st_mv, s->mv.data(), S * tb * 2, hipMemcpyHostToDevice, ctx->stream));

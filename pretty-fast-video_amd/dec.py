@@ -214,14 +214,21 @@ class BatchDecoder:
     ``advance_frames()`` returns the ``[n, frame_bytes]`` array of decoded frames (a view into page-locked memory, valid
     until the call after next), ``None`` for a step of drop frames, or ``False`` at the end of the streams."""
 
-    def __init__(self, streams, ctx: Context, threads: int = 8):
+    def __init__(self, streams, ctx: Context, threads: int = 8, entropy=None):
+        """``entropy``: where the run streams of the packets are read, as for :class:`Decoder` (PFV_OPT_ENTROPY_DECODE)"""
         self.ctx = ctx
         self.data = [np.frombuffer(bytes(s.read() if hasattr(s, "read") else s), dtype=np.uint8) for s in streams]
         self.n = len(self.data)
         ptrs = (ctypes.c_void_p * self.n)(*[d.ctypes.data for d in self.data])
         lens = (ctypes.c_size_t * self.n)(*[d.size for d in self.data])
         h = ctypes.c_void_p()
-        rc = ctx._lib.pfv_batch_decoder_create(ctx.handle, ptrs, lens, self.n, int(threads), ctypes.byref(h))
+        before = ctx.get_option(_lib.PFV_OPT_ENTROPY_DECODE)
+        if entropy is not None:
+            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, Decoder.ENTROPY[entropy])
+        try:
+            rc = ctx._lib.pfv_batch_decoder_create(ctx.handle, ptrs, lens, self.n, int(threads), ctypes.byref(h))
+        finally:
+            ctx.set_option(_lib.PFV_OPT_ENTROPY_DECODE, before)
         if rc:
             msg = ctx._lib.pfv_last_error(ctx.handle)
             raise DecodeError(rc, msg.decode() if msg else "")
@@ -243,6 +250,12 @@ class BatchDecoder:
         if rc == 2:
             return None
         return np.ctypeslib.as_array(ctypes.cast(out, ctypes.POINTER(ctypes.c_uint8)), shape=(self.n, self.frame_bytes))
+
+    def entropy_counts(self) -> dict:
+        """packets whose run streams the device read / that its stage left to the host parser (pfv_batch_decoder_entropy_counts)"""
+        a = (ctypes.c_long * 2)()
+        self.ctx._lib.pfv_batch_decoder_entropy_counts(self.handle, a)
+        return {"packets_read_on_device": int(a[0]), "packets_left_to_host_parser": int(a[1])}
 
     @property
     def dense_steps(self) -> int:

@@ -279,23 +279,30 @@ def check_batch_decoder(pkg, ctx, oracle, w, h, quality, n_streams, n_frames, go
         (enc.encode_iframes if t % gop == 0 else enc.encode_pframes)()
     enc.finish(); enc.close()
     data = [b.getvalue() for b in bufs]
-    odecs = [OracleStreamDecoder(oracle, d) for d in data]
-    dec = pkg.BatchDecoder(data, ctx, threads=3)
-    assert (dec.width, dec.height, dec.framerate) == (w, h, 30)
-    steps = 0
-    while True:
-        fr = dec.advance_frames()
-        if fr is False:
-            break
-        for s in range(n_streams):
-            rc, want = odecs[s].advance_frame()
-            assert rc == 1 and np.array_equal(fr[s], want), f"step {steps} stream {s}"
-        steps += 1
-    assert steps == n_frames and dec.advance_frames() is False
-    for od in odecs:
-        assert od.advance_frame()[0] == 0            # the oracle is at EOF too
-    assert not noise or dec.dense_steps > 0          # white noise must have taken the dense path (other content may, too)
-    dec.close()
+    for mode in ("host", "device"):       # the run streams read by the host pool / by the device's entropy stage (every step)
+        odecs = [OracleStreamDecoder(oracle, d) for d in data]
+        dec = pkg.BatchDecoder(data, ctx, threads=3, entropy=mode)
+        assert (dec.width, dec.height, dec.framerate) == (w, h, 30)
+        steps = 0
+        while True:
+            fr = dec.advance_frames()
+            if fr is False:
+                break
+            for s in range(n_streams):
+                rc, want = odecs[s].advance_frame()
+                assert rc == 1 and np.array_equal(fr[s], want), f"step {steps} stream {s} (payloads read on the {mode})"
+            steps += 1
+        assert steps == n_frames and dec.advance_frames() is False
+        for od in odecs:
+            assert od.advance_frame()[0] == 0            # the oracle is at EOF too
+        counts = dec.entropy_counts()
+        if mode == "host":
+            assert not noise or dec.dense_steps > 0      # white noise must have taken the dense path (other content may, too)
+            assert counts == {"packets_read_on_device": 0, "packets_left_to_host_parser": 0}
+        else:
+            assert counts["packets_read_on_device"] + counts["packets_left_to_host_parser"] == n_streams * n_frames, counts
+            assert counts["packets_read_on_device"] > 0, counts
+        dec.close()
 
 
 def check_encoder_keeps_nothing(pkg, ctx, w=48, h=32):
