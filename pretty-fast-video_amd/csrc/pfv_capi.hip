@@ -1902,8 +1902,26 @@ struct DecEntd {
 };
 constexpr uint32_t kDecEntdMinBytes = 64 * 1024;   // below this the launches cost more than the host parser needs for the packet
 
+// device side of one packet's window in pfv_decoder.  Two alternate: the window of the NEXT packet (uploads, k_entd_*, status) runs on a
+// second stream under the decode launch and the frame download of the current one.
+struct DecWindow {
+    uint8_t *bytes_dev = nullptr; size_t bytes_cap = 0;
+    uint2 *groups_dev = nullptr; size_t groups_cap = 0;
+    uint32_t *sub_dev = nullptr; size_t sub_cap = 0;
+    EdPacket *pk_dev = nullptr;
+    uint32_t *status_dev = nullptr, *coded_dev = nullptr;
+    int16_t *coef_dev = nullptr;
+    int8_t *mv_dev = nullptr;
+    uint8_t *has_dev = nullptr;
+    PinnedBuf<uint32_t> status_host;
+    hipEvent_t done = nullptr;
+    DecEvent *owner = nullptr;           // the packet whose window is enqueued / was decoded from this set
+};
+
 struct pfv_decoder {
-    DecEntd entd;
+    DecEntd entd;                        // switches, shape and counters of the device entropy stage (its buffers: win[])
+    DecWindow win[2];
+    hipStream_t win_stream = nullptr;
     pfv_ctx *ctx = nullptr;
     pfv_dec_session *hot = nullptr;
     const uint8_t *data = nullptr;
@@ -2769,10 +2787,20 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
         DecEntd &v = d->entd;
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
-        hipError_t he = hipMalloc((void **)&v.pk_dev, sizeof(EdPacket));
-        if (he == hipSuccess) he = hipMalloc((void **)&v.status_dev, sizeof(uint32_t));
-        if (he == hipSuccess) he = hipMalloc((void **)&v.coded_dev, (size_t)d->total_blocks * sizeof(uint32_t));
-        v.on = he == hipSuccess && v.status_host.resize(1);
+        const size_t tbs = (size_t)d->total_blocks;
+        hipError_t he = hipStreamCreateWithFlags(&d->win_stream, hipStreamNonBlocking);
+        bool host_ok = true;
+        for (DecWindow &w : d->win) {
+            if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, sizeof(EdPacket));
+            if (he == hipSuccess) he = hipMalloc((void **)&w.status_dev, sizeof(uint32_t));
+            if (he == hipSuccess) he = hipMalloc((void **)&w.coded_dev, tbs * sizeof(uint32_t));
+            if (he == hipSuccess) he = hipMalloc((void **)&w.coef_dev, tbs * 512);
+            if (he == hipSuccess) he = hipMalloc((void **)&w.mv_dev, tbs * 2);
+            if (he == hipSuccess) he = hipMalloc((void **)&w.has_dev, tbs);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+            host_ok = host_ok && w.status_host.resize(1);
+        }
+        v.on = he == hipSuccess && host_ok;
         if (!v.on) (void)hipGetLastError();
         if (!v.on && v.force) {
             pfv_decoder_destroy(d);
@@ -2917,6 +2945,8 @@ static void dec_rewind(pfv_decoder *d, std::unique_lock<std::mutex> &lk, size_t 
         if (!running) break;
         d->cv_done.wait(lk);
     }
+    if (d->win_stream) (void)hipStreamSynchronize(d->win_stream);          // a window enqueued ahead reads its event's buffers
+    d->win[0].owner = d->win[1].owner = nullptr;
     for (auto &e : d->ring) e->state = DecEvent::FREE;
     d->head = d->count = 0;
     d->scan_pos = d->pos = pos;
@@ -2957,8 +2987,13 @@ PFV_API void pfv_decoder_destroy(pfv_decoder *d)
     dec_stop_workers(d);
     (void)hipSetDevice(d->ctx->device);
     (void)hipStreamSynchronize(d->ctx->stream);
-    for (void *p : {(void *)d->entd.bytes_dev, (void *)d->entd.pk_dev, (void *)d->entd.status_dev, (void *)d->entd.coded_dev, (void *)d->entd.groups_dev, (void *)d->entd.sub_dev})
-        if (p) (void)hipFree(p);
+    if (d->win_stream) { (void)hipStreamSynchronize(d->win_stream); (void)hipStreamDestroy(d->win_stream); }
+    for (DecWindow &w : d->win) {
+        for (void *p : {(void *)w.bytes_dev, (void *)w.pk_dev, (void *)w.status_dev, (void *)w.coded_dev, (void *)w.groups_dev, (void *)w.sub_dev, (void *)w.coef_dev,
+                        (void *)w.mv_dev, (void *)w.has_dev})
+            if (p) (void)hipFree(p);
+        if (w.done) (void)hipEventDestroy(w.done);
+    }
     pfv_dec_session_destroy(d->hot);
     delete d;
 }
@@ -2983,59 +3018,87 @@ PFV_API int pfv_decoder_reset(pfv_decoder *d)
 
 }  // extern "C"
 
-// One packet through the device's entropy stage, then the decode launch: coefficients in the session's staging array.
+// The window of packet e on set w: uploads, cleared coefficient array, k_entd_*, status download -- all on the window stream.
+static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
+{
+    pfv_ctx *ctx = d->ctx;
+    DecEntd &v = d->entd;
+    hipStream_t st = d->win_stream;
+    const size_t tb = (size_t)d->total_blocks;
+    const EdPacket &k = *e->pk.data();
+    const uint32_t ng = (k.n_sub + kEdThreads - 1) / kEdThreads;
+    auto room = [&](auto **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return PFV_OK;
+        if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }           // the set is idle: its last window was consumed and decoded
+        need += need / 2;
+        HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(**p)));
+        *cap = need;
+        return PFV_OK;
+    };
+    int rc;
+    if ((rc = room(&w.bytes_dev, &w.bytes_cap, (size_t)e->plen + 64))) return rc;
+    if ((rc = room(&w.groups_dev, &w.groups_cap, (size_t)ng + 1))) return rc;
+    if ((rc = room(&w.sub_dev, &w.sub_cap, ((size_t)k.n_sub + 1) * 4))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(w.bytes_dev, e->bytes.data(), (size_t)e->plen + 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(w.pk_dev, e->pk.data(), sizeof(EdPacket), hipMemcpyHostToDevice, st));
+    if (ng) HIP_TRY(ctx, hipMemcpyAsync(w.groups_dev, e->groups.data(), ng * sizeof(uint2), hipMemcpyHostToDevice, st));
+    if (e->type == 2) {
+        HIP_TRY(ctx, hipMemcpyAsync(w.mv_dev, e->mv.data(), tb * 2, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, e->has.data(), tb, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(w.coded_dev, e->coded.data(), tb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(w.coef_dev, 0, tb * 512, st));
+    HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, sizeof(uint32_t), st));
+    if (ng) {
+        const size_t ts = w.sub_cap / 4;
+        EdBufs b{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.sub_dev + 3 * ts, w.coded_dev, w.coef_dev, w.status_dev, 0u, 0u};
+        entd_launch(st, b, 1u, ng, v.launches, v.inner);
+        if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(w.status_host.data(), w.status_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(w.done, st));
+    w.owner = e;
+    return PFV_OK;
+}
+// One packet through the device's entropy stage, then the decode launch; before the frame is fetched, the window of the
+// packet behind it -- if its headers are ready -- is put on the window stream, where it runs under this frame's decode and download.
 static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
 {
     pfv_ctx *ctx = d->ctx;
     pfv_dec_session *hot = d->hot;
     DecEntd &v = d->entd;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = dec_staging(hot);
-    if (rc) return rc;
     const size_t tb = (size_t)d->total_blocks;
-    const EdPacket &k = *e->pk.data();
-    const uint32_t ng = (k.n_sub + kEdThreads - 1) / kEdThreads;
-    auto room = [&](auto **p, size_t *cap, size_t need) -> int {
-        if (need <= *cap) return PFV_OK;
-        if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(*p); *p = nullptr; *cap = 0; }
-        need += need / 2;
-        HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(**p)));
-        *cap = need;
-        return PFV_OK;
-    };
-    if ((rc = room(&v.bytes_dev, &v.bytes_cap, (size_t)e->plen + 64))) return rc;
-    if ((rc = room(&v.groups_dev, &v.groups_cap, (size_t)ng + 1))) return rc;
-    if ((rc = room(&v.sub_dev, &v.sub_cap, ((size_t)k.n_sub + 1) * 4))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev, e->bytes.data(), (size_t)e->plen + 16, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, e->pk.data(), sizeof(EdPacket), hipMemcpyHostToDevice, ctx->stream));
-    if (ng) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, e->groups.data(), ng * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    if (e->type == 2) {
-        HIP_TRY(ctx, hipMemcpyAsync(hot->st_mv, e->mv.data(), tb * 2, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(hot->st_has, e->has.data(), tb, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev, e->coded.data(), tb * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    int rc;
+    DecWindow *w = d->win[0].owner == e ? &d->win[0] : d->win[1].owner == e ? &d->win[1] : nullptr;
+    if (!w) {                     // not enqueued ahead: now
+        w = &d->win[0];
+        d->win[1].owner = nullptr;
+        if ((rc = dec_window_enqueue(d, e, *w))) { w->owner = nullptr; return rc; }
     }
-    HIP_TRY(ctx, hipMemsetAsync(hot->st_coef, 0, tb * 512, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, sizeof(uint32_t), ctx->stream));
-    if (ng) {
-        const size_t ts = v.sub_cap / 4;
-        EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, hot->st_coef, v.status_dev, 0u, 0u};
-        entd_launch(ctx->stream, b, 1u, ng, v.launches, v.inner);
-        if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data(), v.status_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (*v.status_host.data()) {   // the device stage is not certain about this payload: the host parser reads it and decides
+    DecWindow *other = w == &d->win[0] ? &d->win[1] : &d->win[0];
+    other->owner = nullptr;       // the packet decoded from it is through (the last call ended with the stream idle)
+    HIP_TRY(ctx, hipEventSynchronize(w->done));
+    w->owner = nullptr;           // consumed (event objects are reused by the ring: a stale match would take this window for a later packet's)
+    if (*w->status_host.data()) {   // the device stage is not certain about this payload: the host parser reads it and decides
         v.packets_host++;
         if (!e->coef.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging for a parsed packet");
         const int prc = e->type == 1 ? parse_iframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->coef.data(), e->qidx)
                                      : parse_pframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
         if (prc) return fail(ctx, prc, "malformed packet payload");
-        HIP_TRY(ctx, hipMemcpyAsync(hot->st_coef, e->coef.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(w->coef_dev, e->coef.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
     } else {
         v.packets_dev++;
     }
-    rc = e->type == 1 ? pfv_dec_iframe_dev(hot, hot->st_coef, e->qidx) : pfv_dec_pframe_dev(hot, hot->st_mv, hot->st_has, hot->st_coef, e->qidx);
+    rc = e->type == 1 ? pfv_dec_iframe_dev(hot, w->coef_dev, e->qidx) : pfv_dec_pframe_dev(hot, w->mv_dev, w->has_dev, w->coef_dev, e->qidx);
     if (rc) return rc;
+    {   // the packet behind this one
+        std::unique_lock<std::mutex> lk(d->m);
+        DecEvent *nx = d->count >= 2 ? d->ring[(d->head + 1) % d->ring.size()].get() : nullptr;
+        const bool ready = nx && nx->state == DecEvent::DONE && nx->kind == DecEvent::FRAME && nx->dev_form && !nx->rc;
+        lk.unlock();
+        if (ready && dec_window_enqueue(d, nx, *other) != PFV_OK) other->owner = nullptr;   // it will be tried again when its turn comes
+    }
     return pfv_dec_check(hot);
 }
 
