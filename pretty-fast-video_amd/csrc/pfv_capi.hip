@@ -1887,17 +1887,11 @@ struct DecEvent {
     PinnedBuf<uint2> groups;             // workgroups of the packet
 };
 
-// the frame-by-frame decoder's device-entropy state: one packet per call through the k_entd_* kernels
+// switches, shape and counters of the device entropy stage in pfv_decoder / pfv_batch_decoder (the buffers: DecWindow)
 struct DecEntd {
     bool on = false, force = false;      // force: every packet (PFV_ENTROPY_DECODE_DEVICE); otherwise payloads of kDecEntdMinBytes and more
     uint32_t sub_bits = kEdSubBits;
     int launches = 4, inner = kEdInner;
-    uint8_t *bytes_dev = nullptr; size_t bytes_cap = 0;
-    EdPacket *pk_dev = nullptr;
-    uint32_t *status_dev = nullptr, *coded_dev = nullptr;
-    uint2 *groups_dev = nullptr; size_t groups_cap = 0;
-    uint32_t *sub_dev = nullptr; size_t sub_cap = 0;
-    PinnedBuf<uint32_t> status_host;
     long packets_dev = 0, packets_host = 0;
 };
 constexpr uint32_t kDecEntdMinBytes = 64 * 1024;   // below this the launches cost more than the host parser needs for the packet
@@ -2346,7 +2340,9 @@ struct BdSet {   // host staging of one step (two sets alternate)
     size_t bytes_total = 0;
 };
 struct pfv_batch_decoder {
-    DecEntd entd;                      // device buffers of the entropy stage (coded_dev: [n][total_blocks]; pk_dev / status_dev: [n])
+    DecEntd entd;                      // switches, shape and counters of the device entropy stage
+    DecWindow win[2];                  // its device buffers, per staging set: [n] packets, [n][total_blocks] lists / headers / coefficients
+    hipStream_t win_stream = nullptr;  // the window of step t + 1 runs here, under the decode and download of step t
     pfv_ctx *ctx = nullptr;
     pfv_dec_session *hot = nullptr;
     int n = 0, width = 0, height = 0, framerate = 0, n_qtables = 0;
@@ -2472,6 +2468,67 @@ static void bd_join(pfv_batch_decoder *b, BdSet *s)
     b->job = nullptr;
 }
 
+}  // extern "C"
+
+// The window of step s on set w (all on the window stream): payloads, packet descriptors, block headers and lists up, coefficient arrays
+// cleared, k_entd_*, statuses down.
+static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
+{
+    pfv_ctx *ctx = b->ctx;
+    DecEntd &v = b->entd;
+    hipStream_t st = b->win_stream;
+    const size_t S = (size_t)b->n, tb = b->total_blocks;
+    size_t total_sub = 0, n_groups = 0;
+    for (size_t k = 0; k < S; k++) {
+        EdPacket &pk = s->pk.data()[k];
+        if (s->host_parse[k] || s->rc[k]) pk.n_sub = 0;
+        pk.sub_first = (uint32_t)total_sub;
+        pk.grp_first = (uint32_t)n_groups;
+        total_sub += pk.n_sub;
+        n_groups += (pk.n_sub + kEdThreads - 1) / kEdThreads;
+    }
+    if (total_sub >= 0xffffffffull) return fail(ctx, PFV_ERR_NOMEM, "batch decoder: payloads too large for one step of the device entropy stage");
+    if (!s->groups.resize(n_groups + 1)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging");
+    {
+        size_t g = 0;
+        for (size_t k = 0; k < S; k++)
+            for (uint32_t blk = 0; blk * (uint32_t)kEdThreads < s->pk.data()[k].n_sub; blk++) s->groups.data()[g++] = make_uint2((unsigned)k, blk);
+    }
+    auto room = [&](auto **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return PFV_OK;
+        if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }               // the set is idle: its last window was consumed and decoded
+        need += need / 2;
+        HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(**p)));
+        *cap = need;
+        return PFV_OK;
+    };
+    int rc;
+    if ((rc = room(&w.bytes_dev, &w.bytes_cap, s->bytes_total + 64))) return rc;
+    if ((rc = room(&w.groups_dev, &w.groups_cap, n_groups + 1))) return rc;
+    if ((rc = room(&w.sub_dev, &w.sub_cap, (total_sub + 1) * 4))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(w.bytes_dev, s->bytes.data(), s->bytes_total, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(w.pk_dev, s->pk.data(), S * sizeof(EdPacket), hipMemcpyHostToDevice, st));
+    if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(w.groups_dev, s->groups.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, st));
+    if (s->type == 2) {
+        HIP_TRY(ctx, hipMemcpyAsync(w.mv_dev, s->mv.data(), S * tb * 2, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, s->has.data(), S * tb, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(w.coded_dev, s->coded.data(), S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(w.coef_dev, 0, S * tb * 512, st));
+    HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, S * sizeof(uint32_t), st));
+    if (n_groups) {
+        const size_t ts = w.sub_cap / 4;
+        EdBufs eb{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.sub_dev + 3 * ts, w.coded_dev, w.coef_dev, w.status_dev, 0u, 0u};
+        entd_launch(st, eb, (unsigned)S, (unsigned)n_groups, v.launches, v.inner);
+        if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(w.status_host.data(), w.status_dev, S * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(w.done, st));
+    w.owner = (DecEvent *)s;       // an identity only: which staging set this window belongs to
+    return PFV_OK;
+}
+
+extern "C" {
 PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b)
 {
     if (!b) return;
@@ -2484,8 +2541,13 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     if (b->frames_dev) (void)hipFree(b->frames_dev);
-    for (void *p : {(void *)b->entd.bytes_dev, (void *)b->entd.pk_dev, (void *)b->entd.status_dev, (void *)b->entd.coded_dev, (void *)b->entd.groups_dev, (void *)b->entd.sub_dev})
-        if (p) (void)hipFree(p);
+    if (b->win_stream) { (void)hipStreamSynchronize(b->win_stream); (void)hipStreamDestroy(b->win_stream); }
+    for (DecWindow &w : b->win) {
+        for (void *p : {(void *)w.bytes_dev, (void *)w.pk_dev, (void *)w.status_dev, (void *)w.coded_dev, (void *)w.groups_dev, (void *)w.sub_dev, (void *)w.coef_dev,
+                        (void *)w.mv_dev, (void *)w.has_dev})
+            if (p) (void)hipFree(p);
+        if (w.done) (void)hipEventDestroy(w.done);
+    }
     pfv_dec_session_destroy(b->hot);
     delete b;
 }
@@ -2536,10 +2598,19 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
         DecEntd &v = b->entd;
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
-        hipError_t he = hipMalloc((void **)&v.pk_dev, S * sizeof(EdPacket));
-        if (he == hipSuccess) he = hipMalloc((void **)&v.status_dev, S * sizeof(uint32_t));
-        if (he == hipSuccess) he = hipMalloc((void **)&v.coded_dev, S * tb * sizeof(uint32_t));
-        bool host_ok = he == hipSuccess && v.status_host.resize(S);
+        hipError_t he = hipStreamCreateWithFlags(&b->win_stream, hipStreamNonBlocking);
+        bool host_ok = true;
+        for (DecWindow &w : b->win) {
+            if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, S * sizeof(EdPacket));
+            if (he == hipSuccess) he = hipMalloc((void **)&w.status_dev, S * sizeof(uint32_t));
+            if (he == hipSuccess) he = hipMalloc((void **)&w.coded_dev, S * tb * sizeof(uint32_t));
+            if (he == hipSuccess) he = hipMalloc((void **)&w.coef_dev, S * tb * 512);
+            if (he == hipSuccess) he = hipMalloc((void **)&w.mv_dev, S * tb * 2);
+            if (he == hipSuccess) he = hipMalloc((void **)&w.has_dev, S * tb);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+            host_ok = host_ok && w.status_host.resize(S);
+        }
+        host_ok = host_ok && he == hipSuccess;
         for (auto &s : b->set) {
             host_ok = host_ok && s.pk.resize(S) && s.coded.resize(S * tb);
             s.host_parse.assign(S, 0);
@@ -2605,58 +2676,35 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
     int rc = PFV_OK;
     if (s->dev_form) {   // the step's payloads through the device's entropy stage, the host parser for what it will not take
         DecEntd &v = b->entd;
-        size_t total_sub = 0, n_groups = 0;
+        DecWindow &w = b->win[slot];
+        if (w.owner != (DecEvent *)s && (rc = bd_window_enqueue(b, s, w))) return rc;     // not enqueued ahead (first step, or its headers were late)
+        HIP_TRY(ctx, hipEventSynchronize(w.done));
+        w.owner = nullptr;
         for (size_t k = 0; k < S; k++) {
-            EdPacket &pk = s->pk.data()[k];
-            if (s->host_parse[k]) pk.n_sub = 0;
-            pk.sub_first = (uint32_t)total_sub;
-            pk.grp_first = (uint32_t)n_groups;
-            total_sub += pk.n_sub;
-            n_groups += (pk.n_sub + kEdThreads - 1) / kEdThreads;
-        }
-        if (total_sub >= 0xffffffffull) return fail(ctx, PFV_ERR_NOMEM, "batch decoder: payloads too large for one step of the device entropy stage");
-        if (!s->groups.resize(n_groups + 1)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging");
-        {
-            size_t g = 0;
-            for (size_t k = 0; k < S; k++)
-                for (uint32_t blk = 0; blk * (uint32_t)kEdThreads < s->pk.data()[k].n_sub; blk++) s->groups.data()[g++] = make_uint2((unsigned)k, blk);
-        }
-        auto room = [&](auto **p, size_t *cap, size_t need) -> int {
-            if (need <= *cap) return PFV_OK;
-            if (*p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(*p); *p = nullptr; *cap = 0; }
-            need += need / 2;
-            HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(**p)));
-            *cap = need;
-            return PFV_OK;
-        };
-        if ((rc = room(&v.bytes_dev, &v.bytes_cap, s->bytes_total + 64))) return rc;
-        if ((rc = room(&v.groups_dev, &v.groups_cap, n_groups + 1))) return rc;
-        if ((rc = room(&v.sub_dev, &v.sub_cap, (total_sub + 1) * 4))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev, s->bytes.data(), s->bytes_total, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, s->pk.data(), S * sizeof(EdPacket), hipMemcpyHostToDevice, ctx->stream));
-        if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, s->groups.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-        if (s->type == 2) HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev, s->coded.data(), S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(hot->st_coef, 0, total * 2, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, S * sizeof(uint32_t), ctx->stream));
-        if (n_groups) {
-            const size_t ts = v.sub_cap / 4;
-            EdBufs eb{v.bytes_dev, v.pk_dev, v.groups_dev, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, hot->st_coef, v.status_dev, 0u, 0u};
-            entd_launch(ctx->stream, eb, (unsigned)S, (unsigned)n_groups, v.launches, v.inner);
-            if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
-        }
-        HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data(), v.status_dev, S * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t k = 0; k < S; k++) {
-            if (!s->host_parse[k] && !v.status_host.data()[k]) { v.packets_dev++; continue; }
+            if (!s->host_parse[k] && !w.status_host.data()[k]) { v.packets_dev++; continue; }
             v.packets_host++;
             if (!b->dense.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
             uint8_t q[3];
             const int prc = s->type == 2 ? parse_pframe(s->payload[k], s->len[k], (int)tb, b->n_qtables, s->mv.data() + k * tb * 2, s->has.data() + k * tb, b->dense.data(), q)
                                          : parse_iframe(s->payload[k], s->len[k], (int)tb, b->n_qtables, b->dense.data(), q);
             if (prc) { b->eof = true; return fail(ctx, prc, "malformed packet payload"); }
-            HIP_TRY(ctx, hipMemcpyAsync(hot->st_coef + k * tb * 256, b->dense.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(w.coef_dev + k * tb * 256, b->dense.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // the one dense staging frame is used again
         }
+        rc = s->type == 2 ? pfv_dec_pframe_dev(hot, w.mv_dev, w.has_dev, w.coef_dev, &s->qidx[0]) : pfv_dec_iframe_dev(hot, w.coef_dev, &s->qidx[0]);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(b->frames[slot].data(), b->frames_dev, S * b->frame_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        BdSet *nx = &b->set[slot ^ 1];
+        bd_scan_and_start(b, nx);
+        if (nx->dev_form) {        // its headers now (the pool and this thread, while the frames above travel), then its window on the second stream
+            bd_join(b, nx);
+            bool sound = true;
+            for (size_t k = 0; k < S; k++) sound = sound && !nx->rc[k];
+            if (sound && bd_window_enqueue(b, nx, b->win[slot ^ 1]) != PFV_OK) b->win[slot ^ 1].owner = nullptr;   // tried again when its turn comes
+        }
+        if ((rc = pfv_dec_check(hot))) return rc;      // synchronises; bad-motion-vector flag (src/common.rs:258-259)
+        *frames_out = b->frames[slot].data();
+        return 1;
     } else {
     const bool lists_on_device_bus = s->idx.pinned && s->val.pinned && s->counts.pinned;   // page-locked: the kernel can read them
     if (!dense && !lists_on_device_bus) {   // pageable staging (locked-memory limit): expand the lists on the host instead
