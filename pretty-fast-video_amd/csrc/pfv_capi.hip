@@ -1793,6 +1793,7 @@ struct pfv_encoder {
     int width = 0, height = 0, framerate = 0, total_blocks = 0;
     bool finished = false;
     bool device_entropy = true;            // payloads built by the k_ent_* kernels instead of serialize_*frame on the host
+    const uint8_t *plane[3] = {nullptr, nullptr, nullptr};   // device path: the caller's planes of the frame being encoded
     bool poisoned = false;                 // a frame failed after prev_frame had moved on: the next frame must be an i-frame
     std::vector<uint8_t> out;              // the writer: bytes produced and not yet handed over (pfv_encoder_drain)
     std::vector<uint8_t> drained;          // what the last pfv_encoder_drain handed over
@@ -1979,6 +1980,10 @@ static int pack_frame(pfv_encoder *e, const uint8_t *y, const uint8_t *u, const 
 {
     if (!y || !u || !v) return fail(e->ctx, PFV_ERR_BAD_ARG, "null plane");
     if (e->finished) return fail(e->ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:80)");
+    if (e->device_entropy) {   // the planes go up from where they lie (encode_on_device): no packing copy -- it was half of a 4K frame's time
+        e->plane[0] = y; e->plane[1] = u; e->plane[2] = v;
+        return PFV_OK;
+    }
     size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
     memcpy(e->frame.data(), y, ny);
     memcpy(e->frame.data() + ny, u, nc);
@@ -2002,15 +2007,21 @@ static int encode_on_device(pfv_encoder *e, bool pframe)
     int rc = enc_staging(s);
     if (!rc) rc = pfv_enc_entropy_enable(s, 0);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s->st_frames, e->frame.data(), (size_t)s->geom.src_frame_bytes, hipMemcpyHostToDevice, ctx->stream));
+    {   // the caller's planes are read until the first synchronisation below (pfv_enc_payload_sizes); every exit before it synchronises too
+        const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
+        hipError_t he = hipMemcpyAsync(s->st_frames, e->plane[0], ny, hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(s->st_frames + ny, e->plane[1], nc, hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(s->st_frames + ny + nc, e->plane[2], nc, hipMemcpyHostToDevice, ctx->stream);
+        if (he != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return hip_fail(ctx, he, "plane upload"); }
+    }
     rc = pframe ? pfv_enc_pframe_dev(s, s->st_frames, s->st_mv, s->st_has, s->st_coef) : pfv_enc_iframe_dev(s, s->st_frames, s->st_coef);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     // from here on prev_frame has moved to this frame: a failure leaves the encoder's reference ahead of the stream
     e->poisoned = true;
     rc = pframe ? pfv_enc_pack_pframe_dev(s, s->st_mv, s->st_has, s->st_coef) : pfv_enc_pack_iframe_dev(s, s->st_coef);
     uint32_t nbytes = 0;
     if (!rc) rc = pfv_enc_payload_sizes(s, &nbytes);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if (!e->payload.resize(std::max<size_t>(nbytes, 1 << 20))) return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
     if ((rc = pfv_enc_payload_fetch(s, 0, e->payload.data(), nbytes))) return rc;
     e->poisoned = false;

@@ -223,10 +223,10 @@ def test_emu_gop_objects(pkg, emu_ctx, oracle):
     """pfv_gop_encoder / pfv_gop_decoder: same bytes / frames as the frame-by-frame objects and the oracle, whatever the batch shape"""
     # three GOPs of 4 + drop frames; shapes: everything in one batch / batches of 2 groups / groups cut after 3 frames (runs continue
     # across batches) / one slot (degenerates to the serial order)
-    data = sc.check_gop_objects(pkg, emu_ctx, oracle, 64, 48, 5, "IPPPIPDPPIPPP", shapes=((8, 15), (2, 3)))
+    data = sc.check_gop_objects(pkg, emu_ctx, oracle, 64, 48, 5, "IPPPIPDPPIPPP", shapes=((8, 15), (2, 3)), alternate_modes=True)
     assert data[-5:] == bytes(5)
     # a stream that starts with p-frames (prev_frame = new_padded, src/enc.rs:46) and has GOPs of unequal length
-    sc.check_gop_objects(pkg, emu_ctx, oracle, 50, 38, 3, "PPIPIPPDIP", shapes=((2, 15), (1, 2)))
+    sc.check_gop_objects(pkg, emu_ctx, oracle, 50, 38, 3, "PPIPIPPDIP", shapes=((2, 15), (1, 2)), alternate_modes=True)
 
 
 def test_emu_gop_decoder_device_entropy(pkg, emu_ctx, oracle):
