@@ -524,8 +524,9 @@ struct GopDecDev {
     PinnedBuf<int16_t> dense_host;       // kGopDevDense frames: packets the host parser reads
     std::vector<GopDevPacket> pk;
     std::vector<int> todo;               // phase 2: the packets the host parser reads, kGopDevDense at a time
-    int phase = 0, todo_first = 0;
-    int pending = 0;                     // tasks of the current phase not yet finished (under the pool's mutex)
+    int todo_first = 0;
+    int pending = 0;                     // phase-2 tasks (packets parsed on the host) not yet finished (under the pool's mutex)
+    std::vector<int> step_pending;       // phase-1 tasks (headers) not yet finished, per frame step
     long packets_dev = 0, packets_host = 0, batches_dev = 0, batches_host = 0;
 };
 
@@ -581,13 +582,22 @@ static void gopd_parse_one(pfv_gop_decoder *d, GopDecSet *s, int k)
     s->rc[(size_t)k] = rc;
 }
 static void gopd_dev_task(pfv_gop_decoder *d, int j);
-// a queued task: (staging set, slot) = parse that packet into the set's lists; (null, j) = task j of the device-entropy path's current phase
+// a queued task: (staging set, slot) = parse that packet into the set's lists; (null, j >= 0) = the headers of packet j of the device-entropy
+// path's batch (phase 1); (null, -1 - j) = the j-th packet of the current group the device stage left to the host parser (phase 2)
 static void gopd_run_task(pfv_gop_decoder *d, const std::pair<GopDecSet *, int> &job)
 {
     if (job.first) gopd_parse_one(d, job.first, job.second);
     else gopd_dev_task(d, job.second);
 }
-static int &gopd_pending_of(pfv_gop_decoder *d, const std::pair<GopDecSet *, int> &job) { return job.first ? job.first->pending : d->dev.pending; }
+// a task has been run (or dropped): its counters, under the pool's mutex.  Device-path tasks count per phase and, in phase 1 (headers), per frame
+// step as well: the windows of a step are enqueued as soon as ITS packets are ready.  True when some waiter may go on.
+static bool gopd_task_done(pfv_gop_decoder *d, const std::pair<GopDecSet *, int> &job)
+{
+    if (job.first) return --job.first->pending == 0;
+    GopDecDev &v = d->dev;
+    if (job.second < 0) return --v.pending == 0;        // a packet parsed on the host (phase 2)
+    return --v.step_pending[(size_t)v.pk[(size_t)job.second].ev->t] == 0;
+}
 static void gopd_worker(pfv_gop_decoder *d)
 {
     std::unique_lock<std::mutex> lk(d->m);
@@ -599,7 +609,7 @@ static void gopd_worker(pfv_gop_decoder *d)
         lk.unlock();
         gopd_run_task(d, job);
         lk.lock();
-        if (--gopd_pending_of(d, job) == 0) d->cv_done.notify_all();
+        if (gopd_task_done(d, job)) d->cv_done.notify_all();
     }
 }
 static void gopd_start_parse(pfv_gop_decoder *d, GopDecSet *s, int n_slots)
@@ -622,7 +632,7 @@ static void gopd_join(pfv_gop_decoder *d, int *pending)
             lk.unlock();
             gopd_run_task(d, job);
             lk.lock();
-            if (--gopd_pending_of(d, job) == 0) d->cv_done.notify_all();
+            if (gopd_task_done(d, job)) d->cv_done.notify_all();
         } else {
             d->cv_done.wait(lk);
         }
@@ -633,11 +643,13 @@ static void gopd_join_parse(pfv_gop_decoder *d, GopDecSet *s) { gopd_join(d, &s-
 static void gopd_drain_pool(pfv_gop_decoder *d)
 {
     std::unique_lock<std::mutex> lk(d->m);
-    for (const auto &job : d->tasks) gopd_pending_of(d, job)--;
+    for (const auto &job : d->tasks) (void)gopd_task_done(d, job);
     d->tasks.clear();
     d->cv_done.wait(lk, [&] {
         for (const GopDecSet &s : d->set)
             if (s.pending > 0) return false;
+        for (int p : d->dev.step_pending)
+            if (p > 0) return false;
         return d->dev.pending <= 0;
     });
 }
@@ -962,17 +974,17 @@ static void gopd_dev_hostparse(pfv_gop_decoder *d, int j)
     p.rc = e->type == 2 ? parse_pframe(e->payload, e->plen, (int)tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, coef, q)
                         : parse_iframe(e->payload, e->plen, (int)tb, d->n_qtables, coef, q);
 }
-static void gopd_dev_task(pfv_gop_decoder *d, int j)
+static void gopd_dev_task(pfv_gop_decoder *d, int code)
 {
-    if (d->dev.phase == 1) gopd_dev_prepare(d, j);
-    else gopd_dev_hostparse(d, j);
+    if (code >= 0) gopd_dev_prepare(d, code);
+    else gopd_dev_hostparse(d, -1 - code);
 }
-static void gopd_dev_run_phase(pfv_gop_decoder *d, int phase, int n_tasks)
+// phase 2: n_tasks packets (v.todo from todo_first on) through the host parser, on the pool and this thread
+static void gopd_dev_hostparse_group(pfv_gop_decoder *d, int n_tasks)
 {
     {
         std::lock_guard<std::mutex> lk(d->m);
-        d->dev.phase = phase;
-        for (int j = 0; j < n_tasks; j++) { d->tasks.emplace_back(nullptr, j); d->dev.pending++; }
+        for (int j = 0; j < n_tasks; j++) { d->tasks.emplace_front(nullptr, -1 - j); d->dev.pending++; }   // ahead of the headers still queued: a step is waiting
         d->cv_work.notify_all();
     }
     gopd_join(d, &d->dev.pending);
@@ -1023,7 +1035,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     std::sort(v.pk.begin(), v.pk.end(), [](const GopDevPacket &a, const GopDevPacket &b) { return a.frame < b.frame; });
     const size_t n = v.pk.size();
     if (!v.pk_host.resize(n) || !v.status_host.resize(n)) return fail(ctx, PFV_ERR_NOMEM, "device-entropy staging");
-    std::vector<size_t> p0((size_t)steps + 1, n), byte0((size_t)steps + 1, 0), grp0((size_t)steps + 1, 0);
+    std::vector<size_t> p0((size_t)steps + 1, n), byte0((size_t)steps + 1, 0);
     size_t bytes_total = 0;
     for (size_t j = 0; j < n; j++) {
         EdPacket &k = v.pk_host.data()[j];
@@ -1037,29 +1049,16 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     for (size_t t = (size_t)steps; t-- > 0;)
         if (p0[t] == n) { p0[t] = p0[t + 1]; byte0[t] = byte0[t + 1]; }
     if (!v.bytes_host.resize(bytes_total + 64)) return fail(ctx, PFV_ERR_NOMEM, "device-entropy payload staging");
-    gopd_dev_run_phase(d, 1, (int)n);
-    d->stats[1] += clk.lap();
-
-    size_t total_sub = 0, n_groups = 0;
+    // room on the device from upper bounds (a lane per sub_bits payload bits), so that nothing has to wait for the headers
+    size_t sub_max = 0, grp_max = 0;
     for (size_t j = 0; j < n; j++) {
-        EdPacket &k = v.pk_host.data()[j];
-        if (v.pk[j].rc || v.pk[j].host_parse) k.n_sub = 0;
-        k.sub_first = (uint32_t)total_sub;
-        k.grp_first = (uint32_t)n_groups;
-        total_sub += k.n_sub;
-        n_groups += (k.n_sub + kEdThreads - 1) / kEdThreads;
+        const size_t lanes = ((size_t)v.pk[j].ev->plen * 8 + v.sub_bits - 1) / v.sub_bits;
+        sub_max += lanes;
+        grp_max += (lanes + kEdThreads - 1) / kEdThreads;
     }
-    if (total_sub >= 0xffffffffull) return 1;
+    if (sub_max >= 0xffffffffull) return 1;
     int rc = PFV_OK;
-    if (!v.groups_host.resize(std::max<size_t>(n_groups, 1))) return fail(ctx, PFV_ERR_NOMEM, "device-entropy staging");
-    {
-        size_t g = 0, t = 0;
-        for (size_t j = 0; j < n; j++) {
-            for (; t <= (size_t)steps && p0[t] <= j; t++) grp0[t] = g;
-            for (uint32_t b = 0; b * (uint32_t)kEdThreads < v.pk_host.data()[j].n_sub; b++) v.groups_host.data()[g++] = make_uint2((unsigned)j, b);
-        }
-        for (; t <= (size_t)steps; t++) grp0[t] = g;
-    }
+    if (!v.groups_host.resize(std::max<size_t>(grp_max, 1))) return fail(ctx, PFV_ERR_NOMEM, "device-entropy staging");
     if ((rc = gopd_dev_room(ctx, &v.bytes_dev, &v.bytes_cap, bytes_total + 64))) return rc;
     if (n > v.pk_cap) {
         if (v.pk_dev) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(v.pk_dev); (void)hipFree(v.status_dev); v.pk_dev = nullptr; v.status_dev = nullptr; v.pk_cap = 0; }
@@ -1067,8 +1066,8 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         HIP_TRY(ctx, hipMalloc((void **)&v.status_dev, (n + n / 4) * sizeof(uint32_t)));
         v.pk_cap = n + n / 4;
     }
-    if ((rc = gopd_dev_room(ctx, &v.groups_dev, &v.groups_cap, std::max<size_t>(n_groups, 1)))) return rc;
-    if ((rc = gopd_dev_room(ctx, &v.sub_dev, &v.sub_cap, std::max<size_t>(total_sub, 1) * 4))) return rc;
+    if ((rc = gopd_dev_room(ctx, &v.groups_dev, &v.groups_cap, std::max<size_t>(grp_max, 1)))) return rc;
+    if ((rc = gopd_dev_room(ctx, &v.sub_dev, &v.sub_cap, std::max<size_t>(sub_max, 1) * 4))) return rc;
     while (v.window_done.size() < (size_t)steps) {
         hipEvent_t ev = nullptr, ev2 = nullptr;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1076,34 +1075,61 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         HIP_TRY(ctx, hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
         v.window_up.push_back(ev2);
     }
-    // every window of the batch: uploads and clears on one stream, the kernels behind them on another
-    HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev, v.pk_host.data(), n * sizeof(EdPacket), hipMemcpyHostToDevice, v.up_stream));
-    if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev, v.groups_host.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, v.up_stream));
     HIP_TRY(ctx, hipMemsetAsync(v.status_dev, 0, n * sizeof(uint32_t), v.up_stream));
-    const size_t ts = v.sub_cap / 4;
-    for (int t = 0; t < steps; t++) {
-        const size_t f0 = (size_t)t * S;
-        const size_t ba = byte0[(size_t)t], bb = byte0[(size_t)t + 1];
-        if (bb > ba) HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev + ba, v.bytes_host.data() + ba, bb - ba, hipMemcpyHostToDevice, v.up_stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + f0 * tb * 2, v.mv_host.data() + f0 * tb * 2, S * tb * 2, hipMemcpyHostToDevice, v.up_stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + f0 * tb, v.has_host.data() + f0 * tb, S * tb, hipMemcpyHostToDevice, v.up_stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev + f0 * tb, v.coded_host.data() + f0 * tb, S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, v.up_stream));
-        HIP_TRY(ctx, hipMemsetAsync(v.coef_dev + f0 * tb * 256, 0, S * tb * 512, v.up_stream));
-        HIP_TRY(ctx, hipEventRecord(v.window_up[(size_t)t], v.up_stream));
-    }
-    for (int t = 0; t < steps; t++) {
-        const size_t pa = p0[(size_t)t], pb = p0[(size_t)t + 1], ga = grp0[(size_t)t], gb = grp0[(size_t)t + 1];
-        HIP_TRY(ctx, hipStreamWaitEvent(v.stream, v.window_up[(size_t)t], 0));
-        if (gb > ga) {
-            EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, v.coef_dev, v.status_dev,
-                     (uint32_t)pa, (uint32_t)ga};
-            const unsigned np = (unsigned)(pb - pa), ng = (unsigned)(gb - ga);
-            entd_launch(v.stream, b, np, ng, v.launches, v.inner);
-            if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
+    // the packets' headers: on the pool, in (step, slot) order; nobody waits for all of them -- a step's window starts when ITS packets are ready
+    {
+        std::lock_guard<std::mutex> lk(d->m);
+        v.step_pending.assign((size_t)steps, 0);
+        for (size_t j = 0; j < n; j++) {
+            d->tasks.emplace_back(nullptr, (int)j);
+            v.step_pending[(size_t)v.pk[j].ev->t]++;
         }
-        if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data() + pa, v.status_dev + pa, (pb - pa) * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
-        HIP_TRY(ctx, hipEventRecord(v.window_done[(size_t)t], v.stream));
+        d->cv_work.notify_all();
     }
+    const size_t ts = v.sub_cap / 4;
+    size_t total_sub = 0, n_groups = 0;
+    int next_window = 0;
+    // the windows of steps [next_window, upto]: uploads and clears on one stream, the kernels behind them on another
+    auto windows_upto = [&](int upto) -> int {
+        for (; next_window <= upto && next_window < steps; next_window++) {
+            const int t = next_window;
+            GopClock wclk;
+            gopd_join(d, &v.step_pending[(size_t)t]);
+            d->stats[1] += wclk.lap();
+            const size_t f0 = (size_t)t * S, pa = p0[(size_t)t], pb = p0[(size_t)t + 1], ga = n_groups;
+            for (size_t j = pa; j < pb; j++) {
+                EdPacket &k = v.pk_host.data()[j];
+                if (v.pk[j].rc || v.pk[j].host_parse) k.n_sub = 0;
+                k.sub_first = (uint32_t)total_sub;
+                k.grp_first = (uint32_t)n_groups;
+                total_sub += k.n_sub;
+                for (uint32_t b = 0; b * (uint32_t)kEdThreads < k.n_sub; b++) v.groups_host.data()[n_groups++] = make_uint2((unsigned)j, b);
+            }
+            const size_t gb = n_groups, ba = byte0[(size_t)t], bb = byte0[(size_t)t + 1];
+            if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev + pa, v.pk_host.data() + pa, (pb - pa) * sizeof(EdPacket), hipMemcpyHostToDevice, v.up_stream));
+            if (gb > ga) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev + ga, v.groups_host.data() + ga, (gb - ga) * sizeof(uint2), hipMemcpyHostToDevice, v.up_stream));
+            if (bb > ba) HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev + ba, v.bytes_host.data() + ba, bb - ba, hipMemcpyHostToDevice, v.up_stream));
+            HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + f0 * tb * 2, v.mv_host.data() + f0 * tb * 2, S * tb * 2, hipMemcpyHostToDevice, v.up_stream));
+            HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + f0 * tb, v.has_host.data() + f0 * tb, S * tb, hipMemcpyHostToDevice, v.up_stream));
+            HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev + f0 * tb, v.coded_host.data() + f0 * tb, S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, v.up_stream));
+            HIP_TRY(ctx, hipMemsetAsync(v.coef_dev + f0 * tb * 256, 0, S * tb * 512, v.up_stream));
+            HIP_TRY(ctx, hipEventRecord(v.window_up[(size_t)t], v.up_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(v.stream, v.window_up[(size_t)t], 0));
+            if (gb > ga) {
+                EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, v.coef_dev, v.status_dev,
+                         (uint32_t)pa, (uint32_t)ga};
+                entd_launch(v.stream, b, (unsigned)(pb - pa), (unsigned)(gb - ga), v.launches, v.inner);
+                const int lrc = launch_check(ctx, "k_entd_*");
+                if (lrc) return lrc;
+            }
+            if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data() + pa, v.status_dev + pa, (pb - pa) * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
+            HIP_TRY(ctx, hipEventRecord(v.window_done[(size_t)t], v.stream));
+            d->stats[3] += wclk.lap();
+        }
+        return PFV_OK;
+    };
+    constexpr int kWindowsAhead = 4;     // windows enqueued ahead of the step being decoded
+    if ((rc = windows_upto(kWindowsAhead))) return rc;
     d->stats[3] += clk.lap();
 
     if (d->gfirst[0] == 2 && d->cont_valid) {   // slot 0 continues the run the previous batch left open
@@ -1119,6 +1145,8 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     std::vector<uint32_t> combos;
     for (int t = 0; t < steps; t++) {
         const size_t f0 = (size_t)t * S, pa = p0[(size_t)t], pb = p0[(size_t)t + 1];
+        if ((rc = windows_upto(t + kWindowsAhead))) return rc;
+        clk.lap();
         HIP_TRY(ctx, hipEventSynchronize(v.window_done[(size_t)t]));
         d->stats[5] += clk.lap();
         // what the device stage was not sure about goes through the host parser, which decides
@@ -1135,7 +1163,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             const int cnt = (int)std::min<size_t>((size_t)kGopDevDense, v.todo.size() - first);
             if (!v.dense_host.resize((size_t)kGopDevDense * tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
             v.todo_first = (int)first;
-            gopd_dev_run_phase(d, 2, cnt);
+            gopd_dev_hostparse_group(d, cnt);
             for (int j = 0; j < cnt; j++) {
                 const GopDevPacket &p = v.pk[(size_t)v.todo[first + (size_t)j]];
                 if (p.rc) continue;
@@ -1151,7 +1179,10 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             if (!p.rc)
                 for (int i = 0; i < 3; i++)
                     if (p.qidx[i] >= hot->n_qtables) p.rc = PFV_ERR_FORMAT;      // the reference panics (src/dec.rs:249-251)
-            if (p.rc && t == 0 && p.ev->type == 1) return 1;                    // not an independent run after all: the chains change
+            if (p.rc && t == 0 && p.ev->type == 1) {                            // not an independent run after all: the chains change
+                gopd_drain_pool(d);                                              // (headers still queued or being read belong to this attempt)
+                return 1;
+            }
         }
         for (size_t j = pa; j < pb; j++) {
             GopDevPacket &p = v.pk[j];
