@@ -2009,9 +2009,10 @@ static int encode_on_device(pfv_encoder *e, bool pframe)
     if (rc) return rc;
     {   // the caller's planes are read until the first synchronisation below (pfv_enc_payload_sizes); every exit before it synchronises too
         const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
-        hipError_t he = hipMemcpyAsync(s->st_frames, e->plane[0], ny, hipMemcpyHostToDevice, ctx->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(s->st_frames + ny, e->plane[1], nc, hipMemcpyHostToDevice, ctx->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(s->st_frames + ny + nc, e->plane[2], nc, hipMemcpyHostToDevice, ctx->stream);
+        const bool packed = e->plane[1] == e->plane[0] + ny && e->plane[2] == e->plane[1] + nc;   // a packed frame: one copy
+        hipError_t he = hipMemcpyAsync(s->st_frames, e->plane[0], packed ? ny + 2 * nc : ny, hipMemcpyHostToDevice, ctx->stream);
+        if (!packed && he == hipSuccess) he = hipMemcpyAsync(s->st_frames + ny, e->plane[1], nc, hipMemcpyHostToDevice, ctx->stream);
+        if (!packed && he == hipSuccess) he = hipMemcpyAsync(s->st_frames + ny + nc, e->plane[2], nc, hipMemcpyHostToDevice, ctx->stream);
         if (he != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return hip_fail(ctx, he, "plane upload"); }
     }
     rc = pframe ? pfv_enc_pframe_dev(s, s->st_frames, s->st_mv, s->st_has, s->st_coef) : pfv_enc_iframe_dev(s, s->st_frames, s->st_coef);

@@ -276,9 +276,13 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
     // the three planes go straight to their place in the step's frame array (VideoFrame, src/frame.rs:3-9: no packing on the host)
     uint8_t *dst = B->frames_dev + ((size_t)t * (size_t)e->max_gops + (size_t)slot) * e->frame_bytes;
     const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
-    HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny, hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(ctx, hipMemcpyAsync(dst + ny, u, nc, hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(ctx, hipMemcpyAsync(dst + ny + nc, v, nc, hipMemcpyHostToDevice, e->copy_stream));
+    if (u == y + ny && v == u + nc) {   // a packed frame: one copy
+        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, hipMemcpyHostToDevice, e->copy_stream));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst + ny, u, nc, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst + ny + nc, v, nc, hipMemcpyHostToDevice, e->copy_stream));
+    }
     B->order.push_back(GopPacket{(uint8_t)type, slot, t});
     e->frames_in++;
     // the caller's planes are free again when the call returns (they are being read by the copy engine until then; the kernels of the
