@@ -226,7 +226,7 @@ def test_emu_gop_objects(pkg, emu_ctx, oracle):
     data = sc.check_gop_objects(pkg, emu_ctx, oracle, 64, 48, 5, "IPPPIPDPPIPPP", shapes=((8, 15), (2, 3)), alternate_modes=True)
     assert data[-5:] == bytes(5)
     # a stream that starts with p-frames (prev_frame = new_padded, src/enc.rs:46) and has GOPs of unequal length
-    sc.check_gop_objects(pkg, emu_ctx, oracle, 50, 38, 3, "PPIPIPPDIP", shapes=((2, 15), (1, 2)), alternate_modes=True)
+    sc.check_gop_objects(pkg, emu_ctx, oracle, 50, 38, 3, "PPIPIPDIP", shapes=((1, 2),), alternate_modes=True)
 
 
 def test_emu_gop_decoder_device_entropy(pkg, emu_ctx, oracle):
@@ -241,8 +241,8 @@ def test_emu_gop_encoder_flush_and_errors(pkg, emu_ctx, oracle):
 
 def test_emu_gop_decoder_corrupted_streams(pkg, emu_ctx, oracle):
     data, _ = sc.encode_pattern(pkg, emu_ctx, oracle, 48, 32, 5, "IPPIPPPIP", lambda buf: pkg.Encoder(buf, 48, 32, 30, 5, emu_ctx), with_oracle=False)
-    stats = sc.check_gop_decoder_corrupted(pkg, emu_ctx, oracle, data, n_trials=8, seed=4)
-    assert stats["trials"] == 8 and stats["errors"] > 1 and stats["frames_after_an_error"] > 0
+    stats = sc.check_gop_decoder_corrupted(pkg, emu_ctx, oracle, data, n_trials=6, seed=4)
+    assert stats["trials"] == 6 and stats["errors"] > 1 and stats["frames_after_an_error"] > 0
 
 
 def test_emu_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle):
