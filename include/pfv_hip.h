@@ -468,6 +468,10 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
                                    size_t payload_budget, pfv_gop_encoder **out);
 PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+/* the same for a packed frame (Y | U | V, pfv_frame_bytes) that already lies in DEVICE memory and is complete when the call is made
+ * (frames a renderer or another kernel left in HBM): nothing crosses PCIe on the way in; the frame may be overwritten on return */
+PFV_API int pfv_gop_encoder_encode_iframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
+PFV_API int pfv_gop_encoder_encode_pframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
 PFV_API int pfv_gop_encoder_encode_dropframe(pfv_gop_encoder *e);
 PFV_API int pfv_gop_encoder_flush(pfv_gop_encoder *e);
 PFV_API int pfv_gop_encoder_finish(pfv_gop_encoder *e);

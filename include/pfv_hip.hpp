@@ -249,6 +249,17 @@ class GopEncoder {
         ctx_.check(pfv_gop_encoder_encode_pframe(h_, f.plane_y.pixels.data(), f.plane_u.pixels.data(), f.plane_v.pixels.data()));
         drain();
     }
+    // a packed frame (Y | U | V) that already lies in device memory, complete when the call is made: nothing crosses PCIe on the way in
+    void encode_iframe_device(const uint8_t *frame_dev)
+    {
+        ctx_.check(pfv_gop_encoder_encode_iframe_dev(h_, frame_dev));
+        drain();
+    }
+    void encode_pframe_device(const uint8_t *frame_dev)
+    {
+        ctx_.check(pfv_gop_encoder_encode_pframe_dev(h_, frame_dev));
+        drain();
+    }
     void encode_dropframe() { ctx_.check(pfv_gop_encoder_encode_dropframe(h_)); }   // src/enc.rs:175-180
     void flush()                              // every frame handed over so far becomes packets at the writer now
     {

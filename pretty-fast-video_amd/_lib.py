@@ -162,6 +162,8 @@ SIGNATURES = [
     ("pfv_gop_encoder_create", c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_size_t, POINTER(_P)]),
     ("pfv_gop_encoder_encode_iframe", c_int, [_P, _P, _P, _P]),
     ("pfv_gop_encoder_encode_pframe", c_int, [_P, _P, _P, _P]),
+    ("pfv_gop_encoder_encode_iframe_dev", c_int, [_P, _P]),
+    ("pfv_gop_encoder_encode_pframe_dev", c_int, [_P, _P]),
     ("pfv_gop_encoder_encode_dropframe", c_int, [_P]),
     ("pfv_gop_encoder_flush", c_int, [_P]),
     ("pfv_gop_encoder_finish", c_int, [_P]),

@@ -246,19 +246,19 @@ static int gop_enc_rotate(pfv_gop_encoder *e)
     return gop_enc_collect(e, e->batch[e->cur]);
 }
 
-static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v);
-static int gop_enc_frame(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v, bool on_device);
+static int gop_enc_frame(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v, bool on_device = false)
 {
     if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
     pfv_ctx *ctx = e->ctx;
     if (!y || !u || !v) return fail(ctx, PFV_ERR_BAD_ARG, "null plane");
     if (e->finished) return fail(ctx, PFV_ERR_STATE, "encoder already finished (src/enc.rs:80)");
     if (e->failed) return fail(ctx, PFV_ERR_STATE, "an earlier batch failed: the stream is incomplete");
-    const int rc = gop_enc_frame_inner(e, type, y, u, v);
+    const int rc = gop_enc_frame_inner(e, type, y, u, v, on_device);
     if (rc) e->failed = true;          // a frame is missing from the stream from here on (the reference's Encoder would have panicked)
     return rc;
 }
-static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, const uint8_t *u, const uint8_t *v, bool on_device)
 {
     pfv_ctx *ctx = e->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -276,12 +276,13 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
     // the three planes go straight to their place in the step's frame array (VideoFrame, src/frame.rs:3-9: no packing on the host)
     uint8_t *dst = B->frames_dev + ((size_t)t * (size_t)e->max_gops + (size_t)slot) * e->frame_bytes;
     const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;   // *_dev: a frame that is in device memory already
     if (u == y + ny && v == u + nc) {   // a packed frame: one copy
-        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, e->copy_stream));
     } else {
-        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny, hipMemcpyHostToDevice, e->copy_stream));
-        HIP_TRY(ctx, hipMemcpyAsync(dst + ny, u, nc, hipMemcpyHostToDevice, e->copy_stream));
-        HIP_TRY(ctx, hipMemcpyAsync(dst + ny + nc, v, nc, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny, kind, e->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst + ny, u, nc, kind, e->copy_stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dst + ny + nc, v, nc, kind, e->copy_stream));
     }
     B->order.push_back(GopPacket{(uint8_t)type, slot, t});
     e->frames_in++;
@@ -374,6 +375,16 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
 // as the call returns; the packet appears (pfv_gop_encoder_drain) when its batch is complete -- pfv_gop_encoder_flush forces that.
 PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v) { return gop_enc_frame(e, 1, y, u, v); }
 PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v) { return gop_enc_frame(e, 2, y, u, v); }
+// the same for a packed frame (Y | U | V, pfv_frame_bytes) that lies in DEVICE memory and is complete when the call is made -- frames a
+// renderer or another kernel left in HBM: nothing crosses PCIe on the way in.  The frame may be overwritten when the call returns.
+static int gop_enc_frame_dev(pfv_gop_encoder *e, int type, const uint8_t *frame_dev)
+{
+    if (!e || !frame_dev) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_encode_*_dev: bad argument");
+    const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
+    return gop_enc_frame(e, type, frame_dev, frame_dev + ny, frame_dev + ny + nc, true);
+}
+PFV_API int pfv_gop_encoder_encode_iframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev) { return gop_enc_frame_dev(e, 1, frame_dev); }
+PFV_API int pfv_gop_encoder_encode_pframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev) { return gop_enc_frame_dev(e, 2, frame_dev); }
 PFV_API int pfv_gop_encoder_encode_dropframe(pfv_gop_encoder *e)
 {
     if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");

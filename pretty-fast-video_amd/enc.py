@@ -226,6 +226,17 @@ class GopEncoder(Encoder):
         self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_pframe(self.handle, *self._planes(frame)))
         self._flush()
 
+    def encode_iframe_dev(self, frame_dev: int):
+        """a packed frame (Y | U | V) that already lies in device memory, complete: pfv_gop_encoder_encode_iframe_dev"""
+        assert not self.finished
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_iframe_dev(self.handle, ctypes.c_void_p(int(frame_dev))))
+        self._flush()
+
+    def encode_pframe_dev(self, frame_dev: int):
+        assert not self.finished
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_pframe_dev(self.handle, ctypes.c_void_p(int(frame_dev))))
+        self._flush()
+
     def encode_dropframe(self):
         assert not self.finished
         self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_dropframe(self.handle))

@@ -431,6 +431,26 @@ def check_gop_objects(pkg, ctx, oracle, w, h, quality, pattern, shapes, frame_sr
             assert len(got) == len(want), (max_gops, max_len, mode, [x[0] for x in got], [x[0] for x in want])
             for k, (a, b) in enumerate(zip(got, want)):
                 assert a == b, f"GOP-batched decoder (max_gops {max_gops}, max_gop_frames {max_len}, payloads read on the {mode}): call {k} gives {a[0]}, the oracle {b[0]}"
+    # frames taken from device memory (pfv_gop_encoder_encode_*_dev): the same stream
+    if True:
+        max_gops, max_len = shapes[0]
+        fbytes = w * h + 2 * (w // 2) * (h // 2)
+        src = frame_src if frame_src is not None else pkg.SyntheticStream(w, h).frame
+        dev = ctx.alloc(fbytes)
+        dbuf = io.BytesIO()
+        denc = pkg.GopEncoder(dbuf, w, h, 30, quality, ctx, max_gops=max_gops, max_gop_frames=max_len)
+        t = 0
+        for c in pattern:
+            if c == "D":
+                denc.encode_dropframe()
+                continue
+            ctx.upload(dev, np.ascontiguousarray(src(t)))
+            (denc.encode_iframe_dev if c == "I" else denc.encode_pframe_dev)(dev)
+            t += 1
+        denc.finish()
+        denc.close()
+        ctx.free(dev)
+        assert dbuf.getvalue() == serial, "GOP-batched encoder fed from device memory wrote a different .pfv stream"
     # frames left in device memory (pfv_gop_decoder_set_output_device): the same bytes, fetched from the addresses the callback gets
     max_gops, max_len = shapes[-1]
     fb = w * h + 2 * (w // 2) * (h // 2)
