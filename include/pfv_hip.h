@@ -539,6 +539,9 @@ PFV_API int pfv_decoder_set_lookahead(pfv_decoder *d, int n_threads);
  * then only read tables and block headers.  counts_out[0]: packets the device read so far, [1]: packets its stage was not certain
  * about and left to the host parser.  Same frames and results either way. */
 PFV_API void pfv_decoder_entropy_counts(const pfv_decoder *d, long counts_out[2]);
+/* on != 0: the decoded frame stays in device memory; the callback's y / u / v are DEVICE pointers to the packed frame (u == y + w*h,
+ * v == u + (w/2)*(h/2)), valid until the next advance call (see pfv_gop_decoder_set_output_device) */
+PFV_API int pfv_decoder_set_output_device(pfv_decoder *d, int on);
 PFV_API int pfv_decoder_width(const pfv_decoder *d);
 PFV_API int pfv_decoder_height(const pfv_decoder *d);
 PFV_API int pfv_decoder_framerate(const pfv_decoder *d);

@@ -181,6 +181,7 @@ SIGNATURES = [
     ("pfv_gop_decoder_stats", c_int, [_P, _P, c_int]),
     ("pfv_gop_decoder_set_output_device", c_int, [_P, c_int]),
     ("pfv_decoder_entropy_counts", None, [_P, _P]),
+    ("pfv_decoder_set_output_device", c_int, [_P, c_int]),
     ("pfv_batch_decoder_entropy_counts", None, [_P, _P]),
     ("pfv_gop_decoder_reset", c_int, [_P]),
     ("pfv_gop_decoder_advance_frame", c_int, [_P, _P, _P]),

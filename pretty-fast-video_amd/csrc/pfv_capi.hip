@@ -1925,6 +1925,7 @@ struct pfv_decoder {
     bool eof = false;
     double delta_accum = 0.0;
     PinnedBuf<uint8_t> retframe;           // Y|U|V, unpadded (src/dec.rs:22)
+    uint8_t *frame_dev = nullptr;          // pfv_decoder_set_output_device: the retframe in device memory instead
     // look-ahead: ring of events in stream order, [head, head + count)
     std::vector<std::unique_ptr<DecEvent>> ring;
     size_t head = 0, count = 0;
@@ -3048,6 +3049,7 @@ PFV_API void pfv_decoder_destroy(pfv_decoder *d)
     (void)hipSetDevice(d->ctx->device);
     (void)hipStreamSynchronize(d->ctx->stream);
     if (d->win_stream) { (void)hipStreamSynchronize(d->win_stream); (void)hipStreamDestroy(d->win_stream); }
+    if (d->frame_dev) (void)hipFree(d->frame_dev);
     for (DecWindow &w : d->win) {
         for (void *p : {(void *)w.bytes_dev, (void *)w.pk_dev, (void *)w.status_dev, (void *)w.coded_dev, (void *)w.groups_dev, (void *)w.sub_dev, (void *)w.coef_dev,
                         (void *)w.mv_dev, (void *)w.has_dev})
@@ -3056,6 +3058,17 @@ PFV_API void pfv_decoder_destroy(pfv_decoder *d)
     }
     pfv_dec_session_destroy(d->hot);
     delete d;
+}
+// on != 0: the decoded frame stays in device memory and the callback's y / u / v are DEVICE pointers to the packed frame (valid until the
+// next advance call) -- for consumers on the GPU; the frame's download, more than half of a 4K call, is not paid
+PFV_API int pfv_decoder_set_output_device(pfv_decoder *d, int on)
+{
+    if (!d) return fail(nullptr, PFV_ERR_BAD_ARG, "null decoder");
+    pfv_ctx *ctx = d->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (on && !d->frame_dev) HIP_TRY(ctx, hipMalloc((void **)&d->frame_dev, pfv_frame_bytes(d->width, d->height)));
+    if (!on && d->frame_dev) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(d->frame_dev); d->frame_dev = nullptr; }
+    return PFV_OK;
 }
 PFV_API void pfv_decoder_entropy_counts(const pfv_decoder *d, long counts_out[2])
 {
@@ -3210,7 +3223,12 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
             rc = e->type == 1 ? pfv_dec_iframe_sparse(d->hot, e->idx.data(), e->val.data(), e->n_sparse, e->qidx)
                               : pfv_dec_pframe_sparse(d->hot, e->mv.data(), e->has.data(), e->idx.data(), e->val.data(),
                                                       e->n_sparse, e->qidx);
-        if (!rc) rc = pfv_dec_get_frame(d->hot, d->retframe.data());   // crop blits (:195-197, 209-211)
+        if (!rc && d->frame_dev) {   // pfv_decoder_set_output_device: the retframe stays in device memory
+            rc = pfv_dec_get_frame_dev(d->hot, d->frame_dev);
+            if (!rc) rc = pfv_ctx_sync(d->ctx);
+        } else if (!rc) {
+            rc = pfv_dec_get_frame(d->hot, d->retframe.data());   // crop blits (:195-197, 209-211)
+        }
         lk.lock();
     }
     e->state = DecEvent::FREE;
@@ -3221,7 +3239,8 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
     if (rc) return rc;
     if (kind == DecEvent::FRAME && onvideo) {
         size_t ny = (size_t)d->width * d->height, nc = (size_t)(d->width / 2) * (d->height / 2);
-        onvideo(user, d->retframe.data(), d->retframe.data() + ny, d->retframe.data() + ny + nc, d->width, d->height);
+        const uint8_t *f = d->frame_dev ? d->frame_dev : d->retframe.data();
+        onvideo(user, f, f + ny, f + ny + nc, d->width, d->height);
     }
     return 1;
 }

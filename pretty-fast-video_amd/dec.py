@@ -46,6 +46,12 @@ class Decoder:
         if lookahead is not None:                                   # packets parsed ahead on this many worker threads
             ctx.check(ctx._lib.pfv_decoder_set_lookahead(h, int(lookahead)))
 
+    def set_output_device(self, on: bool = True):
+        """frames stay in device memory: ``onvideo`` then gets the packed frame's DEVICE address (an int; planes back to back),
+        valid until the next advance call (pfv_decoder_set_output_device)"""
+        self.ctx.check(self.ctx._lib.pfv_decoder_set_output_device(self.handle, 1 if on else 0))
+        self._device_out = bool(on)
+
     def entropy_counts(self) -> dict:
         """packets whose run streams the device read / that its stage left to the host parser (pfv_decoder_entropy_counts)"""
         a = (ctypes.c_long * 2)()
@@ -65,6 +71,9 @@ class Decoder:
         self.ctx.check(self.ctx._lib.pfv_decoder_reset(self.handle))
 
     def _callback(self, onvideo):
+        if getattr(self, "_device_out", False):
+            return _CB(lambda _user, y, u, v, w, h: onvideo(int(y or 0)))
+
         def cb(_user, y, u, v, w, h):
             def arr(p, n):
                 return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)).copy()

@@ -72,6 +72,19 @@ def check_stream_roundtrip(pkg, ctx, oracle, w, h, quality, n_frames, gop, drop_
     for a, b in zip(frames, oframes):
         assert np.array_equal(a, b)
     assert dec.advance_frame(lambda fr: None) is False               # stays at EOF (dec.rs:171-173)
+    # frames left in device memory (pfv_decoder_set_output_device): fetched from the address the callback gets
+    ddec = pkg.Decoder(io.BytesIO(data), ctx)
+    ddec.set_output_device(True)
+    dframes = []
+
+    def on_dev(addr):
+        a = np.empty(w * h + 2 * (w // 2) * (h // 2), np.uint8)
+        ctx.download(a, addr)
+        dframes.append(a)
+    while ddec.advance_frame(on_dev):
+        pass
+    ddec.close()
+    assert len(dframes) == len(frames) and all(np.array_equal(a, b) for a, b in zip(dframes, frames)), "frames left in device memory differ"
     dec.reset()                                                      # dec.rs:148-152
     again = []
     assert dec.advance_frame(lambda fr: again.append(fr.packed())) is True
