@@ -2421,6 +2421,7 @@ static void bd_worker(pfv_batch_decoder *b)
 static void bd_scan_and_start(pfv_batch_decoder *b, BdSet *s)
 {
     s->type = 0;
+    s->dev_form = false;        // only a step of frame packets takes the device form (set below)
     int first = -1;
     bool all_empty = true, any_empty = false;
     for (int k = 0; k < b->n; k++) {
