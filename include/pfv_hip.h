@@ -350,6 +350,22 @@ PFV_API int pfv_dec_pframe(pfv_dec_session *s, const int8_t *mv, const uint8_t *
 PFV_API int pfv_dec_iframe_sparse(pfv_dec_session *s, const uint32_t *idx, const int16_t *val, size_t n, const uint8_t qidx[3]);
 PFV_API int pfv_dec_pframe_sparse(pfv_dec_session *s, const int8_t *mv, const uint8_t *has_coef, const uint32_t *idx,
                                   const int16_t *val, size_t n, const uint8_t qidx[3]);
+/* Coefficient lists (round 5): a frame's non-zero coefficients as 32-bit entries instead of its dense [macroblock][256] array -- the form the
+ * stream decoders' entropy stage hands to the decode kernels, which expand a strip's entries straight into their LDS zigzag stage (the
+ * reference expands runs into the macroblock it is about to decode, src/dec.rs:258-296, 378-417); nothing is cleared and nothing but the
+ * values travels.
+ *   entry   value (i16) << 16 | (macroblock index & 255) << 8 | position in the macroblock (0..255), ascending by (macroblock, position);
+ *   range   per macroblock two uint32: its entries are [begin, end) of its slot's list; ascending over ALL macroblocks of the frame (one
+ *           without entries: begin == end at its place).  The ranges are the kernels' loop bounds: they are not validated on the device.
+ * entries_dev: per slot of the session's window a DEVICE pointer to the slot's list (a device array of device pointers);
+ * ranges_dev: [slot][macroblock][2].  Same result as the dense call on the expanded arrays. */
+PFV_API int pfv_dec_iframe_lists_dev(pfv_dec_session *s, const uint32_t *const *entries_dev, const uint32_t *ranges_dev, const uint8_t qidx[3]);
+PFV_API int pfv_dec_pframe_lists_dev(pfv_dec_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev, const uint32_t *const *entries_dev,
+                                     const uint32_t *ranges_dev, const uint8_t qidx[3]);
+/* host helper: one frame's dense coefficients ([total_blocks][256]; has_coef NULL: every macroblock is read) as a coefficient list.  Room for
+ * `cap` entries and total_blocks ranges; *n_out = entries written; returns 1 when `cap` does not suffice (total_blocks x 256 always does). */
+PFV_API int pfv_coef_lists_from_dense(const int16_t *coef, const uint8_t *has_coef, int total_blocks, uint32_t *entries_out, size_t cap,
+                                      uint32_t *ranges_out, size_t *n_out);
 /* Decoder::advance_frame's crop of framebuffer into retframe (src/dec.rs:195-197,
  * 209-211): frames_out = n_streams unpadded frames (Y|U|V). */
 PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev);

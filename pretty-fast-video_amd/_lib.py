@@ -123,6 +123,9 @@ SIGNATURES = [
     ("pfv_enc_payload_fetch", c_int, [_P, c_int, _P, c_size_t]),
     ("pfv_dec_iframe_sparse", c_int, [_P, _P, _P, c_size_t, _P]),
     ("pfv_dec_pframe_sparse", c_int, [_P, _P, _P, _P, _P, c_size_t, _P]),
+    ("pfv_dec_iframe_lists_dev", c_int, [_P, _P, _P, _P]),
+    ("pfv_dec_pframe_lists_dev", c_int, [_P, _P, _P, _P, _P, _P]),
+    ("pfv_coef_lists_from_dense", c_int, [_P, _P, c_int, _P, c_size_t, _P, POINTER(c_size_t)]),
     ("pfv_dec_session_create", c_int, [_P, c_int, c_int, _P, c_int, c_int, POINTER(_P)]),
     ("pfv_dec_session_destroy", None, [_P]),
     ("pfv_dec_iframe_dev", c_int, [_P, _P, _P]),

@@ -525,16 +525,44 @@ static void launch_enc_pframe(pfv_ctx *ctx, bool flt, bool small, bool compactio
 {
     launch_enc_pframe_kernels(ctx->stream, flt, small, compaction ? kPencCompactMax : 0, g, penc_blocks(ctx, g), src, ref, mv, has, coef, recon, qt, min_err);
 }
-static void launch_dec_iframe(pfv_ctx *ctx, bool small, const FrameGeom &g, const int16_t *coef, uint8_t *out, const QTab *qt, uint8_t *frames_out)
+// where a decode launch finds its coefficients: the dense [slot][macroblock][256] array, or coefficient lists (pfv_device.h: CoefLists)
+struct DecCoefs {
+    const int16_t *dense = nullptr;
+    CoefLists lists{nullptr, nullptr};
+    DecCoefs() = default;
+    DecCoefs(const int16_t *d) : dense(d) {}
+    DecCoefs(const uint32_t *const *entries, const uint2 *ranges) : lists{entries, ranges} {}
+    bool is_lists() const { return lists.entries != nullptr; }
+    DecCoefs shifted(size_t slot, size_t mbs_per_frame) const
+    {
+        DecCoefs c;
+        if (dense) c.dense = dense + slot * mbs_per_frame * 256;
+        if (lists.entries) c.lists = CoefLists{lists.entries + slot, lists.ranges + slot * mbs_per_frame};
+        return c;
+    }
+};
+static void launch_dec_iframe(pfv_ctx *ctx, bool small, const FrameGeom &g, const DecCoefs &c, uint8_t *out, const QTab *qt, uint8_t *frames_out)
 {
-    if (small) hipLaunchKernelGGL(k_dec_iframe<16>, dim3(half_strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef, out, qt, frames_out);
-    else hipLaunchKernelGGL(k_dec_iframe<8>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, coef, out, qt, frames_out);
+    const dim3 grid(small ? half_strip_blocks(g) : strip_blocks(g)), block(kThreads);
+    if (c.is_lists()) {
+        if (small) hipLaunchKernelGGL((k_dec_iframe<16, true>), grid, block, 0, ctx->stream, g, c.dense, c.lists, out, qt, frames_out);
+        else hipLaunchKernelGGL((k_dec_iframe<8, true>), grid, block, 0, ctx->stream, g, c.dense, c.lists, out, qt, frames_out);
+    } else {
+        if (small) hipLaunchKernelGGL((k_dec_iframe<16, false>), grid, block, 0, ctx->stream, g, c.dense, c.lists, out, qt, frames_out);
+        else hipLaunchKernelGGL((k_dec_iframe<8, false>), grid, block, 0, ctx->stream, g, c.dense, c.lists, out, qt, frames_out);
+    }
 }
-static void launch_dec_pframe(pfv_ctx *ctx, bool small, const FrameGeom &g, const int8_t *mv, const uint8_t *has, const int16_t *coef, const uint8_t *ref,
+static void launch_dec_pframe(pfv_ctx *ctx, bool small, const FrameGeom &g, const int8_t *mv, const uint8_t *has, const DecCoefs &c, const uint8_t *ref,
                               uint8_t *out, const QTab *qt, int *flag, uint8_t *frames_out)
 {
-    if (small) hipLaunchKernelGGL(k_dec_pframe<16>, dim3(half_strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, mv, has, coef, ref, out, qt, flag, frames_out);
-    else hipLaunchKernelGGL(k_dec_pframe<8>, dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, mv, has, coef, ref, out, qt, flag, frames_out);
+    const dim3 grid(small ? half_strip_blocks(g) : strip_blocks(g)), block(kThreads);
+    if (c.is_lists()) {
+        if (small) hipLaunchKernelGGL((k_dec_pframe<16, true>), grid, block, 0, ctx->stream, g, mv, has, c.dense, c.lists, ref, out, qt, flag, frames_out);
+        else hipLaunchKernelGGL((k_dec_pframe<8, true>), grid, block, 0, ctx->stream, g, mv, has, c.dense, c.lists, ref, out, qt, flag, frames_out);
+    } else {
+        if (small) hipLaunchKernelGGL((k_dec_pframe<16, false>), grid, block, 0, ctx->stream, g, mv, has, c.dense, c.lists, ref, out, qt, flag, frames_out);
+        else hipLaunchKernelGGL((k_dec_pframe<8, false>), grid, block, 0, ctx->stream, g, mv, has, c.dense, c.lists, ref, out, qt, flag, frames_out);
+    }
 }
 
 static int launch_check(pfv_ctx *ctx, const char *what)
@@ -1517,7 +1545,7 @@ static int dec_geom(pfv_dec_session *s, const uint8_t qidx[3], FrameGeom *g)
 static int dec_crop_win(pfv_dec_session *s, int first, int count, uint8_t *frames_out_dev, size_t out_stride);
 
 // Slots [first, first + count) of a session (see enc_launch): same launch on shifted bases, ping-pong index untouched.
-static int dec_launch(pfv_dec_session *s, bool pframe, int first, int count, const int8_t *mv_dev, const uint8_t *has_dev, const int16_t *coef_dev,
+static int dec_launch(pfv_dec_session *s, bool pframe, int first, int count, const int8_t *mv_dev, const uint8_t *has_dev, const DecCoefs &coefs,
                       const uint8_t qidx[3])
 {
     pfv_ctx *ctx = s->ctx;
@@ -1532,41 +1560,79 @@ static int dec_launch(pfv_dec_session *s, bool pframe, int first, int count, con
     g.n_streams = count;
     const int nxt = s->cur ^ 1;
     if (pframe) {
-        launch_dec_pframe(ctx, use_small_grid(s->lane_mapping, g), g, mv_dev + mb0 * 2, has_dev + mb0, coef_dev + mb0 * 256, s->fb[s->cur] + pad0,
-                          s->fb[nxt] + pad0, s->qtab_dev, s->flag_dev + first, crop);
+        launch_dec_pframe(ctx, use_small_grid(s->lane_mapping, g), g, mv_dev + mb0 * 2, has_dev + mb0, coefs.shifted((size_t)first, (size_t)s->geom.mbs_per_frame),
+                          s->fb[s->cur] + pad0, s->fb[nxt] + pad0, s->qtab_dev, s->flag_dev + first, crop);
         rc = launch_check(ctx, "k_dec_pframe");
     } else {
-        launch_dec_iframe(ctx, use_small_grid(s->lane_mapping, g), g, coef_dev + mb0 * 256, s->fb[nxt] + pad0, s->qtab_dev, crop);
+        launch_dec_iframe(ctx, use_small_grid(s->lane_mapping, g), g, coefs.shifted((size_t)first, (size_t)s->geom.mbs_per_frame), s->fb[nxt] + pad0, s->qtab_dev, crop);
         rc = launch_check(ctx, "k_dec_iframe");
     }
     return rc;
 }
 
-PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, const uint8_t qidx[3])
+}  // extern "C"
+// one frame operation on the session's window: the launch, the ping-pong, the separate crop pass where the fused one does not apply
+static int dec_step(pfv_dec_session *s, bool pframe, const int8_t *mv_dev, const uint8_t *has_coef_dev, const DecCoefs &coefs, const uint8_t qidx[3])
 {
-    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
     pfv_ctx *ctx = s->ctx;
-    if (!coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_dev: null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = dec_launch(s, false, s->win_first, s->win_count, nullptr, nullptr, coef_dev, qidx);
+    int rc = dec_launch(s, pframe, s->win_first, s->win_count, mv_dev, has_coef_dev, coefs, qidx);
     if (rc) return rc;
     s->cur ^= 1;
     if (s->frames_out && !fused_output_ok(s)) return dec_crop_win(s, s->win_first, s->win_count, s->frames_out, s->out_stride);
     return PFV_OK;
+}
+extern "C" {
+
+PFV_API int pfv_dec_iframe_dev(pfv_dec_session *s, const int16_t *coef_dev, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (!coef_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_dev: null buffer");
+    return dec_step(s, false, nullptr, nullptr, coef_dev, qidx);
 }
 
 PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev,
                                const int16_t *coef_dev, const uint8_t qidx[3])
 {
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
-    pfv_ctx *ctx = s->ctx;
-    if (!mv_dev || !has_coef_dev || !coef_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_dev: null buffer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = dec_launch(s, true, s->win_first, s->win_count, mv_dev, has_coef_dev, coef_dev, qidx);
-    if (rc) return rc;
-    s->cur ^= 1;
-    if (s->frames_out && !fused_output_ok(s)) return dec_crop_win(s, s->win_first, s->win_count, s->frames_out, s->out_stride);
-    return PFV_OK;
+    if (!mv_dev || !has_coef_dev || !coef_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_dev: null buffer");
+    return dec_step(s, true, mv_dev, has_coef_dev, coef_dev, qidx);
+}
+
+// The same two operations on COEFFICIENT LISTS (round 5; the form the stream decoders' entropy stage produces, see pfv_hip.h): per slot of
+// the session's window a pointer to its list of entries and, per macroblock, the range of its entries.  Same result as the dense call on
+// the expanded arrays.  The ranges must be what pfv_coef_lists_from_dense / the decoders produce (ascending, inside the slot's list): they
+// are the kernels' loop bounds and are not validated on the device.
+PFV_API int pfv_dec_iframe_lists_dev(pfv_dec_session *s, const uint32_t *const *entries_dev, const uint32_t *ranges_dev, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (!entries_dev || !ranges_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_lists_dev: null buffer");
+    return dec_step(s, false, nullptr, nullptr, DecCoefs(entries_dev, (const uint2 *)ranges_dev), qidx);
+}
+PFV_API int pfv_dec_pframe_lists_dev(pfv_dec_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev, const uint32_t *const *entries_dev,
+                                     const uint32_t *ranges_dev, const uint8_t qidx[3])
+{
+    if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
+    if (!mv_dev || !has_coef_dev || !entries_dev || !ranges_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_lists_dev: null buffer");
+    return dec_step(s, true, mv_dev, has_coef_dev, DecCoefs(entries_dev, (const uint2 *)ranges_dev), qidx);
+}
+// Host helper: one frame's dense coefficients ([total_blocks][256]) as a coefficient list.  has_coef (nullable: every macroblock) says which
+// macroblocks are read.  entries_out has room for `cap` entries, ranges_out for total_blocks (begin, end) pairs; *n_out = entries written.
+// Returns 1 when more than `cap` entries would be needed (total_blocks x 256 always suffices).
+PFV_API int pfv_coef_lists_from_dense(const int16_t *coef, const uint8_t *has_coef, int total_blocks, uint32_t *entries_out, size_t cap, uint32_t *ranges_out,
+                                      size_t *n_out)
+{
+    if (!coef || !entries_out || !ranges_out || !n_out || total_blocks <= 0) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_coef_lists_from_dense: bad argument");
+    ListSink sink{entries_out, cap, (uint2 *)ranges_out, (size_t)total_blocks};
+    bool full = false;
+    for (size_t b = 0; b < (size_t)total_blocks && !full; b++) {
+        if (has_coef && !has_coef[b]) continue;
+        for (size_t i = 0; i < 256 && !full; i++)
+            if (coef[b * 256 + i]) full = !sink.put(b * 256 + i, coef[b * 256 + i]);
+    }
+    sink.finish();
+    *n_out = sink.n;
+    return full ? 1 : PFV_OK;
 }
 
 // one flag per slot (k_dec_pframe raises flag[stream]); PFV_ERR_BAD_MV when any is set, all cleared
@@ -1820,7 +1886,7 @@ static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, si
                              uint32_t *coded, EdPacket &k, uint8_t *bytes_dst)
 {
     EntdPrep p;
-    k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = k.grp_first = 0;
+    k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = k.grp_first = k.list_cap = 0;
     k.sub_bits = sub_bits;
     k.pframe = type == 2 ? 1u : 0u;
     k.total_blocks = (uint32_t)tb;
@@ -1840,7 +1906,9 @@ static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, si
     int n_syms = 0;
     for (uint8_t t : h.table) n_syms += t != 0;
     const uint64_t bits = (uint64_t)plen * 8, bit0 = r.position();
-    if (n_syms < 2 || bits >= (1ull << 32) || bit0 >= bits) { p.host_parse = true; return p; }   // zero-length codes / 32-bit positions / no bits left
+    // zero-length codes / no bits left / 64 MiB and more: a run costs two bits or more and covers at most 16 coefficients, so below 2^29 bits
+    // the kernels' counters (coefficients and values per packet, 32 bits each, summed side by side in one 64-bit word) cannot overflow
+    if (n_syms < 2 || bits >= (1ull << 29) || bit0 >= bits) { p.host_parse = true; return p; }
     HuffmanTree tree(h.table);
     for (int s = 0; s < 16; s++) {
         k.code_val[s] = (uint16_t)tree.code((uint8_t)s).val;
@@ -1850,10 +1918,89 @@ static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, si
     k.bit0 = (uint32_t)bit0;
     k.total_coefs = (uint32_t)(n_coded * 256);
     k.n_sub = (uint32_t)((bits - bit0 + sub_bits - 1) / sub_bits);
+    k.list_cap = (uint32_t)std::min<uint64_t>(n_coded * 256, (bits - bit0) / 3 + 1);   // <= entd_pool_cap(tb, plen): the room the caller set aside
     memcpy(bytes_dst, payload, plen);
     memset(bytes_dst + plen, 0, 16);
     return p;
 }
+// Entries a packet's coefficient list can need, known before any of it is read: a value costs three bits or more (two tree codes of a bit or
+// more -- tables of fewer than two symbols go to the host parser -- and coeff_size >= 1 value bits), and there are no more values than
+// coefficients.  Rounded up to whole 16-byte lines so that the lists of a pool start aligned.
+static inline size_t entd_pool_cap(size_t tb, size_t plen) { return (std::min(tb * 256, plen * 8 / 3 + 1) + 3) & ~(size_t)3; }
+
+// Device side of the coefficient lists of `frames` frames (pfv_device.h: CoefLists): a pool of entries the frames' lists are cut from, the
+// table of list pointers the decode kernels index by slot, the macroblocks' ranges.  A list that does not fit its place in the pool -- only a
+// packet the HOST parser read can need more than entd_pool_cap (a one-symbol table: values of one or two bits) -- gets a buffer of its own
+// for the life of the batch (spill).
+struct ListPool {
+    uint32_t *ent = nullptr; size_t ent_cap = 0;       // entries
+    uint32_t **ptr_dev = nullptr;                      // [frames]
+    uint2 *ranges_dev = nullptr;                       // [frames][tb]
+    size_t frames = 0, tb = 0;
+    PinnedBuf<uint32_t *> ptr_host;
+    std::vector<uint32_t *> spill;
+    int create(pfv_ctx *ctx, size_t n_frames, size_t total_blocks, size_t entries)
+    {
+        frames = n_frames; tb = total_blocks;
+        HIP_TRY(ctx, hipMalloc((void **)&ptr_dev, n_frames * sizeof(uint32_t *)));
+        HIP_TRY(ctx, hipMalloc((void **)&ranges_dev, n_frames * total_blocks * sizeof(uint2)));
+        if (entries) { HIP_TRY(ctx, hipMalloc((void **)&ent, entries * sizeof(uint32_t))); ent_cap = entries; }
+        if (!ptr_host.resize(n_frames)) return fail(ctx, PFV_ERR_NOMEM, "pinned list-pointer staging");
+        for (size_t f = 0; f < n_frames; f++) ptr_host.data()[f] = nullptr;
+        return PFV_OK;
+    }
+    // room for `entries` in the pool; the caller has made sure nothing on the device still uses it
+    int room(pfv_ctx *ctx, size_t entries)
+    {
+        if (entries <= ent_cap) return PFV_OK;
+        if (ent) { (void)hipFree(ent); ent = nullptr; ent_cap = 0; }
+        entries += entries / 4;
+        HIP_TRY(ctx, hipMalloc((void **)&ent, entries * sizeof(uint32_t)));
+        ent_cap = entries;
+        return PFV_OK;
+    }
+    void drop_spill()
+    {
+        for (uint32_t *p : spill) (void)hipFree(p);
+        spill.clear();
+    }
+    void destroy()
+    {
+        drop_spill();
+        for (void *p : {(void *)ent, (void *)ptr_dev, (void *)ranges_dev})
+            if (p) (void)hipFree(p);
+        ent = nullptr; ptr_dev = nullptr; ranges_dev = nullptr; ent_cap = 0;
+    }
+    DecCoefs coefs(size_t first_frame = 0) const { return DecCoefs(ptr_dev + first_frame, ranges_dev + first_frame * tb); }
+};
+
+// A packet through the HOST parser into list form, for a decoder whose coefficients travel as lists: entries and ranges into page-locked
+// staging (`ent` with room for `cap` entries, `ranges` [tb]).  kSinkFull: more than `cap` entries (parse again with room for tb x 256).
+static int parse_to_lists(const uint8_t *payload, size_t plen, int type, size_t tb, int n_qtables, int8_t *mv, uint8_t *has, uint32_t *ent, size_t cap, uint2 *ranges,
+                          size_t *n_out, uint8_t qidx[3])
+{
+    ListSink sink{ent, cap, ranges, tb};
+    const int rc = type == 2 ? parse_pframe_to(payload, plen, (int)tb, n_qtables, mv, has, sink, qidx) : parse_iframe_to(payload, plen, (int)tb, n_qtables, sink, qidx);
+    sink.finish();
+    *n_out = sink.n;
+    return rc;
+}
+// ... and onto the device, in frame `f`'s place of the pool (or a buffer of its own when it is longer than the place: `place_cap` entries),
+// on `stream`; the staging is free again when the stream has passed this point
+static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, const uint32_t *ent, size_t n, const uint2 *ranges, hipStream_t stream)
+{
+    uint32_t *dst = lp.ptr_host.data()[f];
+    if (n > place_cap || !dst) {
+        HIP_TRY(ctx, hipMalloc((void **)&dst, std::max<size_t>(n, 1) * sizeof(uint32_t)));
+        lp.spill.push_back(dst);
+        lp.ptr_host.data()[f] = dst;
+        HIP_TRY(ctx, hipMemcpyAsync(lp.ptr_dev + f, lp.ptr_host.data() + f, sizeof(uint32_t *), hipMemcpyHostToDevice, stream));
+    }
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(dst, ent, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(lp.ranges_dev + f * lp.tb, ranges, lp.tb * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    return PFV_OK;
+}
+
 // the launches of one window: np packets from b.packet0 on, ng workgroups from b.group0 on (b.groups already points at the first of them)
 static void entd_launch(hipStream_t stream, const EdBufs &b, unsigned np, unsigned ng, int launches, int inner)
 {
@@ -1905,17 +2052,42 @@ struct DecWindow {
     uint32_t *sub_dev = nullptr; size_t sub_cap = 0;
     EdPacket *pk_dev = nullptr;
     uint32_t *status_dev = nullptr, *coded_dev = nullptr;
-    int16_t *coef_dev = nullptr;
+    unsigned long long *wgsum_dev = nullptr; size_t wgsum_cap = 0;
+    ListPool lists;                      // the window's coefficients: one list per packet (pfv_device.h: CoefLists)
+    std::vector<size_t> list_room;       // per packet: the size of its list's place in the pool
     int8_t *mv_dev = nullptr;
     uint8_t *has_dev = nullptr;
     PinnedBuf<uint32_t> status_host;
     hipEvent_t done = nullptr;
     DecEvent *owner = nullptr;           // the packet whose window is enqueued / was decoded from this set
+    void destroy()
+    {
+        for (void *p : {(void *)bytes_dev, (void *)pk_dev, (void *)status_dev, (void *)coded_dev, (void *)groups_dev, (void *)sub_dev, (void *)wgsum_dev, (void *)mv_dev, (void *)has_dev})
+            if (p) (void)hipFree(p);
+        lists.destroy();
+        if (done) (void)hipEventDestroy(done);
+    }
+};
+// host staging of one packet the host parser reads into list form (a decoder whose coefficients travel as lists)
+struct ListStage {
+    PinnedBuf<uint32_t> ent;
+    PinnedBuf<uint2> ranges;
+    size_t n = 0;
+    // kSinkFull cannot come back: a list of the place's size is tried first, then one with room for every coefficient
+    int parse(const uint8_t *payload, size_t plen, int type, size_t tb, int n_qtables, int8_t *mv, uint8_t *has, size_t place_cap, uint8_t qidx[3])
+    {
+        if (!ent.resize(std::max<size_t>(place_cap, 4)) || !ranges.resize(tb)) return PFV_ERR_NOMEM;
+        int rc = parse_to_lists(payload, plen, type, tb, n_qtables, mv, has, ent.data(), place_cap, ranges.data(), &n, qidx);
+        if (rc != kSinkFull) return rc;
+        if (!ent.resize(tb * 256)) return PFV_ERR_NOMEM;
+        return parse_to_lists(payload, plen, type, tb, n_qtables, mv, has, ent.data(), tb * 256, ranges.data(), &n, qidx);
+    }
 };
 
 struct pfv_decoder {
     DecEntd entd;                        // switches, shape and counters of the device entropy stage (its buffers: win[])
     DecWindow win[2];
+    ListStage hp;                        // a packet the device stage left to the host parser
     hipStream_t win_stream = nullptr;
     pfv_ctx *ctx = nullptr;
     pfv_dec_session *hot = nullptr;
@@ -2364,6 +2536,7 @@ struct pfv_batch_decoder {
     std::vector<size_t> len, pos;
     BdSet set[2];
     PinnedBuf<int16_t> dense;          // fallback for steps whose lists overflow
+    ListStage hp;                      // device-entropy steps: a packet the device stage left to the host parser
     PinnedBuf<uint8_t> frames[2];
     uint8_t *frames_dev = nullptr;
     long step = 0, dense_steps = 0;
@@ -2520,6 +2693,17 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
     if ((rc = room(&w.bytes_dev, &w.bytes_cap, s->bytes_total + 64))) return rc;
     if ((rc = room(&w.groups_dev, &w.groups_cap, n_groups + 1))) return rc;
     if ((rc = room(&w.sub_dev, &w.sub_cap, (total_sub + 1) * 4))) return rc;
+    if ((rc = room(&w.wgsum_dev, &w.wgsum_cap, n_groups + 1))) return rc;
+    {   // every packet's list: its place in the window's pool from the packet's size
+        size_t total = 0;
+        w.list_room.assign(S, 0);
+        for (size_t k = 0; k < S; k++) { w.list_room[k] = entd_pool_cap(tb, s->len[k]); total += w.list_room[k]; }
+        w.lists.drop_spill();
+        if ((rc = w.lists.room(ctx, total))) return rc;
+        total = 0;
+        for (size_t k = 0; k < S; k++) { w.lists.ptr_host.data()[k] = w.lists.ent + total; total += w.list_room[k]; }
+        HIP_TRY(ctx, hipMemcpyAsync(w.lists.ptr_dev, w.lists.ptr_host.data(), S * sizeof(uint32_t *), hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(w.bytes_dev, s->bytes.data(), s->bytes_total, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(w.pk_dev, s->pk.data(), S * sizeof(EdPacket), hipMemcpyHostToDevice, st));
     if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(w.groups_dev, s->groups.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, st));
@@ -2528,11 +2712,10 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
         HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, s->has.data(), S * tb, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(w.coded_dev, s->coded.data(), S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(ctx, hipMemsetAsync(w.coef_dev, 0, S * tb * 512, st));
     HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, S * sizeof(uint32_t), st));
     if (n_groups) {
         const size_t ts = w.sub_cap / 4;
-        EdBufs eb{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.sub_dev + 3 * ts, w.coded_dev, w.coef_dev, w.status_dev, 0u, 0u};
+        EdBufs eb{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.ranges_dev, w.status_dev, 0u, 0u};
         entd_launch(st, eb, (unsigned)S, (unsigned)n_groups, v.launches, v.inner);
         if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
     }
@@ -2556,12 +2739,7 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     if (b->frames_dev) (void)hipFree(b->frames_dev);
     if (b->win_stream) { (void)hipStreamSynchronize(b->win_stream); (void)hipStreamDestroy(b->win_stream); }
-    for (DecWindow &w : b->win) {
-        for (void *p : {(void *)w.bytes_dev, (void *)w.pk_dev, (void *)w.status_dev, (void *)w.coded_dev, (void *)w.groups_dev, (void *)w.sub_dev, (void *)w.coef_dev,
-                        (void *)w.mv_dev, (void *)w.has_dev})
-            if (p) (void)hipFree(p);
-        if (w.done) (void)hipEventDestroy(w.done);
-    }
+    for (DecWindow &w : b->win) w.destroy();
     pfv_dec_session_destroy(b->hot);
     delete b;
 }
@@ -2618,7 +2796,7 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
             if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, S * sizeof(EdPacket));
             if (he == hipSuccess) he = hipMalloc((void **)&w.status_dev, S * sizeof(uint32_t));
             if (he == hipSuccess) he = hipMalloc((void **)&w.coded_dev, S * tb * sizeof(uint32_t));
-            if (he == hipSuccess) he = hipMalloc((void **)&w.coef_dev, S * tb * 512);
+            if (he == hipSuccess && w.lists.create(ctx, S, tb, 0) != PFV_OK) he = hipErrorOutOfMemory;
             if (he == hipSuccess) he = hipMalloc((void **)&w.mv_dev, S * tb * 2);
             if (he == hipSuccess) he = hipMalloc((void **)&w.has_dev, S * tb);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
@@ -2697,15 +2875,14 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
         for (size_t k = 0; k < S; k++) {
             if (!s->host_parse[k] && !w.status_host.data()[k]) { v.packets_dev++; continue; }
             v.packets_host++;
-            if (!b->dense.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
             uint8_t q[3];
-            const int prc = s->type == 2 ? parse_pframe(s->payload[k], s->len[k], (int)tb, b->n_qtables, s->mv.data() + k * tb * 2, s->has.data() + k * tb, b->dense.data(), q)
-                                         : parse_iframe(s->payload[k], s->len[k], (int)tb, b->n_qtables, b->dense.data(), q);
+            const int prc = b->hp.parse(s->payload[k], s->len[k], s->type, tb, b->n_qtables, s->mv.data() + k * tb * 2, s->has.data() + k * tb, w.list_room[k], q);
+            if (prc == PFV_ERR_NOMEM) return fail(ctx, prc, "pinned list staging");
             if (prc) { b->eof = true; return fail(ctx, prc, "malformed packet payload"); }
-            HIP_TRY(ctx, hipMemcpyAsync(w.coef_dev + k * tb * 256, b->dense.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // the one dense staging frame is used again
+            if ((rc = upload_lists(ctx, w.lists, k, w.list_room[k], b->hp.ent.data(), b->hp.n, b->hp.ranges.data(), ctx->stream))) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // the one staging list is used again
         }
-        rc = s->type == 2 ? pfv_dec_pframe_dev(hot, w.mv_dev, w.has_dev, w.coef_dev, &s->qidx[0]) : pfv_dec_iframe_dev(hot, w.coef_dev, &s->qidx[0]);
+        rc = dec_step(hot, s->type == 2, w.mv_dev, w.has_dev, w.lists.coefs(), &s->qidx[0]);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(b->frames[slot].data(), b->frames_dev, S * b->frame_bytes, hipMemcpyDeviceToHost, ctx->stream));
         BdSet *nx = &b->set[slot ^ 1];
@@ -2856,7 +3033,7 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
             if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, sizeof(EdPacket));
             if (he == hipSuccess) he = hipMalloc((void **)&w.status_dev, sizeof(uint32_t));
             if (he == hipSuccess) he = hipMalloc((void **)&w.coded_dev, tbs * sizeof(uint32_t));
-            if (he == hipSuccess) he = hipMalloc((void **)&w.coef_dev, tbs * 512);
+            if (he == hipSuccess && w.lists.create(ctx, 1, tbs, 0) != PFV_OK) he = hipErrorOutOfMemory;
             if (he == hipSuccess) he = hipMalloc((void **)&w.mv_dev, tbs * 2);
             if (he == hipSuccess) he = hipMalloc((void **)&w.has_dev, tbs);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
@@ -3051,12 +3228,7 @@ PFV_API void pfv_decoder_destroy(pfv_decoder *d)
     (void)hipStreamSynchronize(d->ctx->stream);
     if (d->win_stream) { (void)hipStreamSynchronize(d->win_stream); (void)hipStreamDestroy(d->win_stream); }
     if (d->frame_dev) (void)hipFree(d->frame_dev);
-    for (DecWindow &w : d->win) {
-        for (void *p : {(void *)w.bytes_dev, (void *)w.pk_dev, (void *)w.status_dev, (void *)w.coded_dev, (void *)w.groups_dev, (void *)w.sub_dev, (void *)w.coef_dev,
-                        (void *)w.mv_dev, (void *)w.has_dev})
-            if (p) (void)hipFree(p);
-        if (w.done) (void)hipEventDestroy(w.done);
-    }
+    for (DecWindow &w : d->win) w.destroy();
     pfv_dec_session_destroy(d->hot);
     delete d;
 }
@@ -3113,6 +3285,12 @@ static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
     if ((rc = room(&w.bytes_dev, &w.bytes_cap, (size_t)e->plen + 64))) return rc;
     if ((rc = room(&w.groups_dev, &w.groups_cap, (size_t)ng + 1))) return rc;
     if ((rc = room(&w.sub_dev, &w.sub_cap, ((size_t)k.n_sub + 1) * 4))) return rc;
+    if ((rc = room(&w.wgsum_dev, &w.wgsum_cap, (size_t)ng + 1))) return rc;
+    w.list_room.assign(1, entd_pool_cap(tb, e->plen));
+    w.lists.drop_spill();
+    if ((rc = w.lists.room(ctx, w.list_room[0]))) return rc;
+    w.lists.ptr_host.data()[0] = w.lists.ent;
+    HIP_TRY(ctx, hipMemcpyAsync(w.lists.ptr_dev, w.lists.ptr_host.data(), sizeof(uint32_t *), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(w.bytes_dev, e->bytes.data(), (size_t)e->plen + 16, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(w.pk_dev, e->pk.data(), sizeof(EdPacket), hipMemcpyHostToDevice, st));
     if (ng) HIP_TRY(ctx, hipMemcpyAsync(w.groups_dev, e->groups.data(), ng * sizeof(uint2), hipMemcpyHostToDevice, st));
@@ -3121,11 +3299,10 @@ static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
         HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, e->has.data(), tb, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(w.coded_dev, e->coded.data(), tb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(ctx, hipMemsetAsync(w.coef_dev, 0, tb * 512, st));
     HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, sizeof(uint32_t), st));
     if (ng) {
         const size_t ts = w.sub_cap / 4;
-        EdBufs b{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.sub_dev + 3 * ts, w.coded_dev, w.coef_dev, w.status_dev, 0u, 0u};
+        EdBufs b{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.ranges_dev, w.status_dev, 0u, 0u};
         entd_launch(st, b, 1u, ng, v.launches, v.inner);
         if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
     }
@@ -3156,15 +3333,14 @@ static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
     w->owner = nullptr;           // consumed (event objects are reused by the ring: a stale match would take this window for a later packet's)
     if (*w->status_host.data()) {   // the device stage is not certain about this payload: the host parser reads it and decides
         v.packets_host++;
-        if (!e->coef.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging for a parsed packet");
-        const int prc = e->type == 1 ? parse_iframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->coef.data(), e->qidx)
-                                     : parse_pframe(e->payload, e->plen, d->total_blocks, d->n_qtables, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
-        if (prc) return fail(ctx, prc, "malformed packet payload");
-        HIP_TRY(ctx, hipMemcpyAsync(w->coef_dev, e->coef.data(), tb * 512, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the staging list's last upload
+        const int prc = d->hp.parse(e->payload, e->plen, e->type, tb, d->n_qtables, e->mv.data(), e->has.data(), w->list_room[0], e->qidx);
+        if (prc) return fail(ctx, prc, prc == PFV_ERR_NOMEM ? "pinned list staging" : "malformed packet payload");
+        if ((rc = upload_lists(ctx, w->lists, 0, w->list_room[0], d->hp.ent.data(), d->hp.n, d->hp.ranges.data(), ctx->stream))) return rc;
     } else {
         v.packets_dev++;
     }
-    rc = e->type == 1 ? pfv_dec_iframe_dev(hot, w->coef_dev, e->qidx) : pfv_dec_pframe_dev(hot, w->mv_dev, w->has_dev, w->coef_dev, e->qidx);
+    rc = dec_step(hot, e->type == 2, w->mv_dev, w->has_dev, w->lists.coefs(), e->qidx);
     if (rc) return rc;
     {   // the packet behind this one
         std::unique_lock<std::mutex> lk(d->m);

@@ -51,4 +51,19 @@ struct FrameGeom {
     long pad_frame_bytes;   // stride between streams, padded frames
 };
 
+// Coefficient lists (round 5): a frame's non-zero coefficients instead of its dense [macroblock][256] array -- what the decode kernels
+// take from the decoders' entropy stage (k_entd_emit) and from the host parser (ListSink), so that nothing is cleared, written sparsely and
+// read back in full.  The reference expands runs straight into the macroblock it is about to decode (src/dec.rs:258-296, 378-417); here a
+// wavefront expands its strip's entries into its LDS zigzag stage.
+//   entry      value (i16) << 16 | (macroblock index & 255) << 8 | position in the macroblock (0..255, subblock-major zigzag order);
+//              ascending by (macroblock, position): the order the run streams are read in;
+//   range      per macroblock (x, y): its entries are [x, y) of the stream's list.  Only read for macroblocks that have coefficients
+//              (every macroblock of an i-frame, has_coeff != 0 in a p-frame); the macroblocks between two coded ones own no entries, so
+//              the entries of a strip of neighbouring macroblocks are one contiguous span.
+struct CoefLists {
+    const uint32_t *const *entries;    // [stream]: the stream's list
+    const uint2 *ranges;               // [stream][mbs_per_frame]
+};
+constexpr uint32_t coef_entry(uint32_t mb, uint32_t pos, int16_t value) { return ((uint32_t)(uint16_t)value << 16) | ((mb & 255u) << 8) | (pos & 255u); }
+
 }  // namespace pfv

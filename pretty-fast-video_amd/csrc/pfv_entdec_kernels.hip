@@ -1,4 +1,4 @@
-// pfv_entdec_kernels.hip -- the decoder's entropy stage on the device (gfx950): packet payloads -> dense coefficient arrays.
+// pfv_entdec_kernels.hip -- the decoder's entropy stage on the device (gfx950): packet payloads -> coefficient lists (pfv_device.h: CoefLists).
 //
 // The reference reads a payload one bit field at a time on one host thread (src/dec.rs:258-296 i-frames: ONE run stream per
 // frame; :378-417 p-frames: one run stream per coded macroblock, back to back; per run a (num_zeroes, coeff_size) pair of tree
@@ -15,10 +15,14 @@
 //                 anything left to do: then end[0] is true (the first lane starts at the true first run) and every end[i] follows
 //                 from a true start.  A packet that has not settled (periodic content can keep a wrong phase for ever) is left to
 //                 the host parser.
-//   k_entd_prefix exclusive prefix over the coefficients each workgroup's subsequences cover (summed by the verifying launch): with a
-//                 workgroup-local prefix in k_entd_emit, the coefficient index every lane's first run starts at.
-//   k_entd_emit   every lane reads its subsequence once more, from its true start and coefficient index, and stores the values
-//                 (zeros are what the buffer was cleared to).  It also decides whether the host parser would have accepted the
+//   k_entd_prefix exclusive prefix over the coefficients each workgroup's subsequences cover and over the values among them (summed by
+//                 the verifying launch): with a workgroup-local prefix in k_entd_emit, the coefficient index every lane's first run
+//                 starts at and the place of its first value in the packet's list.
+//   k_entd_emit   every lane reads its subsequence once more, from its true start, and appends its values to the packet's coefficient
+//                 list: one 32-bit entry per value, contiguous per lane, per workgroup and per packet -- nothing is cleared and nothing
+//                 but the values is written (round 4 scattered 2-byte values into a zeroed [macroblock][256] array: 46 x the bytes).
+//                 The run that crosses into a macroblock writes that macroblock's first entry index and its predecessor's end
+//                 (ranges; a p-frame's through the coded-macroblock list).  It also decides whether the host parser would have accepted the
 //                 payload and produced the same array: anything it is not sure of -- a field that runs past the payload, a value
 //                 behind the last coefficient, a macroblock whose runs do not end exactly on its 256th coefficient -- marks the
 //                 packet, and a marked packet is parsed by the host code instead (pfv_host.hip: read_runs), which alone
@@ -30,6 +34,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "pfv_device.h"
 
 namespace pfv {
 
@@ -50,9 +56,10 @@ struct EdPacket {
     uint32_t sub_bits;             // payload bits per lane
     uint32_t sub_first;            // index of subsequence 0 in the per-subsequence arrays
     uint32_t grp_first;            // index of its first workgroup in the per-workgroup array
+    uint32_t list_cap;             // entries the packet's list has room for (entd_list_cap: what its bits can hold at most)
     uint32_t pframe;               // 1: values go through the coded-macroblock list
     uint32_t total_blocks;         // macroblocks per frame
-    unsigned long long frame_off;  // which frame of the has / coded-list / coefficient arrays this packet fills
+    unsigned long long frame_off;  // which frame of the has / coded-list / range / list-pointer arrays this packet fills
     uint16_t code_val[16];         // the packet's tree codes, LSB first (src/huffman.rs:204-217)
     uint8_t code_len[16];          // 0: the symbol has no code
 };
@@ -61,10 +68,11 @@ struct EdBufs {
     const uint8_t *bytes;          // payloads
     const EdPacket *packets;
     const uint2 *groups;           // workgroups of k_entd_sync / k_entd_emit: (packet, which kEdThreads subsequences of it)
-    uint32_t *end, *used, *cnt;    // per subsequence
-    uint32_t *wgsum;               // per workgroup of k_entd_sync: the coefficients its subsequences cover, then (k_entd_prefix) those before it
+    uint32_t *end, *used, *cnt;    // per subsequence; cnt = coefficients covered | values among them << 16 (a lane reads < 2^9 + 45 bits: < 2^13 of either)
+    unsigned long long *wgsum;     // per workgroup of k_entd_sync: the sums of its lanes' cnt fields (coefficients | values << 32), then (k_entd_prefix) those before it
     const uint32_t *coded;         // [frame][total_blocks]: the k-th coded macroblock of the frame (p-frames; from the host's pass over the block headers)
-    int16_t *coef;                 // [frame][total_blocks][256], cleared
+    uint32_t *const *lists;        // [frame]: where the frame's entries go (EdPacket::list_cap of them fit)
+    uint2 *ranges;                 // [frame][total_blocks]: per macroblock, its entries [x, y) of the frame's list
     uint32_t *status;              // per packet: kEd* bits
     uint32_t packet0;              // k_entd_prefix: the launch's first packet (one workgroup per packet)
     uint32_t group0;               // index of b.groups[0] among all workgroups of the batch (EdPacket::grp_first counts from there too)
@@ -152,22 +160,25 @@ __device__ __forceinline__ uint32_t ed_limit(const EdPacket &pk, uint32_t i)
     return lim < pk.total_bits ? (uint32_t)lim : pk.total_bits;
 }
 
-// workgroup scan helper: exclusive prefix of one value per lane (kEdThreads lanes), total in *sum
-__device__ __forceinline__ uint32_t ed_block_exclusive(uint32_t v, uint32_t *scratch, int tid, uint32_t *sum)
+// workgroup scan helper: exclusive prefix of one value per lane (kEdThreads lanes), total in *sum.  The values carry two counters
+// (coefficients | values << 32) that cannot carry into each other: a packet's run streams are < 2^32 bits and a coefficient costs a bit
+// or more only for degenerate tables, which never come here.
+__device__ __forceinline__ unsigned long long ed_block_exclusive(unsigned long long v, unsigned long long *scratch, int tid, unsigned long long *sum)
 {
     scratch[tid] = v;
     __syncthreads();
     for (int d = 1; d < kEdThreads; d <<= 1) {
-        const uint32_t add = tid >= d ? scratch[tid - d] : 0u;
+        const unsigned long long add = tid >= d ? scratch[tid - d] : 0ull;
         __syncthreads();
         scratch[tid] += add;
         __syncthreads();
     }
-    const uint32_t incl = scratch[tid];
+    const unsigned long long incl = scratch[tid];
     if (sum) *sum = scratch[kEdThreads - 1];
     __syncthreads();
     return incl - v;
 }
+__device__ __forceinline__ unsigned long long ed_split(uint32_t cnt) { return (unsigned long long)(cnt & 0xffffu) | ((unsigned long long)(cnt >> 16) << 32); }
 
 // one workgroup per entry of b.groups.  Inside a launch the lanes of a workgroup pass their ends along through LDS and repeat until
 // none of them has a new start (a lane whose read had not met the true one by its end changes its neighbour's start, and so on: a few
@@ -180,6 +191,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
     __shared__ uint8_t clen[16];
     __shared__ uint32_t s_end[kEdThreads];
     __shared__ uint32_t lw[kEdStageWords];
+    __shared__ unsigned long long scratch[kEdThreads];
     __shared__ int any_work;
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
@@ -189,7 +201,9 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
     const size_t at = (size_t)pk.sub_first + i;
     uint32_t used = kEdNoStart, end = 0, count = 0, before = 0;
     if (mine && !first_round) { used = b.used[at]; end = b.end[at]; count = b.cnt[at]; }
-    if (mine && !first_round && tid == 0 && i > 0) before = b.end[at - 1];       // the workgroup in front: as the last launch left it
+    // the workgroup in front may be storing this very word (its last lane's end, below) in this launch: either value will do -- an old one is
+    // caught by a later launch, the verifying one at the latest -- but the access is a relaxed atomic on both sides, not a data race
+    if (mine && !first_round && tid == 0 && i > 0) before = __atomic_load_n(b.end + at - 1, __ATOMIC_RELAXED);
     const uint32_t limit = mine ? ed_limit(pk, i) : 0;
     bool built = false, dirty = false;
     uint32_t base = 0;
@@ -225,7 +239,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
                 uint32_t zeros, nb;
                 int value;
                 ed_run(r, tab, cval, clen, zeros, nb, value);
-                count += zeros + (nb ? 1u : 0u);
+                count += zeros + (nb ? 0x10001u : 0u);
             }
             end = r.pos;
             used = start;
@@ -234,44 +248,46 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_ro
         __syncthreads();
     }
     if (dirty) {
-        b.end[at] = end;
+        if (tid == kEdThreads - 1) __atomic_store_n(b.end + at, end, __ATOMIC_RELAXED);   // read by the workgroup behind, maybe in this launch
+        else b.end[at] = end;
         b.used[at] = used;
         b.cnt[at] = count;
     }
     if (verify) {   // settled (otherwise the launch has returned above): what the workgroup's subsequences cover, for k_entd_prefix
-        uint32_t sum = 0;
-        (void)ed_block_exclusive(mine ? count : 0u, s_end, tid, &sum);
+        unsigned long long sum = 0;
+        (void)ed_block_exclusive(mine ? ed_split(count) : 0ull, scratch, tid, &sum);
         if (tid == 0) b.wgsum[b.group0 + blockIdx.x] = sum;
     }
 }
 
-// one workgroup per packet: wgsum[g] = coefficients covered by the packet's workgroups before g
+// one workgroup per packet: wgsum[g] = coefficients covered by (and values of) the packet's workgroups before g
 __global__ void __launch_bounds__(kEdThreads) k_entd_prefix(EdBufs b)
 {
-    __shared__ uint32_t scratch[kEdThreads];
+    __shared__ unsigned long long scratch[kEdThreads];
     const EdPacket &pk = b.packets[b.packet0 + blockIdx.x];
     const int tid = (int)threadIdx.x;
     if (pk.n_sub == 0 || (b.status[b.packet0 + blockIdx.x] & kEdUnsettled)) return;
     const uint32_t n = (pk.n_sub + kEdThreads - 1) / kEdThreads;
-    uint32_t *w = b.wgsum + pk.grp_first;
-    uint32_t carry = 0;
+    unsigned long long *w = b.wgsum + pk.grp_first;
+    unsigned long long carry = 0;
     for (uint32_t g0 = 0; g0 < n; g0 += kEdThreads) {
-        const uint32_t g = g0 + (uint32_t)tid, v = g < n ? w[g] : 0u;
-        uint32_t sum = 0;
-        const uint32_t ex = ed_block_exclusive(v, scratch, tid, &sum);
+        const uint32_t g = g0 + (uint32_t)tid;
+        const unsigned long long v = g < n ? w[g] : 0ull;
+        unsigned long long sum = 0;
+        const unsigned long long ex = ed_block_exclusive(v, scratch, tid, &sum);
         if (g < n) w[g] = carry + ex;
         carry += sum;
     }
 }
 
-// workgroups as k_entd_sync: the values of subsequence i into the coefficient array
+// workgroups as k_entd_sync: the values of subsequence i into the packet's coefficient list, the macroblocks' ranges beside them
 __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tab[4096];
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
     __shared__ uint32_t lw[kEdStageWords];
-    __shared__ uint32_t scratch[kEdThreads];
+    __shared__ unsigned long long scratch[kEdThreads];
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
     if (b.status[grp.x] & kEdUnsettled) return;           // set by an earlier launch
@@ -281,53 +297,72 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
     ed_build_table(tab, cval, clen, pk, tid);
     const bool mine = i < pk.n_sub;
     const size_t at = (size_t)pk.sub_first + i;
-    const uint32_t vlocal = ed_block_exclusive(mine ? b.cnt[at] : 0u, scratch, tid, nullptr);   // coefficients covered by the workgroup's lanes before this one
+    // what the workgroup's lanes before this one cover: coefficients (low half) and values (high half)
+    const unsigned long long before = b.wgsum[b.group0 + blockIdx.x] + ed_block_exclusive(mine ? ed_split(b.cnt[at]) : 0ull, scratch, tid, nullptr);
     if (!mine) return;
     const uint32_t start = i == 0 ? pk.bit0 : b.end[at - 1];
-    const uint32_t limit = ed_limit(pk, i), total = pk.total_coefs;
-    uint32_t V = b.wgsum[b.group0 + blockIdx.x] + vlocal;
+    const uint32_t limit = ed_limit(pk, i), total = pk.total_coefs, cap = pk.list_cap;
+    uint32_t V = (uint32_t)before;             // the coefficient index the lane's first run starts at
+    uint32_t O = (uint32_t)(before >> 32);     // the list index of its first value
+    if ((before & 0xffffffffull) >= total) return;                    // behind the last coefficient: nothing of this lane is read (src/dec.rs:261, :382)
     const uint32_t *coded = b.coded + pk.frame_off * pk.total_blocks;
-    int16_t *coef = b.coef + pk.frame_off * pk.total_blocks * 256u;
+    uint2 *ranges = b.ranges + pk.frame_off * pk.total_blocks;
+    uint32_t *list = b.lists[pk.frame_off];
     bool odd = false;
     EdReader r{lw, base, start};
     if (pk.pframe) {
-        uint32_t cur = kEdNoStart;       // which coded macroblock mb_coef belongs to: the list is read when the macroblock changes, not per value
-        int16_t *mb_coef = coef;
+        // one run stream per coded macroblock, closed exactly on its 256th coefficient: a macroblock's first run starts at V % 256 == 0
+        // (its range begins at O), the run that brings V to the next multiple of 256 ends it
+        uint32_t mb = 0;                 // the macroblock V lies in (read from the list of coded macroblocks when V enters it)
+        if (V & 255u) mb = coded[V >> 8];
         while (r.pos < limit && V < total) {
             uint32_t zeros, nb;
             int value;
+            if (!(V & 255u)) { mb = coded[V >> 8]; ranges[mb].x = O; }
             ed_run(r, tab, cval, clen, zeros, nb, value);
             if (r.pos > pk.total_bits) { odd = true; break; }        // the run's fields run past the payload
             const uint32_t local = (V & 255u) + zeros;
             V += zeros;
             if (local >= 256u) {                                       // the run closes the macroblock: exactly, and without a value
                 if (local != 256u || nb) { odd = true; break; }
+                ranges[mb].y = O;
                 continue;
             }
             if (nb) {
-                if ((V >> 8) != cur) {
-                    cur = V >> 8;
-                    mb_coef = coef + (size_t)coded[cur] * 256u;
-                }
-                mb_coef[local] = (int16_t)value;
+                if (O < cap) list[O] = coef_entry(mb, local, (int16_t)value);
+                O++;
                 V++;
+                if (local == 255u) ranges[mb].y = O;                  // the macroblock's last coefficient: no closing run follows
             }
         }
     } else {
+        // ONE run stream over all macroblocks: the run that reaches or crosses the boundary 256 k -- V <= 256 k < V + zeros + (a value ? 1 : 0)
+        // -- knows how many values lie before it
         while (r.pos < limit && V < total) {
             uint32_t zeros, nb;
             int value;
             ed_run(r, tab, cval, clen, zeros, nb, value);
             if (r.pos > pk.total_bits) { odd = true; break; }
+            const uint32_t k = (V + 255u) >> 8, after = V + zeros + (nb ? 1u : 0u);
+            if ((k << 8) < after && (k << 8) < total) {               // zeros <= 15: at most one boundary per run
+                ranges[k].x = O;
+                if (k) ranges[k - 1].y = O;
+            }
             V += zeros;
             if (V >= total) {                                          // the closing run of the frame
                 if (nb) odd = true;
                 break;
             }
-            if (nb) coef[V++] = (int16_t)value;
+            if (nb) {
+                if (O < cap) list[O] = coef_entry(V >> 8, V & 255u, (int16_t)value);
+                O++;
+                V++;
+            }
         }
+        if (V >= total && !odd) ranges[(total >> 8) - 1].y = O;      // the lane whose run reached the last coefficient
     }
     if (!odd && i + 1 == pk.n_sub && V < total) odd = true;          // the payload ends before the last coefficient
+    if (!odd && O > cap) odd = true;                                  // cannot happen for a payload the host parser accepts (entd_list_cap); never written past
     if (odd) atomicOr(b.status + grp.x, kEdIrregular);
 }
 

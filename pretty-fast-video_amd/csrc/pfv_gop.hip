@@ -517,9 +517,11 @@ struct GopDecDev {
     uint8_t *bytes_dev = nullptr; size_t bytes_cap = 0;
     EdPacket *pk_dev = nullptr; uint32_t *status_dev = nullptr; size_t pk_cap = 0;
     uint2 *groups_dev = nullptr; size_t groups_cap = 0;
-    uint32_t *sub_dev = nullptr; size_t sub_cap = 0;     // end | used | cnt | vstart
+    uint32_t *sub_dev = nullptr; size_t sub_cap = 0;     // end | used | cnt (a fourth of the array each; the last fourth is spare)
+    unsigned long long *wgsum_dev = nullptr; size_t wgsum_cap = 0;   // per workgroup
     uint32_t *coded_dev = nullptr;
-    int16_t *coef_dev = nullptr;
+    ListPool lists;                      // the batch's coefficients: one list per frame (pfv_device.h: CoefLists), no dense arrays
+    std::vector<size_t> list_off, list_room;   // per packet: its list's place in the pool (entd_pool_cap entries)
     int8_t *mv_dev = nullptr;
     uint8_t *has_dev = nullptr;
     hipStream_t stream = nullptr;        // the entropy stage's own stream: it works ahead of the decode kernels and their downloads
@@ -536,7 +538,10 @@ struct GopDecDev {
     long unsettled = 0, irregular = 0;   // why packets were left to the host parser
     PinnedBuf<uint32_t> status_host;
     PinnedBuf<int> flags_host;           // [step][max_gops]
-    PinnedBuf<int16_t> dense_host;       // kGopDevDense frames: packets the host parser reads
+    PinnedBuf<uint32_t> hp_ent;          // up to kGopDevDense packets the host parser reads, in list form: entries (a packet's share: its place's size) ...
+    PinnedBuf<uint2> hp_ranges;          // ... and ranges [kGopDevDense][tb]
+    PinnedBuf<uint32_t> hp_full;         // one packet whose list outgrew its place (tb x 256 entries)
+    size_t hp_off[kGopDevDense] = {}, hp_n[kGopDevDense] = {};
     std::vector<GopDevPacket> pk;
     std::vector<int> todo;               // phase 2: the packets the host parser reads, kGopDevDense at a time
     int todo_first = 0;
@@ -983,11 +988,10 @@ static void gopd_dev_hostparse(pfv_gop_decoder *d, int j)
     GopDecDev &v = d->dev;
     GopDevPacket &p = v.pk[(size_t)v.todo[(size_t)(v.todo_first + j)]];
     const GopDecEvent *e = p.ev;
-    const size_t tb = d->total_blocks;
-    int16_t *coef = v.dense_host.data() + (size_t)j * tb * 256;
+    const size_t tb = d->total_blocks, pj = (size_t)v.todo[(size_t)(v.todo_first + j)];
     uint8_t q[3];
-    p.rc = e->type == 2 ? parse_pframe(e->payload, e->plen, (int)tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, coef, q)
-                        : parse_iframe(e->payload, e->plen, (int)tb, d->n_qtables, coef, q);
+    p.rc = parse_to_lists(e->payload, e->plen, e->type, tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, v.hp_ent.data() + v.hp_off[j],
+                          v.list_room[pj], v.hp_ranges.data() + (size_t)j * tb, &v.hp_n[j], q);
 }
 static void gopd_dev_task(pfv_gop_decoder *d, int code)
 {
@@ -1083,6 +1087,21 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     }
     if ((rc = gopd_dev_room(ctx, &v.groups_dev, &v.groups_cap, std::max<size_t>(grp_max, 1)))) return rc;
     if ((rc = gopd_dev_room(ctx, &v.sub_dev, &v.sub_cap, std::max<size_t>(sub_max, 1) * 4))) return rc;
+    if ((rc = gopd_dev_room(ctx, &v.wgsum_dev, &v.wgsum_cap, std::max<size_t>(grp_max, 1)))) return rc;
+    // the coefficient lists: every packet's place in the pool from its size alone (entd_pool_cap), the frames' list pointers with them
+    v.list_off.assign(n, 0); v.list_room.assign(n, 0);
+    size_t list_total = 0;
+    for (size_t j = 0; j < n; j++) {
+        v.list_off[j] = list_total;
+        v.list_room[j] = entd_pool_cap(tb, v.pk[j].ev->plen);
+        list_total += v.list_room[j];
+    }
+    if (list_total > v.lists.ent_cap) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the previous batch's decode launches read the pool
+    v.lists.drop_spill();                                                                     // (ctx->stream is idle between batches: the frames were waited for)
+    if ((rc = v.lists.room(ctx, std::max<size_t>(list_total, 4)))) return rc;
+    for (size_t f = 0; f < v.frames_cap; f++) v.lists.ptr_host.data()[f] = nullptr;
+    for (size_t j = 0; j < n; j++) v.lists.ptr_host.data()[v.pk[j].frame] = v.lists.ent + v.list_off[j];
+    HIP_TRY(ctx, hipMemcpyAsync(v.lists.ptr_dev, v.lists.ptr_host.data(), v.frames_cap * sizeof(uint32_t *), hipMemcpyHostToDevice, v.up_stream));
     while (v.window_done.size() < (size_t)steps) {
         hipEvent_t ev = nullptr, ev2 = nullptr;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1127,12 +1146,11 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + f0 * tb * 2, v.mv_host.data() + f0 * tb * 2, S * tb * 2, hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + f0 * tb, v.has_host.data() + f0 * tb, S * tb, hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev + f0 * tb, v.coded_host.data() + f0 * tb, S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, v.up_stream));
-            HIP_TRY(ctx, hipMemsetAsync(v.coef_dev + f0 * tb * 256, 0, S * tb * 512, v.up_stream));
             HIP_TRY(ctx, hipEventRecord(v.window_up[(size_t)t], v.up_stream));
             HIP_TRY(ctx, hipStreamWaitEvent(v.stream, v.window_up[(size_t)t], 0));
             if (gb > ga) {
-                EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.sub_dev + 3 * ts, v.coded_dev, v.coef_dev, v.status_dev,
-                         (uint32_t)pa, (uint32_t)ga};
+                EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.wgsum_dev, v.coded_dev, v.lists.ptr_dev, v.lists.ranges_dev,
+                         v.status_dev, (uint32_t)pa, (uint32_t)ga};
                 entd_launch(v.stream, b, (unsigned)(pb - pa), (unsigned)(gb - ga), v.launches, v.inner);
                 const int lrc = launch_check(ctx, "k_entd_*");
                 if (lrc) return lrc;
@@ -1176,15 +1194,33 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         }
         for (size_t first = 0; first < v.todo.size(); first += (size_t)kGopDevDense) {
             const int cnt = (int)std::min<size_t>((size_t)kGopDevDense, v.todo.size() - first);
-            if (!v.dense_host.resize((size_t)kGopDevDense * tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned dense staging");
+            size_t need = 0;
+            for (int j = 0; j < cnt; j++) { v.hp_off[j] = need; need += v.list_room[(size_t)v.todo[first + (size_t)j]]; }
+            if (!v.hp_ent.resize(need) || !v.hp_ranges.resize((size_t)kGopDevDense * tb)) return fail(ctx, PFV_ERR_NOMEM, "pinned list staging");
             v.todo_first = (int)first;
             gopd_dev_hostparse_group(d, cnt);
+            bool overflowed = false;
             for (int j = 0; j < cnt; j++) {
-                const GopDevPacket &p = v.pk[(size_t)v.todo[first + (size_t)j]];
+                const size_t pj = (size_t)v.todo[first + (size_t)j];
+                const GopDevPacket &p = v.pk[pj];
+                if (p.rc == kSinkFull) overflowed = true;
                 if (p.rc) continue;
-                HIP_TRY(ctx, hipMemcpyAsync(v.coef_dev + p.frame * tb * 256, v.dense_host.data() + (size_t)j * tb * 256, tb * 512, hipMemcpyHostToDevice, ctx->stream));
+                if ((rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_ent.data() + v.hp_off[j], v.hp_n[j], v.hp_ranges.data() + (size_t)j * tb, ctx->stream))) return rc;
             }
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the dense staging is used again
+            // more values than the packet's bits could hold at three bits each (a one-symbol table: values of one or two bits): once more, with
+            // room for every coefficient; its list gets a buffer of its own
+            for (int j = 0; overflowed && j < cnt; j++) {
+                const size_t pj = (size_t)v.todo[first + (size_t)j];
+                GopDevPacket &p = v.pk[pj];
+                if (p.rc != kSinkFull) continue;
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (!v.hp_full.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned list staging");
+                uint8_t q[3];
+                p.rc = parse_to_lists(p.ev->payload, p.ev->plen, p.ev->type, tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, v.hp_full.data(), tb * 256,
+                                      v.hp_ranges.data() + (size_t)j * tb, &v.hp_n[j], q);
+                if (!p.rc && (rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_full.data(), v.hp_n[j], v.hp_ranges.data() + (size_t)j * tb, ctx->stream))) return rc;
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the staging is used again
         }
         if (!v.todo.empty()) d->stats[1] += clk.lap();
         combos.clear();
@@ -1223,7 +1259,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             if (rc) return;
             const uint32_t c = combos[(size_t)ci];
             const uint8_t q[3] = {(uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24)};
-            rc = dec_launch(hot, (c & 0xffu) == 2, first, count, v.mv_dev + f0 * tb * 2, v.has_dev + f0 * tb, v.coef_dev + f0 * tb * 256, q);
+            rc = dec_launch(hot, (c & 0xffu) == 2, first, count, v.mv_dev + f0 * tb * 2, v.has_dev + f0 * tb, v.lists.coefs(f0), q);
             if (!rc) rc = gopd_step_out(d, t, first, count);
         });
         if (rc) return rc;
@@ -1268,8 +1304,9 @@ PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d)
     for (hipEvent_t ev : d->dev.window_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : d->dev.window_up) (void)hipEventDestroy(ev);
     for (void *p : {(void *)d->dev.bytes_dev, (void *)d->dev.pk_dev, (void *)d->dev.status_dev, (void *)d->dev.groups_dev, (void *)d->dev.sub_dev, (void *)d->dev.coded_dev,
-                    (void *)d->dev.coef_dev, (void *)d->dev.mv_dev, (void *)d->dev.has_dev})
+                    (void *)d->dev.wgsum_dev, (void *)d->dev.mv_dev, (void *)d->dev.has_dev})
         if (p) (void)hipFree(p);
+    d->dev.lists.destroy();
     pfv_dec_session_destroy(d->hot);
     delete d;
 }
@@ -1330,14 +1367,16 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
     if (!rc && ctx->opt_entropy_decode != PFV_ENTROPY_DECODE_HOST && tb > 0) {
         GopDecDev &v = d->dev;
         const size_t F = S * (size_t)max_gop_frames;
-        const size_t need = F * tb * (512 + 2 + 1 + 4 + 64);
+        // per frame: motion vectors, flags, coded list, ranges; the coefficient lists at 4 bytes per 3 payload bits at most (entd_pool_cap)
+        const size_t list_guess = std::min(std::min(len, F * (tb * 512 / 8 + 64)) * 8 / 3 + F * 4, F * tb * 256);
+        const size_t need = F * tb * (2 + 1 + 4 + 8 + 64) + list_guess * 4;
         size_t free_b = 0, total_b = 0;
         bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2;
         if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
         if (fits) {
             hipError_t e2 = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking);
             if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&v.up_stream, hipStreamNonBlocking);
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.coef_dev, F * tb * 512);
+            if (e2 == hipSuccess && v.lists.create(ctx, F, tb, list_guess) != PFV_OK) e2 = hipErrorOutOfMemory;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.mv_dev, F * tb * 2);
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.has_dev, F * tb);
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.coded_dev, F * tb * 4);
@@ -1348,7 +1387,8 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.bytes_dev, bytes_guess);
             if (e2 == hipSuccess) { v.bytes_cap = bytes_guess; e2 = hipMalloc((void **)&v.sub_dev, sub_guess * 4 * sizeof(uint32_t)); }
             if (e2 == hipSuccess) { v.sub_cap = sub_guess * 4; e2 = hipMalloc((void **)&v.groups_dev, (sub_guess / kEdThreads + F) * sizeof(uint2)); }
-            if (e2 == hipSuccess) { v.groups_cap = sub_guess / kEdThreads + F; e2 = hipMalloc((void **)&v.pk_dev, F * sizeof(EdPacket)); }
+            if (e2 == hipSuccess) { v.groups_cap = sub_guess / kEdThreads + F; e2 = hipMalloc((void **)&v.wgsum_dev, v.groups_cap * sizeof(unsigned long long)); }
+            if (e2 == hipSuccess) { v.wgsum_cap = v.groups_cap; e2 = hipMalloc((void **)&v.pk_dev, F * sizeof(EdPacket)); }
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.status_dev, F * sizeof(uint32_t));
             if (e2 == hipSuccess) v.pk_cap = F;
             const bool host_ok = e2 == hipSuccess && v.mv_host.resize(F * tb * 2) && v.has_host.resize(F * tb) && v.coded_host.resize(F * tb) && v.bytes_host.resize(bytes_guess) &&
@@ -1360,10 +1400,11 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
                 v.on = true;
             } else {
                 (void)hipGetLastError();
-                for (void **p : {(void **)&v.coef_dev, (void **)&v.mv_dev, (void **)&v.has_dev, (void **)&v.coded_dev, (void **)&v.bytes_dev, (void **)&v.sub_dev,
+                for (void **p : {(void **)&v.wgsum_dev, (void **)&v.mv_dev, (void **)&v.has_dev, (void **)&v.coded_dev, (void **)&v.bytes_dev, (void **)&v.sub_dev,
                                  (void **)&v.groups_dev, (void **)&v.pk_dev, (void **)&v.status_dev})
                     if (*p) { (void)hipFree(*p); *p = nullptr; }
-                v.bytes_cap = v.sub_cap = v.groups_cap = v.pk_cap = 0;
+                v.lists.destroy();
+                v.bytes_cap = v.sub_cap = v.groups_cap = v.pk_cap = v.wgsum_cap = 0;
                 if (v.stream) { (void)hipStreamDestroy(v.stream); v.stream = nullptr; }
                 if (v.up_stream) { (void)hipStreamDestroy(v.up_stream); v.up_stream = nullptr; }
                 if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE)

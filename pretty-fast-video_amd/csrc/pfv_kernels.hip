@@ -450,6 +450,59 @@ __device__ __forceinline__ void stage_coef_half(int *stage, const uint4 (&buf)[2
     for (int j = 0; j < 2; j++) reinterpret_cast<uint4 *>(stage)[stage_chunk(j * 64 + lane)] = buf[j];
 }
 
+// ------------------------------------------------------------------ coefficient lists -> zigzag stage (pfv_device.h: CoefLists)
+// The decoders' other source of coefficients: the wavefront's macroblocks own one contiguous span [lo, hi) of their stream's list
+// (entries ascending by macroblock and position).  The stage is cleared and the span's entries are scattered into it with ds_write_b16 --
+// what the reference's run loop does per macroblock (src/dec.rs:261-296, 378-417: `coefficients[out_idx] = coeff` onto zeros), 64
+// entries per step.  8 lanes per macroblock: the stage holds one HALF of 8 macroblocks per pass (slot = macroblock, entries of the other
+// half are passed over); 16 lanes: both halves of 4 macroblocks (slot = 2 x macroblock + half).  `mb_low`: the low 8 bits of the frame-
+// relative index of the wavefront's first macroblock -- an entry names its macroblock by those bits, and a wavefront spans at most 8.
+// Entries that name a macroblock outside the wavefront's (a list that does not belong to these ranges) are dropped, not written.
+struct ListSpan {
+    const uint32_t *ent;   // the stream's list
+    uint32_t lo, hi;       // the wavefront's span (lo == hi: no entries)
+    uint32_t e0, e1;       // entries lo + lane and lo + 64 + lane, fetched ahead (most p-frame strips hold no more)
+};
+__device__ __forceinline__ ListSpan list_span(const uint32_t *ent, bool mine, const uint2 &rng, int lane)
+{
+    // lanes with `mine` hold their macroblock's range; macroblock order = lane order, so the span runs from the first such lane's
+    // begin to the last one's end
+    const unsigned long long owners = __ballot(mine);
+    ListSpan sp{ent, 0u, 0u, 0u, 0u};
+    if (owners) {
+        const int first = __builtin_ctzll(owners), last = 63 - __builtin_clzll(owners);
+        sp.lo = (uint32_t)__builtin_amdgcn_readlane((int)rng.x, first);
+        sp.hi = (uint32_t)__builtin_amdgcn_readlane((int)rng.y, last);
+        if (sp.hi < sp.lo) sp.hi = sp.lo;
+    }
+    const uint32_t k = sp.lo + (uint32_t)lane;
+    if (k < sp.hi) sp.e0 = ent[k];
+    if (k + 64u < sp.hi) sp.e1 = ent[k + 64u];
+    return sp;
+}
+template <int LPM>
+__device__ __forceinline__ void stage_list_put(int16_t *stage, uint32_t e, int mb_low, int h)
+{
+    const int pos = (int)(e & 255u), mbl = (int)(((e >> 8) - (uint32_t)mb_low) & 255u);
+    if (LPM == 8) {
+        if ((pos >> 7) == h && mbl < kStripMB) stage[mbl * (2 * kStagePitch) + (pos & 127)] = (int16_t)(e >> 16);
+    } else {
+        if (mbl < kStripMB / 2) stage[(mbl * 2 + (pos >> 7)) * (2 * kStagePitch) + (pos & 127)] = (int16_t)(e >> 16);
+    }
+}
+template <int LPM>
+__device__ __forceinline__ void stage_list_half(int *xw, const ListSpan &sp, int lane, int mb_low, int h)
+{
+#pragma unroll
+    for (int j = 0; j < 2; j++) reinterpret_cast<uint4 *>(xw)[stage_chunk(j * 64 + lane)] = make_uint4(0, 0, 0, 0);
+    wave_lds_sync();
+    int16_t *stage = reinterpret_cast<int16_t *>(xw);
+    const uint32_t k = sp.lo + (uint32_t)lane;
+    if (k < sp.hi) stage_list_put<LPM>(stage, sp.e0, mb_low, h);
+    if (k + 64u < sp.hi) stage_list_put<LPM>(stage, sp.e1, mb_low, h);
+    for (uint32_t j = k + 128u; j < sp.hi; j += 64u) stage_list_put<LPM>(stage, sp.ent[j], mb_low, h);
+}
+
 // ------------------------------------------------------------------ half-macroblock pipelines (per lane: 2 subblocks)
 // Forward: row-layout inputs (24.8 fixed point) -> quantised coefficients in column layout
 // (left in v) and scattered in zigzag order into the strip's coefficient stage.
@@ -1649,8 +1702,8 @@ __global__ __launch_bounds__(kThreads16) void k_enc_pframe16(FrameGeom g, const 
 // ================================================================== I-frame decode
 // reference: VideoPlane::decode_plane / decode_plane_into (src/common.rs:423-446, 477-496)
 // frames_out != nullptr: also write the cropped, tightly packed retframe (n_streams frames).
-template <int LPM = 8>
-__global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int16_t *__restrict__ coef,
+template <int LPM = 8, bool LISTS = false>
+__global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int16_t *__restrict__ coef, CoefLists cl,
                                                           uint8_t *__restrict__ out, const QTab *__restrict__ qtabs,
                                                           uint8_t *__restrict__ frames_out)
 {
@@ -1671,7 +1724,13 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
 
     const int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint4 cbuf[kPasses][2];
-    if (LPM == 8) {
+    ListSpan span;
+    if (LISTS) {   // every macroblock of an i-frame has a range (src/dec.rs:258-296: one run stream over all of them)
+        const bool mine = m < sp.n_mb;
+        uint2 rng = make_uint2(0u, 0u);
+        if (mine) rng = cl.ranges[(long)sp.stream * g.mbs_per_frame + sp.mb_first + m];
+        span = list_span(cl.entries[sp.stream], mine, rng, lane);
+    } else if (LPM == 8) {
         fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
         fetch_coef_half(cbuf[kPasses - 1], coef_mb0, sp.n_mb, lane, 1);
     } else {
@@ -1684,7 +1743,8 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
 #pragma unroll
     for (int pass = 0; pass < kPasses; pass++) {
         const int h = LPM == 8 ? pass : (slot & 1);
-        stage_coef_half(xw, cbuf[pass], lane);
+        if (LISTS) stage_list_half<LPM>(xw, span, lane, sp.mb_first + half_strip * 4, pass);
+        else stage_coef_half(xw, cbuf[pass], lane);
         wave_lds_sync();
         int v[2][8];
         gather_half(v, xw, slot, lq);
@@ -1719,9 +1779,9 @@ __device__ __forceinline__ uint4 load_unaligned16(const uint8_t *p)
                       __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
 }
 
-template <int LPM = 8>
+template <int LPM = 8, bool LISTS = false>
 __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8_t *__restrict__ mv,
-                                                          const uint8_t *__restrict__ has, const int16_t *__restrict__ coef,
+                                                          const uint8_t *__restrict__ has, const int16_t *__restrict__ coef, CoefLists cl,
                                                           const uint8_t *__restrict__ ref, uint8_t *__restrict__ out,
                                                           const QTab *__restrict__ qtabs, int *__restrict__ err_flag,
                                                           uint8_t *__restrict__ frames_out)
@@ -1746,6 +1806,8 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     // first round trip: block headers and (independent of them) the quantiser constants
     int mx = mv[mbi * 2 + 0], my = mv[mbi * 2 + 1];
     const bool coded = mb_valid && has[mbi] != 0;
+    uint2 rng = make_uint2(0u, 0u);
+    if (LISTS) rng = cl.ranges[mbi];      // read whether coded or not (no dependent round trip); only a coded macroblock's is used
     fill_qtable<false>(qtab_lds[wave], qtabs + p.qsel, lane);
 
     const int mbx = sp.x0 + m * 16, mby = sp.y0;
@@ -1760,8 +1822,11 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     const bool any_coded = __any(coded);
     const int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint4 cbuf[kPasses][2];
+    ListSpan span;
     if (any_coded) {
-        if (LPM == 8) {
+        if (LISTS) {
+            span = list_span(cl.entries[sp.stream], coded, rng, lane);
+        } else if (LPM == 8) {
             fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
             fetch_coef_half(cbuf[kPasses - 1], coef_mb0, sp.n_mb, lane, 1);
         } else {
@@ -1785,7 +1850,8 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
 #pragma unroll
         for (int pass = 0; pass < kPasses; pass++) {
             const int h = LPM == 8 ? pass : (slot & 1);
-            stage_coef_half(xw, cbuf[pass], lane);
+            if (LISTS) stage_list_half<LPM>(xw, span, lane, sp.mb_first + half_strip * 4, pass);
+            else stage_coef_half(xw, cbuf[pass], lane);
             wave_lds_sync();
             int v[2][8], pp[2][8];
             const int codedmask = coded ? -1 : 0;

@@ -159,6 +159,7 @@ static inline unsigned hipemu_cvt_pk_u8_f32(float v, unsigned idx, unsigned old)
 }
 #define __builtin_amdgcn_cvt_pk_u8_f32 hipemu_cvt_pk_u8_f32
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_readlane(v, l) hipemu::wave_exchange((v), (l))   // every lane of the wavefront executes it (the source lane is uniform)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))

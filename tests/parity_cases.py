@@ -655,6 +655,37 @@ def check_sparse_decode(pkg, ctx, w=100, h=60, n_streams=2, seed=11):
     a.close(); b.close()
 
 
+def check_lists_decode(pkg, ctx, w=100, h=60, n_streams=2, seed=13, kinds=("typical", "sparse", "zero", "dense", "edges")):
+    """pfv_dec_*_lists_dev (coefficient lists expanded in the kernels' LDS stage) == pfv_dec_* on the dense array: an i-frame, then
+    p-frames with every third macroblock or so skipped, two sessions side by side; the framebuffer after every frame"""
+    rng = np.random.default_rng(seed)
+    q = np.stack(pkg.qtables_from_quality(5)[:4])
+    a = pkg.DecoderSession(ctx, w, h, q, n_streams)
+    b = pkg.DecoderSession(ctx, w, h, q, n_streams)
+    nb, S = a.total_blocks, n_streams
+    n_entries = 0
+    for frame, kind in enumerate(kinds):
+        coef = np.stack([_hostile_coefficients(rng, nb, kind) for _ in range(S)])
+        if frame == 0:
+            entries, ranges = b.coef_lists(coef)
+            a.decode_iframe(coef)
+            b.decode_iframe_lists(entries, ranges)
+        else:
+            mv = np.zeros((S, nb, 2), np.int8)                 # zero motion is legal for every macroblock
+            has = (rng.random((S, nb)) < 0.7).astype(np.uint8)
+            if kind == "zero":
+                has[:] = 1                                      # coded macroblocks without a single value: empty ranges
+            entries, ranges = b.coef_lists(coef, has)
+            # the macroblocks a p-frame skips own no entries, whatever their coefficients say
+            assert sum(e.size for e in entries) == int(np.count_nonzero(coef.reshape(S, nb, 256)[has.astype(bool)]))
+            a.decode_pframe(mv, has, coef)
+            b.decode_pframe_lists(mv, has, entries, ranges)
+        n_entries += sum(e.size for e in entries)
+        assert np.array_equal(a.framebuffer(), b.framebuffer()), f"lists != dense decode, frame {frame} ({kind})"
+    a.close(); b.close()
+    return n_entries
+
+
 def check_async_entropy(pkg, ctx, oracle, w, h, n_streams, n_frames=6):
     """entropy stage on its own HIP stream with two alternating sets of encode outputs: payloads equal the oracle's
     serialisation of the same encode outputs, frame by frame"""

@@ -14,7 +14,7 @@ import stream_cases as sc
 # Both lane mappings of the codec kernels (pfv_kernels.hip, "Lane mappings").  At these sizes the automatic choice is the
 # small-grid mapping (16 lanes per macroblock); the kernel-level tests below run a second time with the batch mapping (8 lanes per
 # macroblock) forced.  The stream-level tests (containers, batch objects) run once, on the automatic choice.
-_BOTH_MAPPINGS = ("plane_ops", "golden", "trap", "session", "sparse_coded", "bad_motion", "gop_graph", "colour", "blit")
+_BOTH_MAPPINGS = ("plane_ops", "golden", "trap", "session", "sparse_coded", "bad_motion", "gop_graph", "colour", "blit", "lists_decode")
 
 
 @pytest.fixture(autouse=True, params=["auto", "lanes8"])
@@ -144,6 +144,13 @@ def test_emu_device_entropy_small_window():
                         os.path.abspath(__file__) + "::test_emu_device_entropy"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "1 passed" in r.stdout
+
+
+def test_emu_lists_decode(pkg, emu_ctx):
+    """coefficient lists expanded in the decode kernels' LDS stage == the dense arrays (both lane mappings); 144 x 16: a strip of 9 macroblocks
+    and chroma strips of 5 (ragged wavefronts); 48 x 32: whole strips"""
+    assert pc.check_lists_decode(pkg, emu_ctx, 48, 32, n_streams=2) > 0
+    assert pc.check_lists_decode(pkg, emu_ctx, 144, 16, n_streams=1, seed=14, kinds=("dense", "typical", "edges")) > 0
 
 
 def test_emu_sparse_decode(pkg, emu_ctx):

@@ -449,6 +449,13 @@ def test_batch_decoder(pkg, gpu_ctx, oracle):
     sc.check_batch_decoder(pkg, gpu_ctx, oracle, 64, 48, 10, n_streams=3, n_frames=3, gop=2, noise=True)
 
 
+def test_lists_decode(pkg, gpu_ctx):
+    """coefficient lists (round 5) through pfv_dec_*_lists_dev == the dense decode, ragged and whole strips, up to 960 x 540"""
+    assert pc.check_lists_decode(pkg, gpu_ctx, 100, 60, n_streams=2) > 0
+    assert pc.check_lists_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12) > 0
+    assert pc.check_lists_decode(pkg, gpu_ctx, 960, 540, n_streams=1, seed=15, kinds=("dense", "dense", "typical", "edges")) > 0
+
+
 def test_sparse_decode(pkg, gpu_ctx):
     pc.check_sparse_decode(pkg, gpu_ctx, 100, 60, n_streams=2)
     pc.check_sparse_decode(pkg, gpu_ctx, 640, 360, n_streams=3, seed=12)
