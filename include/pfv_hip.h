@@ -97,14 +97,15 @@ PFV_API const char *pfv_version(void);
  *       PFV_LANES_PER_MB_8 / PFV_LANES_PER_MB_16   force one of them
  *   PFV_OPT_ENTROPY_DECODE  where pfv_gop_decoder turns packet payloads into coefficients (src/dec.rs:258-296, 378-417):
  *       PFV_ENTROPY_DECODE_AUTO (default)  on the device (k_entd_*: self-synchronising parallel read of the run streams) when the
- *                                          batch's coefficient arrays fit the device's free memory, on the host otherwise
+ *                                          batch's coefficient lists fit the device's free memory, on the host otherwise
  *       PFV_ENTROPY_DECODE_HOST            the host parser pool (n_threads of pfv_gop_decoder_create)
  *       PFV_ENTROPY_DECODE_DEVICE          the device, or PFV_ERR_NOMEM from pfv_gop_decoder_create
  *     Either way a payload the device stage is not sure about (damaged, degenerate code table, periodic content whose read does
  *     not settle) is parsed by the host code, which alone decides about errors.
  *   PFV_OPT_ENTDEC_LANE_BITS / _LAUNCHES / _INNER_ROUNDS  shape of the device stage (measurements, and tests that force the "not settled"
- *       road): payload bits per lane (a multiple of 32 in 32..512, default 256), k_entd_sync launches before the verifying one (1..64,
- *       default 4), settling rounds inside a workgroup per launch (1..1024, default 24) */
+ *       road): payload bits per lane (a multiple of 32 in 32..256, default 256), read launches before the verifying one (1..64, default 3:
+ *       the full read k_entd_sync, then k_entd_fix for the seams between its workgroups), settling rounds inside a workgroup of the full
+ *       read (1..1024, default 24) */
 typedef enum pfv_option {
     PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2, PFV_OPT_LANE_MAPPING = 3, PFV_OPT_ENTROPY_DECODE = 4,
     PFV_OPT_ENTDEC_LANE_BITS = 5, PFV_OPT_ENTDEC_LAUNCHES = 6, PFV_OPT_ENTDEC_INNER_ROUNDS = 7
@@ -355,17 +356,18 @@ PFV_API int pfv_dec_pframe_sparse(pfv_dec_session *s, const int8_t *mv, const ui
  * reference expands runs into the macroblock it is about to decode, src/dec.rs:258-296, 378-417); nothing is cleared and nothing but the
  * values travels.
  *   entry   value (i16) << 16 | (macroblock index & 255) << 8 | position in the macroblock (0..255), ascending by (macroblock, position);
- *   range   per macroblock two uint32: its entries are [begin, end) of its slot's list; ascending over ALL macroblocks of the frame (one
- *           without entries: begin == end at its place).  The ranges are the kernels' loop bounds: they are not validated on the device.
+ *   count   per macroblock m and one more behind the last (total_blocks + 1 per frame): the entries that belong to macroblocks before m,
+ *           so m owns [count[m], count[m + 1]); a macroblock a p-frame skips owns none.  The counts are the kernels' loop bounds: they
+ *           are not validated on the device.
  * entries_dev: per slot of the session's window a DEVICE pointer to the slot's list (a device array of device pointers);
- * ranges_dev: [slot][macroblock][2].  Same result as the dense call on the expanded arrays. */
-PFV_API int pfv_dec_iframe_lists_dev(pfv_dec_session *s, const uint32_t *const *entries_dev, const uint32_t *ranges_dev, const uint8_t qidx[3]);
+ * counts_dev: [slot][total_blocks + 1].  Same result as the dense call on the expanded arrays. */
+PFV_API int pfv_dec_iframe_lists_dev(pfv_dec_session *s, const uint32_t *const *entries_dev, const uint32_t *counts_dev, const uint8_t qidx[3]);
 PFV_API int pfv_dec_pframe_lists_dev(pfv_dec_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev, const uint32_t *const *entries_dev,
-                                     const uint32_t *ranges_dev, const uint8_t qidx[3]);
+                                     const uint32_t *counts_dev, const uint8_t qidx[3]);
 /* host helper: one frame's dense coefficients ([total_blocks][256]; has_coef NULL: every macroblock is read) as a coefficient list.  Room for
- * `cap` entries and total_blocks ranges; *n_out = entries written; returns 1 when `cap` does not suffice (total_blocks x 256 always does). */
+ * `cap` entries and total_blocks + 1 counts; *n_out = entries written; returns 1 when `cap` does not suffice (total_blocks x 256 always does). */
 PFV_API int pfv_coef_lists_from_dense(const int16_t *coef, const uint8_t *has_coef, int total_blocks, uint32_t *entries_out, size_t cap,
-                                      uint32_t *ranges_out, size_t *n_out);
+                                      uint32_t *counts_out, size_t *n_out);
 /* Decoder::advance_frame's crop of framebuffer into retframe (src/dec.rs:195-197,
  * 209-211): frames_out = n_streams unpadded frames (Y|U|V). */
 PFV_API int pfv_dec_get_frame_dev(pfv_dec_session *s, uint8_t *frames_out_dev);

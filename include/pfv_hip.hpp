@@ -315,13 +315,17 @@ class GopDecoder {
     uint32_t height() const { return (uint32_t)pfv_gop_decoder_height(h_); }
     uint32_t framerate() const { return (uint32_t)pfv_gop_decoder_framerate(h_); }
     void reset() { ctx_.check(pfv_gop_decoder_reset(h_)); }
+    // With set_output_device(true) the frames live in device memory: the host-frame callbacks below would read device pointers, so they
+    // refuse (use the *_device forms).
     bool advance_delta(double delta, const OnVideo &onvideo)
     {
+        if (device_out_) throw std::logic_error("GopDecoder::advance_delta: frames stay in device memory (set_output_device): use advance_delta_device");
         cb_ = &onvideo;
         return result(pfv_gop_decoder_advance_delta(h_, delta, &GopDecoder::trampoline, this));
     }
     bool advance_frame(const OnVideo &onvideo)
     {
+        if (device_out_) throw std::logic_error("GopDecoder::advance_frame: frames stay in device memory (set_output_device): use advance_frame_device");
         cb_ = &onvideo;
         return result(pfv_gop_decoder_advance_frame(h_, &GopDecoder::trampoline, this));
     }
@@ -334,6 +338,15 @@ class GopDecoder {
         if (!device_out_) throw std::logic_error("GopDecoder::advance_frame_device: set_output_device(true) first");
         dcb_ = &onvideo;
         const int rc = pfv_gop_decoder_advance_frame(h_, &GopDecoder::trampoline_device, this);
+        dcb_ = nullptr;
+        if (rc < 0) ctx_.check(rc);
+        return rc == 1;
+    }
+    bool advance_delta_device(double delta, const OnVideoDevice &onvideo)       // Decoder::advance_delta (src/dec.rs:154-167), frames in device memory
+    {
+        if (!device_out_) throw std::logic_error("GopDecoder::advance_delta_device: set_output_device(true) first");
+        dcb_ = &onvideo;
+        const int rc = pfv_gop_decoder_advance_delta(h_, delta, &GopDecoder::trampoline_device, this);
         dcb_ = nullptr;
         if (rc < 0) ctx_.check(rc);
         return rc == 1;

@@ -77,7 +77,7 @@ struct pfv_ctx {
     int opt_tile_compaction = 1;                      // pfv_ctx_set_option(PFV_OPT_TILE_COMPACTION)
     int opt_lane_mapping = PFV_LANES_AUTO;            // pfv_ctx_set_option(PFV_OPT_LANE_MAPPING)
     int opt_entropy_decode = PFV_ENTROPY_DECODE_AUTO; // pfv_ctx_set_option(PFV_OPT_ENTROPY_DECODE)
-    int opt_entdec_lane_bits = (int)kEdSubBits, opt_entdec_launches = 4, opt_entdec_inner = kEdInner;   // PFV_OPT_ENTDEC_*
+    int opt_entdec_lane_bits = (int)kEdSubBits, opt_entdec_launches = 3, opt_entdec_inner = kEdInner;   // PFV_OPT_ENTDEC_*
     std::vector<struct pfv_comm *> comms;             // live communicators on this context (pfv_comm.hip): torn down with it
 };
 static void comm_teardown(struct pfv_comm *c);
@@ -136,7 +136,7 @@ PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value)
         ctx->opt_entropy_decode = value;
         return PFV_OK;
     case PFV_OPT_ENTDEC_LANE_BITS:
-        if (value < 32 || value > (int)kEdMaxSubBits || value % 32) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENTDEC_LANE_BITS: a multiple of 32 in 32..512");
+        if (value < 32 || value > (int)kEdMaxSubBits || value % 32) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_ENTDEC_LANE_BITS: a multiple of 32 in 32..256");
         ctx->opt_entdec_lane_bits = value;
         return PFV_OK;
     case PFV_OPT_ENTDEC_LAUNCHES:
@@ -531,13 +531,13 @@ struct DecCoefs {
     CoefLists lists{nullptr, nullptr};
     DecCoefs() = default;
     DecCoefs(const int16_t *d) : dense(d) {}
-    DecCoefs(const uint32_t *const *entries, const uint2 *ranges) : lists{entries, ranges} {}
+    DecCoefs(const uint32_t *const *entries, const uint32_t *counts) : lists{entries, counts} {}
     bool is_lists() const { return lists.entries != nullptr; }
     DecCoefs shifted(size_t slot, size_t mbs_per_frame) const
     {
         DecCoefs c;
         if (dense) c.dense = dense + slot * mbs_per_frame * 256;
-        if (lists.entries) c.lists = CoefLists{lists.entries + slot, lists.ranges + slot * mbs_per_frame};
+        if (lists.entries) c.lists = CoefLists{lists.entries + slot, lists.counts + slot * (mbs_per_frame + 1)};
         return c;
     }
 };
@@ -1600,30 +1600,30 @@ PFV_API int pfv_dec_pframe_dev(pfv_dec_session *s, const int8_t *mv_dev, const u
 }
 
 // The same two operations on COEFFICIENT LISTS (round 5; the form the stream decoders' entropy stage produces, see pfv_hip.h): per slot of
-// the session's window a pointer to its list of entries and, per macroblock, the range of its entries.  Same result as the dense call on
-// the expanded arrays.  The ranges must be what pfv_coef_lists_from_dense / the decoders produce (ascending, inside the slot's list): they
-// are the kernels' loop bounds and are not validated on the device.
-PFV_API int pfv_dec_iframe_lists_dev(pfv_dec_session *s, const uint32_t *const *entries_dev, const uint32_t *ranges_dev, const uint8_t qidx[3])
+// the session's window a pointer to its list of entries and, per macroblock (+ 1), the number of entries before it.  Same result as the
+// dense call on the expanded arrays.  The counts must be what pfv_coef_lists_from_dense / the decoders produce (ascending, within the
+// slot's list): they are the kernels' loop bounds and are not validated on the device.
+PFV_API int pfv_dec_iframe_lists_dev(pfv_dec_session *s, const uint32_t *const *entries_dev, const uint32_t *counts_dev, const uint8_t qidx[3])
 {
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
-    if (!entries_dev || !ranges_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_lists_dev: null buffer");
-    return dec_step(s, false, nullptr, nullptr, DecCoefs(entries_dev, (const uint2 *)ranges_dev), qidx);
+    if (!entries_dev || !counts_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_iframe_lists_dev: null buffer");
+    return dec_step(s, false, nullptr, nullptr, DecCoefs(entries_dev, counts_dev), qidx);
 }
 PFV_API int pfv_dec_pframe_lists_dev(pfv_dec_session *s, const int8_t *mv_dev, const uint8_t *has_coef_dev, const uint32_t *const *entries_dev,
-                                     const uint32_t *ranges_dev, const uint8_t qidx[3])
+                                     const uint32_t *counts_dev, const uint8_t qidx[3])
 {
     if (!s) return fail(nullptr, PFV_ERR_BAD_ARG, "null session");
-    if (!mv_dev || !has_coef_dev || !entries_dev || !ranges_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_lists_dev: null buffer");
-    return dec_step(s, true, mv_dev, has_coef_dev, DecCoefs(entries_dev, (const uint2 *)ranges_dev), qidx);
+    if (!mv_dev || !has_coef_dev || !entries_dev || !counts_dev) return fail(s->ctx, PFV_ERR_BAD_ARG, "pfv_dec_pframe_lists_dev: null buffer");
+    return dec_step(s, true, mv_dev, has_coef_dev, DecCoefs(entries_dev, counts_dev), qidx);
 }
 // Host helper: one frame's dense coefficients ([total_blocks][256]) as a coefficient list.  has_coef (nullable: every macroblock) says which
-// macroblocks are read.  entries_out has room for `cap` entries, ranges_out for total_blocks (begin, end) pairs; *n_out = entries written.
+// macroblocks are read.  entries_out has room for `cap` entries, counts_out for total_blocks + 1 counts; *n_out = entries written.
 // Returns 1 when more than `cap` entries would be needed (total_blocks x 256 always suffices).
-PFV_API int pfv_coef_lists_from_dense(const int16_t *coef, const uint8_t *has_coef, int total_blocks, uint32_t *entries_out, size_t cap, uint32_t *ranges_out,
+PFV_API int pfv_coef_lists_from_dense(const int16_t *coef, const uint8_t *has_coef, int total_blocks, uint32_t *entries_out, size_t cap, uint32_t *counts_out,
                                       size_t *n_out)
 {
-    if (!coef || !entries_out || !ranges_out || !n_out || total_blocks <= 0) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_coef_lists_from_dense: bad argument");
-    ListSink sink{entries_out, cap, (uint2 *)ranges_out, (size_t)total_blocks};
+    if (!coef || !entries_out || !counts_out || !n_out || total_blocks <= 0) return fail(nullptr, PFV_ERR_BAD_ARG, "pfv_coef_lists_from_dense: bad argument");
+    ListSink sink{entries_out, cap, counts_out, (size_t)total_blocks};
     bool full = false;
     for (size_t b = 0; b < (size_t)total_blocks && !full; b++) {
         if (has_coef && !has_coef[b]) continue;
@@ -1875,7 +1875,8 @@ struct pfv_encoder {
 // are independent bit streams, only the device decode behind them is sequential.
 // ------------------------------------------------------------------ the decoders' entropy stage on the device: host half
 // What only a serial read of a packet can give the k_entd_* kernels (pfv_entdec_kernels.hip): the table (-> the tree's codes), the q
-// indices, a p-frame's block headers (-> motion vectors, has_coeff, the list of coded macroblocks, the first bit of the run streams).
+// indices, a p-frame's block headers (-> motion vectors, has_coeff, the first bit of the run streams; the list of coded macroblocks is made
+// on the device from the has_coeff bytes, k_entd_coded).
 // The payload is copied to `bytes_dst` (page-locked staging, >= plen + 16 bytes).  The caller has set k.byte_off / k.frame_off.
 struct EntdPrep {
     int rc = 0;                  // a status the host parser would have returned before it read any run (header, q index, truncated block headers)
@@ -1929,13 +1930,13 @@ static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, si
 static inline size_t entd_pool_cap(size_t tb, size_t plen) { return (std::min(tb * 256, plen * 8 / 3 + 1) + 3) & ~(size_t)3; }
 
 // Device side of the coefficient lists of `frames` frames (pfv_device.h: CoefLists): a pool of entries the frames' lists are cut from, the
-// table of list pointers the decode kernels index by slot, the macroblocks' ranges.  A list that does not fit its place in the pool -- only a
+// table of list pointers the decode kernels index by slot, the frames' counts.  A list that does not fit its place in the pool -- only a
 // packet the HOST parser read can need more than entd_pool_cap (a one-symbol table: values of one or two bits) -- gets a buffer of its own
 // for the life of the batch (spill).
 struct ListPool {
     uint32_t *ent = nullptr; size_t ent_cap = 0;       // entries
     uint32_t **ptr_dev = nullptr;                      // [frames]
-    uint2 *ranges_dev = nullptr;                       // [frames][tb]
+    uint32_t *counts_dev = nullptr;                    // [frames][tb + 1]
     size_t frames = 0, tb = 0;
     PinnedBuf<uint32_t *> ptr_host;
     std::vector<uint32_t *> spill;
@@ -1943,7 +1944,7 @@ struct ListPool {
     {
         frames = n_frames; tb = total_blocks;
         HIP_TRY(ctx, hipMalloc((void **)&ptr_dev, n_frames * sizeof(uint32_t *)));
-        HIP_TRY(ctx, hipMalloc((void **)&ranges_dev, n_frames * total_blocks * sizeof(uint2)));
+        HIP_TRY(ctx, hipMalloc((void **)&counts_dev, n_frames * (total_blocks + 1) * sizeof(uint32_t)));
         if (entries) { HIP_TRY(ctx, hipMalloc((void **)&ent, entries * sizeof(uint32_t))); ent_cap = entries; }
         if (!ptr_host.resize(n_frames)) return fail(ctx, PFV_ERR_NOMEM, "pinned list-pointer staging");
         for (size_t f = 0; f < n_frames; f++) ptr_host.data()[f] = nullptr;
@@ -1967,19 +1968,19 @@ struct ListPool {
     void destroy()
     {
         drop_spill();
-        for (void *p : {(void *)ent, (void *)ptr_dev, (void *)ranges_dev})
+        for (void *p : {(void *)ent, (void *)ptr_dev, (void *)counts_dev})
             if (p) (void)hipFree(p);
-        ent = nullptr; ptr_dev = nullptr; ranges_dev = nullptr; ent_cap = 0;
+        ent = nullptr; ptr_dev = nullptr; counts_dev = nullptr; ent_cap = 0;
     }
-    DecCoefs coefs(size_t first_frame = 0) const { return DecCoefs(ptr_dev + first_frame, ranges_dev + first_frame * tb); }
+    DecCoefs coefs(size_t first_frame = 0) const { return DecCoefs(ptr_dev + first_frame, counts_dev + first_frame * (tb + 1)); }
 };
 
-// A packet through the HOST parser into list form, for a decoder whose coefficients travel as lists: entries and ranges into page-locked
-// staging (`ent` with room for `cap` entries, `ranges` [tb]).  kSinkFull: more than `cap` entries (parse again with room for tb x 256).
-static int parse_to_lists(const uint8_t *payload, size_t plen, int type, size_t tb, int n_qtables, int8_t *mv, uint8_t *has, uint32_t *ent, size_t cap, uint2 *ranges,
+// A packet through the HOST parser into list form, for a decoder whose coefficients travel as lists: entries and counts into page-locked
+// staging (`ent` with room for `cap` entries, `counts` [tb + 1]).  kSinkFull: more than `cap` entries (parse again with room for tb x 256).
+static int parse_to_lists(const uint8_t *payload, size_t plen, int type, size_t tb, int n_qtables, int8_t *mv, uint8_t *has, uint32_t *ent, size_t cap, uint32_t *counts,
                           size_t *n_out, uint8_t qidx[3])
 {
-    ListSink sink{ent, cap, ranges, tb};
+    ListSink sink{ent, cap, counts, tb};
     const int rc = type == 2 ? parse_pframe_to(payload, plen, (int)tb, n_qtables, mv, has, sink, qidx) : parse_iframe_to(payload, plen, (int)tb, n_qtables, sink, qidx);
     sink.finish();
     *n_out = sink.n;
@@ -1987,7 +1988,7 @@ static int parse_to_lists(const uint8_t *payload, size_t plen, int type, size_t 
 }
 // ... and onto the device, in frame `f`'s place of the pool (or a buffer of its own when it is longer than the place: `place_cap` entries),
 // on `stream`; the staging is free again when the stream has passed this point
-static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, const uint32_t *ent, size_t n, const uint2 *ranges, hipStream_t stream)
+static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, const uint32_t *ent, size_t n, const uint32_t *counts, hipStream_t stream)
 {
     uint32_t *dst = lp.ptr_host.data()[f];
     if (n > place_cap || !dst) {
@@ -1997,15 +1998,18 @@ static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, 
         HIP_TRY(ctx, hipMemcpyAsync(lp.ptr_dev + f, lp.ptr_host.data() + f, sizeof(uint32_t *), hipMemcpyHostToDevice, stream));
     }
     if (n) HIP_TRY(ctx, hipMemcpyAsync(dst, ent, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(ctx, hipMemcpyAsync(lp.ranges_dev + f * lp.tb, ranges, lp.tb * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    HIP_TRY(ctx, hipMemcpyAsync(lp.counts_dev + f * (lp.tb + 1), counts, (lp.tb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     return PFV_OK;
 }
 
 // the launches of one window: np packets from b.packet0 on, ng workgroups from b.group0 on (b.groups already points at the first of them)
-static void entd_launch(hipStream_t stream, const EdBufs &b, unsigned np, unsigned ng, int launches, int inner)
+static void entd_launch(hipStream_t stream, const EdBufs &b, const uint8_t *has_dev, unsigned np, unsigned ng, int launches, int inner)
 {
-    for (int round = 0; round <= launches; round++)
-        hipLaunchKernelGGL(k_entd_sync, dim3(ng), dim3(kEdThreads), 0, stream, b, round == 0 ? 1 : 0, round == launches ? 1 : 0, round == launches ? 1 : inner);
+    hipLaunchKernelGGL(k_entd_coded, dim3(np), dim3(kEdThreads), 0, stream, b, has_dev);
+    hipLaunchKernelGGL(k_entd_sync, dim3(ng), dim3(kEdThreads), 0, stream, b, inner);                      // every subsequence, settled inside the workgroups
+    for (int round = 1; round < launches; round++)                                                           // the seams between them (a second pass finds nothing, as a rule)
+        hipLaunchKernelGGL(k_entd_fix, dim3((ng + kEdFixThreads - 1) / kEdFixThreads), dim3(kEdFixThreads), 0, stream, b, (uint32_t)ng);
+    hipLaunchKernelGGL(k_entd_verify, dim3(ng), dim3(kEdThreads), 0, stream, b);
     hipLaunchKernelGGL(k_entd_prefix, dim3(np), dim3(kEdThreads), 0, stream, b);
     hipLaunchKernelGGL(k_entd_emit, dim3(ng), dim3(kEdThreads), 0, stream, b);
 }
@@ -2030,7 +2034,6 @@ struct DecEvent {
     // device-entropy form (PFV_OPT_ENTROPY_DECODE): what entd_prepare left for the k_entd_* kernels instead of a parsed packet
     bool dev_form = false, host_parse = false;
     PinnedBuf<uint8_t> bytes;            // the payload (+ 16)
-    PinnedBuf<uint32_t> coded;           // p-frames: the coded macroblocks, in order
     PinnedBuf<EdPacket> pk;              // 1
     PinnedBuf<uint2> groups;             // workgroups of the packet
 };
@@ -2039,7 +2042,7 @@ struct DecEvent {
 struct DecEntd {
     bool on = false, force = false;      // force: every packet (PFV_ENTROPY_DECODE_DEVICE); otherwise payloads of kDecEntdMinBytes and more
     uint32_t sub_bits = kEdSubBits;
-    int launches = 4, inner = kEdInner;
+    int launches = 3, inner = kEdInner;
     long packets_dev = 0, packets_host = 0;
 };
 constexpr uint32_t kDecEntdMinBytes = 64 * 1024;   // below this the launches cost more than the host parser needs for the packet
@@ -2070,17 +2073,16 @@ struct DecWindow {
 };
 // host staging of one packet the host parser reads into list form (a decoder whose coefficients travel as lists)
 struct ListStage {
-    PinnedBuf<uint32_t> ent;
-    PinnedBuf<uint2> ranges;
+    PinnedBuf<uint32_t> ent, counts;
     size_t n = 0;
     // kSinkFull cannot come back: a list of the place's size is tried first, then one with room for every coefficient
     int parse(const uint8_t *payload, size_t plen, int type, size_t tb, int n_qtables, int8_t *mv, uint8_t *has, size_t place_cap, uint8_t qidx[3])
     {
-        if (!ent.resize(std::max<size_t>(place_cap, 4)) || !ranges.resize(tb)) return PFV_ERR_NOMEM;
-        int rc = parse_to_lists(payload, plen, type, tb, n_qtables, mv, has, ent.data(), place_cap, ranges.data(), &n, qidx);
+        if (!ent.resize(std::max<size_t>(place_cap, 4)) || !counts.resize(tb + 1)) return PFV_ERR_NOMEM;
+        int rc = parse_to_lists(payload, plen, type, tb, n_qtables, mv, has, ent.data(), place_cap, counts.data(), &n, qidx);
         if (rc != kSinkFull) return rc;
         if (!ent.resize(tb * 256)) return PFV_ERR_NOMEM;
-        return parse_to_lists(payload, plen, type, tb, n_qtables, mv, has, ent.data(), tb * 256, ranges.data(), &n, qidx);
+        return parse_to_lists(payload, plen, type, tb, n_qtables, mv, has, ent.data(), tb * 256, counts.data(), &n, qidx);
     }
 };
 
@@ -2519,7 +2521,6 @@ struct BdSet {   // host staging of one step (two sets alternate)
     bool dev_form = false;
     PinnedBuf<uint8_t> bytes;          // the payloads, 16-byte aligned starts
     PinnedBuf<EdPacket> pk;            // [n]
-    PinnedBuf<uint32_t> coded;         // [n][total_blocks]
     PinnedBuf<uint2> groups;
     std::vector<uint8_t> host_parse;   // per stream: the host parser reads this packet
     size_t bytes_total = 0;
@@ -2556,7 +2557,7 @@ static void bd_parse_one(pfv_batch_decoder *b, BdSet *s, int k)
     if (s->dev_form) {   // the device reads the run streams: table, q indices, block headers and the payload's copy here
         EdPacket &pk = s->pk.data()[k];
         const EntdPrep r = entd_prepare(s->payload[(size_t)k], (uint32_t)s->len[(size_t)k], s->type, tb, b->n_qtables, b->entd.sub_bits, s->mv.data() + (size_t)k * tb * 2,
-                                        s->has.data() + (size_t)k * tb, s->coded.data() + (size_t)k * tb, pk, s->bytes.data() + pk.byte_off);
+                                        s->has.data() + (size_t)k * tb, nullptr, pk, s->bytes.data() + pk.byte_off);
         s->rc[(size_t)k] = r.rc;
         s->host_parse[(size_t)k] = r.host_parse;
         memcpy(&s->qidx[(size_t)k * 3], r.qidx, 3);
@@ -2710,13 +2711,12 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
     if (s->type == 2) {
         HIP_TRY(ctx, hipMemcpyAsync(w.mv_dev, s->mv.data(), S * tb * 2, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, s->has.data(), S * tb, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(w.coded_dev, s->coded.data(), S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, S * sizeof(uint32_t), st));
     if (n_groups) {
         const size_t ts = w.sub_cap / 4;
-        EdBufs eb{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.ranges_dev, w.status_dev, 0u, 0u};
-        entd_launch(st, eb, (unsigned)S, (unsigned)n_groups, v.launches, v.inner);
+        EdBufs eb{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.counts_dev, w.status_dev, 0u, 0u};
+        entd_launch(st, eb, w.has_dev, (unsigned)S, (unsigned)n_groups, v.launches, v.inner);
         if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(w.status_host.data(), w.status_dev, S * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2804,7 +2804,7 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
         }
         host_ok = host_ok && he == hipSuccess;
         for (auto &s : b->set) {
-            host_ok = host_ok && s.pk.resize(S) && s.coded.resize(S * tb);
+            host_ok = host_ok && s.pk.resize(S);
             s.host_parse.assign(S, 0);
         }
         v.on = host_ok;
@@ -2879,7 +2879,7 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
             const int prc = b->hp.parse(s->payload[k], s->len[k], s->type, tb, b->n_qtables, s->mv.data() + k * tb * 2, s->has.data() + k * tb, w.list_room[k], q);
             if (prc == PFV_ERR_NOMEM) return fail(ctx, prc, "pinned list staging");
             if (prc) { b->eof = true; return fail(ctx, prc, "malformed packet payload"); }
-            if ((rc = upload_lists(ctx, w.lists, k, w.list_room[k], b->hp.ent.data(), b->hp.n, b->hp.ranges.data(), ctx->stream))) return rc;
+            if ((rc = upload_lists(ctx, w.lists, k, w.list_room[k], b->hp.ent.data(), b->hp.n, b->hp.counts.data(), ctx->stream))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // the one staging list is used again
         }
         rc = dec_step(hot, s->type == 2, w.mv_dev, w.has_dev, w.lists.coefs(), &s->qidx[0]);
@@ -3066,13 +3066,13 @@ static void dec_parse(pfv_decoder *d, DecEvent *e)   // any thread; touches only
     if (d->entd.on && (d->entd.force || e->plen >= kDecEntdMinBytes)) {   // the device reads the run streams: only the headers here
         const uint32_t max_sub = (uint32_t)(((uint64_t)e->plen * 8 + d->entd.sub_bits - 1) / d->entd.sub_bits);
         if (!e->bytes.resize((size_t)e->plen + 32) || !e->pk.resize(1) || !e->groups.resize((size_t)max_sub / kEdThreads + 1) ||
-            (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb) || !e->coded.resize(tb)))) {
+            (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb)))) {
             e->rc = PFV_ERR_NOMEM;
             return;
         }
         EdPacket &k = *e->pk.data();
         k.byte_off = 0; k.frame_off = 0;
-        const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, d->entd.sub_bits, e->mv.data(), e->has.data(), e->coded.data(), k, e->bytes.data());
+        const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, d->entd.sub_bits, e->mv.data(), e->has.data(), nullptr, k, e->bytes.data());
         e->rc = r.rc;
         memcpy(e->qidx, r.qidx, 3);
         e->dev_form = true;
@@ -3297,13 +3297,12 @@ static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
     if (e->type == 2) {
         HIP_TRY(ctx, hipMemcpyAsync(w.mv_dev, e->mv.data(), tb * 2, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, e->has.data(), tb, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(w.coded_dev, e->coded.data(), tb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, sizeof(uint32_t), st));
     if (ng) {
         const size_t ts = w.sub_cap / 4;
-        EdBufs b{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.ranges_dev, w.status_dev, 0u, 0u};
-        entd_launch(st, b, 1u, ng, v.launches, v.inner);
+        EdBufs b{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.counts_dev, w.status_dev, 0u, 0u};
+        entd_launch(st, b, w.has_dev, 1u, ng, v.launches, v.inner);
         if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(w.status_host.data(), w.status_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -3336,7 +3335,7 @@ static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the staging list's last upload
         const int prc = d->hp.parse(e->payload, e->plen, e->type, tb, d->n_qtables, e->mv.data(), e->has.data(), w->list_room[0], e->qidx);
         if (prc) return fail(ctx, prc, prc == PFV_ERR_NOMEM ? "pinned list staging" : "malformed packet payload");
-        if ((rc = upload_lists(ctx, w->lists, 0, w->list_room[0], d->hp.ent.data(), d->hp.n, d->hp.ranges.data(), ctx->stream))) return rc;
+        if ((rc = upload_lists(ctx, w->lists, 0, w->list_room[0], d->hp.ent.data(), d->hp.n, d->hp.counts.data(), ctx->stream))) return rc;
     } else {
         v.packets_dev++;
     }

@@ -57,12 +57,12 @@ struct FrameGeom {
 // wavefront expands its strip's entries into its LDS zigzag stage.
 //   entry      value (i16) << 16 | (macroblock index & 255) << 8 | position in the macroblock (0..255, subblock-major zigzag order);
 //              ascending by (macroblock, position): the order the run streams are read in;
-//   range      per macroblock (x, y): its entries are [x, y) of the stream's list.  Only read for macroblocks that have coefficients
-//              (every macroblock of an i-frame, has_coeff != 0 in a p-frame); the macroblocks between two coded ones own no entries, so
-//              the entries of a strip of neighbouring macroblocks are one contiguous span.
+//   count      per macroblock m, and one more behind the last: the number of entries that belong to macroblocks BEFORE m -- an exclusive
+//              prefix over the frame, so macroblock m owns entries [count[m], count[m + 1]) and a strip of neighbouring macroblocks one
+//              contiguous span (a macroblock without coefficients, or one a p-frame skips, owns none).
 struct CoefLists {
     const uint32_t *const *entries;    // [stream]: the stream's list
-    const uint2 *ranges;               // [stream][mbs_per_frame]
+    const uint32_t *counts;            // [stream][mbs_per_frame + 1]
 };
 constexpr uint32_t coef_entry(uint32_t mb, uint32_t pos, int16_t value) { return ((uint32_t)(uint16_t)value << 16) | ((mb & 255u) << 8) | (pos & 255u); }
 

@@ -11,18 +11,21 @@
 //                 first run boundary at or behind the end of subsequence i when reading from `start` -- round 1 takes the
 //                 subsequence's own first bit for `start` (a guess), every later round takes end[i - 1] and only runs where that
 //                 differs from what the lane used before.  Rounds are cheap inside a workgroup (256 lanes pass their ends along in
-//                 LDS until nothing changes) and are launches between workgroups.  A last launch only verifies that no lane has
-//                 anything left to do: then end[0] is true (the first lane starts at the true first run) and every end[i] follows
-//                 from a true start.  A packet that has not settled (periodic content can keep a wrong phase for ever) is left to
-//                 the host parser.
+//                 LDS until nothing changes; the lanes that still have work are packed into as few wavefronts as they need).
+//   k_entd_fix    between workgroups the ends travel through memory: one thread per seam reads the workgroup's first lane from its
+//                 true start and follows the change until it meets the recorded read.
+//   k_entd_verify reads nothing and checks that no lane has anything left to do: then end[0] is true (the first lane starts at the
+//                 true first run) and every end[i] follows from a true start.  A packet that has not settled (periodic content can
+//                 keep a wrong phase for ever) is left to the host parser.
 //   k_entd_prefix exclusive prefix over the coefficients each workgroup's subsequences cover and over the values among them (summed by
 //                 the verifying launch): with a workgroup-local prefix in k_entd_emit, the coefficient index every lane's first run
 //                 starts at and the place of its first value in the packet's list.
 //   k_entd_emit   every lane reads its subsequence once more, from its true start, and appends its values to the packet's coefficient
 //                 list: one 32-bit entry per value, contiguous per lane, per workgroup and per packet -- nothing is cleared and nothing
 //                 but the values is written (round 4 scattered 2-byte values into a zeroed [macroblock][256] array: 46 x the bytes).
-//                 The run that crosses into a macroblock writes that macroblock's first entry index and its predecessor's end
-//                 (ranges; a p-frame's through the coded-macroblock list).  It also decides whether the host parser would have accepted the
+//                 The run that enters a macroblock knows how many values lie before it: the frame's exclusive counts (a p-frame's
+//                 through the list of coded macroblocks).  Entries and counts leave the workgroup through LDS as whole lines.
+//                 It also decides whether the host parser would have accepted the
 //                 payload and produced the same array: anything it is not sure of -- a field that runs past the payload, a value
 //                 behind the last coefficient, a macroblock whose runs do not end exactly on its 256th coefficient -- marks the
 //                 packet, and a marked packet is parsed by the host code instead (pfv_host.hip: read_runs), which alone
@@ -70,9 +73,9 @@ struct EdBufs {
     const uint2 *groups;           // workgroups of k_entd_sync / k_entd_emit: (packet, which kEdThreads subsequences of it)
     uint32_t *end, *used, *cnt;    // per subsequence; cnt = coefficients covered | values among them << 16 (a lane reads < 2^9 + 45 bits: < 2^13 of either)
     unsigned long long *wgsum;     // per workgroup of k_entd_sync: the sums of its lanes' cnt fields (coefficients | values << 32), then (k_entd_prefix) those before it
-    const uint32_t *coded;         // [frame][total_blocks]: the k-th coded macroblock of the frame (p-frames; from the host's pass over the block headers)
+    uint32_t *coded;               // [frame][total_blocks]: the k-th coded macroblock of the frame (p-frames; k_entd_coded, from the has_coeff bytes)
     uint32_t *const *lists;        // [frame]: where the frame's entries go (EdPacket::list_cap of them fit)
-    uint2 *ranges;                 // [frame][total_blocks]: per macroblock, its entries [x, y) of the frame's list
+    uint32_t *counts;              // [frame][total_blocks + 1]: per macroblock, the entries before it (CoefLists::counts)
     uint32_t *status;              // per packet: kEd* bits
     uint32_t packet0;              // k_entd_prefix: the launch's first packet (one workgroup per packet)
     uint32_t group0;               // index of b.groups[0] among all workgroups of the batch (EdPacket::grp_first counts from there too)
@@ -100,7 +103,7 @@ __device__ __forceinline__ void ed_build_table(uint8_t *tab, uint16_t *cval, uin
 
 // The bits a workgroup reads -- its 256 subsequences and what the last run of a lane hangs over -- are staged in LDS once (coalesced);
 // a lane then takes 32-bit windows at any bit position with one two-word read and one v_alignbit, and keeps no bit-buffer state.
-constexpr uint32_t kEdMaxSubBits = 512;                                    // the staging area is sized for this
+constexpr uint32_t kEdMaxSubBits = 256;                                    // the staging area is sized for this
 constexpr uint32_t kEdStageWords = kEdThreads * kEdMaxSubBits / 32 + 8;    // + 256 bits: a run starts < 45 bits behind a lane's limit, a window reads 64 behind its position
 struct EdReader {
     const uint32_t *lw;    // LDS: the payload from bit `base` on
@@ -180,83 +183,194 @@ __device__ __forceinline__ unsigned long long ed_block_exclusive(unsigned long l
 }
 __device__ __forceinline__ unsigned long long ed_split(uint32_t cnt) { return (unsigned long long)(cnt & 0xffffu) | ((unsigned long long)(cnt >> 16) << 32); }
 
-// one workgroup per entry of b.groups.  Inside a launch the lanes of a workgroup pass their ends along through LDS and repeat until
-// none of them has a new start (a lane whose read had not met the true one by its end changes its neighbour's start, and so on: a few
-// short rounds instead of launches); between workgroups the ends travel through memory, launch to launch.  verify != 0: nothing is
-// read, a lane that still has work marks the packet.
-__global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int first_round, int verify, int inner)
+// one workgroup per entry of b.groups: every lane reads its subsequence from the guess, then the lanes pass their ends along through LDS
+// and those with a new start read again, until none has one (a lane whose read had not met the true one by its end changes its
+// neighbour's start, and so on: ~68 % of the lanes are right after the second read, a third of the rest after each further one).  From the
+// third round on few lanes have work, but a wavefront with ONE such lane takes as long as a full one: the lanes with work are packed
+// (ballot + popcount ranks -> a list in LDS) and thread t reads for the t-th of them, so a round occupies ceil(n / 64) wavefronts, not 4.
+// The workgroup's first lane keeps its guess: the seams between workgroups are k_entd_fix's.
+__global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tab[4096];
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
-    __shared__ uint32_t s_end[kEdThreads];
     __shared__ uint32_t lw[kEdStageWords];
-    __shared__ unsigned long long scratch[kEdThreads];
-    __shared__ int any_work;
+    __shared__ uint32_t s_used[kEdThreads], s_end[kEdThreads], s_cnt[kEdThreads];     // the lanes' state
+    __shared__ uint32_t s_list[kEdThreads], s_start[kEdThreads];                        // this round's lanes with work, packed
+    __shared__ uint32_t s_wt[kEdThreads / 64];
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
-    const int tid = (int)threadIdx.x;
-    const uint32_t i = grp.y * kEdThreads + (uint32_t)tid;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i0 = grp.y * kEdThreads, i = i0 + (uint32_t)tid;
     const bool mine = i < pk.n_sub;
-    const size_t at = (size_t)pk.sub_first + i;
-    uint32_t used = kEdNoStart, end = 0, count = 0, before = 0;
-    if (mine && !first_round) { used = b.used[at]; end = b.end[at]; count = b.cnt[at]; }
-    // the workgroup in front may be storing this very word (its last lane's end, below) in this launch: either value will do -- an old one is
-    // caught by a later launch, the verifying one at the latest -- but the access is a relaxed atomic on both sides, not a data race
-    if (mine && !first_round && tid == 0 && i > 0) before = __atomic_load_n(b.end + at - 1, __ATOMIC_RELAXED);
-    const uint32_t limit = mine ? ed_limit(pk, i) : 0;
-    bool built = false, dirty = false;
-    uint32_t base = 0;
+    const uint32_t base = ed_stage(lw, b.bytes, pk, grp.y, tid);
+    s_used[tid] = kEdNoStart; s_end[tid] = 0; s_cnt[tid] = 0;
+    ed_build_table(tab, cval, clen, pk, tid);      // ends on a barrier
     for (int it = 0; it < inner; it++) {
-        s_end[tid] = end;
-        if (tid == 0) any_work = 0;
-        __syncthreads();
         uint32_t start = kEdNoStart;
         bool work = false;
         if (mine) {
             if (i == 0) start = pk.bit0;
-            else if (first_round && it == 0) start = pk.bit0 + i * pk.sub_bits;  // a guess: the subsequence's own first bit
-            else if (tid == 0) start = first_round ? used : before;
+            else if (it == 0) start = pk.bit0 + i * pk.sub_bits;      // a guess: the subsequence's own first bit
+            else if (tid == 0) start = s_used[0];
             else start = s_end[tid - 1];
-            work = used != start;
+            work = s_used[tid] != start;
         }
-        if (work) any_work = 1;
+        const unsigned long long mask = __ballot(work);
+        if (lane == 0) s_wt[wave] = (uint32_t)__popcll(mask);
         __syncthreads();
-        if (!any_work) break;
-        if (verify) {
-            if (work) atomicOr(b.status + grp.x, kEdUnsettled);
-            return;
-        }
-        if (!built) {
-            base = ed_stage(lw, b.bytes, pk, grp.y, tid);
-            ed_build_table(tab, cval, clen, pk, tid);
-            built = true;
-        }
+        uint32_t off = 0, n_work = 0;
+        for (int w = 0; w < kEdThreads / 64; w++) { off += w < wave ? s_wt[w] : 0u; n_work += s_wt[w]; }
+        if (n_work == 0) break;
         if (work) {
-            count = 0;
-            EdReader r{lw, base, start};
+            const uint32_t slot = off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            s_list[slot] = (uint32_t)tid;
+            s_start[slot] = start;
+        }
+        __syncthreads();
+        if ((uint32_t)tid < n_work) {
+            const uint32_t l = s_list[tid], limit = ed_limit(pk, i0 + l);
+            uint32_t count = 0;
+            EdReader r{lw, base, s_start[tid]};
             while (r.pos < limit) {
                 uint32_t zeros, nb;
                 int value;
                 ed_run(r, tab, cval, clen, zeros, nb, value);
                 count += zeros + (nb ? 0x10001u : 0u);
             }
-            end = r.pos;
-            used = start;
-            dirty = true;
+            s_used[l] = s_start[tid]; s_end[l] = r.pos; s_cnt[l] = count;
         }
         __syncthreads();
     }
-    if (dirty) {
-        if (tid == kEdThreads - 1) __atomic_store_n(b.end + at, end, __ATOMIC_RELAXED);   // read by the workgroup behind, maybe in this launch
-        else b.end[at] = end;
-        b.used[at] = used;
-        b.cnt[at] = count;
+    if (mine) {
+        const size_t at = (size_t)pk.sub_first + i;
+        b.end[at] = s_end[tid];
+        b.used[at] = s_used[tid];
+        b.cnt[at] = s_cnt[tid];
     }
-    if (verify) {   // settled (otherwise the launch has returned above): what the workgroup's subsequences cover, for k_entd_prefix
-        unsigned long long sum = 0;
-        (void)ed_block_exclusive(mine ? ed_split(count) : 0ull, scratch, tid, &sum);
-        if (tid == 0) b.wgsum[b.group0 + blockIdx.x] = sum;
+}
+
+// The seams: one THREAD per workgroup of k_entd_sync.  That workgroup's first lane read from its guess; its true start is the end of the
+// lane in front of it.  The thread reads the lane again from there and goes on into the lanes behind it until a read ends where the
+// recorded one did (from there on nothing changes) -- one to three lanes, as a rule.  No table and no staged workgroup: the lane's few
+// words and the packet's 16 codes go into the thread's own slice of LDS, codes are matched one by one (what a whole workgroup spent on
+// staging and a table for ONE lane's read was half the time of the full pass: 160 us against 330 per twenty 4K packets).
+// A seam whose repair runs into the next seam's lanes while that one is being repaired is found by k_entd_verify (unsettled -> host parser).
+constexpr int kEdFixThreads = 64;
+constexpr uint32_t kEdFixWords = kEdMaxSubBits / 32 + 7;      // a lane's bits from its start (< 45 bits behind its first) to 45 + 64 behind its limit; odd: no bank conflicts
+static_assert(kEdFixWords % 2 == 1, "per-thread LDS slices on an odd pitch");
+__global__ void __launch_bounds__(kEdFixThreads) k_entd_fix(EdBufs b, uint32_t n_groups)
+{
+    __shared__ uint32_t lw[kEdFixThreads][kEdFixWords];
+    __shared__ uint16_t cval[kEdFixThreads][17];
+    __shared__ uint8_t clen[kEdFixThreads][17];
+    const int tid = (int)threadIdx.x;
+    const uint32_t g = blockIdx.x * kEdFixThreads + (uint32_t)tid;
+    if (g >= n_groups) return;
+    const uint2 grp = b.groups[g];
+    if (grp.y == 0) return;                        // a packet's first lane starts at its first run: true
+    const EdPacket &pk = b.packets[grp.x];
+    for (int s = 0; s < 16; s++) { cval[tid][s] = pk.code_val[s]; clen[tid][s] = pk.code_len[s]; }
+    const uint32_t *src = (const uint32_t *)(b.bytes + pk.byte_off);
+    const uint32_t have = (pk.total_bits + 31u) / 32u + 3u;
+    uint32_t i = grp.y * kEdThreads;
+    size_t at = (size_t)pk.sub_first + i;
+    uint32_t start = __atomic_load_n(b.end + at - 1, __ATOMIC_RELAXED);
+    for (; i < pk.n_sub; i++, at++) {
+        if (b.used[at] == start) break;
+        const uint32_t limit = ed_limit(pk, i), w0 = start >> 5;
+        for (uint32_t k = 0; k < kEdFixWords; k++) lw[tid][k] = w0 + k < have ? src[w0 + k] : 0u;
+        uint32_t count = 0;
+        EdReader r{lw[tid], w0 * 32u, start};
+        while (r.pos < limit) {
+            // one run without the table (ed_run's fields, code by code)
+            uint32_t w = r.window();
+            uint32_t e = ed_long_code(w, cval[tid], clen[tid]);
+            r.pos += e & 15u;
+            const uint32_t zeros = e >> 4;
+            w = r.window();
+            e = ed_long_code(w, cval[tid], clen[tid]);
+            const uint32_t nb = e >> 4;
+            r.pos += (e & 15u) + nb;
+            count += zeros + (nb ? 0x10001u : 0u);
+        }
+        const uint32_t old_end = b.end[at];
+        b.used[at] = start;
+        __atomic_store_n(b.end + at, r.pos, __ATOMIC_RELAXED);
+        b.cnt[at] = count;
+        if (r.pos == old_end) break;               // met the recorded read: the lanes behind are as they were
+        start = r.pos;
+    }
+}
+
+// one workgroup per entry of b.groups, nothing is read: a lane whose recorded start is not the end of the lane in front of it marks the
+// packet (then end[0] was not followed through: the host parser reads it); the coefficients and values the workgroup's lanes cover,
+// summed for k_entd_prefix.
+__global__ void __launch_bounds__(kEdThreads) k_entd_verify(EdBufs b)
+{
+    __shared__ uint32_t s_end[kEdThreads];
+    __shared__ unsigned long long scratch[kEdThreads];
+    const uint2 grp = b.groups[blockIdx.x];
+    const EdPacket &pk = b.packets[grp.x];
+    const int tid = (int)threadIdx.x;
+    const uint32_t i = grp.y * kEdThreads + (uint32_t)tid;
+    const bool mine = i < pk.n_sub;
+    const size_t at = (size_t)pk.sub_first + i;
+    uint32_t used = kEdNoStart, end = 0, count = 0;
+    if (mine) { used = b.used[at]; end = b.end[at]; count = b.cnt[at]; }
+    s_end[tid] = end;
+    __syncthreads();
+    if (mine) {
+        const uint32_t start = i == 0 ? pk.bit0 : tid == 0 ? b.end[at - 1] : s_end[tid - 1];
+        if (used != start) atomicOr(b.status + grp.x, kEdUnsettled);
+    }
+    unsigned long long sum = 0;
+    (void)ed_block_exclusive(mine ? ed_split(count) : 0ull, scratch, tid, &sum);
+    if (tid == 0) b.wgsum[b.group0 + blockIdx.x] = sum;
+}
+
+// one workgroup per packet: a p-frame's list of coded macroblocks (coded[k] = the k-th macroblock with has_coeff set, src/dec.rs:378-380)
+// from its has_coeff bytes -- 4 bytes per macroblock that need not cross PCIe.  Rounds of 16 384 macroblocks: a thread takes 64 of them
+// (four independent 16-byte loads, kept in registers), counts the non-zero bytes, and writes its macroblocks behind those of the threads
+// and rounds before it.  (A first version read 64 bytes per wavefront and step with a ballot in between, a second read every byte again
+// behind stores the compiler could not move the loads across: 99 and 56 us of waiting for one load after the other.)
+__global__ void __launch_bounds__(kEdThreads) k_entd_coded(EdBufs b, const uint8_t *has_all)
+{
+    __shared__ unsigned long long scratch[kEdThreads];
+    const EdPacket &pk = b.packets[b.packet0 + blockIdx.x];
+    if (!pk.pframe || pk.n_sub == 0) return;
+    const int tid = (int)threadIdx.x;
+    const uint32_t tb = pk.total_blocks;
+    const uint8_t *has = has_all + pk.frame_off * tb;
+    uint32_t *coded = b.coded + pk.frame_off * tb;
+    uint32_t carry = 0;
+    for (uint32_t r0 = 0; r0 < tb; r0 += kEdThreads * 64u) {
+        const uint32_t lo = min(tb, r0 + (uint32_t)tid * 64u), hi = min(tb, lo + 64u);
+        uint32_t w[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const uint32_t m = lo + 16u * (uint32_t)q;
+            if (m + 16u <= hi) {
+                __builtin_memcpy(&v, has + m, 16);      // any alignment: a frame's row starts wherever total_blocks puts it
+            } else if (m < hi) {
+                uint8_t t[16] = {0};
+                for (uint32_t k = m; k < hi; k++) t[k - m] = has[k];
+                __builtin_memcpy(&v, t, 16);
+            }
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        uint32_t n = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) n += (uint32_t)__builtin_popcount((w[q] | ((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u);   // non-zero bytes
+        unsigned long long total = 0;
+        uint32_t at = carry + (uint32_t)ed_block_exclusive((unsigned long long)n, scratch, tid, &total);
+        carry += (uint32_t)total;
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((w[q] >> (8 * k)) & 0xffu) coded[at++] = lo + 4u * (uint32_t)q + (uint32_t)k;
     }
 }
 
@@ -280,7 +394,25 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_prefix(EdBufs b)
     }
 }
 
-// workgroups as k_entd_sync: the values of subsequence i into the packet's coefficient list, the macroblocks' ranges beside them
+// What a workgroup of k_entd_emit stages in LDS: its entries (the workgroup's share of the packet's list is contiguous), the counts of the
+// macroblocks that START inside it (contiguous in coefficient space) and, p-frames, the slice of the coded-macroblock list those need.  What
+// does not fit -- content far denser than any real frame -- goes to memory directly.
+#ifndef PFV_ED_OUT_CAP
+#define PFV_ED_OUT_CAP 4096             // tests build a variant with tiny stages so that small frames take the straight-to-memory paths
+#endif
+#ifndef PFV_ED_MB_CAP
+#define PFV_ED_MB_CAP 1024
+#endif
+constexpr uint32_t kEdOutCap = PFV_ED_OUT_CAP;    // entries
+constexpr uint32_t kEdMbCap = PFV_ED_MB_CAP;      // macroblock starts
+
+// counts[m] = n for the macroblocks (prev, mb]: the coded macroblock `mb` and the skipped ones in front of it own nothing before entry n
+__device__ __forceinline__ void ed_fill_counts(uint32_t *counts, uint32_t prev, uint32_t mb, uint32_t n)
+{
+    for (uint32_t m = prev + 1u; m <= mb; m++) counts[m] = n;       // prev == 0xffffffff: from macroblock 0
+}
+
+// workgroups as k_entd_sync: the values of subsequence i into the packet's coefficient list, the frame's counts beside them
 __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tab[4096];
@@ -288,82 +420,117 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
     __shared__ uint8_t clen[16];
     __shared__ uint32_t lw[kEdStageWords];
     __shared__ unsigned long long scratch[kEdThreads];
+    __shared__ uint32_t s_out[kEdOutCap];
+    __shared__ uint32_t s_start[kEdMbCap];
+    __shared__ uint32_t s_mb[kEdMbCap + 1];
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
-    if (b.status[grp.x] & kEdUnsettled) return;           // set by an earlier launch
+    if (b.status[grp.x] & kEdUnsettled) return;           // set by an earlier launch (the whole workgroup leaves)
     const int tid = (int)threadIdx.x;
     const uint32_t i = grp.y * kEdThreads + (uint32_t)tid;
     const uint32_t base = ed_stage(lw, b.bytes, pk, grp.y, tid);
     ed_build_table(tab, cval, clen, pk, tid);
     const bool mine = i < pk.n_sub;
     const size_t at = (size_t)pk.sub_first + i;
-    // what the workgroup's lanes before this one cover: coefficients (low half) and values (high half)
-    const unsigned long long before = b.wgsum[b.group0 + blockIdx.x] + ed_block_exclusive(mine ? ed_split(b.cnt[at]) : 0ull, scratch, tid, nullptr);
-    if (!mine) return;
-    const uint32_t start = i == 0 ? pk.bit0 : b.end[at - 1];
-    const uint32_t limit = ed_limit(pk, i), total = pk.total_coefs, cap = pk.list_cap;
+    // what the packet's workgroups before this one cover, what this one's lanes do, and this lane's place among them: coefficients (low
+    // half) and values (high half)
+    const unsigned long long wg0 = b.wgsum[b.group0 + blockIdx.x];
+    unsigned long long wg_sum = 0;
+    const unsigned long long before = wg0 + ed_block_exclusive(mine ? ed_split(b.cnt[at]) : 0ull, scratch, tid, &wg_sum);
+    const uint32_t total = pk.total_coefs, cap = pk.list_cap, n_k = total >> 8;
+    const uint32_t Vwg = (uint32_t)wg0, Owg = (uint32_t)(wg0 >> 32), n_wg = (uint32_t)(wg_sum >> 32);
+    // the macroblocks whose first coefficient lies in the workgroup: [ka, kb) in coefficient space (the k-th CODED macroblock of a p-frame)
+    const uint32_t ka = (uint32_t)min((unsigned long long)n_k, ((wg0 & 0xffffffffull) + 255ull) >> 8);
+    const uint32_t kb = (uint32_t)min((unsigned long long)n_k, ((wg0 & 0xffffffffull) + (wg_sum & 0xffffffffull) + 255ull) >> 8);
+    const uint32_t *coded = b.coded + pk.frame_off * pk.total_blocks;
+    uint32_t *counts = b.counts + pk.frame_off * (pk.total_blocks + 1u);
+    uint32_t *list = b.lists[pk.frame_off];
+    if (pk.pframe) {   // s_mb[j] = coded[ka - 1 + j]: the macroblocks that start here and the one the workgroup's first run may still be inside
+        const uint32_t n_stage = min(kb - ka + 1u, kEdMbCap + 1u);
+        for (uint32_t j = (uint32_t)tid; j < n_stage; j += kEdThreads) s_mb[j] = ka + j >= 1u ? coded[ka + j - 1u] : 0xffffffffu;
+        __syncthreads();
+    }
     uint32_t V = (uint32_t)before;             // the coefficient index the lane's first run starts at
     uint32_t O = (uint32_t)(before >> 32);     // the list index of its first value
-    if ((before & 0xffffffffull) >= total) return;                    // behind the last coefficient: nothing of this lane is read (src/dec.rs:261, :382)
-    const uint32_t *coded = b.coded + pk.frame_off * pk.total_blocks;
-    uint2 *ranges = b.ranges + pk.frame_off * pk.total_blocks;
-    uint32_t *list = b.lists[pk.frame_off];
+    const bool active = mine && (before & 0xffffffffull) < total;     // behind the last coefficient nothing is read (src/dec.rs:261, :382)
     bool odd = false;
-    EdReader r{lw, base, start};
-    if (pk.pframe) {
-        // one run stream per coded macroblock, closed exactly on its 256th coefficient: a macroblock's first run starts at V % 256 == 0
-        // (its range begins at O), the run that brings V to the next multiple of 256 ends it
-        uint32_t mb = 0;                 // the macroblock V lies in (read from the list of coded macroblocks when V enters it)
-        if (V & 255u) mb = coded[V >> 8];
-        while (r.pos < limit && V < total) {
-            uint32_t zeros, nb;
-            int value;
-            if (!(V & 255u)) { mb = coded[V >> 8]; ranges[mb].x = O; }
-            ed_run(r, tab, cval, clen, zeros, nb, value);
-            if (r.pos > pk.total_bits) { odd = true; break; }        // the run's fields run past the payload
-            const uint32_t local = (V & 255u) + zeros;
-            V += zeros;
-            if (local >= 256u) {                                       // the run closes the macroblock: exactly, and without a value
-                if (local != 256u || nb) { odd = true; break; }
-                ranges[mb].y = O;
-                continue;
+    if (active) {
+        const uint32_t start = i == 0 ? pk.bit0 : b.end[at - 1];
+        const uint32_t limit = ed_limit(pk, i);
+        EdReader r{lw, base, start};
+        if (pk.pframe) {
+            // one run stream per coded macroblock, closed exactly on its 256th coefficient: a macroblock's first run starts at V % 256 == 0
+            auto mb_of = [&](uint32_t k) -> uint32_t { const uint32_t j = k + 1u - ka; return j <= kEdMbCap ? s_mb[j] : coded[k]; };
+            uint32_t mb = (V & 255u) ? mb_of(V >> 8) : 0u;     // the macroblock V lies in
+            while (r.pos < limit && V < total) {
+                uint32_t zeros, nb;
+                int value;
+                if (!(V & 255u)) {                                     // a macroblock starts: O values lie before it
+                    const uint32_t k = V >> 8, j = k - ka;
+                    mb = mb_of(k);
+                    if (j < kEdMbCap) s_start[j] = O;
+                    else ed_fill_counts(counts, k ? mb_of(k - 1u) : 0xffffffffu, mb, O);
+                }
+                ed_run(r, tab, cval, clen, zeros, nb, value);
+                if (r.pos > pk.total_bits) { odd = true; break; }     // the run's fields run past the payload
+                const uint32_t local = (V & 255u) + zeros;
+                V += zeros;
+                if (local >= 256u) {                                    // the run closes the macroblock: exactly, and without a value
+                    if (local != 256u || nb) { odd = true; break; }
+                    continue;
+                }
+                if (nb) {
+                    const uint32_t e = coef_entry(mb, local, (int16_t)value), ol = O - Owg;
+                    if (ol < kEdOutCap) s_out[ol] = e;
+                    else if (O < cap) list[O] = e;
+                    O++;
+                    V++;
+                }
             }
-            if (nb) {
-                if (O < cap) list[O] = coef_entry(mb, local, (int16_t)value);
-                O++;
-                V++;
-                if (local == 255u) ranges[mb].y = O;                  // the macroblock's last coefficient: no closing run follows
+            if (V >= total && !odd) ed_fill_counts(counts, mb_of(n_k - 1u), pk.total_blocks, O);   // behind the last coded macroblock: all values
+        } else {
+            // ONE run stream over all macroblocks: the run that reaches or crosses the boundary 256 k -- V <= 256 k < V + zeros + (a value ? 1 : 0)
+            // -- knows how many values lie before macroblock k
+            while (r.pos < limit && V < total) {
+                uint32_t zeros, nb;
+                int value;
+                ed_run(r, tab, cval, clen, zeros, nb, value);
+                if (r.pos > pk.total_bits) { odd = true; break; }
+                const uint32_t k = (V + 255u) >> 8, after = V + zeros + (nb ? 1u : 0u);
+                if ((k << 8) < after && k < n_k) {                      // zeros <= 15: at most one boundary per run
+                    if (k - ka < kEdMbCap) s_start[k - ka] = O;
+                    else counts[k] = O;
+                }
+                V += zeros;
+                if (V >= total) {                                       // the closing run of the frame
+                    if (nb) odd = true;
+                    break;
+                }
+                if (nb) {
+                    const uint32_t e = coef_entry(V >> 8, V & 255u, (int16_t)value), ol = O - Owg;
+                    if (ol < kEdOutCap) s_out[ol] = e;
+                    else if (O < cap) list[O] = e;
+                    O++;
+                    V++;
+                }
             }
+            if (V >= total && !odd) counts[n_k] = O;                   // the lane whose run reached the last coefficient
         }
-    } else {
-        // ONE run stream over all macroblocks: the run that reaches or crosses the boundary 256 k -- V <= 256 k < V + zeros + (a value ? 1 : 0)
-        // -- knows how many values lie before it
-        while (r.pos < limit && V < total) {
-            uint32_t zeros, nb;
-            int value;
-            ed_run(r, tab, cval, clen, zeros, nb, value);
-            if (r.pos > pk.total_bits) { odd = true; break; }
-            const uint32_t k = (V + 255u) >> 8, after = V + zeros + (nb ? 1u : 0u);
-            if ((k << 8) < after && (k << 8) < total) {               // zeros <= 15: at most one boundary per run
-                ranges[k].x = O;
-                if (k) ranges[k - 1].y = O;
-            }
-            V += zeros;
-            if (V >= total) {                                          // the closing run of the frame
-                if (nb) odd = true;
-                break;
-            }
-            if (nb) {
-                if (O < cap) list[O] = coef_entry(V >> 8, V & 255u, (int16_t)value);
-                O++;
-                V++;
-            }
-        }
-        if (V >= total && !odd) ranges[(total >> 8) - 1].y = O;      // the lane whose run reached the last coefficient
+        if (!odd && i + 1 == pk.n_sub && V < total) odd = true;      // the payload ends before the last coefficient
+        if (!odd && O > cap) odd = true;                              // cannot happen for a payload the host parser accepts (entd_list_cap); never written past
     }
-    if (!odd && i + 1 == pk.n_sub && V < total) odd = true;          // the payload ends before the last coefficient
-    if (!odd && O > cap) odd = true;                                  // cannot happen for a payload the host parser accepts (entd_list_cap); never written past
     if (odd) atomicOr(b.status + grp.x, kEdIrregular);
+    __syncthreads();
+    // the staged entries and counts leave as whole lines
+    const uint32_t n_out = min(n_wg, kEdOutCap);
+    for (uint32_t j = (uint32_t)tid; j < n_out; j += kEdThreads)
+        if (Owg + j < cap) list[Owg + j] = s_out[j];
+    const uint32_t n_mb = min(kb - ka, kEdMbCap);
+    if (pk.pframe) {
+        for (uint32_t j = (uint32_t)tid; j < n_mb; j += kEdThreads) ed_fill_counts(counts, s_mb[j], s_mb[j + 1u], s_start[j]);
+    } else {
+        for (uint32_t j = (uint32_t)tid; j < n_mb; j += kEdThreads) counts[ka + j] = s_start[j];
+    }
 }
 
 }  // namespace pfv

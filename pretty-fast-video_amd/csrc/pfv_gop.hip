@@ -532,14 +532,13 @@ struct GopDecDev {
     PinnedBuf<int8_t> mv_host;
     PinnedBuf<EdPacket> pk_host;
     PinnedBuf<uint2> groups_host;
-    PinnedBuf<uint32_t> coded_host;      // [frame][total_blocks]
     uint32_t sub_bits = kEdSubBits;      // payload bits per lane (PFV_OPT_ENTDEC_LANE_BITS)
-    int launches = 4, inner = kEdInner;  // k_entd_sync launches before the verifying one, rounds inside each (PFV_OPT_ENTDEC_LAUNCHES / _INNER_ROUNDS)
+    int launches = 3, inner = kEdInner;  // read launches before the verifying one (k_entd_sync + launches - 1 x k_entd_fix), rounds inside the first (PFV_OPT_ENTDEC_LAUNCHES / _INNER_ROUNDS)
     long unsettled = 0, irregular = 0;   // why packets were left to the host parser
     PinnedBuf<uint32_t> status_host;
     PinnedBuf<int> flags_host;           // [step][max_gops]
     PinnedBuf<uint32_t> hp_ent;          // up to kGopDevDense packets the host parser reads, in list form: entries (a packet's share: its place's size) ...
-    PinnedBuf<uint2> hp_ranges;          // ... and ranges [kGopDevDense][tb]
+    PinnedBuf<uint32_t> hp_counts;       // ... and counts [kGopDevDense][tb + 1]
     PinnedBuf<uint32_t> hp_full;         // one packet whose list outgrew its place (tb x 256 entries)
     size_t hp_off[kGopDevDense] = {}, hp_n[kGopDevDense] = {};
     std::vector<GopDevPacket> pk;
@@ -977,7 +976,7 @@ static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
     EdPacket &k = v.pk_host.data()[j];
     const size_t tb = d->total_blocks;
     const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, v.sub_bits, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb,
-                                    v.coded_host.data() + p.frame * tb, k, v.bytes_host.data() + k.byte_off);
+                                    nullptr, k, v.bytes_host.data() + k.byte_off);
     p.rc = r.rc;
     p.host_parse = r.host_parse;
     memcpy(p.qidx, r.qidx, 3);
@@ -991,7 +990,7 @@ static void gopd_dev_hostparse(pfv_gop_decoder *d, int j)
     const size_t tb = d->total_blocks, pj = (size_t)v.todo[(size_t)(v.todo_first + j)];
     uint8_t q[3];
     p.rc = parse_to_lists(e->payload, e->plen, e->type, tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, v.hp_ent.data() + v.hp_off[j],
-                          v.list_room[pj], v.hp_ranges.data() + (size_t)j * tb, &v.hp_n[j], q);
+                          v.list_room[pj], v.hp_counts.data() + (size_t)j * (tb + 1), &v.hp_n[j], q);
 }
 static void gopd_dev_task(pfv_gop_decoder *d, int code)
 {
@@ -1145,13 +1144,12 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             if (bb > ba) HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev + ba, v.bytes_host.data() + ba, bb - ba, hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + f0 * tb * 2, v.mv_host.data() + f0 * tb * 2, S * tb * 2, hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + f0 * tb, v.has_host.data() + f0 * tb, S * tb, hipMemcpyHostToDevice, v.up_stream));
-            HIP_TRY(ctx, hipMemcpyAsync(v.coded_dev + f0 * tb, v.coded_host.data() + f0 * tb, S * tb * sizeof(uint32_t), hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipEventRecord(v.window_up[(size_t)t], v.up_stream));
             HIP_TRY(ctx, hipStreamWaitEvent(v.stream, v.window_up[(size_t)t], 0));
             if (gb > ga) {
-                EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.wgsum_dev, v.coded_dev, v.lists.ptr_dev, v.lists.ranges_dev,
+                EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.wgsum_dev, v.coded_dev, v.lists.ptr_dev, v.lists.counts_dev,
                          v.status_dev, (uint32_t)pa, (uint32_t)ga};
-                entd_launch(v.stream, b, (unsigned)(pb - pa), (unsigned)(gb - ga), v.launches, v.inner);
+                entd_launch(v.stream, b, v.has_dev, (unsigned)(pb - pa), (unsigned)(gb - ga), v.launches, v.inner);
                 const int lrc = launch_check(ctx, "k_entd_*");
                 if (lrc) return lrc;
             }
@@ -1196,7 +1194,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             const int cnt = (int)std::min<size_t>((size_t)kGopDevDense, v.todo.size() - first);
             size_t need = 0;
             for (int j = 0; j < cnt; j++) { v.hp_off[j] = need; need += v.list_room[(size_t)v.todo[first + (size_t)j]]; }
-            if (!v.hp_ent.resize(need) || !v.hp_ranges.resize((size_t)kGopDevDense * tb)) return fail(ctx, PFV_ERR_NOMEM, "pinned list staging");
+            if (!v.hp_ent.resize(need) || !v.hp_counts.resize((size_t)kGopDevDense * (tb + 1))) return fail(ctx, PFV_ERR_NOMEM, "pinned list staging");
             v.todo_first = (int)first;
             gopd_dev_hostparse_group(d, cnt);
             bool overflowed = false;
@@ -1205,7 +1203,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
                 const GopDevPacket &p = v.pk[pj];
                 if (p.rc == kSinkFull) overflowed = true;
                 if (p.rc) continue;
-                if ((rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_ent.data() + v.hp_off[j], v.hp_n[j], v.hp_ranges.data() + (size_t)j * tb, ctx->stream))) return rc;
+                if ((rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_ent.data() + v.hp_off[j], v.hp_n[j], v.hp_counts.data() + (size_t)j * (tb + 1), ctx->stream))) return rc;
             }
             // more values than the packet's bits could hold at three bits each (a one-symbol table: values of one or two bits): once more, with
             // room for every coefficient; its list gets a buffer of its own
@@ -1217,8 +1215,8 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
                 if (!v.hp_full.resize(tb * 256)) return fail(ctx, PFV_ERR_NOMEM, "pinned list staging");
                 uint8_t q[3];
                 p.rc = parse_to_lists(p.ev->payload, p.ev->plen, p.ev->type, tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, v.hp_full.data(), tb * 256,
-                                      v.hp_ranges.data() + (size_t)j * tb, &v.hp_n[j], q);
-                if (!p.rc && (rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_full.data(), v.hp_n[j], v.hp_ranges.data() + (size_t)j * tb, ctx->stream))) return rc;
+                                      v.hp_counts.data() + (size_t)j * (tb + 1), &v.hp_n[j], q);
+                if (!p.rc && (rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_full.data(), v.hp_n[j], v.hp_counts.data() + (size_t)j * (tb + 1), ctx->stream))) return rc;
             }
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the staging is used again
         }
@@ -1367,9 +1365,9 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
     if (!rc && ctx->opt_entropy_decode != PFV_ENTROPY_DECODE_HOST && tb > 0) {
         GopDecDev &v = d->dev;
         const size_t F = S * (size_t)max_gop_frames;
-        // per frame: motion vectors, flags, coded list, ranges; the coefficient lists at 4 bytes per 3 payload bits at most (entd_pool_cap)
+        // per frame: motion vectors, flags, coded list, counts; the coefficient lists at 4 bytes per 3 payload bits at most (entd_pool_cap)
         const size_t list_guess = std::min(std::min(len, F * (tb * 512 / 8 + 64)) * 8 / 3 + F * 4, F * tb * 256);
-        const size_t need = F * tb * (2 + 1 + 4 + 8 + 64) + list_guess * 4;
+        const size_t need = F * tb * (2 + 1 + 4 + 4 + 64) + list_guess * 4;
         size_t free_b = 0, total_b = 0;
         bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2;
         if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
@@ -1391,7 +1389,7 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
             if (e2 == hipSuccess) { v.wgsum_cap = v.groups_cap; e2 = hipMalloc((void **)&v.pk_dev, F * sizeof(EdPacket)); }
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.status_dev, F * sizeof(uint32_t));
             if (e2 == hipSuccess) v.pk_cap = F;
-            const bool host_ok = e2 == hipSuccess && v.mv_host.resize(F * tb * 2) && v.has_host.resize(F * tb) && v.coded_host.resize(F * tb) && v.bytes_host.resize(bytes_guess) &&
+            const bool host_ok = e2 == hipSuccess && v.mv_host.resize(F * tb * 2) && v.has_host.resize(F * tb) && v.bytes_host.resize(bytes_guess) &&
                                  v.pk_host.resize(F) && v.status_host.resize(F) && v.groups_host.resize(sub_guess / kEdThreads + F) && v.flags_host.resize(F);
             if (host_ok) {
                 memset(v.mv_host.data(), 0, F * tb * 2);

@@ -404,36 +404,28 @@ struct SparseSink {
         return true;
     }
 };
-// Coefficient lists (pfv_device.h: CoefLists), the form the decode kernels expand in LDS: one 32-bit entry per value, the macroblocks'
-// ranges beside them -- EVERY macroblock's, ascending (one without entries gets an empty range at its place in the list: a wavefront takes
-// its strip's span from the first and the last of its macroblocks).  finish() closes the last macroblock and the ones behind it.  The
-// parsers hand over ascending indices (the run streams are read front to back).
+// Coefficient lists (pfv_device.h: CoefLists), the form the decode kernels expand in LDS: one 32-bit entry per value and, per macroblock
+// (and one more behind the last), the number of entries before it.  finish() writes the counts behind the last value.  The parsers hand
+// over ascending indices (the run streams are read front to back).
 struct ListSink {
     uint32_t *ent;
     size_t cap;
-    uint2 *ranges;                 // [total_blocks]
+    uint32_t *counts;              // [total_blocks + 1]
     size_t total_blocks;
     size_t n = 0;
-    size_t next_mb = 0;            // ranges of the macroblocks before this one are written (the last of them still open)
+    size_t next_mb = 0;            // counts[0 .. next_mb) are written
     bool put(size_t i, int16_t v)
     {
         if (n >= cap) return false;
         const size_t mb = i >> 8;
-        if (mb >= next_mb) {
-            if (next_mb) ranges[next_mb - 1].y = (uint32_t)n;
-            for (size_t k = next_mb; k < mb; k++) ranges[k] = make_uint2((uint32_t)n, (uint32_t)n);
-            ranges[mb].x = (uint32_t)n;
-            next_mb = mb + 1;
-        }
+        for (; next_mb <= mb; next_mb++) counts[next_mb] = (uint32_t)n;
         ent[n++] = coef_entry((uint32_t)mb, (uint32_t)i & 255u, v);
         return true;
     }
     bool put_if(size_t c, size_t i, int16_t v) { return c ? put(i, v) : true; }
     void finish()
     {
-        if (next_mb) ranges[next_mb - 1].y = (uint32_t)n;
-        for (size_t k = next_mb; k < total_blocks; k++) ranges[k] = make_uint2((uint32_t)n, (uint32_t)n);
-        next_mb = total_blocks;
+        for (; next_mb <= total_blocks; next_mb++) counts[next_mb] = (uint32_t)n;
     }
 };
 constexpr int kSinkFull = 1;   // SparseSink / ListSink ran out of room: the caller falls back (dense form; a list of the frame's full size)

@@ -452,7 +452,7 @@ __device__ __forceinline__ void stage_coef_half(int *stage, const uint4 (&buf)[2
 
 // ------------------------------------------------------------------ coefficient lists -> zigzag stage (pfv_device.h: CoefLists)
 // The decoders' other source of coefficients: the wavefront's macroblocks own one contiguous span [lo, hi) of their stream's list
-// (entries ascending by macroblock and position).  The stage is cleared and the span's entries are scattered into it with ds_write_b16 --
+// (entries ascending by macroblock and position; lo, hi from the frame's exclusive counts).  The stage is cleared and the span's entries are scattered into it with ds_write_b16 --
 // what the reference's run loop does per macroblock (src/dec.rs:261-296, 378-417: `coefficients[out_idx] = coeff` onto zeros), 64
 // entries per step.  8 lanes per macroblock: the stage holds one HALF of 8 macroblocks per pass (slot = macroblock, entries of the other
 // half are passed over); 16 lanes: both halves of 4 macroblocks (slot = 2 x macroblock + half).  `mb_low`: the low 8 bits of the frame-
@@ -463,18 +463,14 @@ struct ListSpan {
     uint32_t lo, hi;       // the wavefront's span (lo == hi: no entries)
     uint32_t e0, e1;       // entries lo + lane and lo + 64 + lane, fetched ahead (most p-frame strips hold no more)
 };
-__device__ __forceinline__ ListSpan list_span(const uint32_t *ent, bool mine, const uint2 &rng, int lane)
+// lo / hi: counts[first macroblock of the wavefront] and counts[one behind its last] -- every lane passes its macroblock's pair (lanes of
+// absent macroblocks: anything): lane 0 holds the first macroblock's begin, lane `last_lane` the last one's end
+__device__ __forceinline__ ListSpan list_span(const uint32_t *ent, uint32_t begin, uint32_t end, int last_lane, int lane)
 {
-    // lanes with `mine` hold their macroblock's range; macroblock order = lane order, so the span runs from the first such lane's
-    // begin to the last one's end
-    const unsigned long long owners = __ballot(mine);
     ListSpan sp{ent, 0u, 0u, 0u, 0u};
-    if (owners) {
-        const int first = __builtin_ctzll(owners), last = 63 - __builtin_clzll(owners);
-        sp.lo = (uint32_t)__builtin_amdgcn_readlane((int)rng.x, first);
-        sp.hi = (uint32_t)__builtin_amdgcn_readlane((int)rng.y, last);
-        if (sp.hi < sp.lo) sp.hi = sp.lo;
-    }
+    sp.lo = (uint32_t)__builtin_amdgcn_readlane((int)begin, 0);
+    sp.hi = (uint32_t)__builtin_amdgcn_readlane((int)end, last_lane);
+    if (sp.hi < sp.lo) sp.hi = sp.lo;
     const uint32_t k = sp.lo + (uint32_t)lane;
     if (k < sp.hi) sp.e0 = ent[k];
     if (k + 64u < sp.hi) sp.e1 = ent[k + 64u];
@@ -1725,11 +1721,11 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
     const int16_t *coef_mb0 = coef + ((long)sp.stream * g.mbs_per_frame + sp.mb_first) * 256;
     uint4 cbuf[kPasses][2];
     ListSpan span;
-    if (LISTS) {   // every macroblock of an i-frame has a range (src/dec.rs:258-296: one run stream over all of them)
-        const bool mine = m < sp.n_mb;
-        uint2 rng = make_uint2(0u, 0u);
-        if (mine) rng = cl.ranges[(long)sp.stream * g.mbs_per_frame + sp.mb_first + m];
-        span = list_span(cl.entries[sp.stream], mine, rng, lane);
+    if (LISTS) {
+        const int last = min(sp.n_mb - half_strip * 4, LPM == 8 ? 8 : 4) - 1;     // the wavefront's last macroblock that exists (0-based, within the wavefront)
+        const uint32_t *cnt = cl.counts + (long)sp.stream * (g.mbs_per_frame + 1) + sp.mb_first + half_strip * 4;
+        const int mw = min(LPM == 8 ? slot : (slot >> 1), last);
+        span = list_span(cl.entries[sp.stream], cnt[mw], cnt[mw + 1], last * (LPM == 8 ? 8 : 16), lane);
     } else if (LPM == 8) {
         fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
         fetch_coef_half(cbuf[kPasses - 1], coef_mb0, sp.n_mb, lane, 1);
@@ -1806,8 +1802,14 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     // first round trip: block headers and (independent of them) the quantiser constants
     int mx = mv[mbi * 2 + 0], my = mv[mbi * 2 + 1];
     const bool coded = mb_valid && has[mbi] != 0;
-    uint2 rng = make_uint2(0u, 0u);
-    if (LISTS) rng = cl.ranges[mbi];      // read whether coded or not (no dependent round trip); only a coded macroblock's is used
+    uint32_t cnt0 = 0, cnt1 = 0;
+    int last_mb = 0;
+    if (LISTS) {   // the macroblock's share of the stream's list (no dependent round trip: read beside the block headers)
+        last_mb = min(sp.n_mb - half_strip * 4, LPM == 8 ? 8 : 4) - 1;
+        const uint32_t *cnt = cl.counts + (long)sp.stream * (g.mbs_per_frame + 1) + sp.mb_first + half_strip * 4;
+        const int mw = min(LPM == 8 ? slot : (slot >> 1), last_mb);
+        cnt0 = cnt[mw]; cnt1 = cnt[mw + 1];
+    }
     fill_qtable<false>(qtab_lds[wave], qtabs + p.qsel, lane);
 
     const int mbx = sp.x0 + m * 16, mby = sp.y0;
@@ -1825,7 +1827,7 @@ __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8
     ListSpan span;
     if (any_coded) {
         if (LISTS) {
-            span = list_span(cl.entries[sp.stream], coded, rng, lane);
+            span = list_span(cl.entries[sp.stream], cnt0, cnt1, last_mb * (LPM == 8 ? 8 : 16), lane);
         } else if (LPM == 8) {
             fetch_coef_half(cbuf[0], coef_mb0, sp.n_mb, lane, 0);
             fetch_coef_half(cbuf[kPasses - 1], coef_mb0, sp.n_mb, lane, 1);

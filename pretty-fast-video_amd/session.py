@@ -191,22 +191,22 @@ class DecoderSession(_Geometry):
         self.ctx.check(self.ctx._lib.pfv_dec_pframe(self.handle, ptr(m), ptr(hc), ptr(c), ptr(self._qidx(qidx))))
 
     def coef_lists(self, coef, has_coef=None):
-        """dense coefficients [n_streams][total_blocks][256] -> (entries per stream, ranges [n_streams][total_blocks][2]): the
+        """dense coefficients [n_streams][total_blocks][256] -> (entries per stream, counts [n_streams][total_blocks + 1]): the
         coefficient-list form of pfv_dec_*_lists_dev (pfv_coef_lists_from_dense)"""
         c = np.ascontiguousarray(coef, dtype=np.int16).reshape(self.n_streams, self.total_blocks * 256)
         hc = None if has_coef is None else np.ascontiguousarray(has_coef, dtype=np.uint8).reshape(self.n_streams, self.total_blocks)
-        entries, ranges = [], np.zeros((self.n_streams, self.total_blocks, 2), dtype=np.uint32)
+        entries, counts = [], np.zeros((self.n_streams, self.total_blocks + 1), dtype=np.uint32)
         for k in range(self.n_streams):
             e = np.empty(self.total_blocks * 256, dtype=np.uint32)
             n = ctypes.c_size_t(0)
             rc = self.ctx._lib.pfv_coef_lists_from_dense(ptr(c[k]), ptr(hc[k]) if hc is not None else None, self.total_blocks, ptr(e), e.size,
-                                                         ptr(ranges[k]), ctypes.byref(n))
+                                                         ptr(counts[k]), ctypes.byref(n))
             assert rc == 0, rc
             entries.append(e[:n.value].copy())
-        return entries, ranges
+        return entries, counts
 
-    def _upload_lists(self, entries, ranges):
-        """entries of all slots back to back in one device buffer + the table of list pointers + the ranges; returns the three device
+    def _upload_lists(self, entries, counts):
+        """entries of all slots back to back in one device buffer + the table of list pointers + the counts; returns the three device
         addresses (the caller frees them)"""
         ctx = self.ctx
         sizes = [max(int(e.size), 1) for e in entries]
@@ -220,14 +220,14 @@ class DecoderSession(_Geometry):
             off += sizes[k]
         ptr_dev = ctx.alloc(8 * self.n_streams)
         ctx.upload(ptr_dev, ptrs)
-        r = np.ascontiguousarray(ranges, dtype=np.uint32)
+        r = np.ascontiguousarray(counts, dtype=np.uint32)
         rng_dev = ctx.alloc(r.nbytes)
         ctx.upload(rng_dev, r)
         return ent_dev, ptr_dev, rng_dev
 
-    def decode_iframe_lists(self, entries, ranges, qidx=(0, 1, 1)):
+    def decode_iframe_lists(self, entries, counts, qidx=(0, 1, 1)):
         """i-frame from coefficient lists (coef_lists): same framebuffer as decode_iframe on the dense array"""
-        bufs = self._upload_lists(entries, ranges)
+        bufs = self._upload_lists(entries, counts)
         try:
             self.ctx.check(self.ctx._lib.pfv_dec_iframe_lists_dev(self.handle, ctypes.c_void_p(bufs[1]), ctypes.c_void_p(bufs[2]), ptr(self._qidx(qidx))))
             self.ctx.sync()
@@ -235,11 +235,11 @@ class DecoderSession(_Geometry):
             for b in bufs:
                 self.ctx.free(b)
 
-    def decode_pframe_lists(self, mv, has_coef, entries, ranges, qidx=(2, 3, 3)):
+    def decode_pframe_lists(self, mv, has_coef, entries, counts, qidx=(2, 3, 3)):
         ctx = self.ctx
         m = np.ascontiguousarray(mv, dtype=np.int8)
         hc = np.ascontiguousarray(has_coef, dtype=np.uint8)
-        bufs = list(self._upload_lists(entries, ranges))
+        bufs = list(self._upload_lists(entries, counts))
         try:
             mv_dev = ctx.alloc(m.nbytes); bufs.append(mv_dev)
             has_dev = ctx.alloc(hc.nbytes); bufs.append(has_dev)

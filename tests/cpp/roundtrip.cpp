@@ -108,6 +108,13 @@ int main(int argc, char **argv)
                        std::equal(got.begin(), got.end(), reinterpret_cast<const uint8_t *>(want.data()));
                 n_dev++;
             };
+            {   // the host-frame callbacks would read device pointers now: they must refuse, not crash (and leave the decoder where it was)
+                bool refused = false;
+                try { gd2.advance_frame([](const pfv::VideoFrame &) {}); } catch (const std::logic_error &) { refused = true; }
+                try { gd2.advance_delta(1.0, [](const pfv::VideoFrame &) {}); refused = false; } catch (const std::logic_error &) {}
+                if (!refused) { std::fprintf(stderr, "GopDecoder::advance_frame / advance_delta accepted a host callback with frames in device memory\n"); return 1; }
+            }
+            if (!gd2.advance_delta_device(1.0 / fps, cmp_dev)) { std::fprintf(stderr, "GopDecoder::advance_delta_device ended the stream early\n"); return 1; }
             while (gd2.advance_frame_device(cmp_dev)) {}
             if (!same || n_dev != n_out) { std::fprintf(stderr, "GopDecoder frames left in device memory differ (%d of %d)\n", n_dev, n_out); return 1; }
             std::printf("gop: %d frames identical to the frame-by-frame objects\n", n_gop);

@@ -48,6 +48,8 @@ static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline unsigned long long min(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+static inline unsigned long long max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 
 namespace hipemu {
 

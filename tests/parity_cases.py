@@ -667,19 +667,19 @@ def check_lists_decode(pkg, ctx, w=100, h=60, n_streams=2, seed=13, kinds=("typi
     for frame, kind in enumerate(kinds):
         coef = np.stack([_hostile_coefficients(rng, nb, kind) for _ in range(S)])
         if frame == 0:
-            entries, ranges = b.coef_lists(coef)
+            entries, counts = b.coef_lists(coef)
             a.decode_iframe(coef)
-            b.decode_iframe_lists(entries, ranges)
+            b.decode_iframe_lists(entries, counts)
         else:
             mv = np.zeros((S, nb, 2), np.int8)                 # zero motion is legal for every macroblock
             has = (rng.random((S, nb)) < 0.7).astype(np.uint8)
             if kind == "zero":
-                has[:] = 1                                      # coded macroblocks without a single value: empty ranges
-            entries, ranges = b.coef_lists(coef, has)
+                has[:] = 1                                      # coded macroblocks without a single value: they own no entries
+            entries, counts = b.coef_lists(coef, has)
             # the macroblocks a p-frame skips own no entries, whatever their coefficients say
             assert sum(e.size for e in entries) == int(np.count_nonzero(coef.reshape(S, nb, 256)[has.astype(bool)]))
             a.decode_pframe(mv, has, coef)
-            b.decode_pframe_lists(mv, has, entries, ranges)
+            b.decode_pframe_lists(mv, has, entries, counts)
         n_entries += sum(e.size for e in entries)
         assert np.array_equal(a.framebuffer(), b.framebuffer()), f"lists != dense decode, frame {frame} ({kind})"
     a.close(); b.close()

@@ -639,13 +639,16 @@ def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIP
     st = pkg.SyntheticStream(w, h)
     flat = [np.full(fb, 16 + 40 * (t // 3), np.uint8) for t in range(len(pattern))]
     noise = [rng.integers(0, 256, fb, dtype=np.uint8) for _ in range(len(pattern))]
-    cases = (("pan", st.frame, quality, None), ("pan_sub64", st.frame, quality, "64"), ("flat", lambda t: flat[t], quality, None), ("noise", lambda t: noise[t], 0, None))
-    for name, src, q, sub_bits in cases:
+    # pan_seams: 32-bit subsequences -- a small frame's payload then spans several workgroups of the full read, and the seams between them
+    # are repaired by k_entd_fix (default launches and rounds: the packets must still settle on the device)
+    cases = (("pan", st.frame, quality, None), ("pan_sub64", st.frame, quality, (64, 1, 1)), ("pan_seams", st.frame, quality, (32, None, None)),
+             ("flat", lambda t: flat[t], quality, None), ("noise", lambda t: noise[t], 0, None), ("noise_seams", lambda t: noise[t], 0, (32, None, None)))
+    for name, src, q, shape in cases:
         data, _ = encode_pattern(pkg, ctx, oracle, w, h, q, pattern, lambda buf: pkg.Encoder(buf, w, h, 30, q, ctx), src, with_oracle=False)
         want = _outcomes_oracle(oracle, data)
         n_packets = sum(c != "D" for c in pattern)
         assert [x[0] for x in want].count("frame") == n_packets
-        dec = pkg.GopDecoder(data, ctx, max_gops=3, max_gop_frames=8, threads=2, entropy="device", entropy_shape=(64, 1, 1) if sub_bits else None)
+        dec = pkg.GopDecoder(data, ctx, max_gops=3, max_gop_frames=8, threads=2, entropy="device", entropy_shape=shape)
         got = []
         while True:
             fr = []
@@ -662,4 +665,6 @@ def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIP
         out[name] = {k: stats[k] for k in ("packets_read_on_device", "packets_left_to_host_parser", "left_unsettled", "left_irregular")}
     assert out["pan"]["packets_read_on_device"] >= min_device_share * n_packets, out
     assert out["pan_sub64"]["left_unsettled"] >= 1 or not expect_unsettled, out
+    assert out["pan_seams"]["packets_read_on_device"] >= min_device_share * n_packets, out
+    assert out["noise_seams"]["packets_read_on_device"] >= 1, out
     return out

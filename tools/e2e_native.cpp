@@ -155,7 +155,9 @@ int main(int argc, char **argv)
              W, H, N, GOP, Q, stream.size(), (double)N * n_mb / t_enc, (double)N * n_mb / t_enc_hbm, t_enc, enc_stats[0], enc_stats[1], enc_stats[2], enc_stats[3], enc_stats[4], EG, DG, threads);
     out += buf;
     uint64_t want_hash = 0;
+    const char *only = getenv("PFV_E2E_ONLY");        // profiling runs: one decode mode by name, nothing behind it
     for (size_t m = 0; m < sizeof modes / sizeof modes[0]; m++) {
+        if (only && strcmp(only, modes[m].name) != 0) continue;
         double best = 1e30, st[10] = {0};
         for (int rep = 0; rep < 3; rep++) {   // the first run of a mode pays for code objects and first-touch of its buffers
             CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTROPY_DECODE, modes[m].entropy));
@@ -177,9 +179,10 @@ int main(int argc, char **argv)
         snprintf(buf, sizeof buf,
                  "%s\"%s\": {\"decode_value\": %.1f, \"decode_s\": %.5f, \"decoder_host_seconds\": {\"scan_s\": %.5f, \"parse_wait_s\": %.5f, \"device_wait_s\": %.5f, "
                  "\"enqueue_s\": %.5f, \"final_wait_s\": %.5f, \"device_entropy_wait_s\": %.5f}, \"packets_read_on_device\": %.0f, \"packets_left_to_host_parser\": %.0f, \"left_unsettled\": %.0f, \"left_irregular\": %.0f}",
-                 m ? ", " : "", modes[m].name, (double)N * n_mb / best, best, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9]);
+                 (m && !only) ? ", " : "", modes[m].name, (double)N * n_mb / best, best, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9]);
         out += buf;
     }
+    if (only) { out += "}}"; puts(out.c_str()); return 0; }
     // ---- the frame-by-frame objects (the reference's own call pattern: one packet per call, src/enc.rs:75-173, src/dec.rs:169-224)
     double t_senc = 0, t_sdec = 0, t_sdec_host = 0, t_sdec_hbm = 0;
     long sdec_counts[2] = {0, 0};

@@ -32,6 +32,25 @@ with pkg.Context(0) as ctx:
     enc.close()
     data = buf.getvalue()
     print("stream", len(data), "bytes,", N, "frames", flush=True)
+    if os.environ.get("PFV_PROBE_COUNT_VALUES") == "1":   # what the entropy stage has to deliver: the non-zero coefficients of every packet (host parser)
+        import ctypes
+        L = pkg._lib.load()
+        pos = 20 + 128 * (data[18] | data[19] << 8)
+        raw = np.frombuffer(data, np.uint8)
+        idx = np.empty(n_mb * 256, np.uint32); val = np.empty(n_mb * 256, np.int16)
+        mv = np.empty(n_mb * 2, np.int8); has = np.empty(n_mb, np.uint8); q = np.zeros(3, np.uint8)
+        per_type = {1: [0, 0, 0], 2: [0, 0, 0]}
+        while pos + 5 <= len(data) and data[pos] != 0:
+            typ, plen = data[pos], int.from_bytes(data[pos + 1:pos + 5], "little")
+            n = ctypes.c_size_t(0)
+            rc = L.pfv_parse_payload_sparse(int(typ == 2), raw[pos + 5:pos + 5 + plen].ctypes.data_as(ctypes.c_void_p), plen, n_mb, 4, mv.ctypes.data_as(ctypes.c_void_p),
+                                            has.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p), idx.size, ctypes.byref(n), q.ctypes.data_as(ctypes.c_void_p))
+            assert rc == 0, rc
+            t = per_type[typ]; t[0] += 1; t[1] += n.value; t[2] += plen
+            pos += 5 + plen
+        for typ, (k, nv, nb) in per_type.items():
+            if k:
+                print(f"packets type {typ}: {k}, values per packet {nv / k:.0f} (= {2 * nv / k / 1e6:.3f} MB of int16), payload bytes per packet {nb / k:.0f}", flush=True)
     digests = {}
     for mode in os.environ.get("PFV_PROBE_MODES", "host,device,device,host,device,device->HBM,device->HBM").split(","):
         import hashlib

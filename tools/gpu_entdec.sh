@@ -11,7 +11,7 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "gop or Go
 fi
 [ "${1:-}" != "quick" ] && { timeout 900 python tools/entdec_probe.py > $O/probe.log 2>&1; tail -12 $O/probe.log; }
 g++ -O2 -std=c++17 -I include tools/e2e_native.cpp -L pretty-fast-video_amd -lpfv_hip -Wl,-rpath,$R/pretty-fast-video_amd -o /tmp/e2e_native
-for sb in 128 256 512; do
+for sb in 128 256; do
   timeout 600 /tmp/e2e_native 3840 2160 300 15 5 10 20 15 $sb > $O/native_$sb.json 2> $O/native.err; tail -3 $O/native.err
   python - $O/native_$sb.json $sb <<'PY'
 import json, sys

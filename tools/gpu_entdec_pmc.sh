@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/entdec_pmc
 mkdir -p $OUT
 cd $R && python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+PFV_PROBE_COUNT_VALUES=1 PFV_PROBE_MODES="device->HBM" timeout 600 python $R/tools/entdec_probe.py 150 2>&1 | grep "packets type" | tee $OUT/values.txt
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   name=$1; shift
