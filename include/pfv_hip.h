@@ -105,7 +105,7 @@ PFV_API const char *pfv_version(void);
  *   PFV_OPT_ENTDEC_LANE_BITS / _LAUNCHES / _INNER_ROUNDS  shape of the device stage (measurements, and tests that force the "not settled"
  *       road): payload bits per lane (a multiple of 32 in 32..256, default 256), read launches before the verifying one (1..64, default 3:
  *       the full read k_entd_sync, then k_entd_fix for the seams between its workgroups), settling rounds inside a workgroup of the full
- *       read (1..1024, default 24) */
+ *       read (1..1024, default 96; a round in which no lane has a new start ends them) */
 typedef enum pfv_option {
     PFV_OPT_ENC_TRANSFORM = 1, PFV_OPT_TILE_COMPACTION = 2, PFV_OPT_LANE_MAPPING = 3, PFV_OPT_ENTROPY_DECODE = 4,
     PFV_OPT_ENTDEC_LANE_BITS = 5, PFV_OPT_ENTDEC_LAUNCHES = 6, PFV_OPT_ENTDEC_INNER_ROUNDS = 7
@@ -233,6 +233,8 @@ PFV_API int pfv_synth_frames_kind_dev(pfv_ctx *ctx, int width, int height, int n
 /* ------------------------------------------------------------------ device memory helpers */
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);
 PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p);
+/* device-to-device copy, asynchronous on the context's stream (ordered like every *_dev call) */
+PFV_API int pfv_dev_copy(pfv_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
 /* page-locked host memory (hipHostMalloc) for the buffers handed to the host-pointer entry points: uploads / downloads
  * from it run at PCIe rate instead of bouncing through the runtime's staging (the reference's Vec<u8> planes,
  * src/plane.rs:1-5, would be allocated here by a binding that cares) */

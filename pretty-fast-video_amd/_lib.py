@@ -92,6 +92,7 @@ SIGNATURES = [
     ("pfv_synth_frames_dev", c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     ("pfv_synth_frames_kind_dev", c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     ("pfv_dev_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
+    ("pfv_dev_copy", c_int, [_P, _P, _P, c_size_t]),
     ("pfv_dev_free", c_int, [_P, _P]),
     ("pfv_host_alloc", c_int, [_P, c_size_t, POINTER(_P)]),
     ("pfv_host_free", c_int, [_P, _P]),

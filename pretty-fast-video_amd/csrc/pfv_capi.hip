@@ -849,6 +849,15 @@ PFV_API int pfv_dev_download(pfv_ctx *ctx, void *dst_host, const void *src_dev, 
     return PFV_OK;
 }
 
+// device-to-device copy on the context's stream (asynchronous: ordered like every *_dev call) -- e.g. a consumer that keeps a frame a decoder
+// left in device memory beyond the call that hands it over
+PFV_API int pfv_dev_copy(pfv_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    if (!ctx || !dst_dev || !src_dev) return fail(ctx, PFV_ERR_BAD_ARG, "pfv_dev_copy: bad argument");
+    HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PFV_OK;
+}
+
 // ------------------------------------------------------------------ frame geometry queries
 PFV_API size_t pfv_frame_bytes(int width, int height)
 {
@@ -2002,6 +2011,16 @@ static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, 
     return PFV_OK;
 }
 
+// The entropy stage's stream: its kernels are chains of dependent LDS reads with a wavefront or two per SIMD (k_entd_fix: one per seam), and
+// they run beside decode kernels that fill every SIMD -- at equal priority a lone wavefront gets one issue slot in nine.  The stage is what
+// the decode launches wait for, so its queue gets the device's greatest priority.
+static hipError_t entd_stream_create(hipStream_t *s)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 // the launches of one window: np packets from b.packet0 on, ng workgroups from b.group0 on (b.groups already points at the first of them)
 static void entd_launch(hipStream_t stream, const EdBufs &b, const uint8_t *has_dev, unsigned np, unsigned ng, int launches, int inner)
 {
@@ -2673,14 +2692,14 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
         pk.sub_first = (uint32_t)total_sub;
         pk.grp_first = (uint32_t)n_groups;
         total_sub += pk.n_sub;
-        n_groups += (pk.n_sub + kEdThreads - 1) / kEdThreads;
+        n_groups += (pk.n_sub + kEdOwn - 1) / kEdOwn;
     }
     if (total_sub >= 0xffffffffull) return fail(ctx, PFV_ERR_NOMEM, "batch decoder: payloads too large for one step of the device entropy stage");
     if (!s->groups.resize(n_groups + 1)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging");
     {
         size_t g = 0;
         for (size_t k = 0; k < S; k++)
-            for (uint32_t blk = 0; blk * (uint32_t)kEdThreads < s->pk.data()[k].n_sub; blk++) s->groups.data()[g++] = make_uint2((unsigned)k, blk);
+            for (uint32_t blk = 0; blk * (uint32_t)kEdOwn < s->pk.data()[k].n_sub; blk++) s->groups.data()[g++] = make_uint2((unsigned)k, blk);
     }
     auto room = [&](auto **p, size_t *cap, size_t need) -> int {
         if (need <= *cap) return PFV_OK;
@@ -2790,7 +2809,7 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
         DecEntd &v = b->entd;
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
-        hipError_t he = hipStreamCreateWithFlags(&b->win_stream, hipStreamNonBlocking);
+        hipError_t he = entd_stream_create(&b->win_stream);
         bool host_ok = true;
         for (DecWindow &w : b->win) {
             if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, S * sizeof(EdPacket));
@@ -3027,7 +3046,7 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
         const size_t tbs = (size_t)d->total_blocks;
-        hipError_t he = hipStreamCreateWithFlags(&d->win_stream, hipStreamNonBlocking);
+        hipError_t he = entd_stream_create(&d->win_stream);
         bool host_ok = true;
         for (DecWindow &w : d->win) {
             if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, sizeof(EdPacket));
@@ -3065,7 +3084,7 @@ static void dec_parse(pfv_decoder *d, DecEvent *e)   // any thread; touches only
     e->dev_form = e->host_parse = false;
     if (d->entd.on && (d->entd.force || e->plen >= kDecEntdMinBytes)) {   // the device reads the run streams: only the headers here
         const uint32_t max_sub = (uint32_t)(((uint64_t)e->plen * 8 + d->entd.sub_bits - 1) / d->entd.sub_bits);
-        if (!e->bytes.resize((size_t)e->plen + 32) || !e->pk.resize(1) || !e->groups.resize((size_t)max_sub / kEdThreads + 1) ||
+        if (!e->bytes.resize((size_t)e->plen + 32) || !e->pk.resize(1) || !e->groups.resize((size_t)max_sub / kEdOwn + 1) ||
             (e->type == 2 && (!e->mv.resize(tb * 2) || !e->has.resize(tb)))) {
             e->rc = PFV_ERR_NOMEM;
             return;
@@ -3078,7 +3097,7 @@ static void dec_parse(pfv_decoder *d, DecEvent *e)   // any thread; touches only
         e->dev_form = true;
         e->host_parse = r.host_parse;
         if (r.rc || r.host_parse) k.n_sub = 0;
-        const uint32_t ng = (k.n_sub + kEdThreads - 1) / kEdThreads;
+        const uint32_t ng = (k.n_sub + kEdOwn - 1) / kEdOwn;
         for (uint32_t g = 0; g < ng; g++) e->groups.data()[g] = make_uint2(0u, g);
         if (!e->rc && e->host_parse) {   // the host parser decides about this one, here, on this thread
             if (!e->coef.resize(tb * 256)) { e->rc = PFV_ERR_NOMEM; return; }
@@ -3272,7 +3291,7 @@ static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
     hipStream_t st = d->win_stream;
     const size_t tb = (size_t)d->total_blocks;
     const EdPacket &k = *e->pk.data();
-    const uint32_t ng = (k.n_sub + kEdThreads - 1) / kEdThreads;
+    const uint32_t ng = (k.n_sub + kEdOwn - 1) / kEdOwn;
     auto room = [&](auto **p, size_t *cap, size_t need) -> int {
         if (need <= *cap) return PFV_OK;
         if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }           // the set is idle: its last window was consumed and decoded

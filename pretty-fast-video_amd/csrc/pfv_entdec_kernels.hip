@@ -43,11 +43,17 @@
 namespace pfv {
 
 constexpr int kEdThreads = 256;
+// A workgroup OWNS kEdOwn consecutive subsequences of its packet; k_entd_sync reads kEdHalo more in front of them with its first threads:
+// what the workgroup in front computes for its last lanes, again, from a guess -- by the halo's end that read has met the true one (it
+// has not with probability ~0.32 per lane: 1e-8 for 16), so the workgroup's first own lane starts right and the seams between workgroups
+// need no second pass (k_entd_fix stays as a cheap check; k_entd_verify finds what it cannot repair).
+constexpr int kEdHalo = 16;
+constexpr int kEdOwn = kEdThreads - kEdHalo;
 constexpr uint32_t kEdSubBits = 256;                // payload bits per lane (default; EdPacket::sub_bits, a multiple of 32 up to kEdMaxSubBits, is what the kernels use)
 constexpr uint32_t kEdIrregular = 1u;               // k_entd_emit: the host parser decides about this packet
 constexpr uint32_t kEdUnsettled = 2u;               // k_entd_sync: the subsequence starts had not settled
 constexpr uint32_t kEdNoStart = 0xffffffffu;
-constexpr int kEdInner = 24;                        // k_entd_sync: rounds inside a workgroup per launch (default)
+constexpr int kEdInner = 96;                        // k_entd_sync: settling rounds inside a workgroup at most (default; a round without work ends them)
 
 // one packet of the batch (made by the host from the packet's first 19 bytes and, p-frames, its block headers)
 struct EdPacket {
@@ -70,7 +76,7 @@ struct EdPacket {
 struct EdBufs {
     const uint8_t *bytes;          // payloads
     const EdPacket *packets;
-    const uint2 *groups;           // workgroups of k_entd_sync / k_entd_emit: (packet, which kEdThreads subsequences of it)
+    const uint2 *groups;           // workgroups of k_entd_sync / k_entd_emit: (packet, which kEdOwn subsequences of it)
     uint32_t *end, *used, *cnt;    // per subsequence; cnt = coefficients covered | values among them << 16 (a lane reads < 2^9 + 45 bits: < 2^13 of either)
     unsigned long long *wgsum;     // per workgroup of k_entd_sync: the sums of its lanes' cnt fields (coefficients | values << 32), then (k_entd_prefix) those before it
     uint32_t *coded;               // [frame][total_blocks]: the k-th coded macroblock of the frame (p-frames; k_entd_coded, from the has_coeff bytes)
@@ -114,10 +120,10 @@ struct EdReader {
         return __builtin_amdgcn_alignbit(lw[k + 1], lw[k], rel & 31u);
     }
 };
-// stage the workgroup's bits: words [first_bit / 32, ...) of the payload; beyond the payload's own words (+ 3: the slack the host left) zeros
-__device__ __forceinline__ uint32_t ed_stage(uint32_t *lw, const uint8_t *bytes, const EdPacket &pk, uint32_t wg, int tid)
+// stage the bits of kEdThreads lanes from subsequence `first_lane` on: words [first_bit / 32, ...) of the payload; beyond the payload's own words (+ 3: the slack the host left) zeros
+__device__ __forceinline__ uint32_t ed_stage(uint32_t *lw, const uint8_t *bytes, const EdPacket &pk, uint32_t first_lane, int tid)
 {
-    const unsigned long long first_bit = (unsigned long long)pk.bit0 + (unsigned long long)wg * kEdThreads * pk.sub_bits;
+    const unsigned long long first_bit = (unsigned long long)pk.bit0 + (unsigned long long)first_lane * pk.sub_bits;
     const uint32_t w0 = (uint32_t)(first_bit >> 5), n = kEdThreads * pk.sub_bits / 32u + 8u, have = (pk.total_bits + 31u) / 32u + 3u;
     const uint32_t *src = (const uint32_t *)(bytes + pk.byte_off);
     for (uint32_t k = (uint32_t)tid; k < n; k += kEdThreads) lw[k] = w0 + k < have ? src[w0 + k] : 0u;
@@ -188,7 +194,7 @@ __device__ __forceinline__ unsigned long long ed_split(uint32_t cnt) { return (u
 // neighbour's start, and so on: ~68 % of the lanes are right after the second read, a third of the rest after each further one).  From the
 // third round on few lanes have work, but a wavefront with ONE such lane takes as long as a full one: the lanes with work are packed
 // (ballot + popcount ranks -> a list in LDS) and thread t reads for the t-th of them, so a round occupies ceil(n / 64) wavefronts, not 4.
-// The workgroup's first lane keeps its guess: the seams between workgroups are k_entd_fix's.
+// The workgroup's first lane keeps its guess: it is the first of the halo (see kEdHalo), whose lanes are not written back.
 __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tab[4096];
@@ -198,12 +204,15 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
     __shared__ uint32_t s_used[kEdThreads], s_end[kEdThreads], s_cnt[kEdThreads];     // the lanes' state
     __shared__ uint32_t s_list[kEdThreads], s_start[kEdThreads];                        // this round's lanes with work, packed
     __shared__ uint32_t s_wt[kEdThreads / 64];
+    __shared__ uint8_t s_head[kEdThreads];                                              // this round: the lane has a new start (its own thread reads it)
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t i0 = grp.y * kEdThreads, i = i0 + (uint32_t)tid;
-    const bool mine = i < pk.n_sub;
-    const uint32_t base = ed_stage(lw, b.bytes, pk, grp.y, tid);
+    // thread t reads subsequence i0 + t: the halo (t < kEdHalo, none in a packet's first workgroup), then the workgroup's own
+    const uint32_t halo = grp.y ? (uint32_t)kEdHalo : 0u, i0 = grp.y * kEdOwn - halo, i = i0 + (uint32_t)tid;
+    const bool mine = (uint32_t)tid < halo + kEdOwn && i < pk.n_sub;
+    const uint32_t n_lanes = min(halo + (uint32_t)kEdOwn, pk.n_sub - i0);               // the workgroup's lanes that exist
+    const uint32_t base = ed_stage(lw, b.bytes, pk, i0, tid);
     s_used[tid] = kEdNoStart; s_end[tid] = 0; s_cnt[tid] = 0;
     ed_build_table(tab, cval, clen, pk, tid);      // ends on a barrier
     for (int it = 0; it < inner; it++) {
@@ -218,6 +227,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
         }
         const unsigned long long mask = __ballot(work);
         if (lane == 0) s_wt[wave] = (uint32_t)__popcll(mask);
+        s_head[tid] = work ? 1 : 0;
         __syncthreads();
         uint32_t off = 0, n_work = 0;
         for (int w = 0; w < kEdThreads / 64; w++) { off += w < wave ? s_wt[w] : 0u; n_work += s_wt[w]; }
@@ -229,20 +239,31 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
         }
         __syncthreads();
         if ((uint32_t)tid < n_work) {
-            const uint32_t l = s_list[tid], limit = ed_limit(pk, i0 + l);
-            uint32_t count = 0;
-            EdReader r{lw, base, s_start[tid]};
-            while (r.pos < limit) {
-                uint32_t zeros, nb;
-                int value;
-                ed_run(r, tab, cval, clen, zeros, nb, value);
-                count += zeros + (nb ? 0x10001u : 0u);
+            // the thread's lane, and -- while its read ends elsewhere than the recorded one did -- the lanes behind it up to the next lane that
+            // has a thread of its own this round: once few lanes have work (the heads of long wrong-phase stretches; p-frames hold a wrong
+            // phase for 20 lanes and more) the correction runs down a stretch in ONE round instead of one lane per round and three barriers
+            uint32_t l = s_list[tid], st = s_start[tid];
+            for (;;) {
+                const uint32_t limit = ed_limit(pk, i0 + l);
+                uint32_t count = 0;
+                EdReader r{lw, base, st};
+                while (r.pos < limit) {
+                    uint32_t zeros, nb;
+                    int value;
+                    ed_run(r, tab, cval, clen, zeros, nb, value);
+                    count += zeros + (nb ? 0x10001u : 0u);
+                }
+                const uint32_t old_end = s_end[l];
+                s_used[l] = st; s_end[l] = r.pos; s_cnt[l] = count;
+                if (r.pos == old_end) break;             // met the recorded read: the lanes behind are as they were
+                l++;
+                if (l >= n_lanes || s_head[l]) break;     // the next lane is another thread's (its start has changed: it is read in the next round)
+                st = r.pos;
             }
-            s_used[l] = s_start[tid]; s_end[l] = r.pos; s_cnt[l] = count;
         }
         __syncthreads();
     }
-    if (mine) {
+    if (mine && (uint32_t)tid >= halo) {      // the halo's lanes belong to the workgroup in front
         const size_t at = (size_t)pk.sub_first + i;
         b.end[at] = s_end[tid];
         b.used[at] = s_used[tid];
@@ -253,43 +274,57 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
 // The seams: one THREAD per workgroup of k_entd_sync.  That workgroup's first lane read from its guess; its true start is the end of the
 // lane in front of it.  The thread reads the lane again from there and goes on into the lanes behind it until a read ends where the
 // recorded one did (from there on nothing changes) -- one to three lanes, as a rule.  No table and no staged workgroup: the lane's few
-// words and the packet's 16 codes go into the thread's own slice of LDS, codes are matched one by one (what a whole workgroup spent on
-// staging and a table for ONE lane's read was half the time of the full pass: 160 us against 330 per twenty 4K packets).
+// words go into the thread's own slice of LDS, the packet's 16 codes into registers, and codes are matched one by one (what a whole
+// workgroup spent on staging and a table for ONE lane's read was half the time of the full pass: 160 us against 330 per twenty 4K
+// packets; with the codes in LDS instead of registers the 32 dependent reads per code made this kernel slower than that: 420 us).
 // A seam whose repair runs into the next seam's lanes while that one is being repaired is found by k_entd_verify (unsettled -> host parser).
 constexpr int kEdFixThreads = 64;
 constexpr uint32_t kEdFixWords = kEdMaxSubBits / 32 + 7;      // a lane's bits from its start (< 45 bits behind its first) to 45 + 64 behind its limit; odd: no bank conflicts
 static_assert(kEdFixWords % 2 == 1, "per-thread LDS slices on an odd pitch");
+// the tree code at the low end of w, from the packet's 16 codes in REGISTERS: c[s] = code | mask << 16 (a symbol without a code: 0xffff | 0,
+// which nothing matches).  Exactly one code matches any bit pattern (a tree of >= 2 symbols is full).  Returns length | symbol << 4.
+__device__ __forceinline__ uint32_t ed_code_regs(uint32_t w, const uint32_t (&c)[16])
+{
+    uint32_t e = 0x10000u;        // mask 1, symbol 0: ed_long_code's answer when nothing matches
+#pragma unroll
+    for (uint32_t s = 0; s < 16; s++)
+        if ((w & (c[s] >> 16)) == (c[s] & 0xffffu)) e = (c[s] & 0xffff0000u) | s;
+    return (uint32_t)__builtin_popcount(e >> 16) | ((e & 15u) << 4);
+}
 __global__ void __launch_bounds__(kEdFixThreads) k_entd_fix(EdBufs b, uint32_t n_groups)
 {
     __shared__ uint32_t lw[kEdFixThreads][kEdFixWords];
-    __shared__ uint16_t cval[kEdFixThreads][17];
-    __shared__ uint8_t clen[kEdFixThreads][17];
     const int tid = (int)threadIdx.x;
     const uint32_t g = blockIdx.x * kEdFixThreads + (uint32_t)tid;
     if (g >= n_groups) return;
     const uint2 grp = b.groups[g];
     if (grp.y == 0) return;                        // a packet's first lane starts at its first run: true
     const EdPacket &pk = b.packets[grp.x];
-    for (int s = 0; s < 16; s++) { cval[tid][s] = pk.code_val[s]; clen[tid][s] = pk.code_len[s]; }
-    const uint32_t *src = (const uint32_t *)(b.bytes + pk.byte_off);
-    const uint32_t have = (pk.total_bits + 31u) / 32u + 3u;
-    uint32_t i = grp.y * kEdThreads;
+    uint32_t i = grp.y * kEdOwn;
     size_t at = (size_t)pk.sub_first + i;
     uint32_t start = __atomic_load_n(b.end + at - 1, __ATOMIC_RELAXED);
+    if (b.used[at] == start) return;               // the guess was right
+    uint32_t c[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const uint32_t l = pk.code_len[s];
+        c[s] = l ? (uint32_t)pk.code_val[s] | (((1u << l) - 1u) << 16) : 0xffffu;
+    }
+    const uint32_t *src = (const uint32_t *)(b.bytes + pk.byte_off);
+    const uint32_t have = (pk.total_bits + 31u) / 32u + 3u;
     for (; i < pk.n_sub; i++, at++) {
         if (b.used[at] == start) break;
         const uint32_t limit = ed_limit(pk, i), w0 = start >> 5;
+#pragma unroll
         for (uint32_t k = 0; k < kEdFixWords; k++) lw[tid][k] = w0 + k < have ? src[w0 + k] : 0u;
         uint32_t count = 0;
         EdReader r{lw[tid], w0 * 32u, start};
         while (r.pos < limit) {
             // one run without the table (ed_run's fields, code by code)
-            uint32_t w = r.window();
-            uint32_t e = ed_long_code(w, cval[tid], clen[tid]);
+            uint32_t e = ed_code_regs(r.window(), c);
             r.pos += e & 15u;
             const uint32_t zeros = e >> 4;
-            w = r.window();
-            e = ed_long_code(w, cval[tid], clen[tid]);
+            e = ed_code_regs(r.window(), c);
             const uint32_t nb = e >> 4;
             r.pos += (e & 15u) + nb;
             count += zeros + (nb ? 0x10001u : 0u);
@@ -313,8 +348,8 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_verify(EdBufs b)
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
     const int tid = (int)threadIdx.x;
-    const uint32_t i = grp.y * kEdThreads + (uint32_t)tid;
-    const bool mine = i < pk.n_sub;
+    const uint32_t i = grp.y * kEdOwn + (uint32_t)tid;
+    const bool mine = tid < kEdOwn && i < pk.n_sub;
     const size_t at = (size_t)pk.sub_first + i;
     uint32_t used = kEdNoStart, end = 0, count = 0;
     if (mine) { used = b.used[at]; end = b.end[at]; count = b.cnt[at]; }
@@ -381,7 +416,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_prefix(EdBufs b)
     const EdPacket &pk = b.packets[b.packet0 + blockIdx.x];
     const int tid = (int)threadIdx.x;
     if (pk.n_sub == 0 || (b.status[b.packet0 + blockIdx.x] & kEdUnsettled)) return;
-    const uint32_t n = (pk.n_sub + kEdThreads - 1) / kEdThreads;
+    const uint32_t n = (pk.n_sub + kEdOwn - 1) / kEdOwn;
     unsigned long long *w = b.wgsum + pk.grp_first;
     unsigned long long carry = 0;
     for (uint32_t g0 = 0; g0 < n; g0 += kEdThreads) {
@@ -427,10 +462,10 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
     const EdPacket &pk = b.packets[grp.x];
     if (b.status[grp.x] & kEdUnsettled) return;           // set by an earlier launch (the whole workgroup leaves)
     const int tid = (int)threadIdx.x;
-    const uint32_t i = grp.y * kEdThreads + (uint32_t)tid;
-    const uint32_t base = ed_stage(lw, b.bytes, pk, grp.y, tid);
+    const uint32_t i = grp.y * kEdOwn + (uint32_t)tid;
+    const uint32_t base = ed_stage(lw, b.bytes, pk, grp.y * kEdOwn, tid);
     ed_build_table(tab, cval, clen, pk, tid);
-    const bool mine = i < pk.n_sub;
+    const bool mine = tid < kEdOwn && i < pk.n_sub;
     const size_t at = (size_t)pk.sub_first + i;
     // what the packet's workgroups before this one cover, what this one's lanes do, and this lane's place among them: coefficients (low
     // half) and values (high half)

@@ -524,7 +524,11 @@ struct GopDecDev {
     std::vector<size_t> list_off, list_room;   // per packet: its list's place in the pool (entd_pool_cap entries)
     int8_t *mv_dev = nullptr;
     uint8_t *has_dev = nullptr;
-    hipStream_t stream = nullptr;        // the entropy stage's own stream: it works ahead of the decode kernels and their downloads
+    // the entropy stage's own streams: it works ahead of the decode kernels and their downloads, and the windows take the streams in turn, so
+    // that one window's settling tail (a few lanes in a few wavefronts, round after round) runs beside the next windows' full reads
+    static constexpr int kStreams = 4;
+    hipStream_t streams[kStreams] = {nullptr, nullptr, nullptr, nullptr};
+    int n_streams = 2;
     hipStream_t up_stream = nullptr;     // ... and the uploads / clears it needs run ahead of it on a third
     std::vector<hipEvent_t> window_done; // per step: payloads read, statuses on the host
     std::vector<hipEvent_t> window_up;   // per step: payloads, headers and cleared coefficient arrays in place
@@ -1039,7 +1043,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     static const char *kBadPayload = "malformed packet payload", *kBadMv = "motion vector points outside the reference plane (src/common.rs:258-259)";
     GopClock clk;
     HIP_TRY(ctx, hipStreamSynchronize(v.up_stream));       // a batch that went to the host path may have left windows behind
-    HIP_TRY(ctx, hipStreamSynchronize(v.stream));
+    for (int k = 0; k < v.n_streams; k++) HIP_TRY(ctx, hipStreamSynchronize(v.streams[k]));
 
     // packets in (step, slot) order: a step's packets, payload bytes, subsequences and workgroups are contiguous
     v.pk.clear();
@@ -1072,7 +1076,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     for (size_t j = 0; j < n; j++) {
         const size_t lanes = ((size_t)v.pk[j].ev->plen * 8 + v.sub_bits - 1) / v.sub_bits;
         sub_max += lanes;
-        grp_max += (lanes + kEdThreads - 1) / kEdThreads;
+        grp_max += (lanes + kEdOwn - 1) / kEdOwn;
     }
     if (sub_max >= 0xffffffffull) return 1;
     int rc = PFV_OK;
@@ -1136,7 +1140,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
                 k.sub_first = (uint32_t)total_sub;
                 k.grp_first = (uint32_t)n_groups;
                 total_sub += k.n_sub;
-                for (uint32_t b = 0; b * (uint32_t)kEdThreads < k.n_sub; b++) v.groups_host.data()[n_groups++] = make_uint2((unsigned)j, b);
+                for (uint32_t b = 0; b * (uint32_t)kEdOwn < k.n_sub; b++) v.groups_host.data()[n_groups++] = make_uint2((unsigned)j, b);
             }
             const size_t gb = n_groups, ba = byte0[(size_t)t], bb = byte0[(size_t)t + 1];
             if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev + pa, v.pk_host.data() + pa, (pb - pa) * sizeof(EdPacket), hipMemcpyHostToDevice, v.up_stream));
@@ -1145,16 +1149,17 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + f0 * tb * 2, v.mv_host.data() + f0 * tb * 2, S * tb * 2, hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + f0 * tb, v.has_host.data() + f0 * tb, S * tb, hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipEventRecord(v.window_up[(size_t)t], v.up_stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(v.stream, v.window_up[(size_t)t], 0));
+            const hipStream_t es = v.streams[t % v.n_streams];
+            HIP_TRY(ctx, hipStreamWaitEvent(es, v.window_up[(size_t)t], 0));
             if (gb > ga) {
                 EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.wgsum_dev, v.coded_dev, v.lists.ptr_dev, v.lists.counts_dev,
                          v.status_dev, (uint32_t)pa, (uint32_t)ga};
-                entd_launch(v.stream, b, v.has_dev, (unsigned)(pb - pa), (unsigned)(gb - ga), v.launches, v.inner);
+                entd_launch(es, b, v.has_dev, (unsigned)(pb - pa), (unsigned)(gb - ga), v.launches, v.inner);
                 const int lrc = launch_check(ctx, "k_entd_*");
                 if (lrc) return lrc;
             }
-            if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data() + pa, v.status_dev + pa, (pb - pa) * sizeof(uint32_t), hipMemcpyDeviceToHost, v.stream));
-            HIP_TRY(ctx, hipEventRecord(v.window_done[(size_t)t], v.stream));
+            if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.status_host.data() + pa, v.status_dev + pa, (pb - pa) * sizeof(uint32_t), hipMemcpyDeviceToHost, es));
+            HIP_TRY(ctx, hipEventRecord(v.window_done[(size_t)t], es));
             d->stats[3] += wclk.lap();
         }
         return PFV_OK;
@@ -1297,7 +1302,8 @@ PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d)
         if (s.done) (void)hipEventDestroy(s.done);
     if (d->frames_dev) (void)hipFree(d->frames_dev);
     if (d->frames_all_dev) (void)hipFree(d->frames_all_dev);
-    if (d->dev.stream) { (void)hipStreamSynchronize(d->dev.stream); (void)hipStreamDestroy(d->dev.stream); }
+    for (hipStream_t st : d->dev.streams)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (d->dev.up_stream) { (void)hipStreamSynchronize(d->dev.up_stream); (void)hipStreamDestroy(d->dev.up_stream); }
     for (hipEvent_t ev : d->dev.window_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : d->dev.window_up) (void)hipEventDestroy(ev);
@@ -1372,7 +1378,10 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
         bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2;
         if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
         if (fits) {
-            hipError_t e2 = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking);
+            hipError_t e2 = hipSuccess;
+            if (getenv("PFV_DBG_ENTD_STREAMS")) v.n_streams = std::min(std::max(atoi(getenv("PFV_DBG_ENTD_STREAMS")), 1), (int)GopDecDev::kStreams);
+            for (int k = 0; k < v.n_streams && e2 == hipSuccess; k++)
+                e2 = getenv("PFV_DBG_ENTD_NOPRIO") ? hipStreamCreateWithFlags(&v.streams[k], hipStreamNonBlocking) : entd_stream_create(&v.streams[k]);
             if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&v.up_stream, hipStreamNonBlocking);
             if (e2 == hipSuccess && v.lists.create(ctx, F, tb, list_guess) != PFV_OK) e2 = hipErrorOutOfMemory;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.mv_dev, F * tb * 2);
@@ -1384,13 +1393,13 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
             const size_t sub_guess = bytes_guess * 8 / v.sub_bits + F;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.bytes_dev, bytes_guess);
             if (e2 == hipSuccess) { v.bytes_cap = bytes_guess; e2 = hipMalloc((void **)&v.sub_dev, sub_guess * 4 * sizeof(uint32_t)); }
-            if (e2 == hipSuccess) { v.sub_cap = sub_guess * 4; e2 = hipMalloc((void **)&v.groups_dev, (sub_guess / kEdThreads + F) * sizeof(uint2)); }
-            if (e2 == hipSuccess) { v.groups_cap = sub_guess / kEdThreads + F; e2 = hipMalloc((void **)&v.wgsum_dev, v.groups_cap * sizeof(unsigned long long)); }
+            if (e2 == hipSuccess) { v.sub_cap = sub_guess * 4; e2 = hipMalloc((void **)&v.groups_dev, (sub_guess / kEdOwn + F) * sizeof(uint2)); }
+            if (e2 == hipSuccess) { v.groups_cap = sub_guess / kEdOwn + F; e2 = hipMalloc((void **)&v.wgsum_dev, v.groups_cap * sizeof(unsigned long long)); }
             if (e2 == hipSuccess) { v.wgsum_cap = v.groups_cap; e2 = hipMalloc((void **)&v.pk_dev, F * sizeof(EdPacket)); }
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.status_dev, F * sizeof(uint32_t));
             if (e2 == hipSuccess) v.pk_cap = F;
             const bool host_ok = e2 == hipSuccess && v.mv_host.resize(F * tb * 2) && v.has_host.resize(F * tb) && v.bytes_host.resize(bytes_guess) &&
-                                 v.pk_host.resize(F) && v.status_host.resize(F) && v.groups_host.resize(sub_guess / kEdThreads + F) && v.flags_host.resize(F);
+                                 v.pk_host.resize(F) && v.status_host.resize(F) && v.groups_host.resize(sub_guess / kEdOwn + F) && v.flags_host.resize(F);
             if (host_ok) {
                 memset(v.mv_host.data(), 0, F * tb * 2);
                 memset(v.has_host.data(), 0, F * tb);
@@ -1403,7 +1412,8 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
                     if (*p) { (void)hipFree(*p); *p = nullptr; }
                 v.lists.destroy();
                 v.bytes_cap = v.sub_cap = v.groups_cap = v.pk_cap = v.wgsum_cap = 0;
-                if (v.stream) { (void)hipStreamDestroy(v.stream); v.stream = nullptr; }
+                for (hipStream_t &st : v.streams)
+                    if (st) { (void)hipStreamDestroy(st); st = nullptr; }
                 if (v.up_stream) { (void)hipStreamDestroy(v.up_stream); v.up_stream = nullptr; }
                 if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE)
                     rc = fail(ctx, PFV_ERR_NOMEM, "pfv_gop_decoder_create: the batch's coefficient arrays do not fit the device (PFV_ENTROPY_DECODE_DEVICE): use a smaller batch");

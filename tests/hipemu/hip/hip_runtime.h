@@ -81,7 +81,7 @@ static inline unsigned long long __ballot(bool p)
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __mul24(int a, int b)   // v_mul_i32_i24: low 32 bits of the product of the operands' low 24 bits, sign-extended
 {
-    const long long x = ((long long)a << 40) >> 40, y = ((long long)b << 40) >> 40;
+    const long long x = (int)((unsigned)a << 8) >> 8, y = (int)((unsigned)b << 8) >> 8;   // (no left shift of a negative value: UBSan runs over this file too)
     return (int)(unsigned)(unsigned long long)(x * y);
 }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }

@@ -3,6 +3,19 @@
 
 #include <stdio.h>
 
+// ThreadSanitizer does not follow swapcontext by itself: tell it which fiber runs (tools/sanitize.sh builds this file with -fsanitize=thread)
+#if defined(__SANITIZE_THREAD__)
+extern "C" {
+void *__tsan_get_current_fiber(void);
+void *__tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void *fiber);
+void __tsan_switch_to_fiber(void *fiber, unsigned flags);
+}
+#define PFV_TSAN_FIBERS 1
+#else
+#define PFV_TSAN_FIBERS 0
+#endif
+
 namespace hipemu {
 
 Graph *g_capture = nullptr;
@@ -15,7 +28,9 @@ struct Fiber {
     void *stack = nullptr;
     bool done = false;
     Idx tid;
+    void *tsan = nullptr;
 };
+void *sched_tsan = nullptr;
 std::vector<Fiber> fibers;
 ucontext_t sched_ctx;
 int cur = -1;
@@ -31,6 +46,9 @@ std::vector<Wave> waves;
 void yield()
 {
     int me = cur;
+#if PFV_TSAN_FIBERS
+    __tsan_switch_to_fiber(sched_tsan, 0);
+#endif
     swapcontext(&fibers[me].ctx, &sched_ctx);
     g_threadIdx = fibers[me].tid;
 }
@@ -38,6 +56,9 @@ void trampoline()
 {
     (*cur_body)();
     fibers[cur].done = true;
+#if PFV_TSAN_FIBERS
+    __tsan_switch_to_fiber(sched_tsan, 0);
+#endif
     swapcontext(&fibers[cur].ctx, &sched_ctx);
 }
 int lane_id() { return (int)(g_threadIdx.x & 63); }
@@ -93,6 +114,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body)
     }
     waves.assign((n_threads + 63) / 64, Wave());
     cur_body = &body;
+#if PFV_TSAN_FIBERS
+    sched_tsan = __tsan_get_current_fiber();     // the host thread that launches (one at a time: the emulator is single-threaded by design)
+#endif
     for (unsigned bz = 0; bz < grid.z; bz++)
         for (unsigned by = 0; by < grid.y; by++)
             for (unsigned bx = 0; bx < grid.x; bx++) {
@@ -117,6 +141,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body)
                         if (f.done) continue;
                         cur = t;
                         g_threadIdx = f.tid;
+#if PFV_TSAN_FIBERS
+                        if (!f.tsan) f.tsan = __tsan_create_fiber(0);
+                        __tsan_switch_to_fiber(f.tsan, 0);
+#endif
                         swapcontext(&sched_ctx, &f.ctx);
                         if (f.done) remaining--;
                     }

@@ -28,6 +28,8 @@ struct Sink {
     long n = 0;
     uint64_t hash = 1469598103934665603ull, touched = 0;
     std::vector<uint8_t> tmp;
+    uint8_t *kept = nullptr;     // frames left in HBM: the sampled frames are copied device-to-device (what a consumer on the GPU would do with
+    int n_kept = 0, cap_kept = 0; // a frame it wants to keep) and fetched for the checksum when the clock has stopped
 };
 static void fnv(uint64_t &h, const uint8_t *p, size_t n)
 {
@@ -43,11 +45,7 @@ static void on_video(void *user, const uint8_t *y, const uint8_t *u, const uint8
     const size_t ny = (size_t)w * h, nc = (size_t)(w / 2) * (h / 2);
     if (s->n % s->every == 0) {
         if (s->device) {
-            s->tmp.resize(ny + 2 * nc);
-            pfv_dev_download(s->ctx, s->tmp.data(), y, ny + 2 * nc);    // the three planes are contiguous
-            fnv(s->hash, s->tmp.data(), ny & ~(size_t)7);
-            fnv(s->hash, s->tmp.data() + ny, nc & ~(size_t)7);
-            fnv(s->hash, s->tmp.data() + ny + nc, nc & ~(size_t)7);
+            if (s->n_kept < s->cap_kept) pfv_dev_copy(s->ctx, s->kept + (size_t)s->n_kept++ * (ny + 2 * nc), y, ny + 2 * nc);    // the three planes are contiguous
         } else {
             fnv(s->hash, y, ny & ~(size_t)7);
             fnv(s->hash, u, nc & ~(size_t)7);
@@ -59,6 +57,21 @@ static void on_video(void *user, const uint8_t *y, const uint8_t *u, const uint8
     s->n++;
 }
 
+// the frames a device-mode sink kept: down, into the checksum (outside the timed region), buffer freed
+static void finish_kept(Sink &s, size_t fb, size_t ny, size_t nc)
+{
+    if (!s.kept) return;
+    s.tmp.resize(fb);
+    for (int k = 0; k < s.n_kept; k++) {
+        pfv_dev_download(s.ctx, s.tmp.data(), s.kept + (size_t)k * fb, fb);
+        fnv(s.hash, s.tmp.data(), ny & ~(size_t)7);
+        fnv(s.hash, s.tmp.data() + ny, nc & ~(size_t)7);
+        fnv(s.hash, s.tmp.data() + ny + nc, nc & ~(size_t)7);
+    }
+    pfv_dev_free(s.ctx, s.kept);
+    s.kept = nullptr;
+}
+
 int main(int argc, char **argv)
 {
     const int W = argc > 1 ? atoi(argv[1]) : 3840, H = argc > 2 ? atoi(argv[2]) : 2160, N = argc > 3 ? atoi(argv[3]) : 300;
@@ -67,6 +80,8 @@ int main(int argc, char **argv)
     pfv_ctx *ctx = nullptr;
     if (pfv_ctx_create(0, &ctx) != PFV_OK) { fprintf(stderr, "no device: %s\n", pfv_last_error(nullptr)); return 1; }
     if (lane_bits) CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTDEC_LANE_BITS, lane_bits));
+    if (getenv("PFV_E2E_INNER")) CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTDEC_INNER_ROUNDS, atoi(getenv("PFV_E2E_INNER"))));       // experiments: settling rounds of k_entd_sync
+    if (getenv("PFV_E2E_LAUNCHES")) CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTDEC_LAUNCHES, atoi(getenv("PFV_E2E_LAUNCHES"))));
     const size_t fb = pfv_frame_bytes(W, H), ny = (size_t)W * H, nc = (size_t)(W / 2) * (H / 2);
     const long n_mb = pfv_total_blocks(W, H);
     // the producer's frames, page-locked
@@ -165,11 +180,14 @@ int main(int argc, char **argv)
             CHECK(pfv_gop_decoder_create(ctx, stream.data(), stream.size(), DG, GOP, threads, &d));
             CHECK(pfv_gop_decoder_set_output_device(d, modes[m].device_out ? 1 : 0));
             Sink s{ctx, W, H, 101, modes[m].device_out};
+            if (modes[m].device_out) { s.cap_kept = N / 101 + 1; CHECK(pfv_dev_alloc(ctx, fb * (size_t)s.cap_kept, (void **)&s.kept)); }
             const double t0 = now();
             int rc;
             while ((rc = pfv_gop_decoder_advance_frame(d, on_video, &s)) == 1) {}
+            if (modes[m].device_out) CHECK(pfv_ctx_sync(ctx));           // the kept frames' copies are part of the consumer's work
             const double el = now() - t0;
             CHECK(rc);
+            finish_kept(s, fb, ny, nc);
             if (s.n != N) { fprintf(stderr, "%s: %ld frames of %d\n", modes[m].name, s.n, N); return 3; }
             if (!want_hash) want_hash = s.hash;
             if (s.hash != want_hash) { fprintf(stderr, "%s: decoded frames differ between modes\n", modes[m].name); return 4; }
@@ -215,11 +233,14 @@ int main(int argc, char **argv)
                 CHECK(pfv_decoder_create(ctx, stream.data(), stream.size(), &d));
                 CHECK(pfv_decoder_set_output_device(d, mode == 2 ? 1 : 0));
                 Sink s{ctx, W, H, 101, mode == 2};
+                if (mode == 2) { s.cap_kept = N / 101 + 1; CHECK(pfv_dev_alloc(ctx, fb * (size_t)s.cap_kept, (void **)&s.kept)); }
                 const double t1 = now();
                 int rc;
                 while ((rc = pfv_decoder_advance_frame(d, on_video, &s)) == 1) {}
+                if (mode == 2) CHECK(pfv_ctx_sync(ctx));
                 const double el = now() - t1;
                 CHECK(rc);
+                finish_kept(s, fb, ny, nc);
                 pfv_decoder_entropy_counts(d, sdec_counts);
                 pfv_decoder_destroy(d);
                 if (s.n != N || s.hash != want_hash) { fprintf(stderr, "frame-by-frame decoder: %ld frames, hash %s\n", s.n, s.hash == want_hash ? "ok" : "differs"); return 6; }
