@@ -2011,16 +2011,6 @@ static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, 
     return PFV_OK;
 }
 
-// The entropy stage's stream: its kernels are chains of dependent LDS reads with a wavefront or two per SIMD (k_entd_fix: one per seam), and
-// they run beside decode kernels that fill every SIMD -- at equal priority a lone wavefront gets one issue slot in nine.  The stage is what
-// the decode launches wait for, so its queue gets the device's greatest priority.
-static hipError_t entd_stream_create(hipStream_t *s)
-{
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
-}
-
 // the launches of one window: np packets from b.packet0 on, ng workgroups from b.group0 on (b.groups already points at the first of them)
 static void entd_launch(hipStream_t stream, const EdBufs &b, const uint8_t *has_dev, unsigned np, unsigned ng, int launches, int inner)
 {
@@ -2809,7 +2799,7 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
         DecEntd &v = b->entd;
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
-        hipError_t he = entd_stream_create(&b->win_stream);
+        hipError_t he = hipStreamCreateWithFlags(&b->win_stream, hipStreamNonBlocking);
         bool host_ok = true;
         for (DecWindow &w : b->win) {
             if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, S * sizeof(EdPacket));
@@ -3046,7 +3036,7 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
         const size_t tbs = (size_t)d->total_blocks;
-        hipError_t he = entd_stream_create(&d->win_stream);
+        hipError_t he = hipStreamCreateWithFlags(&d->win_stream, hipStreamNonBlocking);
         bool host_ok = true;
         for (DecWindow &w : d->win) {
             if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, sizeof(EdPacket));

@@ -194,6 +194,10 @@ __device__ __forceinline__ unsigned long long ed_split(uint32_t cnt) { return (u
 // neighbour's start, and so on: ~68 % of the lanes are right after the second read, a third of the rest after each further one).  From the
 // third round on few lanes have work, but a wavefront with ONE such lane takes as long as a full one: the lanes with work are packed
 // (ballot + popcount ranks -> a list in LDS) and thread t reads for the t-th of them, so a round occupies ceil(n / 64) wavefronts, not 4.
+// (Measured and dropped: letting a thread run on into the lanes behind its own while its read ends elsewhere than the recorded one -- the
+// correction then crosses a wrong-phase stretch in one round instead of one lane per round -- made the whole decode 24 % SLOWER, 0.96
+// against 1.26 G macroblocks/s for config 4 with one entropy stream: p-frames hold a wrong phase for 20 lanes and more, and such a
+// stretch read by ONE thread idles the other 63 lanes of its wavefront for its whole length.)
 // The workgroup's first lane keeps its guess: it is the first of the halo (see kEdHalo), whose lanes are not written back.
 __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
 {
@@ -204,14 +208,12 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
     __shared__ uint32_t s_used[kEdThreads], s_end[kEdThreads], s_cnt[kEdThreads];     // the lanes' state
     __shared__ uint32_t s_list[kEdThreads], s_start[kEdThreads];                        // this round's lanes with work, packed
     __shared__ uint32_t s_wt[kEdThreads / 64];
-    __shared__ uint8_t s_head[kEdThreads];                                              // this round: the lane has a new start (its own thread reads it)
     const uint2 grp = b.groups[blockIdx.x];
     const EdPacket &pk = b.packets[grp.x];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // thread t reads subsequence i0 + t: the halo (t < kEdHalo, none in a packet's first workgroup), then the workgroup's own
     const uint32_t halo = grp.y ? (uint32_t)kEdHalo : 0u, i0 = grp.y * kEdOwn - halo, i = i0 + (uint32_t)tid;
     const bool mine = (uint32_t)tid < halo + kEdOwn && i < pk.n_sub;
-    const uint32_t n_lanes = min(halo + (uint32_t)kEdOwn, pk.n_sub - i0);               // the workgroup's lanes that exist
     const uint32_t base = ed_stage(lw, b.bytes, pk, i0, tid);
     s_used[tid] = kEdNoStart; s_end[tid] = 0; s_cnt[tid] = 0;
     ed_build_table(tab, cval, clen, pk, tid);      // ends on a barrier
@@ -227,7 +229,6 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
         }
         const unsigned long long mask = __ballot(work);
         if (lane == 0) s_wt[wave] = (uint32_t)__popcll(mask);
-        s_head[tid] = work ? 1 : 0;
         __syncthreads();
         uint32_t off = 0, n_work = 0;
         for (int w = 0; w < kEdThreads / 64; w++) { off += w < wave ? s_wt[w] : 0u; n_work += s_wt[w]; }
@@ -239,27 +240,16 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
         }
         __syncthreads();
         if ((uint32_t)tid < n_work) {
-            // the thread's lane, and -- while its read ends elsewhere than the recorded one did -- the lanes behind it up to the next lane that
-            // has a thread of its own this round: once few lanes have work (the heads of long wrong-phase stretches; p-frames hold a wrong
-            // phase for 20 lanes and more) the correction runs down a stretch in ONE round instead of one lane per round and three barriers
-            uint32_t l = s_list[tid], st = s_start[tid];
-            for (;;) {
-                const uint32_t limit = ed_limit(pk, i0 + l);
-                uint32_t count = 0;
-                EdReader r{lw, base, st};
-                while (r.pos < limit) {
-                    uint32_t zeros, nb;
-                    int value;
-                    ed_run(r, tab, cval, clen, zeros, nb, value);
-                    count += zeros + (nb ? 0x10001u : 0u);
-                }
-                const uint32_t old_end = s_end[l];
-                s_used[l] = st; s_end[l] = r.pos; s_cnt[l] = count;
-                if (r.pos == old_end) break;             // met the recorded read: the lanes behind are as they were
-                l++;
-                if (l >= n_lanes || s_head[l]) break;     // the next lane is another thread's (its start has changed: it is read in the next round)
-                st = r.pos;
+            const uint32_t l = s_list[tid], limit = ed_limit(pk, i0 + l);
+            uint32_t count = 0;
+            EdReader r{lw, base, s_start[tid]};
+            while (r.pos < limit) {
+                uint32_t zeros, nb;
+                int value;
+                ed_run(r, tab, cval, clen, zeros, nb, value);
+                count += zeros + (nb ? 0x10001u : 0u);
             }
+            s_used[l] = s_start[tid]; s_end[l] = r.pos; s_cnt[l] = count;
         }
         __syncthreads();
     }

@@ -525,10 +525,13 @@ struct GopDecDev {
     int8_t *mv_dev = nullptr;
     uint8_t *has_dev = nullptr;
     // the entropy stage's own streams: it works ahead of the decode kernels and their downloads, and the windows take the streams in turn, so
-    // that one window's settling tail (a few lanes in a few wavefronts, round after round) runs beside the next windows' full reads
+    // that one window's settling tail (a few lanes in a few wavefronts, round after round) runs beside the next windows' full reads.
+    // Measured, config 4 with the frames left in HBM (tools/gpu_inner_sweep.sh, three passes each): one stream 1.25-1.27 G macroblocks/s at
+    // the device's greatest stream priority (1.22-1.29 without), two / three streams 1.12-1.24 / 1.16-1.25 (0.89-1.10 without priority: the
+    // decode launches then wait behind them), four streams at normal priority 1.27-1.40.
     static constexpr int kStreams = 4;
     hipStream_t streams[kStreams] = {nullptr, nullptr, nullptr, nullptr};
-    int n_streams = 2;
+    int n_streams = kStreams;
     hipStream_t up_stream = nullptr;     // ... and the uploads / clears it needs run ahead of it on a third
     std::vector<hipEvent_t> window_done; // per step: payloads read, statuses on the host
     std::vector<hipEvent_t> window_up;   // per step: payloads, headers and cleared coefficient arrays in place
@@ -1379,9 +1382,7 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
         if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
         if (fits) {
             hipError_t e2 = hipSuccess;
-            if (getenv("PFV_DBG_ENTD_STREAMS")) v.n_streams = std::min(std::max(atoi(getenv("PFV_DBG_ENTD_STREAMS")), 1), (int)GopDecDev::kStreams);
-            for (int k = 0; k < v.n_streams && e2 == hipSuccess; k++)
-                e2 = getenv("PFV_DBG_ENTD_NOPRIO") ? hipStreamCreateWithFlags(&v.streams[k], hipStreamNonBlocking) : entd_stream_create(&v.streams[k]);
+            for (int k = 0; k < v.n_streams && e2 == hipSuccess; k++) e2 = hipStreamCreateWithFlags(&v.streams[k], hipStreamNonBlocking);
             if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&v.up_stream, hipStreamNonBlocking);
             if (e2 == hipSuccess && v.lists.create(ctx, F, tb, list_guess) != PFV_OK) e2 = hipErrorOutOfMemory;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.mv_dev, F * tb * 2);

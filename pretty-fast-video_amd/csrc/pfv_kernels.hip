@@ -1033,6 +1033,9 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
                     eB[k] = c == 1 ? rb[k + 1] : __builtin_amdgcn_alignbyte(rb[o + 1], rb[o], 2);
                 }
                 ab[c] = dot_ab(bot, eB[0], eB[1], eB[2], eB[3], dot_ab(top, eT[0], eT[1], eT[2], eT[3], 0));
+#ifdef PFV_ABL_SEARCH_BB   // ablation (results invalid): what a sliding sum of squares could save at most -- the off-centre rows' squares cost nothing
+                if (my != 0) continue;
+#endif
                 bb[c] = sq4(eB[0], eB[1], eB[2], eB[3], sq4(eT[0], eT[1], eT[2], eT[3], 0));
             }
         } else {
@@ -1058,6 +1061,9 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
                     eB[k] = c ? __builtin_amdgcn_alignbyte(dB[k + 1], dB[k], c) : dB[k];
                 }
                 ab[c] = dot_ab(bot, eB[0], eB[1], eB[2], eB[3], dot_ab(top, eT[0], eT[1], eT[2], eT[3], 0));
+#ifdef PFV_ABL_SEARCH_BB
+                if (my != 0) continue;
+#endif
                 bb[c] = sq4(eB[0], eB[1], eB[2], eB[3], sq4(eT[0], eT[1], eT[2], eT[3], 0));
             }
         }

@@ -306,6 +306,102 @@ def check_gop_batched_session(pkg, ctx, oracle, width, height, quality, n_frames
     return {"gops": n_gops, "launches_per_operation": launches, "frames": n_frames}
 
 
+def check_gop_batched_clip(pkg, ctx, oracle, width, height, quality, n_frames, gop, seed=None, threads=1, dec_gops=None):
+    """The launch shape `bench.py --workload config5` times, whole clip: ONE stream of n_frames, all its GOPs in the slots of a launch (frame t
+    of every GOP per frame operation), against the oracle's SERIAL encoder over the same frames (src/enc.rs:84-97: an i-frame never reads
+    prev_frame, so the GOPs are independent; README.md:34-41 GOP pattern).  Like check_gop_batched_session, but sized for 300 4K frames:
+    what the device produces per frame -- coefficients, motion vectors, skip flags, device-built packet payload, display-order decoded frame
+    -- is kept as 128-bit BLAKE2 digests and compared with the digests of the oracle's output frame by frame (7.5 GB of coefficients need
+    not sit in memory twice).  Then the packets, as a .pfv stream, through pfv_gop_decoder with the payloads read by the device's entropy
+    stage, dec_gops GOPs per batch: every frame it delivers against the oracle's reconstruction."""
+    import ctypes
+    import hashlib
+    dig = lambda a: hashlib.blake2b(np.ascontiguousarray(a), digest_size=16).digest()
+    L = _oracle_serializers(oracle)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    seed = pkg.synth.SEED if seed is None else int(seed)
+    n_gops = (n_frames + gop - 1) // gop
+    enc = pkg.EncoderSession(ctx, width, height, quality, n_gops)
+    tabs = pkg.qtables_from_quality(quality)
+    dec = pkg.DecoderSession(ctx, width, height, np.stack(tabs[:4]), n_gops)
+    enc.enable_entropy()
+    nb, fb = enc.total_blocks, enc.frame_bytes
+    d_frames, d_out = ctx.alloc(n_frames * fb), ctx.alloc(n_frames * fb)
+    for t in range(n_frames):
+        ctx.synth_frames_dev(width, height, [seed], t, d_frames + t * fb)
+    d_coef, d_mv, d_has = ctx.alloc(n_gops * nb * 512), ctx.alloc(n_gops * nb * 2), ctx.alloc(n_gops * nb)
+    enc.set_frame_stride(gop * fb)
+    coef, mv, has = np.empty((n_gops, nb, 256), np.int16), np.empty((n_gops, nb, 2), np.int8), np.empty((n_gops, nb), np.uint8)
+    got, payloads = [None] * n_frames, [None] * n_frames
+    for t in range(min(gop, n_frames)):
+        count = sum(1 for g in range(n_gops) if g * gop + t < n_frames)
+        enc.set_window(0, count)
+        dec.set_window(0, count)
+        dec.set_output_strided_dev(d_out + t * fb, gop * fb)
+        if t == 0:
+            enc.encode_iframe_dev(d_frames, d_coef)
+            enc.pack_iframe_dev(d_coef)
+            dec.decode_iframe_dev(d_coef)
+        else:
+            enc.encode_pframe_dev(d_frames + t * fb, d_mv, d_has, d_coef)
+            enc.pack_pframe_dev(d_mv, d_has, d_coef)
+            dec.decode_pframe_dev(d_mv, d_has, d_coef)
+        dec.check()
+        sizes = enc.payload_sizes()
+        ctx.download(coef, d_coef); ctx.download(mv, d_mv); ctx.download(has, d_has)
+        for g in range(count):
+            f = g * gop + t
+            payloads[f] = enc.payload(g, int(sizes[g]))
+            got[f] = (dig(coef[g]), dig(mv[g]) if t else None, dig(has[g]) if t else None, hashlib.blake2b(payloads[f], digest_size=16).digest())
+    out = np.empty(fb, np.uint8)
+    frame = np.empty(fb, np.uint8)
+    oenc = oracle.encoder(width, height, quality, threads)
+    ref = np.zeros(int(ctx._lib.pfv_payload_worst_case(width, height)) + 64, np.uint8)
+    want_frames = []
+    for f in range(n_frames):
+        ctx.download(frame, d_frames + f * fb)
+        if f % gop == 0:
+            ocoef = oenc.encode_iframe(frame); omv = ohas = None
+            n = L.pfvo_serialize_iframe(P(ocoef), nb, P(ref), ref.size)
+        else:
+            omv, ohas, ocoef = oenc.encode_pframe(frame)
+            n = L.pfvo_serialize_pframe(P(omv), P(ohas), P(ocoef), nb, P(ref), ref.size)
+        pf = pkg.VideoFrame.from_packed(width, height, oenc.prev_frame(), padded=True)
+        crop = np.concatenate([pf.plane_y.image()[:height, :width].reshape(-1), pf.plane_u.image()[:height // 2, :width // 2].reshape(-1),
+                               pf.plane_v.image()[:height // 2, :width // 2].reshape(-1)])
+        g = got[f]
+        assert g[0] == dig(ocoef), f"frame {f}: coefficients differ from the serial oracle"
+        if f % gop:
+            assert g[1] == dig(omv), f"frame {f}: motion vectors differ"
+            assert g[2] == dig(ohas), f"frame {f}: skip flags differ"
+        assert len(payloads[f]) == n and g[3] == hashlib.blake2b(ref[:n].tobytes(), digest_size=16).digest(), f"frame {f}: packet payload differs from the serial oracle"
+        ctx.download(out, d_out + f * fb)
+        assert np.array_equal(out, crop), f"frame {f}: decoded frame (display order) differs from the serial oracle"
+        want_frames.append(dig(crop))
+    for p in (d_frames, d_out, d_coef, d_mv, d_has):
+        ctx.free(p)
+    enc.close(); dec.close()
+    # the same packets as a .pfv stream (src/enc.rs:190-235: magic, version, geometry, the four q-tables; type:u8 len:u32 payload) through the
+    # GOP-batched decoder object, payloads read on the device
+    head = b"PFVIDEO\0" + (211).to_bytes(4, "little") + b"".join(int(v).to_bytes(2, "little") for v in (width, height, 30, 4))
+    head += b"".join(np.asarray(tabs[k], dtype="<u2").tobytes() for k in range(4))
+    stream = head + b"".join(bytes([1 if f % gop == 0 else 2]) + len(payloads[f]).to_bytes(4, "little") + payloads[f] for f in range(n_frames)) + bytes(5)
+    gdec = pkg.GopDecoder(stream, ctx, max_gops=dec_gops or n_gops, max_gop_frames=gop, threads=max(2, min(threads, 15)), raw=True, entropy="device")
+    n_got = [0]
+
+    def onvideo(y, u, v):
+        f = n_got[0]
+        assert hashlib.blake2b(np.concatenate([y, u, v]), digest_size=16).digest() == want_frames[f], f"frame {f}: pfv_gop_decoder (device entropy) differs from the oracle"
+        n_got[0] += 1
+    while gdec.advance_frame(onvideo):
+        pass
+    stats = gdec.stats()
+    gdec.close()
+    assert n_got[0] == n_frames
+    return {"gops": n_gops, "frames": n_frames, "stream_bytes": len(stream), "packets_read_on_device": stats["packets_read_on_device"],
+            "packets_left_to_host_parser": stats["packets_left_to_host_parser"]}
+
+
 def check_golden(pkg, ctx, oracle):
     """the HIP path against the committed known-answer vectors (tests/golden/hotpath_vectors.npz)"""
     import os

@@ -63,6 +63,13 @@ def test_emu_session_gop_batched(pkg, emu_ctx, oracle):
     pc.check_gop_batched_session(pkg, emu_ctx, oracle, 50, 38, 2, n_frames=6, gop=3)       # ragged planes: byte-wise crop path
 
 
+def test_emu_gop_batched_clip(pkg, emu_ctx, oracle):
+    """the whole-clip form of the same check (digests per frame, then the packets through pfv_gop_decoder with device entropy), toy size:
+    23 frames, GOP 5 -> 5 slots, the last GOP short; decoded 2 GOPs per batch"""
+    r = pc.check_gop_batched_clip(pkg, emu_ctx, oracle, 64, 48, 5, n_frames=23, gop=5, dec_gops=2)
+    assert r["gops"] == 5 and r["frames"] == 23 and r["packets_read_on_device"] + r["packets_left_to_host_parser"] == 23
+
+
 def test_emu_session_low_motion(pkg, emu_ctx, oracle):
     """static background + moving objects: tiles with few coded macroblocks take the compaction path, reconstruction included"""
     stats = pc.check_session(pkg, emu_ctx, oracle, 272, 144, 5, n_streams=2, n_frames=4, kind="low_motion")

@@ -231,6 +231,19 @@ def test_gop_batched_session_vs_serial_oracle(pkg, gpu_ctx, oracle, geom):
     assert r["gops"] == (n + 14) // 15 and r["launches_per_operation"] == 15 and r["frames"] == n
 
 
+def test_config5_launch_shape_4k_300_frames_vs_oracle(pkg, gpu_ctx, oracle):
+    """The launch shape `bench.py --workload config5` times, at its size: one 3840x2160 stream of 300 frames, GOP 15, all 20 GOPs in the slots
+    of a launch (20 x 48 720 macroblocks per frame operation) -- every frame's coefficients, motion vectors, skip flags, device-built packet
+    payload and display-order decoded frame against the oracle's SERIAL encoder (BLAKE2 digests per frame), then the 300 packets as a .pfv
+    stream through pfv_gop_decoder, 20 GOPs per batch, payloads read by the device's entropy stage: every delivered frame against the
+    oracle's reconstruction (BASELINE configs #4 / #5; src/enc.rs:84-97, README.md:34-41)."""
+    threads = min(32, len(os.sched_getaffinity(0)))
+    r = pc.check_gop_batched_clip(pkg, gpu_ctx, oracle, 3840, 2160, 5, n_frames=300, gop=15, threads=threads)
+    oracle.L.pfvo_pool_shutdown()
+    assert r["gops"] == 20 and r["frames"] == 300
+    assert r["packets_read_on_device"] == 300, r        # the synthetic content settles: nothing is left to the host parser
+
+
 def test_gop_batched_session_low_motion_and_static(pkg, gpu_ctx, oracle):
     """the same with content that takes the skip-aware paths inside the batch (tile compaction, wavefronts with nothing coded)"""
     pc.check_gop_batched_session(pkg, gpu_ctx, oracle, 640, 368, 5, n_frames=22, gop=5, kind="low_motion", threads=8)
