@@ -467,7 +467,7 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
  *   max_gops        runs ("groups") per batch = slots per launch; a group starts at every i-frame
  *   max_gop_frames  frames of a group inside one batch; a longer run continues in the next batch (its reference frame is
  *                   carried over on the device), and so does a stream that starts with p-frames
- *   payload_budget  device bytes for the packet payloads of one batch (0: the batch's raw frame bytes, at least 16 MiB);
+ *   payload_budget  device bytes for the packet payloads of one batch (0: twice the batch's raw frame bytes, at least 16 MiB);
  *                   PFV_ERR_NOMEM from the call that completes a batch whose payloads do not fit
  * Encoder: the planes may be reused when an encode call returns; frames are uploaded on a copy stream while the kernels of the
  * previous batch run.  A packet reaches pfv_gop_encoder_drain when its batch is complete (max_gops groups seen, flush, finish);
@@ -488,8 +488,9 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
                                    size_t payload_budget, pfv_gop_encoder **out);
 PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
-/* the same for a packed frame (Y | U | V, pfv_frame_bytes) that already lies in DEVICE memory and is complete when the call is made
- * (frames a renderer or another kernel left in HBM): nothing crosses PCIe on the way in; the frame may be overwritten on return */
+/* the same for a packed frame (Y | U | V, pfv_frame_bytes) that already lies in DEVICE memory (frames a renderer or another kernel left in
+ * HBM): nothing crosses PCIe on the way in.  Ordered on the context's stream like every *_dev call: the frame is read behind the work
+ * enqueued there before the call and may be overwritten by work enqueued there after it; no host wait. */
 PFV_API int pfv_gop_encoder_encode_iframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
 PFV_API int pfv_gop_encoder_encode_pframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
 PFV_API int pfv_gop_encoder_encode_dropframe(pfv_gop_encoder *e);

@@ -45,9 +45,16 @@ struct GopEncBatch {
     EntEntry *entries_dev = nullptr;   // [max_gop_frames][max_gops]
     unsigned long long *cursor_dev = nullptr;
     hipEvent_t ev_uploaded = nullptr, ev_done = nullptr;
+    // the payloads come over step by step, under the kernels of the steps behind them: after step t the arena's fill level is copied to
+    // cursor_steps[t] (page-locked) and ev_step[t] recorded; whoever next looks at the batch (any encode call, the collection) fetches the
+    // bytes the finished steps added (gop_enc_fetch)
+    std::vector<hipEvent_t> ev_step;
+    PinnedBuf<unsigned long long> cursor_steps;
+    int steps_fetched = 0;
+    size_t fetched_bytes = 0;
     PinnedBuf<uint8_t> payload_host;   // the batch's payloads on the host (page-locked): the pending segments point into it
     std::vector<uint8_t> heads;        // 5 bytes per packet of the batch
-    void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; steps = 0; }
+    void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; steps = 0; steps_fetched = 0; fetched_bytes = 0; }
     int frames() const { int n = 0; for (int l : len) n += l; return n; }
 };
 
@@ -58,7 +65,8 @@ struct pfv_gop_encoder {
     size_t frame_bytes = 0, total_blocks = 0, arena_cap = 0;
     GopEncBatch batch[2];
     int cur = 0;                           // batch being filled
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // plane uploads
+    hipStream_t down_stream = nullptr;     // payload downloads (its own stream: an upload's wait must not queue behind them)
     int16_t *coef = nullptr;               // encode outputs of one step, max_gops wide
     int8_t *mv = nullptr;
     uint8_t *has = nullptr;
@@ -147,6 +155,8 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
         });
         if (rc) return rc;
         s->cur ^= 1;
+        HIP_TRY(ctx, hipMemcpyAsync(B.cursor_steps.data() + t, B.cursor_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(B.ev_step[(size_t)t], ctx->stream));
     }
     // the last group may go on in the next batch: its reference frame is in the buffer its last step wrote
     e->cont_valid = true;
@@ -154,6 +164,8 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
     e->cont_buf = (cur0 + B.len[(size_t)G - 1]) & 1;
     HIP_TRY(ctx, hipEventRecord(B.ev_done, ctx->stream));
     B.steps = steps;
+    B.steps_fetched = 0;
+    B.fetched_bytes = 0;
     B.in_flight = true;
     e->batches++;
     e->stats[1] += clk.lap();
@@ -170,6 +182,35 @@ static void gop_enc_materialize(pfv_gop_encoder *e)
     for (const pfv_iovec &v : e->segs) e->out.insert(e->out.end(), v.data, v.data + v.len);
     e->segs.clear();
     e->segs_in = 0;
+}
+
+// The payload bytes the finished steps of an in-flight batch added to its arena: device -> the batch's landing zone, on the download stream.
+// wait: every step (the batch is being collected); otherwise only the steps whose event has fired (called from the encode calls, so that
+// the bytes travel under the kernels of the steps and the batch behind them instead of after the last kernel).
+static int gop_enc_fetch(pfv_gop_encoder *e, GopEncBatch &B, bool wait)
+{
+    pfv_ctx *ctx = e->ctx;
+    if (!B.in_flight) return PFV_OK;
+    if (B.steps_fetched < B.steps && (e->segs_in & (1u << (unsigned)(&B - e->batch)))) gop_enc_materialize(e);   // segments of the batch's previous use that nobody took yet
+    while (B.steps_fetched < B.steps) {
+        hipEvent_t ev = B.ev_step[(size_t)B.steps_fetched];
+        if (wait) HIP_TRY(ctx, hipEventSynchronize(ev));
+        else if (hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); break; }
+        const size_t upto = std::min((size_t)B.cursor_steps.data()[B.steps_fetched], e->arena_cap);
+        if (upto > B.payload_host.size()) {
+            // the landing zone is too small (page-locking is slow: it grows in big steps): what has arrived moves to the new one
+            HIP_TRY(ctx, hipStreamSynchronize(e->down_stream));
+            PinnedBuf<uint8_t> bigger;
+            if (!bigger.resize(std::min(e->arena_cap, upto + upto / 2 + ((size_t)4 << 20)))) return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
+            memcpy(bigger.data(), B.payload_host.data(), B.fetched_bytes);
+            std::swap(bigger.p, B.payload_host.p); std::swap(bigger.n, B.payload_host.n); std::swap(bigger.pinned, B.payload_host.pinned);
+        }
+        if (upto > B.fetched_bytes)
+            HIP_TRY(ctx, hipMemcpyAsync(B.payload_host.data() + B.fetched_bytes, B.arena + B.fetched_bytes, upto - B.fetched_bytes, hipMemcpyDeviceToHost, e->down_stream));
+        B.fetched_bytes = std::max(B.fetched_bytes, upto);
+        B.steps_fetched++;
+    }
+    return PFV_OK;
 }
 
 // wait for a batch, bring its payloads over and write its packets in stream order
@@ -190,12 +231,14 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
     // the batch is complete on the device; its results come over on the copy stream (idle: every upload was waited for), NOT behind
     // the kernels of the next batch, which may already be queued on the context's stream
     GopClock clk;
+    {   // the steps' payloads as they complete (most have come over already, under the kernels), then the batch's entry table
+        const int frc = gop_enc_fetch(e, B, true);
+        if (frc) { e->failed = true; return frc; }
+    }
     HIP_TRY(ctx, hipEventSynchronize(B.ev_done));
     e->stats[2] += clk.lap();
-    HIP_TRY(ctx, hipMemcpyAsync(e->entries_host.data(), B.entries_dev, n_ent * sizeof(EntEntry), hipMemcpyDeviceToHost, e->copy_stream));
-    HIP_TRY(ctx, hipMemcpyAsync(e->cursor_host, B.cursor_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
-    HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
-    const size_t used = (size_t)*e->cursor_host;
+    HIP_TRY(ctx, hipMemcpyAsync(e->entries_host.data(), B.entries_dev, n_ent * sizeof(EntEntry), hipMemcpyDeviceToHost, e->down_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(e->down_stream));
     int rc = PFV_OK;
     for (const GopPacket &p : B.order) {
         if (p.type == 3) continue;
@@ -207,12 +250,6 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
         e->failed = true;
         return fail(ctx, rc, rc == PFV_ERR_FORMAT ? "coefficient needs more than 15 size bits (src/rle.rs:44)"
                                                   : "the batch's packet payloads exceed the payload budget given to pfv_gop_encoder_create");
-    }
-    // page-locking is slow (tens of milliseconds per 100 MB): the landing zone grows in big steps, not batch by batch
-    if (used > B.payload_host.size() && !B.payload_host.resize(used + used / 2 + ((size_t)4 << 20))) { e->failed = true; return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging"); }
-    if (used) {
-        HIP_TRY(ctx, hipMemcpyAsync(B.payload_host.data(), B.arena, used, hipMemcpyDeviceToHost, e->copy_stream));
-        HIP_TRY(ctx, hipStreamSynchronize(e->copy_stream));
     }
     e->stats[3] += clk.lap();
     // packets in stream order as segments: 5 header bytes (src/enc.rs:301-305, :453-457), then the payload where it lies
@@ -272,11 +309,21 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
         if (!B->len.empty()) { if ((rc = gop_enc_rotate(e))) return rc; B = &e->batch[e->cur]; }
         B->len.push_back(0); B->first_type.push_back(2);
     }
+    if ((rc = gop_enc_fetch(e, e->batch[e->cur ^ 1], false))) return rc;      // the batch in flight: the payloads of its finished steps start travelling
     const int slot = (int)B->len.size() - 1, t = B->len.back()++;
     // the three planes go straight to their place in the step's frame array (VideoFrame, src/frame.rs:3-9: no packing on the host)
     uint8_t *dst = B->frames_dev + ((size_t)t * (size_t)e->max_gops + (size_t)slot) * e->frame_bytes;
     const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;   // *_dev: a frame that is in device memory already
+    if (on_device) {
+        // ordered on the CONTEXT's stream like every *_dev call of the library (behind whatever produced the frame there, ahead of whatever
+        // overwrites it there), and without a host wait: the batch's kernels are enqueued on that stream behind the copy.  (Round 4 copied on
+        // the upload stream and waited for it per frame: 300 waits were a third of the 22 ms a 300-frame 4K clip took.)
+        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, ctx->stream));
+        B->order.push_back(GopPacket{(uint8_t)type, slot, t});
+        e->frames_in++;
+        return PFV_OK;
+    }
     if (u == y + ny && v == u + nc) {   // a packed frame: one copy
         HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, e->copy_stream));
     } else {
@@ -310,7 +357,9 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
         if (B.cursor_dev) (void)hipFree(B.cursor_dev);
         if (B.ev_uploaded) (void)hipEventDestroy(B.ev_uploaded);
         if (B.ev_done) (void)hipEventDestroy(B.ev_done);
+        for (hipEvent_t ev : B.ev_step) (void)hipEventDestroy(ev);
     }
+    if (e->down_stream) { (void)hipStreamSynchronize(e->down_stream); (void)hipStreamDestroy(e->down_stream); }
     if (e->coef) (void)hipFree(e->coef);
     if (e->mv) (void)hipFree(e->mv);
     if (e->has) (void)hipFree(e->has);
@@ -322,7 +371,7 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
 
 // Encoder::new (src/enc.rs:37-73) + the batch shape.  max_gops: groups per batch = slots per launch; max_gop_frames: frames a group may
 // have inside one batch (a longer run continues in the next batch); payload_budget: bytes of device memory for the packet payloads of
-// ONE batch (0: the batch's raw frame bytes, at least 16 MiB) -- a batch whose payloads exceed it fails with PFV_ERR_NOMEM.
+// ONE batch (0: twice the batch's raw frame bytes, at least 16 MiB) -- a batch whose payloads exceed it fails with PFV_ERR_NOMEM.
 PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int max_gops, int max_gop_frames,
                                    size_t payload_budget, pfv_gop_encoder **out)
 {
@@ -339,10 +388,19 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
     e->frame_bytes = pfv_frame_bytes(width, height);
     e->total_blocks = (size_t)pfv_total_blocks(width, height);
     const size_t cap_frames = (size_t)max_gops * (size_t)max_gop_frames, nmb = (size_t)max_gops * e->total_blocks;
-    e->arena_cap = payload_budget ? payload_budget : std::max<size_t>(cap_frames * e->frame_bytes, (size_t)16 << 20);
+    // default: twice the batch's raw frame bytes -- 16 bits per sample; noise at the finest quantiser costs 10-12 (run code + size code + value
+    // bits), so only pathological tables get near it (the frame-by-frame object sizes for the format's worst case, 31 bits per coefficient)
+    e->arena_cap = payload_budget ? payload_budget : std::max<size_t>(2 * cap_frames * e->frame_bytes, (size_t)16 << 20);
     e->arena_cap = (e->arena_cap + 15) & ~(size_t)15;
     hipError_t he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->down_stream, hipStreamNonBlocking);
     for (GopEncBatch &B : e->batch) {
+        for (int t = 0; t < max_gop_frames && he == hipSuccess; t++) {
+            hipEvent_t ev = nullptr;
+            he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (he == hipSuccess) B.ev_step.push_back(ev);
+        }
+        if (he == hipSuccess && !B.cursor_steps.resize((size_t)max_gop_frames)) he = hipErrorOutOfMemory;
         if (he == hipSuccess) he = hipMalloc((void **)&B.frames_dev, cap_frames * e->frame_bytes);
         if (he == hipSuccess) he = hipMalloc((void **)&B.arena, e->arena_cap);
         if (he == hipSuccess) he = hipMalloc((void **)&B.entries_dev, cap_frames * sizeof(EntEntry));
@@ -375,8 +433,9 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
 // as the call returns; the packet appears (pfv_gop_encoder_drain) when its batch is complete -- pfv_gop_encoder_flush forces that.
 PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v) { return gop_enc_frame(e, 1, y, u, v); }
 PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v) { return gop_enc_frame(e, 2, y, u, v); }
-// the same for a packed frame (Y | U | V, pfv_frame_bytes) that lies in DEVICE memory and is complete when the call is made -- frames a
-// renderer or another kernel left in HBM: nothing crosses PCIe on the way in.  The frame may be overwritten when the call returns.
+// the same for a packed frame (Y | U | V, pfv_frame_bytes) that lies in DEVICE memory -- frames a renderer or another kernel left in HBM:
+// nothing crosses PCIe on the way in.  Ordered on the context's stream like every *_dev call: the frame is read behind the work enqueued
+// there before the call and may be overwritten by work enqueued there after it (a producer on another stream: pfv_ctx_wait_event).
 static int gop_enc_frame_dev(pfv_gop_encoder *e, int type, const uint8_t *frame_dev)
 {
     if (!e || !frame_dev) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_encode_*_dev: bad argument");
