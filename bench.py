@@ -190,14 +190,16 @@ def cpu_baseline(width, height, quality, frames_one_stream, n_mb, budget_s=12.0)
         if rate2 > rate:
             rate, reps, el = rate2, reps2, el2
     ora.L.pfvo_pool_shutdown()
-    return {"value": rate, "unit": "macroblocks/s", "cores": best, "kind": "port",
+    quota = facts["cgroup_cpu_quota"]
+    usable = ncpu if quota in (None, "max") else max(1, min(ncpu, int(round(float(quota)))))     # CPUs' worth of time the container may actually burn
+    return {"value": rate, "unit": "macroblocks/s", "cores": best, "usable_cpus": usable, "kind": "port",
             "value_best": rate, "threads_best": best, "value_1thread": trials[1],
             "trials_threads_to_value": {str(k): round(v) for k, v in trials.items()}, **facts,
             "pframe_encode_value": penc["n"] / penc["s"] if penc["s"] > 0 else None,
             "sample": f"{reps} x GOP-{len(frames_one_stream)} encode+decode of one {width}x{height} stream ({reps * len(frames_one_stream) * n_mb} "
                       f"macroblocks, {el:.1f} s) on the best pool size; C oracle = port of the reference's algorithm with its per-plane "
-                      f"fork/join over a persistent pool (`cores` = pool size used = threads_best; host_cpus / cgroup_cpu_quota / affinity_cpus = what "
-                      f"this container may use of the node)"}
+                      f"fork/join over a persistent pool (`cores` = pool size used = threads_best, running on `usable_cpus` = min(affinity, cgroup quota) "
+                      f"CPUs' worth of time; host_cpus / cgroup_cpu_quota / affinity_cpus = what this container may use of the node)"}
 
 
 class Timer:
@@ -428,21 +430,29 @@ class GopBatchSet:
     15 + 15 launches of 20 x 48 720 macroblocks instead of 300 + 300 launches of 48 720.  The decoded frames land in display order
     (strided fused crop)."""
 
-    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, gop=GOP, kind="pan"):
+    def __init__(self, pkg, ctx, W, H, Q, seeds, n_frames, gop=GOP, kind="pan", dec_ctx=None):
+        """dec_ctx: a second context for the decoder (wall_pipelined): the decoder works through batch k - 1 while the encoder works through
+        batch k, the two streams meet once per batch"""
         self.pkg, self.ctx, self.W, self.H, self.Q, self.S, self.n_frames, self.gop = pkg, ctx, W, H, Q, len(seeds), n_frames, gop
         self.seeds = [int(s) for s in seeds]
-        self.kind, self.dec_ctx = kind, None
+        self.kind, self.dec_ctx = kind, dec_ctx
         lib = pkg._lib.load()
         self.fb = fb = int(lib.pfv_frame_bytes(W, H))
         self.n_gops = (n_frames + gop - 1) // gop
         assert self.S == 1 or n_frames % gop == 0, "several streams: equal GOPs only (slot = stream x GOPs + GOP needs one stride)"
         self.slots = self.S * self.n_gops
         self.enc = pkg.EncoderSession(ctx, W, H, Q, self.slots)
-        self.dec = pkg.DecoderSession(ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), self.slots)
+        self.dec = pkg.DecoderSession(dec_ctx or ctx, W, H, np.stack(pkg.qtables_from_quality(Q)[:4]), self.slots)
         self.n_mb = self.enc.total_blocks
         self.launch_streams = self.slots
         self._bufs = []
         n = self.slots
+        self.ev_enc = self.ev_dec = None
+        if dec_ctx is not None:      # two alternating sets of a batch's encode outputs (one buffer triple per frame step)
+            one = lambda: (self._alloc(n * self.n_mb * 512), self._alloc(n * self.n_mb * 2), self._alloc(n * self.n_mb))
+            self.pass_sets = [[one() for _ in range(min(n_frames, gop))] for _ in range(2)]
+            self.ev_enc = [ctx.event(), ctx.event()]
+            self.ev_dec = [dec_ctx.event(), dec_ctx.event()]
         self.frames = self._alloc(self.S * n_frames * fb)        # [stream][frame in display order][frame_bytes]
         self.out_frames = self._alloc(self.S * n_frames * fb)    # the decoded stream, display order
         self.coef, self.mv, self.has = self._alloc(n * self.n_mb * 512), self._alloc(n * self.n_mb * 2), self._alloc(n * self.n_mb)
@@ -511,8 +521,57 @@ class GopBatchSet:
                 enc.encode_pframe_dev(self.frames + t * fb, m, h, c)
                 enc.pack_pframe_dev(m, h, c)
 
+    def wall_pipelined(self, reps):
+        """macroblocks/s of `reps` passes over the batch with the decoder ONE BATCH behind the encoder on its own context (host clock, both
+        streams synchronised on both sides; every batch is encoded AND decoded inside the timed region)"""
+        enc, dec, ectx, dctx, fb = self.enc, self.dec, self.ctx, self.dec_ctx, self.fb
+        steps = min(self.gop, self.n_frames)
+
+        def enc_batch(j):
+            for t in range(steps):
+                n = self.active(t)
+                if n != self.slots or t == 0:
+                    enc.set_window(0, n)
+                coef, mv, has = self.pass_sets[j & 1][t]
+                if t == 0:
+                    enc.encode_iframe_dev(self.frames, coef)
+                else:
+                    enc.encode_pframe_dev(self.frames + t * fb, mv, has, coef)
+            ectx.record(self.ev_enc[j & 1])
+
+        def dec_batch(j):
+            dctx.wait_event(self.ev_enc[j & 1])
+            for t in range(steps):
+                n = self.active(t)
+                if n != self.slots or t == 0:
+                    dec.set_window(0, n)
+                dec.set_output_strided_dev(self.out_frames + t * fb, self.gop * fb)
+                coef, mv, has = self.pass_sets[j & 1][t]
+                if t == 0:
+                    dec.decode_iframe_dev(coef)
+                else:
+                    dec.decode_pframe_dev(mv, has, coef)
+            dctx.record(self.ev_dec[j & 1])
+
+        def run(n):
+            for j in range(n + 1):
+                if j < n:
+                    if j >= 2:
+                        ectx.wait_event(self.ev_dec[j & 1])
+                    enc_batch(j)
+                if j >= 1:
+                    dec_batch(j - 1)
+        run(1)
+        self.sync()
+        t0 = time.perf_counter()
+        run(reps)
+        self.sync()
+        return reps * self.n_frames * self.S * self.n_mb / (time.perf_counter() - t0)
+
     def sync(self):
         self.ctx.sync()
+        if self.dec_ctx is not None:
+            self.dec_ctx.sync()
 
     def verify(self):
         """decoder == encoder for every GOP that ran to the last step, and the display-order output holds each GOP's last frame"""
@@ -549,6 +608,11 @@ class GopBatchSet:
         self.sync()
         self.enc.close()
         self.dec.close()
+        if self.ev_enc:
+            for e in self.ev_enc:
+                self.ctx.event_destroy(e)
+            for e in self.ev_dec:
+                self.dec_ctx.event_destroy(e)
         for p in self._bufs:
             self.ctx.free(p)
         self._bufs = []
@@ -660,6 +724,48 @@ def low_motion_side(pkg, ctx, timer, W, H, Q, seeds, n_frames, default_kern_ms, 
                    "transform that skipped every skipped macroblock at no cost would take"}
     ss.close()
     return res
+
+
+def lookahead_side(pkg, ctx, Q):
+    """What the throughput costs in BUFFERING (round-4 review, item 5).  The reference's API is frame at a time (src/enc.rs:75, :125,
+    src/dec.rs:154-224); the device is only full when many frame operations share a launch.  Encode+decode macroblocks/s at kernel scope (host
+    clock, frames resident) for ONE stream by how much of it is in flight: one frame (one launch per frame operation), one GOP (the same
+    launches, decoder one GOP behind the encoder on a second context), 4 and 20 GOPs (frame t of every GOP per launch; `two_contexts`: the
+    decoder one batch behind on a second context, priorities as in single_stream).  frames_in_flight = what a caller has to hold before
+    the first packet / frame comes out."""
+    out = {"unit": "macroblocks/s (encode+decode, kernel scope, one stream, quality %d)" % Q, "rows": []}
+    ectx, dctx = pkg.Context(ctx.device, priority=1), pkg.Context(ctx.device, priority=-1)
+    try:
+        for name, W, H in (("1080p", 1920, 1080), ("4k", 3840, 2160)):
+            seed = [pkg.synth.SEED]
+            reps1 = 8 if name == "1080p" else 3
+            ss = StreamSet(pkg, ctx, W, H, Q, seed, GOP)
+            one = ss.wall(reps1)
+            ss.close()
+            ss = StreamSet(pkg, ectx, W, H, Q, seed, GOP, dec_ctx=dctx)
+            one_gop = ss.wall_pipelined(4 * reps1)
+            ss.verify()
+            ss.close()
+            out["rows"].append({"geometry": name, "in_flight": "1 frame", "frames_in_flight": 1, "value": one})
+            out["rows"].append({"geometry": name, "in_flight": "1 GOP (decoder one GOP behind, two contexts)", "frames_in_flight": 2 * GOP, "value": one_gop})
+            for k in (4, 20):
+                reps = max(2, (24 if name == "1080p" else 6) // k * 2)
+                gb = GopBatchSet(pkg, ctx, W, H, Q, seed, k * GOP)
+                plain = gb.wall(reps)
+                gb.verify()
+                gb.close()
+                row = {"geometry": name, "in_flight": f"{k} GOPs per launch", "frames_in_flight": k * GOP, "value": plain}
+                if k == 4:      # two sets of 15 x k slots of encode outputs: 1.5 GB (4K); not worth 15 GB for 20 GOPs, whose launches fill the device already
+                    gb = GopBatchSet(pkg, ectx, W, H, Q, seed, k * GOP, dec_ctx=dctx)
+                    row["two_contexts"] = gb.wall_pipelined(2 * reps)
+                    row["two_contexts_frames_in_flight"] = 2 * k * GOP
+                    gb.verify()
+                    gb.close()
+                out["rows"].append(row)
+    finally:
+        dctx.close()
+        ectx.close()
+    return out
 
 
 def single_stream_side(pkg, ctx, Q, reps=6):
@@ -1294,6 +1400,7 @@ def main():
                 ss.close()                            # give the 4.5 GB of resident input back first
                 for name, fn in (("low_motion", lambda: low_motion_side(pkg, ctx, timer, W, H, Q, [int(r[1]) for r in mine], NF, kern_ms, coded_frac)),
                                  ("single_stream", lambda: single_stream_side(pkg, ctx, Q)),
+                                 ("lookahead", lambda: lookahead_side(pkg, ctx, Q)),
                                  ("batch_encoder_end_to_end", lambda: batch_encoder_side(pkg, ctx, Q)),
                                  ("config4", lambda: stream_4k_side(pkg, ctx, Q, pkg.synth.SEED))):
                     t1 = time.perf_counter()
