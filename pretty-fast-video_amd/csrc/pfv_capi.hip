@@ -1883,20 +1883,26 @@ struct pfv_encoder {
 // parsed (bits -> coefficients / block headers, dec.rs:226-296, 328-417) ahead of their turn by worker threads: packets
 // are independent bit streams, only the device decode behind them is sequential.
 // ------------------------------------------------------------------ the decoders' entropy stage on the device: host half
-// What only a serial read of a packet can give the k_entd_* kernels (pfv_entdec_kernels.hip): the table (-> the tree's codes), the q
-// indices, a p-frame's block headers (-> motion vectors, has_coeff, the first bit of the run streams; the list of coded macroblocks is made
-// on the device from the has_coeff bytes, k_entd_coded).
+// What the host reads of a packet for the k_entd_* kernels (pfv_entdec_kernels.hip): its first 19 bytes -- the table (-> the tree's codes) and
+// the q indices.  A p-frame's block headers are read on the device since round 5 (k_hdr_*: motion vectors, has_coeff, the first bit of the run
+// streams), the list of coded macroblocks is made there from the has_coeff bytes (k_entd_coded).
 // The payload is copied to `bytes_dst` (page-locked staging, >= plen + 16 bytes).  The caller has set k.byte_off / k.frame_off.
+// header workgroups (k_hdr_*) of a p-frame packet: 2 048 bits each, as many as its headers can take (16 bits per macroblock) or its payload has
+static inline uint32_t entd_hdr_wgs(size_t tb, size_t plen)
+{
+    const size_t bits = plen * 8 > kHdrBit0 ? plen * 8 - kHdrBit0 : 0;
+    return (uint32_t)((std::min(bits, tb * 16) + kHdrWgBits - 1) / kHdrWgBits);
+}
 struct EntdPrep {
     int rc = 0;                  // a status the host parser would have returned before it read any run (header, q index, truncated block headers)
     bool host_parse = false;     // the host parser has to read this packet (degenerate code table, 512 MiB or more, no bits behind the headers)
     uint8_t qidx[3] = {0, 0, 0};
 };
-static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, size_t tb, int n_qtables, uint32_t sub_bits, int8_t *mv, uint8_t *has,
-                             uint32_t *coded, EdPacket &k, uint8_t *bytes_dst)
+static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, size_t tb, int n_qtables, uint32_t sub_bits, EdPacket &k, uint8_t *bytes_dst)
 {
     EntdPrep p;
     k.total_bits = k.bit0 = k.total_coefs = k.n_sub = k.sub_first = k.grp_first = k.list_cap = 0;
+    k.org = k.first_sub = k.hdr_first = k.hdr_wgs = 0;
     k.sub_bits = sub_bits;
     k.pframe = type == 2 ? 1u : 0u;
     k.total_blocks = (uint32_t)tb;
@@ -1907,15 +1913,9 @@ static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, si
     p.rc = parse_head(r, h, n_qtables);
     if (p.rc) return p;
     memcpy(p.qidx, h.qidx, 3);
-    size_t n_coded = tb;
-    if (type == 2) {
-        n_coded = parse_block_headers(r, (int)tb, mv, has, coded);
-        if (!r.ok()) { p.rc = PFV_ERR_IO; return p; }
-    }
-    if (n_coded == 0) return p;                                // no run stream: nothing is read behind the headers (src/dec.rs:378-380)
     int n_syms = 0;
     for (uint8_t t : h.table) n_syms += t != 0;
-    const uint64_t bits = (uint64_t)plen * 8, bit0 = r.position();
+    const uint64_t bits = (uint64_t)plen * 8, bit0 = r.position();      // behind the table and the q indices: bit 152
     // zero-length codes / no bits left / 64 MiB and more: a run costs two bits or more and covers at most 16 coefficients, so below 2^29 bits
     // the kernels' counters (coefficients and values per packet, 32 bits each, summed side by side in one 64-bit word) cannot overflow
     if (n_syms < 2 || bits >= (1ull << 29) || bit0 >= bits) { p.host_parse = true; return p; }
@@ -1925,10 +1925,16 @@ static EntdPrep entd_prepare(const uint8_t *payload, uint32_t plen, int type, si
         k.code_len[s] = (uint8_t)tree.code((uint8_t)s).len;
     }
     k.total_bits = (uint32_t)bits;
-    k.bit0 = (uint32_t)bit0;
-    k.total_coefs = (uint32_t)(n_coded * 256);
+    k.bit0 = k.org = (uint32_t)bit0;
     k.n_sub = (uint32_t)((bits - bit0 + sub_bits - 1) / sub_bits);
-    k.list_cap = (uint32_t)std::min<uint64_t>(n_coded * 256, (bits - bit0) / 3 + 1);   // <= entd_pool_cap(tb, plen): the room the caller set aside
+    if (type == 2) {
+        // the block headers (src/dec.rs:351-372) are read on the device (k_hdr_*): where the run streams start, how many macroblocks are coded
+        // and what the list can need is written into the descriptor there; the subsequences are counted from bit 152
+        k.hdr_wgs = entd_hdr_wgs(tb, plen);
+    } else {
+        k.total_coefs = (uint32_t)(tb * 256);
+        k.list_cap = (uint32_t)std::min<uint64_t>(tb * 256, (bits - bit0) / 3 + 1);   // <= entd_pool_cap(tb, plen): the room the caller set aside
+    }
     memcpy(bytes_dst, payload, plen);
     memset(bytes_dst + plen, 0, 16);
     return p;
@@ -2012,9 +2018,14 @@ static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, 
 }
 
 // the launches of one window: np packets from b.packet0 on, ng workgroups from b.group0 on (b.groups already points at the first of them)
-static void entd_launch(hipStream_t stream, const EdBufs &b, const uint8_t *has_dev, unsigned np, unsigned ng, int launches, int inner)
+static void entd_launch(hipStream_t stream, const EdBufs &b, unsigned np, unsigned ng, unsigned max_hdr_wgs, int launches, int inner)
 {
-    hipLaunchKernelGGL(k_entd_coded, dim3(np), dim3(kEdThreads), 0, stream, b, has_dev);
+    if (max_hdr_wgs) {   // the p-frames' block headers first: they complete the packet descriptors the kernels below read
+        hipLaunchKernelGGL(k_hdr_map, dim3(max_hdr_wgs, np), dim3(kEdThreads), 0, stream, b);
+        hipLaunchKernelGGL(k_hdr_scan, dim3(np), dim3(kEdThreads), 0, stream, b);
+        hipLaunchKernelGGL(k_hdr_emit, dim3(max_hdr_wgs, np), dim3(kEdThreads), 0, stream, b);
+    }
+    hipLaunchKernelGGL(k_entd_coded, dim3(np), dim3(kEdThreads), 0, stream, b);
     hipLaunchKernelGGL(k_entd_sync, dim3(ng), dim3(kEdThreads), 0, stream, b, inner);                      // every subsequence, settled inside the workgroups
     for (int round = 1; round < launches; round++)                                                           // the seams between them (a second pass finds nothing, as a rule)
         hipLaunchKernelGGL(k_entd_fix, dim3((ng + kEdFixThreads - 1) / kEdFixThreads), dim3(kEdFixThreads), 0, stream, b, (uint32_t)ng);
@@ -2065,6 +2076,8 @@ struct DecWindow {
     EdPacket *pk_dev = nullptr;
     uint32_t *status_dev = nullptr, *coded_dev = nullptr;
     unsigned long long *wgsum_dev = nullptr; size_t wgsum_cap = 0;
+    uint32_t *hdr_maps_dev = nullptr; size_t hdr_maps_cap = 0;      // k_hdr_*: [header workgroup][8]
+    uint4 *hdr_start_dev = nullptr; size_t hdr_start_cap = 0;       // [header workgroup]
     ListPool lists;                      // the window's coefficients: one list per packet (pfv_device.h: CoefLists)
     std::vector<size_t> list_room;       // per packet: the size of its list's place in the pool
     int8_t *mv_dev = nullptr;
@@ -2074,7 +2087,8 @@ struct DecWindow {
     DecEvent *owner = nullptr;           // the packet whose window is enqueued / was decoded from this set
     void destroy()
     {
-        for (void *p : {(void *)bytes_dev, (void *)pk_dev, (void *)status_dev, (void *)coded_dev, (void *)groups_dev, (void *)sub_dev, (void *)wgsum_dev, (void *)mv_dev, (void *)has_dev})
+        for (void *p : {(void *)bytes_dev, (void *)pk_dev, (void *)status_dev, (void *)coded_dev, (void *)groups_dev, (void *)sub_dev, (void *)wgsum_dev, (void *)mv_dev, (void *)has_dev,
+                        (void *)hdr_maps_dev, (void *)hdr_start_dev})
             if (p) (void)hipFree(p);
         lists.destroy();
         if (done) (void)hipEventDestroy(done);
@@ -2565,8 +2579,7 @@ static void bd_parse_one(pfv_batch_decoder *b, BdSet *s, int k)
     const size_t tb = b->total_blocks;
     if (s->dev_form) {   // the device reads the run streams: table, q indices, block headers and the payload's copy here
         EdPacket &pk = s->pk.data()[k];
-        const EntdPrep r = entd_prepare(s->payload[(size_t)k], (uint32_t)s->len[(size_t)k], s->type, tb, b->n_qtables, b->entd.sub_bits, s->mv.data() + (size_t)k * tb * 2,
-                                        s->has.data() + (size_t)k * tb, nullptr, pk, s->bytes.data() + pk.byte_off);
+        const EntdPrep r = entd_prepare(s->payload[(size_t)k], (uint32_t)s->len[(size_t)k], s->type, tb, b->n_qtables, b->entd.sub_bits, pk, s->bytes.data() + pk.byte_off);
         s->rc[(size_t)k] = r.rc;
         s->host_parse[(size_t)k] = r.host_parse;
         memcpy(&s->qidx[(size_t)k * 3], r.qidx, 3);
@@ -2675,14 +2688,18 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
     DecEntd &v = b->entd;
     hipStream_t st = b->win_stream;
     const size_t S = (size_t)b->n, tb = b->total_blocks;
-    size_t total_sub = 0, n_groups = 0;
+    size_t total_sub = 0, n_groups = 0, hdr_total = 0;
+    unsigned max_hdr = 0;
     for (size_t k = 0; k < S; k++) {
         EdPacket &pk = s->pk.data()[k];
-        if (s->host_parse[k] || s->rc[k]) pk.n_sub = 0;
+        if (s->host_parse[k] || s->rc[k]) pk.n_sub = pk.hdr_wgs = 0;
         pk.sub_first = (uint32_t)total_sub;
         pk.grp_first = (uint32_t)n_groups;
+        pk.hdr_first = (uint32_t)hdr_total;
         total_sub += pk.n_sub;
         n_groups += (pk.n_sub + kEdOwn - 1) / kEdOwn;
+        hdr_total += pk.hdr_wgs;
+        max_hdr = std::max(max_hdr, (unsigned)pk.hdr_wgs);
     }
     if (total_sub >= 0xffffffffull) return fail(ctx, PFV_ERR_NOMEM, "batch decoder: payloads too large for one step of the device entropy stage");
     if (!s->groups.resize(n_groups + 1)) return fail(ctx, PFV_ERR_NOMEM, "pinned staging");
@@ -2704,6 +2721,8 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
     if ((rc = room(&w.groups_dev, &w.groups_cap, n_groups + 1))) return rc;
     if ((rc = room(&w.sub_dev, &w.sub_cap, (total_sub + 1) * 4))) return rc;
     if ((rc = room(&w.wgsum_dev, &w.wgsum_cap, n_groups + 1))) return rc;
+    if ((rc = room(&w.hdr_maps_dev, &w.hdr_maps_cap, (hdr_total + 1) * 8))) return rc;
+    if ((rc = room(&w.hdr_start_dev, &w.hdr_start_cap, hdr_total + 1))) return rc;
     {   // every packet's list: its place in the window's pool from the packet's size
         size_t total = 0;
         w.list_room.assign(S, 0);
@@ -2717,15 +2736,12 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
     HIP_TRY(ctx, hipMemcpyAsync(w.bytes_dev, s->bytes.data(), s->bytes_total, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(w.pk_dev, s->pk.data(), S * sizeof(EdPacket), hipMemcpyHostToDevice, st));
     if (n_groups) HIP_TRY(ctx, hipMemcpyAsync(w.groups_dev, s->groups.data(), n_groups * sizeof(uint2), hipMemcpyHostToDevice, st));
-    if (s->type == 2) {
-        HIP_TRY(ctx, hipMemcpyAsync(w.mv_dev, s->mv.data(), S * tb * 2, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, s->has.data(), S * tb, hipMemcpyHostToDevice, st));
-    }
     HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, S * sizeof(uint32_t), st));
     if (n_groups) {
         const size_t ts = w.sub_cap / 4;
-        EdBufs eb{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.counts_dev, w.status_dev, 0u, 0u};
-        entd_launch(st, eb, w.has_dev, (unsigned)S, (unsigned)n_groups, v.launches, v.inner);
+        EdBufs eb{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.counts_dev, w.status_dev, 0u, 0u,
+                  w.hdr_maps_dev, w.hdr_start_dev, w.mv_dev, w.has_dev};
+        entd_launch(st, eb, (unsigned)S, (unsigned)n_groups, max_hdr, v.launches, v.inner);
         if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(w.status_host.data(), w.status_dev, S * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2889,6 +2905,10 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
             if (prc == PFV_ERR_NOMEM) return fail(ctx, prc, "pinned list staging");
             if (prc) { b->eof = true; return fail(ctx, prc, "malformed packet payload"); }
             if ((rc = upload_lists(ctx, w.lists, k, w.list_room[k], b->hp.ent.data(), b->hp.n, b->hp.counts.data(), ctx->stream))) return rc;
+            if (s->type == 2) {     // its block headers with it (the device's read of them is not what is decoded)
+                HIP_TRY(ctx, hipMemcpyAsync(w.mv_dev + k * tb * 2, s->mv.data() + k * tb * 2, tb * 2, hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(w.has_dev + k * tb, s->has.data() + k * tb, tb, hipMemcpyHostToDevice, ctx->stream));
+            }
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                 // the one staging list is used again
         }
         rc = dec_step(hot, s->type == 2, w.mv_dev, w.has_dev, w.lists.coefs(), &s->qidx[0]);
@@ -3081,12 +3101,12 @@ static void dec_parse(pfv_decoder *d, DecEvent *e)   // any thread; touches only
         }
         EdPacket &k = *e->pk.data();
         k.byte_off = 0; k.frame_off = 0;
-        const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, d->entd.sub_bits, e->mv.data(), e->has.data(), nullptr, k, e->bytes.data());
+        const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, d->entd.sub_bits, k, e->bytes.data());
         e->rc = r.rc;
         memcpy(e->qidx, r.qidx, 3);
         e->dev_form = true;
         e->host_parse = r.host_parse;
-        if (r.rc || r.host_parse) k.n_sub = 0;
+        if (r.rc || r.host_parse) k.n_sub = k.hdr_wgs = 0;
         const uint32_t ng = (k.n_sub + kEdOwn - 1) / kEdOwn;
         for (uint32_t g = 0; g < ng; g++) e->groups.data()[g] = make_uint2(0u, g);
         if (!e->rc && e->host_parse) {   // the host parser decides about this one, here, on this thread
@@ -3223,7 +3243,7 @@ PFV_API int pfv_decoder_set_lookahead(pfv_decoder *d, int n_threads)
     std::unique_lock<std::mutex> lk(d->m);
     dec_rewind(d, lk, d->pos);
     d->ring.clear();
-    for (int i = 0; i < n_threads + 1; i++) d->ring.emplace_back(new DecEvent());
+    for (int i = 0; i < std::max(n_threads + 1, 2); i++) d->ring.emplace_back(new DecEvent());     // two at least: the packet behind the current one is scanned (and, without threads, prepared by the caller's thread)
     lk.unlock();
     for (int i = 0; i < n_threads; i++) d->workers.emplace_back(dec_worker, d);
     return PFV_OK;
@@ -3295,6 +3315,8 @@ static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
     if ((rc = room(&w.groups_dev, &w.groups_cap, (size_t)ng + 1))) return rc;
     if ((rc = room(&w.sub_dev, &w.sub_cap, ((size_t)k.n_sub + 1) * 4))) return rc;
     if ((rc = room(&w.wgsum_dev, &w.wgsum_cap, (size_t)ng + 1))) return rc;
+    if ((rc = room(&w.hdr_maps_dev, &w.hdr_maps_cap, ((size_t)k.hdr_wgs + 1) * 8))) return rc;
+    if ((rc = room(&w.hdr_start_dev, &w.hdr_start_cap, (size_t)k.hdr_wgs + 1))) return rc;
     w.list_room.assign(1, entd_pool_cap(tb, e->plen));
     w.lists.drop_spill();
     if ((rc = w.lists.room(ctx, w.list_room[0]))) return rc;
@@ -3303,15 +3325,12 @@ static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
     HIP_TRY(ctx, hipMemcpyAsync(w.bytes_dev, e->bytes.data(), (size_t)e->plen + 16, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(w.pk_dev, e->pk.data(), sizeof(EdPacket), hipMemcpyHostToDevice, st));
     if (ng) HIP_TRY(ctx, hipMemcpyAsync(w.groups_dev, e->groups.data(), ng * sizeof(uint2), hipMemcpyHostToDevice, st));
-    if (e->type == 2) {
-        HIP_TRY(ctx, hipMemcpyAsync(w.mv_dev, e->mv.data(), tb * 2, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(w.has_dev, e->has.data(), tb, hipMemcpyHostToDevice, st));
-    }
     HIP_TRY(ctx, hipMemsetAsync(w.status_dev, 0, sizeof(uint32_t), st));
     if (ng) {
         const size_t ts = w.sub_cap / 4;
-        EdBufs b{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.counts_dev, w.status_dev, 0u, 0u};
-        entd_launch(st, b, w.has_dev, 1u, ng, v.launches, v.inner);
+        EdBufs b{w.bytes_dev, w.pk_dev, w.groups_dev, w.sub_dev, w.sub_dev + ts, w.sub_dev + 2 * ts, w.wgsum_dev, w.coded_dev, w.lists.ptr_dev, w.lists.counts_dev, w.status_dev, 0u, 0u,
+                 w.hdr_maps_dev, w.hdr_start_dev, w.mv_dev, w.has_dev};
+        entd_launch(st, b, 1u, ng, k.hdr_wgs, v.launches, v.inner);
         if ((rc = launch_check(ctx, "k_entd_*"))) return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(w.status_host.data(), w.status_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -3345,6 +3364,10 @@ static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
         const int prc = d->hp.parse(e->payload, e->plen, e->type, tb, d->n_qtables, e->mv.data(), e->has.data(), w->list_room[0], e->qidx);
         if (prc) return fail(ctx, prc, prc == PFV_ERR_NOMEM ? "pinned list staging" : "malformed packet payload");
         if ((rc = upload_lists(ctx, w->lists, 0, w->list_room[0], d->hp.ent.data(), d->hp.n, d->hp.counts.data(), ctx->stream))) return rc;
+        if (e->type == 2) {         // its block headers with it (the device's read of them is not what is decoded)
+            HIP_TRY(ctx, hipMemcpyAsync(w->mv_dev, e->mv.data(), tb * 2, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(w->has_dev, e->has.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+        }
     } else {
         v.packets_dev++;
     }
@@ -3353,6 +3376,15 @@ static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
     {   // the packet behind this one
         std::unique_lock<std::mutex> lk(d->m);
         DecEvent *nx = d->count >= 2 ? d->ring[(d->head + 1) % d->ring.size()].get() : nullptr;
+        if (nx && nx->state == DecEvent::QUEUED && d->workers.empty()) {
+            // no parser threads (pfv_decoder_set_lookahead(d, 0)): this thread reads the next packet's first 19 bytes and stages its payload now,
+            // while the decode just launched runs -- with the block headers read on the device that is all a big packet needs from the host
+            nx->state = DecEvent::RUNNING;
+            lk.unlock();
+            dec_parse(d, nx);
+            lk.lock();
+            nx->state = DecEvent::DONE;
+        }
         const bool ready = nx && nx->state == DecEvent::DONE && nx->kind == DecEvent::FRAME && nx->dev_form && !nx->rc;
         lk.unlock();
         if (ready && dec_window_enqueue(d, nx, *other) != PFV_OK) other->owner = nullptr;   // it will be tried again when its turn comes

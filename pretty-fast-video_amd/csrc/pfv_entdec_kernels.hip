@@ -59,9 +59,15 @@ constexpr int kEdInner = 96;                        // k_entd_sync: settling rou
 struct EdPacket {
     unsigned long long byte_off;   // payload position in the device byte buffer (multiple of 4; >= 16 readable bytes behind the payload)
     uint32_t total_bits;           // payload size in bits
-    uint32_t bit0;                 // first bit of the run streams (behind the table, the q indices and the block headers)
+    uint32_t bit0;                 // first bit of the run streams (behind the table, the q indices and the block headers); a p-frame whose block
+                                   // headers are read on the device (k_hdr_*): written there, with total_coefs, list_cap and first_sub
+    uint32_t org;                  // bit the subsequences are counted from: subsequence i is [org + i sub_bits, org + (i + 1) sub_bits).  = bit0 when the
+                                   // host read the headers; the first bit behind the q indices (152) when the device does -- the grids are sized
+                                   // before anybody knows where the headers end, the subsequences in front of bit0 simply have no lane
+    uint32_t first_sub;            // the subsequence bit0 lies in: its lane starts at bit0 (a true run boundary), the ones before it do nothing
+    uint32_t hdr_first, hdr_wgs;   // k_hdr_*: the packet's place in the per-workgroup header arrays, its header workgroups (0: headers read on the host)
     uint32_t total_coefs;          // coefficients the run streams cover: macroblocks x 256 (i-frame), coded macroblocks x 256 (p-frame)
-    uint32_t n_sub;                // subsequences = ceil((total_bits - bit0) / sub_bits); 0: nothing to read
+    uint32_t n_sub;                // subsequences = ceil((total_bits - org) / sub_bits); 0: nothing to read
     uint32_t sub_bits;             // payload bits per lane
     uint32_t sub_first;            // index of subsequence 0 in the per-subsequence arrays
     uint32_t grp_first;            // index of its first workgroup in the per-workgroup array
@@ -85,6 +91,11 @@ struct EdBufs {
     uint32_t *status;              // per packet: kEd* bits
     uint32_t packet0;              // k_entd_prefix: the launch's first packet (one workgroup per packet)
     uint32_t group0;               // index of b.groups[0] among all workgroups of the batch (EdPacket::grp_first counts from there too)
+    // block headers read on the device (k_hdr_*; packets with hdr_wgs != 0)
+    uint32_t *hdr_maps;            // [header workgroup][8]: where a reader that enters the workgroup's bits at entry e leaves them, and what it passes
+    uint4 *hdr_start;              // [header workgroup]: the TRUE reader's entry, macroblocks and coded macroblocks before the workgroup
+    int8_t *mv;                    // [frame][total_blocks][2]   written by k_hdr_emit
+    uint8_t *has;                  // [frame][total_blocks]
 };
 
 // tab[v] = (code length | symbol << 4) of the tree code at the low end of the 12 bits v, 0 when that code is longer than 12 bits.
@@ -123,7 +134,7 @@ struct EdReader {
 // stage the bits of kEdThreads lanes from subsequence `first_lane` on: words [first_bit / 32, ...) of the payload; beyond the payload's own words (+ 3: the slack the host left) zeros
 __device__ __forceinline__ uint32_t ed_stage(uint32_t *lw, const uint8_t *bytes, const EdPacket &pk, uint32_t first_lane, int tid)
 {
-    const unsigned long long first_bit = (unsigned long long)pk.bit0 + (unsigned long long)first_lane * pk.sub_bits;
+    const unsigned long long first_bit = (unsigned long long)pk.org + (unsigned long long)first_lane * pk.sub_bits;
     const uint32_t w0 = (uint32_t)(first_bit >> 5), n = kEdThreads * pk.sub_bits / 32u + 8u, have = (pk.total_bits + 31u) / 32u + 3u;
     const uint32_t *src = (const uint32_t *)(bytes + pk.byte_off);
     for (uint32_t k = (uint32_t)tid; k < n; k += kEdThreads) lw[k] = w0 + k < have ? src[w0 + k] : 0u;
@@ -165,7 +176,7 @@ __device__ __forceinline__ void ed_run(EdReader &r, const uint8_t *tab, const ui
 
 __device__ __forceinline__ uint32_t ed_limit(const EdPacket &pk, uint32_t i)
 {
-    const unsigned long long lim = (unsigned long long)pk.bit0 + (unsigned long long)(i + 1u) * pk.sub_bits;
+    const unsigned long long lim = (unsigned long long)pk.org + (unsigned long long)(i + 1u) * pk.sub_bits;
     return lim < pk.total_bits ? (uint32_t)lim : pk.total_bits;
 }
 
@@ -213,7 +224,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // thread t reads subsequence i0 + t: the halo (t < kEdHalo, none in a packet's first workgroup), then the workgroup's own
     const uint32_t halo = grp.y ? (uint32_t)kEdHalo : 0u, i0 = grp.y * kEdOwn - halo, i = i0 + (uint32_t)tid;
-    const bool mine = (uint32_t)tid < halo + kEdOwn && i < pk.n_sub;
+    const bool mine = (uint32_t)tid < halo + kEdOwn && i < pk.n_sub && i >= pk.first_sub;
     const uint32_t base = ed_stage(lw, b.bytes, pk, i0, tid);
     s_used[tid] = kEdNoStart; s_end[tid] = 0; s_cnt[tid] = 0;
     ed_build_table(tab, cval, clen, pk, tid);      // ends on a barrier
@@ -221,8 +232,8 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
         uint32_t start = kEdNoStart;
         bool work = false;
         if (mine) {
-            if (i == 0) start = pk.bit0;
-            else if (it == 0) start = pk.bit0 + i * pk.sub_bits;      // a guess: the subsequence's own first bit
+            if (i == pk.first_sub) start = pk.bit0;
+            else if (it == 0) start = pk.org + i * pk.sub_bits;       // a guess: the subsequence's own first bit
             else if (tid == 0) start = s_used[0];
             else start = s_end[tid - 1];
             work = s_used[tid] != start;
@@ -291,6 +302,7 @@ __global__ void __launch_bounds__(kEdFixThreads) k_entd_fix(EdBufs b, uint32_t n
     if (grp.y == 0) return;                        // a packet's first lane starts at its first run: true
     const EdPacket &pk = b.packets[grp.x];
     uint32_t i = grp.y * kEdOwn;
+    if (i <= pk.first_sub) return;                 // the run streams begin in or behind this lane: it starts at bit0 (or has nothing to read)
     size_t at = (size_t)pk.sub_first + i;
     uint32_t start = __atomic_load_n(b.end + at - 1, __ATOMIC_RELAXED);
     if (b.used[at] == start) return;               // the guess was right
@@ -339,14 +351,14 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_verify(EdBufs b)
     const EdPacket &pk = b.packets[grp.x];
     const int tid = (int)threadIdx.x;
     const uint32_t i = grp.y * kEdOwn + (uint32_t)tid;
-    const bool mine = tid < kEdOwn && i < pk.n_sub;
+    const bool mine = tid < kEdOwn && i < pk.n_sub && i >= pk.first_sub;
     const size_t at = (size_t)pk.sub_first + i;
     uint32_t used = kEdNoStart, end = 0, count = 0;
     if (mine) { used = b.used[at]; end = b.end[at]; count = b.cnt[at]; }
     s_end[tid] = end;
     __syncthreads();
     if (mine) {
-        const uint32_t start = i == 0 ? pk.bit0 : tid == 0 ? b.end[at - 1] : s_end[tid - 1];
+        const uint32_t start = i == pk.first_sub ? pk.bit0 : tid == 0 ? b.end[at - 1] : s_end[tid - 1];
         if (used != start) atomicOr(b.status + grp.x, kEdUnsettled);
     }
     unsigned long long sum = 0;
@@ -354,19 +366,195 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_verify(EdBufs b)
     if (tid == 0) b.wgsum[b.group0 + blockIdx.x] = sum;
 }
 
+// ------------------------------------------------------------------ a p-frame's block headers (src/dec.rs:351-372), read on the device
+// [has_mvec:1][has_coeff:1]([mx:7s][my:7s] if has_mvec) per macroblock, back to back from bit 152 on: a serial chain -- where header b + 1
+// starts depends on header b's first bit -- and, until round 5, the last thing the decoders read on the HOST (0.1 ms per 4K packet and
+// 3 bytes per macroblock over PCIe).  But every header is 2 or 16 bits: in units of 2 bits a header advances by 1 or by 8, so a reader that
+// enters a chunk of 32 units (64 bits) does so at one of 8 offsets, and what it does from there -- how many headers it passes, how many of
+// them coded, at which offset it enters the next chunk -- depends on the chunk's bits alone.  That is a map {0..7} -> {0..7} x counts per
+// chunk; maps compose (associatively), so the true reader's way through all chunks is a scan over maps and not a guess (unlike the run
+// streams, nothing here has to settle):
+//   k_hdr_map   a workgroup takes 32 chunks: thread (c, e) walks chunk c from entry e; the 32 chunk maps are composed into the
+//               workgroup's map (2 048 bits per map);
+//   k_hdr_scan  one workgroup per packet: its workgroup maps (32 B each) in LDS, ONE thread follows entry 0 through them -- 380 dependent
+//               LDS reads for a 4K frame -- and leaves every workgroup its true entry and the macroblock / coded-macroblock counts
+//               before it; the workgroups behind the last header (the run streams' bits) are marked;
+//   k_hdr_emit  the workgroups again: chunk maps recomputed, the true entry followed through the 32 chunks, then a thread per chunk walks
+//               its headers and writes motion vectors and has_coeff of the macroblocks it passes.  The thread that passes the frame's
+//               last macroblock knows where the run streams start and how many macroblocks are coded: it completes the packet
+//               descriptor (bit0, total_coefs, list_cap, first_sub) for the k_entd_* kernels behind it.
+// A payload that ends inside its headers, or has no bit left behind them although macroblocks are coded, is marked irregular: the host
+// parser reads it (and decides what it is).
+constexpr uint32_t kHdrBit0 = 152;               // 16 table bytes + 3 q-table indices (src/dec.rs:236-246)
+constexpr uint32_t kHdrChunkUnits = 32;          // 64 bits
+constexpr uint32_t kHdrChunksPerWg = kEdThreads / 8;
+constexpr uint32_t kHdrWgBits = kHdrChunksPerWg * kHdrChunkUnits * 2;     // 2 048
+
+// 96 payload bits from bit position p on (zeros behind the payload's words): a chunk's 64 and what its last header hangs over
+struct HdrBits { uint32_t w0, w1, w2; };
+__device__ __forceinline__ HdrBits hdr_load(const uint8_t *bytes, const EdPacket &pk, unsigned long long p)
+{
+    const uint32_t *src = (const uint32_t *)(bytes + pk.byte_off);
+    const uint32_t have = (pk.total_bits + 31u) / 32u + 3u, k = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+    uint32_t d[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) d[j] = k + j < have ? src[k + j] : 0u;
+    return HdrBits{__builtin_amdgcn_alignbit(d[1], d[0], sh), __builtin_amdgcn_alignbit(d[2], d[1], sh), __builtin_amdgcn_alignbit(d[3], d[2], sh)};
+}
+// one chunk from entry e: exit offset | headers passed << 3 | coded among them << 9
+__device__ __forceinline__ uint32_t hdr_walk(const HdrBits &x, uint32_t e)
+{
+    const unsigned long long v = (unsigned long long)x.w0 | ((unsigned long long)x.w1 << 32);
+    uint32_t u = e, nb = 0, nc = 0;
+    while (u < kHdrChunkUnits) {
+        const uint32_t f = (uint32_t)(v >> (2u * u)) & 3u;      // bit 0: has_mvec, bit 1: has_coeff
+        nb++;
+        nc += f >> 1;
+        u += (f & 1u) ? 8u : 1u;
+    }
+    return (u - kHdrChunkUnits) | (nb << 3) | (nc << 9);
+}
+// the chunk maps of a workgroup into LDS (cm[chunk][entry]) and, composed, its own map (thread 0..7: entry e) -- wm[e] = exit | headers << 3 |
+// coded << 14; s_entry / s_nb / s_nc (optional): the way of ONE reader, entering at `e0`, through the chunks
+__device__ __forceinline__ void hdr_wg_maps(uint16_t (*cm)[8], const uint8_t *bytes, const EdPacket &pk, uint32_t wg, uint32_t n_chunks, int tid)
+{
+    const uint32_t c = (uint32_t)tid >> 3, e = (uint32_t)tid & 7u, chunk = wg * kHdrChunksPerWg + c;
+    uint32_t m = e;                                  // a chunk behind the payload passes a reader on as it came
+    if (chunk < n_chunks) m = hdr_walk(hdr_load(bytes, pk, (unsigned long long)kHdrBit0 + (unsigned long long)chunk * 64ull), e);
+    cm[c][e] = (uint16_t)m;
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t hdr_chunks(const EdPacket &pk)
+{
+    const unsigned long long bits = pk.total_bits > kHdrBit0 ? (unsigned long long)(pk.total_bits - kHdrBit0) : 0ull;
+    return (uint32_t)((min(bits, (unsigned long long)pk.total_blocks * 16ull) + 63ull) / 64ull);
+}
+
+// grid (header workgroups of the longest packet, packets of the window)
+__global__ void __launch_bounds__(kEdThreads) k_hdr_map(EdBufs b)
+{
+    __shared__ uint16_t cm[kHdrChunksPerWg][8];
+    const EdPacket &pk = b.packets[b.packet0 + blockIdx.y];
+    if (blockIdx.x >= pk.hdr_wgs) return;
+    const int tid = (int)threadIdx.x;
+    hdr_wg_maps(cm, b.bytes, pk, blockIdx.x, hdr_chunks(pk), tid);
+    if (tid < 8) {
+        uint32_t x = (uint32_t)tid, nb = 0, nc = 0;
+        for (uint32_t c = 0; c < kHdrChunksPerWg; c++) {
+            const uint32_t m = cm[c][x];
+            x = m & 7u; nb += (m >> 3) & 63u; nc += m >> 9;
+        }
+        b.hdr_maps[((size_t)pk.hdr_first + blockIdx.x) * 8u + (uint32_t)tid] = x | (nb << 3) | (nc << 14);
+    }
+}
+
+// one workgroup per packet of the window
+constexpr uint32_t kHdrScanTile = 1024;          // workgroup maps in LDS at a time (32 KiB: 2 Mbit of headers)
+__global__ void __launch_bounds__(kEdThreads) k_hdr_scan(EdBufs b)
+{
+    __shared__ uint32_t wm[kHdrScanTile][8];
+    __shared__ uint32_t carry[3];
+    const EdPacket &pk = b.packets[b.packet0 + blockIdx.x];
+    if (pk.hdr_wgs == 0) return;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) { carry[0] = 0; carry[1] = 0; carry[2] = 0; }
+    for (uint32_t t0 = 0; t0 < pk.hdr_wgs; t0 += kHdrScanTile) {
+        const uint32_t n = min(kHdrScanTile, pk.hdr_wgs - t0);
+        __syncthreads();
+        for (uint32_t k = (uint32_t)tid; k < n * 8u; k += kEdThreads) wm[k >> 3][k & 7u] = b.hdr_maps[((size_t)pk.hdr_first + t0) * 8u + k];
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t e = carry[0], nb = carry[1], nc = carry[2];
+            for (uint32_t w = 0; w < n; w++) {
+                b.hdr_start[(size_t)pk.hdr_first + t0 + w] = make_uint4(e, nb, nc, 0u);
+                const uint32_t m = wm[w][e];
+                e = m & 7u; nb += (m >> 3) & 0x7ffu; nc += m >> 14;
+            }
+            carry[0] = e; carry[1] = nb; carry[2] = nc;
+        }
+    }
+    __syncthreads();
+    // fewer headers than macroblocks in all the bits there are: the payload ends inside its headers (the host parser reports it)
+    if (tid == 0 && carry[1] < pk.total_blocks) atomicOr(b.status + b.packet0 + blockIdx.x, kEdIrregular);
+}
+
+// grid as k_hdr_map
+__global__ void __launch_bounds__(kEdThreads) k_hdr_emit(EdBufs b)
+{
+    __shared__ uint16_t cm[kHdrChunksPerWg][8];
+    __shared__ uint32_t c_entry[kHdrChunksPerWg], c_nb[kHdrChunksPerWg], c_nc[kHdrChunksPerWg];
+    EdPacket &pk = const_cast<EdPacket &>(b.packets[b.packet0 + blockIdx.y]);
+    if (blockIdx.x >= pk.hdr_wgs) return;
+    const uint4 st = b.hdr_start[(size_t)pk.hdr_first + blockIdx.x];
+    const uint32_t tb = pk.total_blocks;
+    if (st.y >= tb) return;                          // behind the last header: these bits are run streams
+    const int tid = (int)threadIdx.x;
+    const uint32_t n_chunks = hdr_chunks(pk);
+    hdr_wg_maps(cm, b.bytes, pk, blockIdx.x, n_chunks, tid);
+    if (tid == 0) {
+        uint32_t e = st.x, nb = st.y, nc = st.z;
+        for (uint32_t c = 0; c < kHdrChunksPerWg; c++) {
+            c_entry[c] = e; c_nb[c] = nb; c_nc[c] = nc;
+            const uint32_t m = cm[c][e];
+            e = m & 7u; nb += (m >> 3) & 63u; nc += m >> 9;
+        }
+    }
+    __syncthreads();
+    if ((uint32_t)tid >= kHdrChunksPerWg) return;
+    const uint32_t chunk = blockIdx.x * kHdrChunksPerWg + (uint32_t)tid;
+    uint32_t blk = c_nb[tid], nc = c_nc[tid];
+    if (chunk >= n_chunks || blk >= tb) return;
+    const unsigned long long p0 = (unsigned long long)kHdrBit0 + (unsigned long long)chunk * 64ull;
+    const HdrBits x = hdr_load(b.bytes, pk, p0);
+    int8_t *mv = b.mv + (pk.frame_off * tb) * 2u;
+    uint8_t *has = b.has + pk.frame_off * tb;
+    uint32_t u = c_entry[tid];
+    while (u < kHdrChunkUnits && blk < tb) {
+        // the header's 16 bits from the chunk's 96
+        const uint32_t sh = 2u * u;
+        const uint32_t lo = sh < 32u ? __builtin_amdgcn_alignbit(x.w1, x.w0, sh) : __builtin_amdgcn_alignbit(x.w2, x.w1, sh - 32u);
+        const uint32_t w = sh == 32u ? x.w1 : lo;        // alignbit takes the shift modulo 32
+        const uint32_t f = w & 3u;
+        int mx = 0, my = 0;
+        if (f & 1u) {
+            mx = (int)(w << 23) >> 25;                   // bits 2..8, two's complement (src/dec.rs:366-369)
+            my = (int)(w << 16) >> 25;                   // bits 9..15
+        }
+        mv[2u * blk] = (int8_t)mx; mv[2u * blk + 1u] = (int8_t)my;
+        has[blk] = (uint8_t)(f >> 1);
+        nc += f >> 1;
+        blk++;
+        u += (f & 1u) ? 8u : 1u;
+        if (blk == tb) {
+            // the frame's last header: the run streams start behind it
+            const unsigned long long bit0 = p0 + 2ull * u;
+            const uint32_t bits = pk.total_bits;
+            if (bit0 > bits || (nc != 0 && bit0 >= bits)) {
+                atomicOr(b.status + b.packet0 + blockIdx.y, kEdIrregular);     // ends inside its headers / nothing behind them: the host parser's case
+                pk.total_coefs = 0;                                             // (nothing of it is read here)
+            } else {
+                pk.bit0 = (uint32_t)bit0;
+                pk.total_coefs = nc * 256u;
+                pk.first_sub = ((uint32_t)bit0 - pk.org) / pk.sub_bits;
+                pk.list_cap = (uint32_t)min((unsigned long long)nc * 256ull, (unsigned long long)(bits - (uint32_t)bit0) / 3ull + 1ull);
+            }
+        }
+    }
+}
+
 // one workgroup per packet: a p-frame's list of coded macroblocks (coded[k] = the k-th macroblock with has_coeff set, src/dec.rs:378-380)
 // from its has_coeff bytes -- 4 bytes per macroblock that need not cross PCIe.  Rounds of 16 384 macroblocks: a thread takes 64 of them
 // (four independent 16-byte loads, kept in registers), counts the non-zero bytes, and writes its macroblocks behind those of the threads
 // and rounds before it.  (A first version read 64 bytes per wavefront and step with a ballot in between, a second read every byte again
 // behind stores the compiler could not move the loads across: 99 and 56 us of waiting for one load after the other.)
-__global__ void __launch_bounds__(kEdThreads) k_entd_coded(EdBufs b, const uint8_t *has_all)
+__global__ void __launch_bounds__(kEdThreads) k_entd_coded(EdBufs b)
 {
     __shared__ unsigned long long scratch[kEdThreads];
     const EdPacket &pk = b.packets[b.packet0 + blockIdx.x];
-    if (!pk.pframe || pk.n_sub == 0) return;
+    if (!pk.pframe || pk.n_sub == 0 || pk.total_coefs == 0) return;
     const int tid = (int)threadIdx.x;
     const uint32_t tb = pk.total_blocks;
-    const uint8_t *has = has_all + pk.frame_off * tb;
+    const uint8_t *has = b.has + pk.frame_off * tb;
     uint32_t *coded = b.coded + pk.frame_off * tb;
     uint32_t carry = 0;
     for (uint32_t r0 = 0; r0 < tb; r0 += kEdThreads * 64u) {
@@ -455,7 +643,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
     const uint32_t i = grp.y * kEdOwn + (uint32_t)tid;
     const uint32_t base = ed_stage(lw, b.bytes, pk, grp.y * kEdOwn, tid);
     ed_build_table(tab, cval, clen, pk, tid);
-    const bool mine = tid < kEdOwn && i < pk.n_sub;
+    const bool mine = tid < kEdOwn && i < pk.n_sub && i >= pk.first_sub;
     const size_t at = (size_t)pk.sub_first + i;
     // what the packet's workgroups before this one cover, what this one's lanes do, and this lane's place among them: coefficients (low
     // half) and values (high half)
@@ -480,7 +668,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_emit(EdBufs b)
     const bool active = mine && (before & 0xffffffffull) < total;     // behind the last coefficient nothing is read (src/dec.rs:261, :382)
     bool odd = false;
     if (active) {
-        const uint32_t start = i == 0 ? pk.bit0 : b.end[at - 1];
+        const uint32_t start = i == pk.first_sub ? pk.bit0 : b.end[at - 1];
         const uint32_t limit = ed_limit(pk, i);
         EdReader r{lw, base, start};
         if (pk.pframe) {

@@ -578,6 +578,8 @@ struct GopDecDev {
     uint2 *groups_dev = nullptr; size_t groups_cap = 0;
     uint32_t *sub_dev = nullptr; size_t sub_cap = 0;     // end | used | cnt (a fourth of the array each; the last fourth is spare)
     unsigned long long *wgsum_dev = nullptr; size_t wgsum_cap = 0;   // per workgroup
+    uint32_t *hdr_maps_dev = nullptr; size_t hdr_maps_cap = 0;       // k_hdr_*: [header workgroup][8]
+    uint4 *hdr_start_dev = nullptr; size_t hdr_start_cap = 0;        // [header workgroup]
     uint32_t *coded_dev = nullptr;
     ListPool lists;                      // the batch's coefficients: one list per frame (pfv_device.h: CoefLists), no dense arrays
     std::vector<size_t> list_off, list_room;   // per packet: its list's place in the pool (entd_pool_cap entries)
@@ -1041,8 +1043,7 @@ static void gopd_dev_prepare(pfv_gop_decoder *d, int j)
     const GopDecEvent *e = p.ev;
     EdPacket &k = v.pk_host.data()[j];
     const size_t tb = d->total_blocks;
-    const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, v.sub_bits, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb,
-                                    nullptr, k, v.bytes_host.data() + k.byte_off);
+    const EntdPrep r = entd_prepare(e->payload, e->plen, e->type, tb, d->n_qtables, v.sub_bits, k, v.bytes_host.data() + k.byte_off);
     p.rc = r.rc;
     p.host_parse = r.host_parse;
     memcpy(p.qidx, r.qidx, 3);
@@ -1072,6 +1073,17 @@ static void gopd_dev_hostparse_group(pfv_gop_decoder *d, int n_tasks)
         d->cv_work.notify_all();
     }
     gopd_join(d, &d->dev.pending);
+}
+// a p-frame packet the HOST parser read: its block headers go up with its lists (the device's own read of them is not what is decoded)
+static int gopd_dev_upload_headers(pfv_gop_decoder *d, const GopDevPacket &p)
+{
+    pfv_ctx *ctx = d->ctx;
+    GopDecDev &v = d->dev;
+    const size_t tb = d->total_blocks;
+    if (p.ev->type != 2) return PFV_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + p.frame * tb * 2, v.mv_host.data() + p.frame * tb * 2, tb * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + p.frame * tb, v.has_host.data() + p.frame * tb, tb, hipMemcpyHostToDevice, ctx->stream));
+    return PFV_OK;
 }
 template <class T>
 static int gopd_dev_room(pfv_ctx *ctx, T **p, size_t *cap, size_t need)
@@ -1153,6 +1165,10 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
     if ((rc = gopd_dev_room(ctx, &v.groups_dev, &v.groups_cap, std::max<size_t>(grp_max, 1)))) return rc;
     if ((rc = gopd_dev_room(ctx, &v.sub_dev, &v.sub_cap, std::max<size_t>(sub_max, 1) * 4))) return rc;
     if ((rc = gopd_dev_room(ctx, &v.wgsum_dev, &v.wgsum_cap, std::max<size_t>(grp_max, 1)))) return rc;
+    size_t hdr_max = 0;
+    for (size_t j = 0; j < n; j++) hdr_max += v.pk[j].ev->type == 2 ? entd_hdr_wgs(tb, v.pk[j].ev->plen) : 0;
+    if ((rc = gopd_dev_room(ctx, &v.hdr_maps_dev, &v.hdr_maps_cap, (hdr_max + 1) * 8))) return rc;
+    if ((rc = gopd_dev_room(ctx, &v.hdr_start_dev, &v.hdr_start_cap, hdr_max + 1))) return rc;
     // the coefficient lists: every packet's place in the pool from its size alone (entd_pool_cap), the frames' list pointers with them
     v.list_off.assign(n, 0); v.list_room.assign(n, 0);
     size_t list_total = 0;
@@ -1186,7 +1202,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         d->cv_work.notify_all();
     }
     const size_t ts = v.sub_cap / 4;
-    size_t total_sub = 0, n_groups = 0;
+    size_t total_sub = 0, n_groups = 0, hdr_total = 0;
     int next_window = 0;
     // the windows of steps [next_window, upto]: uploads and clears on one stream, the kernels behind them on another
     auto windows_upto = [&](int upto) -> int {
@@ -1196,11 +1212,15 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             gopd_join(d, &v.step_pending[(size_t)t]);
             d->stats[1] += wclk.lap();
             const size_t f0 = (size_t)t * S, pa = p0[(size_t)t], pb = p0[(size_t)t + 1], ga = n_groups;
+            unsigned max_hdr = 0;
             for (size_t j = pa; j < pb; j++) {
                 EdPacket &k = v.pk_host.data()[j];
-                if (v.pk[j].rc || v.pk[j].host_parse) k.n_sub = 0;
+                if (v.pk[j].rc || v.pk[j].host_parse) k.n_sub = k.hdr_wgs = 0;
                 k.sub_first = (uint32_t)total_sub;
                 k.grp_first = (uint32_t)n_groups;
+                k.hdr_first = (uint32_t)hdr_total;
+                hdr_total += k.hdr_wgs;
+                max_hdr = std::max(max_hdr, (unsigned)k.hdr_wgs);
                 total_sub += k.n_sub;
                 for (uint32_t b = 0; b * (uint32_t)kEdOwn < k.n_sub; b++) v.groups_host.data()[n_groups++] = make_uint2((unsigned)j, b);
             }
@@ -1208,15 +1228,13 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
             if (pb > pa) HIP_TRY(ctx, hipMemcpyAsync(v.pk_dev + pa, v.pk_host.data() + pa, (pb - pa) * sizeof(EdPacket), hipMemcpyHostToDevice, v.up_stream));
             if (gb > ga) HIP_TRY(ctx, hipMemcpyAsync(v.groups_dev + ga, v.groups_host.data() + ga, (gb - ga) * sizeof(uint2), hipMemcpyHostToDevice, v.up_stream));
             if (bb > ba) HIP_TRY(ctx, hipMemcpyAsync(v.bytes_dev + ba, v.bytes_host.data() + ba, bb - ba, hipMemcpyHostToDevice, v.up_stream));
-            HIP_TRY(ctx, hipMemcpyAsync(v.mv_dev + f0 * tb * 2, v.mv_host.data() + f0 * tb * 2, S * tb * 2, hipMemcpyHostToDevice, v.up_stream));
-            HIP_TRY(ctx, hipMemcpyAsync(v.has_dev + f0 * tb, v.has_host.data() + f0 * tb, S * tb, hipMemcpyHostToDevice, v.up_stream));
             HIP_TRY(ctx, hipEventRecord(v.window_up[(size_t)t], v.up_stream));
             const hipStream_t es = v.streams[t % v.n_streams];
             HIP_TRY(ctx, hipStreamWaitEvent(es, v.window_up[(size_t)t], 0));
             if (gb > ga) {
                 EdBufs b{v.bytes_dev, v.pk_dev, v.groups_dev + ga, v.sub_dev, v.sub_dev + ts, v.sub_dev + 2 * ts, v.wgsum_dev, v.coded_dev, v.lists.ptr_dev, v.lists.counts_dev,
-                         v.status_dev, (uint32_t)pa, (uint32_t)ga};
-                entd_launch(es, b, v.has_dev, (unsigned)(pb - pa), (unsigned)(gb - ga), v.launches, v.inner);
+                         v.status_dev, (uint32_t)pa, (uint32_t)ga, v.hdr_maps_dev, v.hdr_start_dev, v.mv_dev, v.has_dev};
+                entd_launch(es, b, (unsigned)(pb - pa), (unsigned)(gb - ga), max_hdr, v.launches, v.inner);
                 const int lrc = launch_check(ctx, "k_entd_*");
                 if (lrc) return lrc;
             }
@@ -1271,6 +1289,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
                 if (p.rc == kSinkFull) overflowed = true;
                 if (p.rc) continue;
                 if ((rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_ent.data() + v.hp_off[j], v.hp_n[j], v.hp_counts.data() + (size_t)j * (tb + 1), ctx->stream))) return rc;
+                if ((rc = gopd_dev_upload_headers(d, p))) return rc;
             }
             // more values than the packet's bits could hold at three bits each (a one-symbol table: values of one or two bits): once more, with
             // room for every coefficient; its list gets a buffer of its own
@@ -1284,6 +1303,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
                 p.rc = parse_to_lists(p.ev->payload, p.ev->plen, p.ev->type, tb, d->n_qtables, v.mv_host.data() + p.frame * tb * 2, v.has_host.data() + p.frame * tb, v.hp_full.data(), tb * 256,
                                       v.hp_counts.data() + (size_t)j * (tb + 1), &v.hp_n[j], q);
                 if (!p.rc && (rc = upload_lists(ctx, v.lists, p.frame, v.list_room[pj], v.hp_full.data(), v.hp_n[j], v.hp_counts.data() + (size_t)j * (tb + 1), ctx->stream))) return rc;
+                if (!p.rc && (rc = gopd_dev_upload_headers(d, p))) return rc;
             }
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the staging is used again
         }
@@ -1370,7 +1390,7 @@ PFV_API void pfv_gop_decoder_destroy(pfv_gop_decoder *d)
     for (hipEvent_t ev : d->dev.window_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : d->dev.window_up) (void)hipEventDestroy(ev);
     for (void *p : {(void *)d->dev.bytes_dev, (void *)d->dev.pk_dev, (void *)d->dev.status_dev, (void *)d->dev.groups_dev, (void *)d->dev.sub_dev, (void *)d->dev.coded_dev,
-                    (void *)d->dev.wgsum_dev, (void *)d->dev.mv_dev, (void *)d->dev.has_dev})
+                    (void *)d->dev.wgsum_dev, (void *)d->dev.mv_dev, (void *)d->dev.has_dev, (void *)d->dev.hdr_maps_dev, (void *)d->dev.hdr_start_dev})
         if (p) (void)hipFree(p);
     d->dev.lists.destroy();
     pfv_dec_session_destroy(d->hot);
@@ -1467,11 +1487,11 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
                 v.on = true;
             } else {
                 (void)hipGetLastError();
-                for (void **p : {(void **)&v.wgsum_dev, (void **)&v.mv_dev, (void **)&v.has_dev, (void **)&v.coded_dev, (void **)&v.bytes_dev, (void **)&v.sub_dev,
+                for (void **p : {(void **)&v.hdr_maps_dev, (void **)&v.hdr_start_dev, (void **)&v.wgsum_dev, (void **)&v.mv_dev, (void **)&v.has_dev, (void **)&v.coded_dev, (void **)&v.bytes_dev, (void **)&v.sub_dev,
                                  (void **)&v.groups_dev, (void **)&v.pk_dev, (void **)&v.status_dev})
                     if (*p) { (void)hipFree(*p); *p = nullptr; }
                 v.lists.destroy();
-                v.bytes_cap = v.sub_cap = v.groups_cap = v.pk_cap = v.wgsum_cap = 0;
+                v.bytes_cap = v.sub_cap = v.groups_cap = v.pk_cap = v.wgsum_cap = v.hdr_maps_cap = v.hdr_start_cap = 0;
                 for (hipStream_t &st : v.streams)
                     if (st) { (void)hipStreamDestroy(st); st = nullptr; }
                 if (v.up_stream) { (void)hipStreamDestroy(v.up_stream); v.up_stream = nullptr; }

@@ -207,7 +207,7 @@ int main(int argc, char **argv)
     }
     if (only) { out += "}}"; puts(out.c_str()); return 0; }
     // ---- the frame-by-frame objects (the reference's own call pattern: one packet per call, src/enc.rs:75-173, src/dec.rs:169-224)
-    double t_senc = 0, t_sdec = 0, t_sdec_host = 0, t_sdec_hbm = 0;
+    double t_senc = 0, t_sdec = 0, t_sdec_host = 0, t_sdec_hbm = 0, t_sdec0 = 0, t_sdec_hbm0 = 0;
     long sdec_counts[2] = {0, 0};
     {
         pfv_encoder *e = nullptr;
@@ -230,19 +230,23 @@ int main(int argc, char **argv)
         t_senc = now() - t0;
         pfv_encoder_destroy(e);
         if (total != stream.size()) { fprintf(stderr, "frame-by-frame encoder wrote %zu bytes, the GOP-batched one %zu\n", total, stream.size()); return 5; }
-        for (int mode = 0; mode < 3; mode++) {   // run streams read by the host parser (look-ahead threads) / by the device stage / + frames left in HBM
-            CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTROPY_DECODE, mode ? PFV_ENTROPY_DECODE_AUTO : PFV_ENTROPY_DECODE_HOST));
+        for (int mode = 0; mode < 5; mode++) {   // run streams read by the host parser (look-ahead threads) / by the device stage / + frames left in HBM; 3, 4 = 1, 2 without parser threads
+            const bool no_threads = mode >= 3;
+            const int m3 = no_threads ? mode - 2 : mode;
+            CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTROPY_DECODE, m3 ? PFV_ENTROPY_DECODE_AUTO : PFV_ENTROPY_DECODE_HOST));
             double best = 1e30;
             for (int rep = 0; rep < 2; rep++) {
                 pfv_decoder *d = nullptr;
                 CHECK(pfv_decoder_create(ctx, stream.data(), stream.size(), &d));
-                CHECK(pfv_decoder_set_output_device(d, mode == 2 ? 1 : 0));
-                Sink s{ctx, W, H, 101, mode == 2};
-                if (mode == 2) { s.cap_kept = N / 101 + 1; CHECK(pfv_dev_alloc(ctx, fb * (size_t)s.cap_kept, (void **)&s.kept)); }
+                if (getenv("PFV_E2E_LOOKAHEAD")) CHECK(pfv_decoder_set_lookahead(d, atoi(getenv("PFV_E2E_LOOKAHEAD"))));     // experiments
+                if (no_threads) CHECK(pfv_decoder_set_lookahead(d, 0));
+                CHECK(pfv_decoder_set_output_device(d, m3 == 2 ? 1 : 0));
+                Sink s{ctx, W, H, 101, m3 == 2};
+                if (m3 == 2) { s.cap_kept = N / 101 + 1; CHECK(pfv_dev_alloc(ctx, fb * (size_t)s.cap_kept, (void **)&s.kept)); }
                 const double t1 = now();
                 int rc;
                 while ((rc = pfv_decoder_advance_frame(d, on_video, &s)) == 1) {}
-                if (mode == 2) CHECK(pfv_ctx_sync(ctx));
+                if (m3 == 2) CHECK(pfv_ctx_sync(ctx));
                 const double el = now() - t1;
                 CHECK(rc);
                 finish_kept(s, fb, ny, nc);
@@ -251,13 +255,13 @@ int main(int argc, char **argv)
                 if (s.n != N || s.hash != want_hash) { fprintf(stderr, "frame-by-frame decoder: %ld frames, hash %s\n", s.n, s.hash == want_hash ? "ok" : "differs"); return 6; }
                 best = el < best ? el : best;
             }
-            (mode == 2 ? t_sdec_hbm : mode ? t_sdec : t_sdec_host) = best;
+            (mode == 4 ? t_sdec_hbm0 : mode == 3 ? t_sdec0 : mode == 2 ? t_sdec_hbm : mode ? t_sdec : t_sdec_host) = best;
         }
     }
     snprintf(buf, sizeof buf, "}, \"frame_by_frame_objects\": {\"encode_value\": %.1f, \"decode_value\": %.1f, \"decode_value_frames_left_in_hbm\": %.1f, \"decode_value_payloads_read_on_host\": %.1f, "
-             "\"packets_read_on_device\": %ld, \"packets_left_to_host_parser\": %ld, \"note\": \"pfv_encoder / pfv_decoder, one packet per call "
-             "(default look-ahead of 4 threads); the same bytes and frames\"", (double)N * n_mb / t_senc, (double)N * n_mb / t_sdec, (double)N * n_mb / t_sdec_hbm, (double)N * n_mb / t_sdec_host,
-             sdec_counts[0], sdec_counts[1]);
+             "\"decode_value_no_parser_threads\": %.1f, \"decode_value_no_parser_threads_frames_left_in_hbm\": %.1f, \"packets_read_on_device\": %ld, \"packets_left_to_host_parser\": %ld, \"note\": \"pfv_encoder / pfv_decoder, one packet per call "
+             "(default look-ahead of 4 threads; no_parser_threads: pfv_decoder_set_lookahead(d, 0) -- the block headers are read on the device, the caller's thread stages the next payload); the same bytes and frames\"", (double)N * n_mb / t_senc, (double)N * n_mb / t_sdec, (double)N * n_mb / t_sdec_hbm, (double)N * n_mb / t_sdec_host,
+             (double)N * n_mb / t_sdec0, (double)N * n_mb / t_sdec_hbm0, sdec_counts[0], sdec_counts[1]);
     out += buf;
     out += "}, \"frames_checked\": \"every 101st frame sampled (every 61st word) in every mode: identical\"}";
     puts(out.c_str());

@@ -26,3 +26,6 @@ run clk GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLE
 run wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+# one file for profiles/: the counted values, the kernels' durations of each pass, the payload's value count
+{ echo "== values (PFV_PROBE_COUNT_VALUES=1: what the stage delivers; the 150-frame probe decodes 10 packets per step: 1 step of i-frames, 14 of p-frames)"; cat $OUT/values.txt
+  for n in clk wait fetch write; do echo "== $n (rocprofv3 --kernel-trace --pmc, tools/gpu_entdec_pmc.sh: tools/entdec_probe.py 150, frames left in HBM; 10 x 4K packets per step; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them)"; grep "k_entd\|k_dec" $OUT/$n.summary.txt; grep "k_entd\|k_dec\|fillBuffer" $OUT/$n.durations.txt; done; } > $OUT/summary_all.txt
