@@ -27,6 +27,24 @@
  *     (the file format stores them as u16, src/enc.rs:201-215).
  *   - A context is not thread-safe; distinct contexts are independent (one HIP stream
  *     each), like distinct Encoder/Decoder instances with their own rayon pools.
+ *
+ * Surface map (round 5: the surface is frozen -- no new object types; every section below carries its tier)
+ *   [A] DROP-IN: what a binding of the reference needs and nothing else -- the six plane operators
+ *       (pfv_encode_plane ... pfv_blit_dev), pfv_qtables_from_quality, the encoder / decoder sessions (pfv_enc_session_*,
+ *       pfv_enc_iframe / _pframe, pfv_dec_session_*, pfv_dec_iframe / _pframe, pfv_dec_get_frame, pfv_dec_check), the stream
+ *       objects with the reference's own call pattern (pfv_encoder_*, pfv_decoder_*: enc::Encoder / dec::Decoder), the
+ *       context and the geometry queries.  Stable; INTEGRATION.md binds exactly these.
+ *   [B] THROUGHPUT FORMS of the same operations -- same bytes, frames and per-call results as tier A, different launch shape
+ *       or residence: the *_dev entry points and device memory helpers, HIP graphs, the session window / frame stride, the
+ *       device entropy stage of the encoder session (pfv_enc_entropy_*, pfv_enc_pack_*), sparse pairs and coefficient
+ *       lists into the decoder session, the batch objects (pfv_batch_encoder_*, pfv_batch_decoder_*), the GOP-batched
+ *       objects (pfv_gop_encoder_*, pfv_gop_decoder_*), frames left in device memory (*_set_output_device, *_dev frames in).
+ *       Stable in meaning; each is parity-tested against tier A and the oracle.
+ *   [C] DIAGNOSTICS, MEASUREMENT AND TEST HOOKS -- not needed by a caller of the codec and free to change: context options
+ *       (pfv_ctx_set_option; PFV_OPT_ENTDEC_* exist for measurements and for tests that force the "not settled" road),
+ *       events / cross-context ordering, the synthetic workload generator, the payload serialisers / parsers on their own,
+ *       object statistics (pfv_*_stats, *_entropy_counts), pfv_version, and the multi-GPU control plane (pfv_comm_*), which
+ *       serves bench.py's sharded job, not the codec.
  */
 #ifndef PFV_HIP_H
 #define PFV_HIP_H
@@ -55,7 +73,7 @@ typedef enum pfv_status {
 
 typedef struct pfv_ctx pfv_ctx;
 
-/* ------------------------------------------------------------------ context */
+/* ------------------------------------------------------------------ context  [A; the priority / option / event / graph calls below: B and C as marked] */
 /* Replaces the `num_threads` / rayon::ThreadPool slot of Encoder::new (src/enc.rs:37,54)
  * and Decoder::new (src/dec.rs:38,125): the parallel resource is a device + stream. */
 /* number of HIP devices visible to the process (0 when there is none) */
@@ -78,7 +96,7 @@ PFV_API void *pfv_ctx_stream(pfv_ctx *ctx);
 PFV_API const char *pfv_last_error(pfv_ctx *ctx);
 PFV_API const char *pfv_version(void);
 
-/* Context options (diagnostics / test parametrisation; the defaults are what production wants).  An option applies to the
+/* [C] Context options (diagnostics / test parametrisation; the defaults are what production wants).  An option applies to the
  * plane-level operators called on the context and to sessions CREATED afterwards (a session keeps the values it was created
  * with).  Results are the same bytes under every value.
  *   PFV_OPT_ENC_TRANSFORM  how the encode kernels evaluate the transforms of the closed loop (src/dct.rs:176-293):
@@ -116,20 +134,20 @@ enum { PFV_ENC_TRANSFORM_AUTO = 0, PFV_ENC_TRANSFORM_INT = 1 };
 PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value);
 PFV_API int pfv_ctx_get_option(pfv_ctx *ctx, int option, int *value);
 
-/* Timing events on the context's stream (HIP events): record costs a microsecond or two, so every launch of a pass can be
+/* [C] Timing events on the context's stream (HIP events): record costs a microsecond or two, so every launch of a pass can be
  * bracketed without disturbing it; pfv_event_elapsed_ms waits for the later event. */
 typedef struct pfv_event pfv_event;
 PFV_API int pfv_event_create(pfv_ctx *ctx, pfv_event **out);
 PFV_API int pfv_event_record(pfv_event *e);
 PFV_API int pfv_event_elapsed_ms(pfv_event *start, pfv_event *stop, float *ms);
 PFV_API void pfv_event_destroy(pfv_event *e);
-/* Ordering between contexts (each has its own HIP stream): ctx's stream waits, on the device, for an event recorded on another
+/* [B] Ordering between contexts (each has its own HIP stream): ctx's stream waits, on the device, for an event recorded on another
  * context's stream.  This is how a decoder on one context consumes what an encoder on another produces while the encoder is
  * already working on the next frame -- Encoder and Decoder are independent objects in the reference (src/enc.rs:12-26,
  * src/dec.rs:15-28), and for a single stream the device is far from full with one of them. */
 PFV_API int pfv_ctx_wait_event(pfv_ctx *ctx, pfv_event *e);
 
-/* HIP graphs over the `*_dev` entry points.  The reference's caller is one Encoder per stream, one call per frame
+/* [B] HIP graphs over the `*_dev` entry points.  The reference's caller is one Encoder per stream, one call per frame
  * (src/enc.rs:125-173); for a single stream the launches, not the kernels, are the cost.  Every `*_dev` call made between
  * pfv_graph_begin and pfv_graph_end on this context is recorded instead of executed (stream capture); pfv_graph_launch
  * replays the whole sequence -- e.g. the 30 launches of a GOP-15 encode + decode -- as one launch.  Device pointers are baked
@@ -149,7 +167,7 @@ PFV_API int pfv_pad16(int x);
 PFV_API int pfv_qtables_from_quality(int quality, int32_t intra_l[64], int32_t intra_c[64], int32_t inter_l[64],
                                      int32_t inter_c[64], float *px_err);
 
-/* ------------------------------------------------------------------ plane-level operators, host buffers */
+/* ------------------------------------------------------------------ plane-level operators, host buffers  [A] */
 /* VideoPlane::encode_plane (src/common.rs:351-386).
  * px: w*h source plane.  coef_out: pad16(w)/16 * pad16(h)/16 macroblocks * 256 int16. */
 PFV_API int pfv_encode_plane(pfv_ctx *ctx, const uint8_t *px, int w, int h, const int32_t q[64], uint8_t clear,
@@ -191,7 +209,7 @@ PFV_API int pfv_double_dev(pfv_ctx *ctx, uint8_t *dst, const uint8_t *src, int s
 PFV_API int pfv_rgb_to_yuv420_dev(pfv_ctx *ctx, const uint8_t *rgb_dev, int width, int height, uint8_t *frame_dev);
 PFV_API int pfv_yuv420_to_rgb_dev(pfv_ctx *ctx, const uint8_t *frame_dev, int width, int height, uint8_t *rgb_dev);
 
-/* ------------------------------------------------------------------ multi-GPU control plane (one process per GPU, RCCL over xGMI)
+/* ------------------------------------------------------------------ multi-GPU control plane (one process per GPU, RCCL over xGMI)  [C]
  * The path shards by stream and by GOP (src/enc.rs:12-26, 84-97): no data-path collective exists.  These carry the few hundred
  * bytes that do travel -- the assignment table (broadcast) and the per-rank counters (reduction / gather) -- on the context's
  * HIP stream.  Rank 0 creates the id, every rank of the job gets the same 128 bytes over the launcher's own channel
@@ -215,7 +233,7 @@ PFV_API int pfv_comm_allreduce_f64(pfv_comm *c, double *values, size_t count, in
 PFV_API int pfv_comm_barrier(pfv_comm *c);
 PFV_API void pfv_comm_destroy(pfv_comm *c);
 
-/* ------------------------------------------------------------------ synthetic workload (not a reference interface)
+/* ------------------------------------------------------------------ synthetic workload (not a reference interface)  [C]
  * The reference's fixtures are Git-LFS stubs; tests and benchmarks run on an integer-only synthetic video (SURVEY.md
  * section 8d) that is generated where it is consumed: frame `t` of n_streams streams (stream s seeded with seeds[s], a HOST
  * array) as packed Y|U|V frames back to back in frames_dev.  Byte-identical to synth.SyntheticStream(w, h, seed).frame(t). */
@@ -230,7 +248,7 @@ enum { PFV_SYNTH_PAN = 0, PFV_SYNTH_LOW_MOTION = 1, PFV_SYNTH_STATIC = 2 };
 PFV_API int pfv_synth_frames_kind_dev(pfv_ctx *ctx, int width, int height, int n_streams, const uint64_t *seeds, int t, int kind,
                                       uint8_t *frames_dev);
 
-/* ------------------------------------------------------------------ device memory helpers */
+/* ------------------------------------------------------------------ device memory helpers  [B] */
 PFV_API int pfv_dev_alloc(pfv_ctx *ctx, size_t bytes, void **out);
 PFV_API int pfv_dev_free(pfv_ctx *ctx, void *p);
 /* device-to-device copy, asynchronous on the context's stream (ordered like every *_dev call) */
@@ -243,7 +261,7 @@ PFV_API int pfv_host_free(pfv_ctx *ctx, void *p);
 PFV_API int pfv_dev_upload(pfv_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 PFV_API int pfv_dev_download(pfv_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
-/* ------------------------------------------------------------------ encoder session (hot-path half of enc::Encoder)
+/* ------------------------------------------------------------------ encoder session (hot-path half of enc::Encoder)  [A; *_dev, window / stride: B]
  * Holds what Encoder holds for the hot path (src/enc.rs:12-26): width/height, the four
  * q-tables, px_err and `prev_frame` (padded, resident in HBM, ping-ponged), for
  * `n_streams` independent streams processed in one launch per frame step.
@@ -295,7 +313,7 @@ PFV_API const uint8_t *pfv_enc_prev_frame_dev(pfv_enc_session *s, int stream);
 /* copy prev_frame of all streams (padded) to host: n_streams * pfv_padded_frame_bytes */
 PFV_API int pfv_enc_prev_frame(pfv_enc_session *s, uint8_t *out_host);
 
-/* ------------------------------------------------------------------ device entropy stage (encoder session)
+/* ------------------------------------------------------------------ device entropy stage (encoder session)  [B]
  * The reference serialises each frame on one host thread: rle_encode per macroblock (src/rle.rs:9-47), one histogram
  * and Huffman tree per frame (rle.rs:40-66, src/huffman.rs:71-119), LSB-first bit packing into the packet payload
  * (write_iframe_packet src/enc.rs:237-320, write_pframe_packet :332-470).  These entry points build the same payload
@@ -328,7 +346,7 @@ PFV_API size_t pfv_enc_payload_capacity(pfv_enc_session *s);
 /* first nbytes of one stream's payload to the host (synchronises) */
 PFV_API int pfv_enc_payload_fetch(pfv_enc_session *s, int stream, uint8_t *out_host, size_t nbytes);
 
-/* ------------------------------------------------------------------ decoder session (hot-path half of dec::Decoder)
+/* ------------------------------------------------------------------ decoder session (hot-path half of dec::Decoder)  [A; *_dev, sparse, lists, strided output: B]
  * Holds `qtables` and the padded `framebuffer` (src/dec.rs:15-28), n_streams-wide.
  * qtables: n_qtables tables of 64 (header order: intra_l, intra_c, inter_l, inter_c;
  * src/enc.rs:199-215). */
@@ -390,7 +408,7 @@ PFV_API int pfv_dec_framebuffer(pfv_dec_session *s, uint8_t *out_host);
 /* asynchronous bad-motion-vector flag (one per slot) raised by the last *_dev p-frame decode(s); reading it syncs. */
 PFV_API int pfv_dec_check(pfv_dec_session *s);
 
-/* ------------------------------------------------------------------ stream-level session objects
+/* ------------------------------------------------------------------ stream-level session objects  [A]
  * enc::Encoder<W: Write> (src/enc.rs:12-188) with the writer being an in-memory byte vector, and
  * dec::Decoder<R: Read + Seek> (src/dec.rs:15-224) over a caller-owned byte slice.  The per-macroblock work runs
  * on the device sessions above; RLE / Huffman / bit packing and the container run on the host.
@@ -414,7 +432,7 @@ PFV_API int pfv_encoder_bytes(pfv_encoder *e, const uint8_t **data, size_t *len)
 PFV_API void pfv_encoder_destroy(pfv_encoder *e);
 /* 1 (default): packet payloads come from the device entropy stage; 0: from the host serialisers.  Same bytes. */
 PFV_API int pfv_encoder_set_device_entropy(pfv_encoder *e, int on);
-/* ------------------------------------------------------------------ batch encoder (n streams per step, pipelined)
+/* ------------------------------------------------------------------ batch encoder (n streams per step, pipelined)  [B]
  * n independent streams of one geometry encoded together -- the reference runs one Encoder per stream (src/enc.rs:12-26);
  * every writer receives exactly the bytes an Encoder of its own would have written.  Per frame step: ONE upload of all
  * frames (on a copy stream, overlapping the host-side collection of the previous step), one kernel launch per stage for
@@ -436,7 +454,7 @@ PFV_API int pfv_batch_encoder_finish(pfv_batch_encoder *b);
 PFV_API int pfv_batch_encoder_take(pfv_batch_encoder *b, int stream, const uint8_t **data, size_t *len);
 PFV_API void pfv_batch_encoder_destroy(pfv_batch_encoder *b);
 
-/* ------------------------------------------------------------------ batch decoder (n streams per step, pipelined)
+/* ------------------------------------------------------------------ batch decoder (n streams per step, pipelined)  [B]
  * n `.pfv` byte streams of one geometry and one packet-type pattern decoded together: per step the packets are bit-parsed on
  * n_threads worker threads (one task per stream; 0 = on the calling thread), one kernel launch decodes all streams, one copy
  * brings the frames back; the parse of step t+1 overlaps the device work of step t.  `streams[k]` must stay valid while the
@@ -458,7 +476,7 @@ PFV_API void pfv_batch_decoder_entropy_counts(const pfv_batch_decoder *b, long c
 PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **frames_out);
 PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
 
-/* ------------------------------------------------------------------ GOP-batched encoder / decoder of ONE stream
+/* ------------------------------------------------------------------ GOP-batched encoder / decoder of ONE stream  [B]
  * enc::Encoder (src/enc.rs:12-188) and dec::Decoder (src/dec.rs:15-224) with the same calls, bytes and frames as pfv_encoder /
  * pfv_decoder, but with the independent GOPs of the stream as the slots of every kernel launch: encode_iframe never reads
  * prev_frame and overwrites every plane of it (src/enc.rs:84-97), decode_plane_into overwrites the framebuffer

@@ -449,7 +449,10 @@ __global__ void __launch_bounds__(kEdThreads) k_hdr_map(EdBufs b)
 }
 
 // one workgroup per packet of the window
-constexpr uint32_t kHdrScanTile = 1024;          // workgroup maps in LDS at a time (32 KiB: 2 Mbit of headers)
+#ifndef PFV_HDR_SCAN_TILE
+#define PFV_HDR_SCAN_TILE 1024                   // tests build a variant with a tile of 2 so that small frames take several tiles
+#endif
+constexpr uint32_t kHdrScanTile = PFV_HDR_SCAN_TILE;   // workgroup maps in LDS at a time (32 KiB: 2 Mbit of headers)
 __global__ void __launch_bounds__(kEdThreads) k_hdr_scan(EdBufs b)
 {
     __shared__ uint32_t wm[kHdrScanTile][8];

@@ -668,3 +668,30 @@ def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIP
     assert out["pan_seams"]["packets_read_on_device"] >= min_device_share * n_packets, out
     assert out["noise_seams"]["packets_read_on_device"] >= 1, out
     return out
+
+
+def check_device_block_headers(pkg, ctx, oracle, w, h, quality=5, pattern="IPPP", seed=3):
+    """A p-frame's block headers read on the device (k_hdr_*): frames large enough for several header workgroups, content that mixes
+    macroblocks with and without motion vectors / coefficients (static background, moving noisy rectangles: 2-bit and 16-bit headers side by
+    side) and the pan content (a vector on nearly every macroblock) -- every frame pfv_gop_decoder delivers with the payloads read on the
+    device against the oracle's decoder, and every p-frame packet must have stayed on the device."""
+    out = {}
+    for kind in ("low_motion", "pan"):
+        st = pkg.SyntheticStream(w, h, seed=pkg.synth.SEED + seed, kind=kind) if kind != "pan" else pkg.SyntheticStream(w, h)
+        data, _ = encode_pattern(pkg, ctx, oracle, w, h, quality, pattern, lambda buf: pkg.Encoder(buf, w, h, 30, quality, ctx), st.frame, with_oracle=False)
+        want = _outcomes_oracle(oracle, data)
+        dec = pkg.GopDecoder(data, ctx, max_gops=2, max_gop_frames=8, threads=2, entropy="device")
+        got = []
+        while True:
+            fr = []
+            more = dec.advance_frame(lambda f: fr.append(f.packed().tobytes()))
+            got.append(("frame", fr[0]) if fr else ("none",))
+            if not more:
+                got.append(("eof",))
+                break
+        stats = dec.stats()
+        dec.close()
+        assert got == want, f"{kind}: frames differ from the oracle's decoder"
+        out[kind] = stats["packets_read_on_device"]
+        assert stats["packets_read_on_device"] == len(pattern), (kind, stats)
+    return out

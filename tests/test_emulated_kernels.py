@@ -249,16 +249,22 @@ def test_emu_gop_decoder_device_entropy(pkg, emu_ctx, oracle):
     assert out["noise"]["packets_read_on_device"] >= 1, out
 
 
+def test_emu_device_block_headers(pkg, emu_ctx, oracle):
+    """k_hdr_*: 272 x 144 (153 + 2 x 45 macroblocks: up to 3 888 header bits = 2 header workgroups), mixed 2- and 16-bit headers"""
+    assert sc.check_device_block_headers(pkg, emu_ctx, oracle, 272, 144, pattern="IPP") == {"low_motion": 3, "pan": 3}
+
+
 def test_emu_gop_decoder_device_entropy_small_stages():
     """the same check on a build whose k_entd_emit stages 8 entries and 2 macroblock starts per workgroup instead of 4096 / 1024: everything
     behind them goes to memory directly (the paths content far denser than any real frame takes)"""
     import subprocess
     import sys
-    env = dict(os.environ, PFV_EMU_DEFS="-DPFV_ED_OUT_CAP=8 -DPFV_ED_MB_CAP=2")
+    env = dict(os.environ, PFV_EMU_DEFS="-DPFV_ED_OUT_CAP=8 -DPFV_ED_MB_CAP=2 -DPFV_HDR_SCAN_TILE=1")      # + the header scan one workgroup map per tile
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
-                        os.path.abspath(__file__) + "::test_emu_gop_decoder_device_entropy"], env=env, capture_output=True, text=True, timeout=900)
+                        os.path.abspath(__file__) + "::test_emu_gop_decoder_device_entropy", os.path.abspath(__file__) + "::test_emu_device_block_headers"],
+                       env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "1 passed" in r.stdout
+    assert "2 passed" in r.stdout
 
 
 def test_emu_gop_encoder_flush_and_errors(pkg, emu_ctx, oracle):

@@ -535,6 +535,13 @@ def test_gop_decoder_device_entropy(pkg, gpu_ctx, oracle, geom):
     oracle.L.pfvo_pool_shutdown()
 
 
+def test_device_block_headers(pkg, gpu_ctx, oracle):
+    """k_hdr_*: the p-frames' block headers read on the device, 1080p (12 240 macroblocks: up to 96 header workgroups) and a ragged geometry"""
+    sc.check_device_block_headers(pkg, gpu_ctx, oracle, 1920, 1080, pattern="IPPP")
+    sc.check_device_block_headers(pkg, gpu_ctx, oracle, 1000, 562, pattern="IPPPPP", seed=9)
+    oracle.L.pfvo_pool_shutdown()
+
+
 def test_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle):
     assert sc.check_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle) >= 1
     sc.check_gop_decoder_dense_iframe_failure(pkg, gpu_ctx, oracle, 320, 240, 0, require_hit=False)   # another geometry; a flip may leave the packet parseable
