@@ -26,7 +26,7 @@ if [ "$WHAT" = tsan ] || [ "$WHAT" = all ]; then
   flags="-fsanitize=thread -fno-omit-frame-pointer"
   echo "== tsan: g++ $flags (tests/conftest.py build_emulator, PFV_EMU_DEFS); tools/sanitize_run.py, one process per step -- $(date -u +%FT%TZ), $(gcc --version | head -1)" > $log
   for s in "${STEPS[@]}"; do
-    PFV_SAN_ONLY="$s" PFV_EMU_DEFS="$flags" LD_PRELOAD="$GCC_LIBDIR/libtsan.so" TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 report_signal_unsafe=0" timeout 1500 python tools/sanitize_run.py >> $log 2>&1 || { rc=1; echo "== step '$s' FAILED" >> $log; }
+    PFV_SAN_ONLY="$s" PFV_EMU_DEFS="$flags" LD_PRELOAD="$GCC_LIBDIR/libtsan.so" TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 report_signal_unsafe=0" timeout 600 python tools/sanitize_run.py >> $log 2>&1 || { rc=1; echo "== step '$s' did not finish (a hang at start-up with no output is the preloaded TSan runtime, see profiles/r05_sanitize_tsan.log)" >> $log; }
   done
   echo "== exit code $rc; sanitizer reports in this log: $(count $log)" >> $log; tail -2 $log
 fi
