@@ -231,6 +231,7 @@ PFV_API int pfv_comm_allgather_dev(pfv_comm *c, const void *send_dev, void *recv
 PFV_API int pfv_comm_allreduce_f64(pfv_comm *c, double *values, size_t count, int op);
 /* all ranks have arrived and everything enqueued before on their streams is done */
 PFV_API int pfv_comm_barrier(pfv_comm *c);
+/* a communicator belongs to its context: pfv_ctx_destroy tears down the ones still alive, and their handles are invalid from then on */
 PFV_API void pfv_comm_destroy(pfv_comm *c);
 
 /* ------------------------------------------------------------------ synthetic workload (not a reference interface)  [C]

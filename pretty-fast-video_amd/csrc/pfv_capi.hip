@@ -79,6 +79,7 @@ struct pfv_ctx {
     int opt_entropy_decode = PFV_ENTROPY_DECODE_AUTO; // pfv_ctx_set_option(PFV_OPT_ENTROPY_DECODE)
     int opt_entdec_lane_bits = (int)kEdSubBits, opt_entdec_launches = 3, opt_entdec_inner = kEdInner;   // PFV_OPT_ENTDEC_*
     std::vector<struct pfv_comm *> comms;             // live communicators on this context (pfv_comm.hip): torn down with it
+    std::mutex comms_m;                               // pfv_comm_init may return on a watchdog thread (comm.py) while the main thread destroys
 };
 static void comm_teardown(struct pfv_comm *c);
 
@@ -218,8 +219,11 @@ PFV_API void pfv_ctx_destroy(pfv_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (pfv_comm *c : ctx->comms) comm_teardown(c);   // communicators the caller did not destroy: they use this context's stream
-    ctx->comms.clear();
+    {   // communicators the caller did not destroy: they use this context's stream.  Their handles are INVALID from here on (pfv_hip.h)
+        std::vector<pfv_comm *> live;
+        { std::lock_guard<std::mutex> lk(ctx->comms_m); live.swap(ctx->comms); }
+        for (pfv_comm *c : live) comm_teardown(c);
+    }
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->qtab_dev) (void)hipFree(ctx->qtab_dev);
@@ -3431,6 +3435,7 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
         lk.unlock();   // workers keep parsing the packets behind this one while the device decodes it
         rc = e->rc;
         if (rc) rc = fail(d->ctx, rc, rc == PFV_ERR_NOMEM ? "pinned staging for a parsed packet" : "malformed packet payload");
+        if (!rc && e->host_parse && !e->dev_form) d->entd.packets_host++;   // a packet of device size the host parser had to read (degenerate table, 64 MiB and more)
         if (!rc && e->dev_form)
             rc = dec_consume_entd(d, e);
         else if (!rc && e->dense)

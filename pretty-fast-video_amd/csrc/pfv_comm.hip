@@ -109,7 +109,7 @@ PFV_API int pfv_comm_init(pfv_ctx *ctx, int rank, int world, const uint8_t id[12
     if (rc != ncclSuccess) { delete c; return rccl_fail(ctx, rc, "ncclCommInitRank"); }
     hipError_t e = hipMalloc((void **)&c->scratch, 64 * sizeof(double));
     if (e != hipSuccess) { a.CommDestroy(c->comm); delete c; return hip_fail(ctx, e, "pfv_comm_init"); }
-    ctx->comms.push_back(c);      // a communicator does not outlive its context: pfv_ctx_destroy tears down what is still here
+    { std::lock_guard<std::mutex> lk(ctx->comms_m); ctx->comms.push_back(c); }      // a communicator does not outlive its context: pfv_ctx_destroy tears down what is still here
     *out = c;
     return PFV_OK;
 }
@@ -170,8 +170,11 @@ PFV_API int pfv_comm_barrier(pfv_comm *c)
 PFV_API void pfv_comm_destroy(pfv_comm *c)
 {
     if (!c) return;
-    auto &live = c->ctx->comms;
-    live.erase(std::remove(live.begin(), live.end(), c), live.end());
+    {
+        std::lock_guard<std::mutex> lk(c->ctx->comms_m);
+        auto &live = c->ctx->comms;
+        live.erase(std::remove(live.begin(), live.end(), c), live.end());
+    }
     comm_teardown(c);
 }
 

@@ -626,7 +626,7 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
     return hit
 
 
-def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIPPPP", min_device_share=1.0, expect_unsettled=True):
+def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIPPPP", min_device_share=1.0, expect_unsettled=True, only=None):
     """The decoder's entropy stage on the device (k_entd_*, PFV_OPT_ENTROPY_DECODE) on VALID streams: (a) the synthetic pan content -- every
     packet's payload is read on the device and every call matches the oracle's decoder; (b) the same stream with the payload cut into 64-bit
     subsequences and one single round of reading (PFV_OPT_ENTDEC_*): the starts have not
@@ -644,6 +644,8 @@ def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIP
     cases = (("pan", st.frame, quality, None), ("pan_sub64", st.frame, quality, (64, 1, 1)), ("pan_seams", st.frame, quality, (32, None, 1024)),
              ("flat", lambda t: flat[t], quality, None), ("noise", lambda t: noise[t], 0, None), ("noise_seams", lambda t: noise[t], 0, (32, None, 1024)))
     for name, src, q, shape in cases:
+        if only and name not in only:
+            continue
         data, _ = encode_pattern(pkg, ctx, oracle, w, h, q, pattern, lambda buf: pkg.Encoder(buf, w, h, 30, q, ctx), src, with_oracle=False)
         want = _outcomes_oracle(oracle, data)
         n_packets = sum(c != "D" for c in pattern)
@@ -663,10 +665,10 @@ def check_gop_device_entropy(pkg, ctx, oracle, w, h, quality=5, pattern="IPPPPIP
         assert stats["packets_read_on_device"] + stats["packets_left_to_host_parser"] == n_packets, (name, stats)
         assert stats["left_unsettled"] + stats["left_irregular"] <= stats["packets_left_to_host_parser"]
         out[name] = {k: stats[k] for k in ("packets_read_on_device", "packets_left_to_host_parser", "left_unsettled", "left_irregular")}
-    assert out["pan"]["packets_read_on_device"] >= min_device_share * n_packets, out
-    assert out["pan_sub64"]["left_unsettled"] >= 1 or not expect_unsettled, out
-    assert out["pan_seams"]["packets_read_on_device"] >= min_device_share * n_packets, out
-    assert out["noise_seams"]["packets_read_on_device"] >= 1, out
+    assert "pan" not in out or out["pan"]["packets_read_on_device"] >= min_device_share * n_packets, out
+    assert "pan_sub64" not in out or out["pan_sub64"]["left_unsettled"] >= 1 or not expect_unsettled, out
+    assert "pan_seams" not in out or out["pan_seams"]["packets_read_on_device"] >= min_device_share * n_packets, out
+    assert "noise_seams" not in out or out["noise_seams"]["packets_read_on_device"] >= 1, out
     return out
 
 

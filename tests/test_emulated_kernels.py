@@ -245,7 +245,8 @@ def test_emu_gop_objects(pkg, emu_ctx, oracle):
 
 def test_emu_gop_decoder_device_entropy(pkg, emu_ctx, oracle):
     """k_entd_*: payloads read by the self-synchronising device stage; unsettled / periodic / long-code content"""
-    out = sc.check_gop_device_entropy(pkg, emu_ctx, oracle, 96, 64, pattern="IPPPIPP")
+    only = ("pan", "noise", "pan_seams") if os.environ.get("PFV_TEST_VARIANT_BUILD") else None      # the variant builds re-run a part (CPU suite time)
+    out = sc.check_gop_device_entropy(pkg, emu_ctx, oracle, 96, 64, pattern="IPPIP", only=only)
     assert out["noise"]["packets_read_on_device"] >= 1, out
 
 
@@ -259,7 +260,7 @@ def test_emu_gop_decoder_device_entropy_small_stages():
     behind them goes to memory directly (the paths content far denser than any real frame takes)"""
     import subprocess
     import sys
-    env = dict(os.environ, PFV_EMU_DEFS="-DPFV_ED_OUT_CAP=8 -DPFV_ED_MB_CAP=2 -DPFV_HDR_SCAN_TILE=1")      # + the header scan one workgroup map per tile
+    env = dict(os.environ, PFV_EMU_DEFS="-DPFV_ED_OUT_CAP=8 -DPFV_ED_MB_CAP=2 -DPFV_HDR_SCAN_TILE=1", PFV_TEST_VARIANT_BUILD="1")      # + the header scan one workgroup map per tile
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
                         os.path.abspath(__file__) + "::test_emu_gop_decoder_device_entropy", os.path.abspath(__file__) + "::test_emu_device_block_headers"],
                        env=env, capture_output=True, text=True, timeout=1500)
