@@ -73,6 +73,16 @@ with pkg.Context(0) as ctx:
                                              min_device_share=0.0, expect_unsettled=False)
             stats["device_entropy_cases"] = stats.get("device_entropy_cases", 0) + 1
             stats["device_entropy_noise_on_device"] = stats.get("device_entropy_noise_on_device", 0) + ed["noise"]["packets_read_on_device"]
+        # round 5: coefficient lists into the decode kernels, the p-frames' block headers read on the device (geometries large enough for
+        # several header workgroups and several workgroups of the run-stream read), the whole-clip form of the GOP-batched session check
+        stats["list_entries"] = stats.get("list_entries", 0) + pc.check_lists_decode(pkg, ctx, w, h, n_streams=S, seed=s)
+        if it % 2 == 0:
+            bw, bh = 2 * int(r.integers(120, 640)), 2 * int(r.integers(60, 360))
+            sc.check_device_block_headers(pkg, ctx, oracle, bw, bh, quality=q, pattern="I" + "P" * int(r.integers(1, 4)), seed=int(r.integers(1, 1000)))
+            stats["device_header_clips"] = stats.get("device_header_clips", 0) + 1
+            cg = int(r.integers(2, 6))
+            pc.check_gop_batched_clip(pkg, ctx, oracle, w, h, q, n_frames=int(r.integers(cg + 1, 4 * cg)), gop=cg, seed=s, dec_gops=int(r.integers(1, 5)))
+            stats["gop_batched_clips"] = stats.get("gop_batched_clips", 0) + 1
         stats.update({"gop_dec_" + k: v for k, v in sc.ENTROPY_COUNTS.items()})
         if w % 32 == 0:     # the fused retframe crop needs 16-byte rows in every plane
             pc.check_gop_graph(pkg, ctx, oracle, w, h, n_streams=S, n_frames=int(r.integers(2, 5)), quality=q)
