@@ -2113,9 +2113,10 @@ struct ListStage {
     }
 };
 
+constexpr int kDecWindows = 4;           // pfv_decoder: windows in flight -- the packet being decoded and up to three behind it
 struct pfv_decoder {
     DecEntd entd;                        // switches, shape and counters of the device entropy stage (its buffers: win[])
-    DecWindow win[2];
+    DecWindow win[kDecWindows];
     ListStage hp;                        // a packet the device stage left to the host parser
     hipStream_t win_stream = nullptr;
     pfv_ctx *ctx = nullptr;
@@ -3218,7 +3219,7 @@ static void dec_rewind(pfv_decoder *d, std::unique_lock<std::mutex> &lk, size_t 
         d->cv_done.wait(lk);
     }
     if (d->win_stream) (void)hipStreamSynchronize(d->win_stream);          // a window enqueued ahead reads its event's buffers
-    d->win[0].owner = d->win[1].owner = nullptr;
+    for (DecWindow &w : d->win) w.owner = nullptr;
     for (auto &e : d->ring) e->state = DecEvent::FREE;
     d->head = d->count = 0;
     d->scan_pos = d->pos = pos;
@@ -3247,7 +3248,7 @@ PFV_API int pfv_decoder_set_lookahead(pfv_decoder *d, int n_threads)
     std::unique_lock<std::mutex> lk(d->m);
     dec_rewind(d, lk, d->pos);
     d->ring.clear();
-    for (int i = 0; i < std::max(n_threads + 1, 2); i++) d->ring.emplace_back(new DecEvent());     // two at least: the packet behind the current one is scanned (and, without threads, prepared by the caller's thread)
+    for (int i = 0; i < std::max(n_threads + 1, kDecWindows); i++) d->ring.emplace_back(new DecEvent());     // kDecWindows at least: the packets behind the current one are scanned (and, without threads, prepared by the caller's thread)
     lk.unlock();
     for (int i = 0; i < n_threads; i++) d->workers.emplace_back(dec_worker, d);
     return PFV_OK;
@@ -3352,14 +3353,15 @@ static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t tb = (size_t)d->total_blocks;
     int rc;
-    DecWindow *w = d->win[0].owner == e ? &d->win[0] : d->win[1].owner == e ? &d->win[1] : nullptr;
-    if (!w) {                     // not enqueued ahead: now
-        w = &d->win[0];
-        d->win[1].owner = nullptr;
+    DecWindow *w = nullptr;
+    for (DecWindow &x : d->win)
+        if (x.owner == e) w = &x;
+    if (!w) {                     // not enqueued ahead: now (every window is free or holds a packet behind this one; the last call ended with the stream idle)
+        for (DecWindow &x : d->win)
+            if (!w && !x.owner) w = &x;
+        if (!w) { w = &d->win[0]; w->owner = nullptr; }
         if ((rc = dec_window_enqueue(d, e, *w))) { w->owner = nullptr; return rc; }
     }
-    DecWindow *other = w == &d->win[0] ? &d->win[1] : &d->win[0];
-    other->owner = nullptr;       // the packet decoded from it is through (the last call ended with the stream idle)
     HIP_TRY(ctx, hipEventSynchronize(w->done));
     w->owner = nullptr;           // consumed (event objects are reused by the ring: a stale match would take this window for a later packet's)
     if (*w->status_host.data()) {   // the device stage is not certain about this payload: the host parser reads it and decides
@@ -3377,11 +3379,17 @@ static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
     }
     rc = dec_step(hot, e->type == 2, w->mv_dev, w->has_dev, w->lists.coefs(), e->qidx);
     if (rc) return rc;
-    {   // the packet behind this one
+    // The packets behind this one: their windows (payload upload, k_hdr_*, k_entd_*, status) go onto the window stream now, where they run
+    // under this frame's decode and download -- up to kDecWindows - 1 of them: one packet's window is a chain of a dozen small kernels
+    // (~0.15 ms of latency for a 4K p-frame), so with a single window ahead the chain of packet t + 1 only started when packet t's decode was
+    // launched and every frame waited for most of it.  The window just consumed is still being read by the decode launched above: it is not
+    // among the free ones until this call has returned.
+    for (size_t k = 1; k < (size_t)kDecWindows; k++) {
         std::unique_lock<std::mutex> lk(d->m);
-        DecEvent *nx = d->count >= 2 ? d->ring[(d->head + 1) % d->ring.size()].get() : nullptr;
-        if (nx && nx->state == DecEvent::QUEUED && d->workers.empty()) {
-            // no parser threads (pfv_decoder_set_lookahead(d, 0)): this thread reads the next packet's first 19 bytes and stages its payload now,
+        DecEvent *nx = d->count > k ? d->ring[(d->head + k) % d->ring.size()].get() : nullptr;
+        if (!nx) break;
+        if (nx->state == DecEvent::QUEUED && d->workers.empty()) {
+            // no parser threads (pfv_decoder_set_lookahead(d, 0)): this thread reads the packet's first 19 bytes and stages its payload now,
             // while the decode just launched runs -- with the block headers read on the device that is all a big packet needs from the host
             nx->state = DecEvent::RUNNING;
             lk.unlock();
@@ -3389,9 +3397,20 @@ static int dec_consume_entd(pfv_decoder *d, DecEvent *e)
             lk.lock();
             nx->state = DecEvent::DONE;
         }
-        const bool ready = nx && nx->state == DecEvent::DONE && nx->kind == DecEvent::FRAME && nx->dev_form && !nx->rc;
+        const bool ready = nx->state == DecEvent::DONE && nx->kind == DecEvent::FRAME && nx->dev_form && !nx->rc;
+        const bool stop = nx->state != DecEvent::DONE || nx->kind == DecEvent::END || nx->kind == DecEvent::ERROR;
         lk.unlock();
-        if (ready && dec_window_enqueue(d, nx, *other) != PFV_OK) other->owner = nullptr;   // it will be tried again when its turn comes
+        if (stop) break;
+        if (!ready) continue;
+        DecWindow *free_w = nullptr;
+        bool has = false;
+        for (DecWindow &x : d->win) {
+            has = has || x.owner == nx;
+            if (!free_w && !x.owner && &x != w) free_w = &x;
+        }
+        if (has) continue;
+        if (!free_w) break;
+        if (dec_window_enqueue(d, nx, *free_w) != PFV_OK) { free_w->owner = nullptr; break; }   // it will be tried again when its turn comes
     }
     return pfv_dec_check(hot);
 }
