@@ -1864,6 +1864,7 @@ struct PinnedBuf {
     }
     T *data() { return p; }
     size_t size() const { return n; }
+    void swap(PinnedBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(pinned, o.pinned); }
 };
 
 struct pfv_encoder {

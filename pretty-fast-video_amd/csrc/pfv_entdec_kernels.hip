@@ -81,7 +81,7 @@ struct EdPacket {
 
 struct EdBufs {
     const uint8_t *bytes;          // payloads
-    const EdPacket *packets;
+    EdPacket *packets;             // read-only for every kernel but k_hdr_emit, which completes a p-frame's descriptor
     const uint2 *groups;           // workgroups of k_entd_sync / k_entd_emit: (packet, which kEdOwn subsequences of it)
     uint32_t *end, *used, *cnt;    // per subsequence; cnt = coefficients covered | values among them << 16 (a lane reads < 2^9 + 45 bits: < 2^13 of either)
     unsigned long long *wgsum;     // per workgroup of k_entd_sync: the sums of its lanes' cnt fields (coefficients | values << 32), then (k_entd_prefix) those before it
@@ -174,6 +174,84 @@ __device__ __forceinline__ void ed_run(EdReader &r, const uint8_t *tab, const ui
     r.pos += used + nb;
 }
 
+// The same reader with the bits in REGISTERS (round 5): `buf` holds the payload from `pos` on, at least 33 valid bits of it, and the staged
+// word behind them is already on its way (`nxt`, fetched a word -- one or two runs -- before it is shifted in).  With EdReader every run
+// was three LDS round trips one after the other (window, first code, second code); the settling rounds and the emit pass are nothing but such
+// chains, a dozen runs per lane and ~21 rounds per launch.  Here the window costs no trip, and the two codes cost ONE where they fit 12 bits
+// together (ed_build_pairs): one dependent LDS read per run.  The pair table's miss path (two single lookups) is taken by a whole wavefront
+// as soon as one lane misses -- which made round 4 drop a pair table: nearly every step of 64 lanes had a miss -- but the rounds that make up the
+// kernels' time run a handful of packed lanes, and a handful rarely misses.
+struct EdBitBuf {
+    const uint32_t *lw;        // LDS: the payload from bit `base` on
+    uint32_t base, pos;
+    unsigned long long buf;    // bits pos .. pos + have - 1, low bit first
+    uint32_t have, kw, nxt;    // valid bits in buf (> 32); lw[kw] = nxt is the word that follows them
+    __device__ __forceinline__ void start(const uint32_t *words, uint32_t base_bit, uint32_t at)
+    {
+        lw = words; base = base_bit; pos = at;
+        const uint32_t rel = at - base_bit, k = rel >> 5, sh = rel & 31u;
+        buf = (((unsigned long long)lw[k + 1] << 32) | lw[k]) >> sh;
+        have = 64u - sh;
+        kw = k + 2u;
+        nxt = lw[kw];
+    }
+    __device__ __forceinline__ uint32_t window() const { return (uint32_t)buf; }
+    __device__ __forceinline__ void consume(uint32_t n)      // n <= 15
+    {
+        buf >>= n; have -= n; pos += n;
+        if (have <= 32u) {
+            buf |= (unsigned long long)nxt << have;
+            have += 32u;
+            kw++;
+            nxt = lw[kw];
+        }
+    }
+};
+// ptab[v] = 0x8000 | coeff_size << 8 | num_zeroes << 4 | bits of both codes, where the two tree codes at the low end of the 12 bits v take 12 bits
+// or fewer together; 0 otherwise.  From the single-code table: 16 entries per thread.
+__device__ __forceinline__ void ed_build_pairs(uint16_t *ptab, const uint8_t *tab, int tid)
+{
+    for (uint32_t v = (uint32_t)tid; v < 4096u; v += kEdThreads) {
+        uint32_t p = 0;
+        const uint32_t e1 = tab[v];
+        if (e1) {
+            const uint32_t l1 = e1 & 15u, e2 = tab[v >> l1], l2 = e2 & 15u;     // the bits behind the first code, zero-filled at the top: a second code of
+            if (e2 && l1 + l2 <= 12u) p = 0x8000u | ((e2 >> 4) << 8) | (e1 & 0xf0u) | (l1 + l2);   // l2 <= 12 - l1 bits lies wholly inside what is known
+        }
+        ptab[v] = (uint16_t)p;
+    }
+    __syncthreads();
+}
+// PAIRS: try the pair table first.  Measured per ten 4K packets (profiles/r05_entropy_decoder.md): k_entd_sync 82 us with EdReader, 86 with this
+// reader and single lookups, 75 with the pair table in every round (its time is the ~20 late rounds of a few packed lanes, where a miss is rare);
+// k_entd_emit -- one pass of full wavefronts, some lane misses in nearly every step and the wavefront pays for both paths -- 90 us with EdReader,
+// 95 with this reader, 106 with the pair table: it keeps EdReader.
+template <bool PAIRS>
+__device__ __forceinline__ void ed_run(EdBitBuf &r, const uint16_t *ptab, const uint8_t *tab, const uint16_t *cval, const uint8_t *clen, uint32_t &zeros, uint32_t &nb,
+                                       int &value)
+{
+    const uint32_t pe = PAIRS ? ptab[r.window() & 4095u] : 0u;
+    if (PAIRS && __builtin_expect((pe & 0x8000u) != 0, 1)) {
+        zeros = (pe >> 4) & 15u;
+        nb = (pe >> 8) & 15u;
+        r.consume(pe & 15u);
+    } else {
+        uint32_t w = r.window();
+        uint32_t e = tab[w & 4095u];
+        if (__builtin_expect(e == 0, 0)) e = ed_long_code(w, cval, clen);
+        zeros = e >> 4;
+        r.consume(e & 15u);
+        w = r.window();
+        e = tab[w & 4095u];
+        if (__builtin_expect(e == 0, 0)) e = ed_long_code(w, cval, clen);
+        nb = e >> 4;
+        r.consume(e & 15u);
+    }
+    const uint32_t raw = r.window() & ((1u << nb) - 1u), sign = (1u << nb) >> 1;
+    value = (int)((raw ^ sign) - sign);
+    r.consume(nb);
+}
+
 __device__ __forceinline__ uint32_t ed_limit(const EdPacket &pk, uint32_t i)
 {
     const unsigned long long lim = (unsigned long long)pk.org + (unsigned long long)(i + 1u) * pk.sub_bits;
@@ -216,6 +294,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
     __shared__ uint16_t cval[16];
     __shared__ uint8_t clen[16];
     __shared__ uint32_t lw[kEdStageWords];
+    __shared__ uint16_t ptab[4096];
     __shared__ uint32_t s_used[kEdThreads], s_end[kEdThreads], s_cnt[kEdThreads];     // the lanes' state
     __shared__ uint32_t s_list[kEdThreads], s_start[kEdThreads];                        // this round's lanes with work, packed
     __shared__ uint32_t s_wt[kEdThreads / 64];
@@ -228,6 +307,7 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
     const uint32_t base = ed_stage(lw, b.bytes, pk, i0, tid);
     s_used[tid] = kEdNoStart; s_end[tid] = 0; s_cnt[tid] = 0;
     ed_build_table(tab, cval, clen, pk, tid);      // ends on a barrier
+    ed_build_pairs(ptab, tab, tid);                // as well
     for (int it = 0; it < inner; it++) {
         uint32_t start = kEdNoStart;
         bool work = false;
@@ -253,11 +333,12 @@ __global__ void __launch_bounds__(kEdThreads) k_entd_sync(EdBufs b, int inner)
         if ((uint32_t)tid < n_work) {
             const uint32_t l = s_list[tid], limit = ed_limit(pk, i0 + l);
             uint32_t count = 0;
-            EdReader r{lw, base, s_start[tid]};
+            EdBitBuf r;
+            r.start(lw, base, s_start[tid]);
             while (r.pos < limit) {
                 uint32_t zeros, nb;
                 int value;
-                ed_run(r, tab, cval, clen, zeros, nb, value);
+                ed_run<true>(r, ptab, tab, cval, clen, zeros, nb, value);
                 count += zeros + (nb ? 0x10001u : 0u);
             }
             s_used[l] = s_start[tid]; s_end[l] = r.pos; s_cnt[l] = count;
@@ -486,7 +567,7 @@ __global__ void __launch_bounds__(kEdThreads) k_hdr_emit(EdBufs b)
 {
     __shared__ uint16_t cm[kHdrChunksPerWg][8];
     __shared__ uint32_t c_entry[kHdrChunksPerWg], c_nb[kHdrChunksPerWg], c_nc[kHdrChunksPerWg];
-    EdPacket &pk = const_cast<EdPacket &>(b.packets[b.packet0 + blockIdx.y]);
+    EdPacket &pk = b.packets[b.packet0 + blockIdx.y];
     if (blockIdx.x >= pk.hdr_wgs) return;
     const uint4 st = b.hdr_start[(size_t)pk.hdr_first + blockIdx.x];
     const uint32_t tb = pk.total_blocks;

@@ -203,7 +203,7 @@ static int gop_enc_fetch(pfv_gop_encoder *e, GopEncBatch &B, bool wait)
             PinnedBuf<uint8_t> bigger;
             if (!bigger.resize(std::min(e->arena_cap, upto + upto / 2 + ((size_t)4 << 20)))) return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
             memcpy(bigger.data(), B.payload_host.data(), B.fetched_bytes);
-            std::swap(bigger.p, B.payload_host.p); std::swap(bigger.n, B.payload_host.n); std::swap(bigger.pinned, B.payload_host.pinned);
+            B.payload_host.swap(bigger);
         }
         if (upto > B.fetched_bytes)
             HIP_TRY(ctx, hipMemcpyAsync(B.payload_host.data() + B.fetched_bytes, B.arena + B.fetched_bytes, upto - B.fetched_bytes, hipMemcpyDeviceToHost, e->down_stream));
@@ -1244,7 +1244,7 @@ static int gopd_decode_batch_dev(pfv_gop_decoder *d)
         }
         return PFV_OK;
     };
-    constexpr int kWindowsAhead = 4;     // windows enqueued ahead of the step being decoded
+    constexpr int kWindowsAhead = 4;     // windows enqueued ahead of the step being decoded (2 .. 15 measured: 1.27-1.38 G whichever, config 4 to HBM)
     if ((rc = windows_upto(kWindowsAhead))) return rc;
     d->stats[3] += clk.lap();
 
