@@ -528,7 +528,8 @@ PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e);
  * decoder: [0] header scan, [1] waiting for the packet parsers, [2] waiting for the device before a staging set is reused,
  *          [3] enqueueing, [4] waiting for a batch's last frames, [5] waiting for the device's entropy stage (PFV_OPT_ENTROPY_DECODE);
  *          counts: [6] packets whose payload the device read, [7] packets of such batches that were left to the host parser, of which
- *          [8] because the device's read had not settled within its rounds and [9] because it found the payload irregular */
+ *          [8] because the device's read had not settled within its rounds and [9] because it found the payload irregular;
+ *          [10] host-parsed packets whose coefficient list outgrew its place in the pool and got a buffer of its own */
 PFV_API int pfv_gop_encoder_stats(const pfv_gop_encoder *e, double *out, int n);
 PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e);
 PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, int max_gops, int max_gop_frames, int n_threads,

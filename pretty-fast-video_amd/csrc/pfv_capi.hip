@@ -1960,6 +1960,7 @@ struct ListPool {
     size_t frames = 0, tb = 0;
     PinnedBuf<uint32_t *> ptr_host;
     std::vector<uint32_t *> spill;
+    long spilled = 0;                                  // lists that got a buffer of their own so far
     int create(pfv_ctx *ctx, size_t n_frames, size_t total_blocks, size_t entries)
     {
         frames = n_frames; tb = total_blocks;
@@ -2014,6 +2015,7 @@ static int upload_lists(pfv_ctx *ctx, ListPool &lp, size_t f, size_t place_cap, 
     if (n > place_cap || !dst) {
         HIP_TRY(ctx, hipMalloc((void **)&dst, std::max<size_t>(n, 1) * sizeof(uint32_t)));
         lp.spill.push_back(dst);
+        lp.spilled++;
         lp.ptr_host.data()[f] = dst;
         HIP_TRY(ctx, hipMemcpyAsync(lp.ptr_dev + f, lp.ptr_host.data() + f, sizeof(uint32_t *), hipMemcpyHostToDevice, stream));
     }

@@ -1512,12 +1512,13 @@ PFV_API long pfv_gop_decoder_batches(const pfv_gop_decoder *d) { return d ? d->b
 /* host seconds so far: out[0] header scan, [1] waiting for packet parsers, [2] waiting for the device before a staging set can be reused,
  * [3] enqueueing (incl. the time since the previous measurement point), [4] waiting for a batch's last frames, [5] waiting for the device's
  * entropy stage; counts: [6] packets whose payload the device read, [7] packets of device-entropy batches the host parser read, of which
- * [8] because the device's read had not settled and [9] because it found the payload irregular; returns entries written */
+ * [8] because the device's read had not settled and [9] because it found the payload irregular; [10] coefficient lists of host-parsed packets that outgrew
+ * their place in the list pool and got a buffer of their own (one-symbol tables); returns entries written */
 PFV_API int pfv_gop_decoder_stats(const pfv_gop_decoder *d, double *out, int n)
 {
     if (!d || !out) return 0;
-    const int k = std::min(n, 10);
-    const double counts[4] = {(double)d->dev.packets_dev, (double)d->dev.packets_host, (double)d->dev.unsettled, (double)d->dev.irregular};
+    const int k = std::min(n, 11);
+    const double counts[5] = {(double)d->dev.packets_dev, (double)d->dev.packets_host, (double)d->dev.unsettled, (double)d->dev.irregular, (double)d->dev.lists.spilled};
     for (int i = 0; i < k; i++) out[i] = i < 6 ? d->stats[i] : counts[i - 6];
     return k;
 }

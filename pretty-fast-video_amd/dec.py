@@ -160,11 +160,11 @@ class GopDecoder(Decoder):
 
     def stats(self) -> dict:
         """host seconds so far, by what the object was waiting for (pfv_gop_decoder_stats)"""
-        a = (ctypes.c_double * 10)()
-        n = self.ctx._lib.pfv_gop_decoder_stats(self.handle, a, 10)
+        a = (ctypes.c_double * 11)()
+        n = self.ctx._lib.pfv_gop_decoder_stats(self.handle, a, 11)
         out = dict(zip(("scan_s", "parse_wait_s", "device_wait_s", "enqueue_s", "final_wait_s", "device_entropy_wait_s", "packets_read_on_device",
-                        "packets_left_to_host_parser", "left_unsettled", "left_irregular"), list(a)[:n]))
-        for k in ("packets_read_on_device", "packets_left_to_host_parser", "left_unsettled", "left_irregular"):
+                        "packets_left_to_host_parser", "left_unsettled", "left_irregular", "lists_spilled"), list(a)[:n]))
+        for k in ("packets_read_on_device", "packets_left_to_host_parser", "left_unsettled", "left_irregular", "lists_spilled"):
             if k in out:
                 out[k] = int(out[k])
         return out

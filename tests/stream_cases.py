@@ -697,3 +697,62 @@ def check_device_block_headers(pkg, ctx, oracle, w, h, quality=5, pattern="IPPP"
         out[kind] = stats["packets_read_on_device"]
         assert stats["packets_read_on_device"] == len(pattern), (kind, stats)
     return out
+
+
+def check_one_symbol_table_lists(pkg, ctx, oracle, w=64, h=48, seed=5):
+    """A packet only the HOST parser can read AND whose coefficient list outgrows the room its bits were given: a code table with ONE symbol
+    (symbol 1: every run is one zero and a 1-bit value, no code bits at all -- a value per payload bit where the lists count on three bits or
+    more).  Valid for the reference (src/huffman.rs: a one-leaf tree reads without consuming bits).  Through pfv_gop_decoder and
+    pfv_batch_decoder with the device entropy stage forced: the device leaves the packet to the host parser (degenerate table), the list
+    overflows its place in the pool, is parsed again with room for every coefficient and gets a buffer of its own; every frame against the
+    oracle's decoder and against the product's host-parser path."""
+    rng = np.random.default_rng(seed)
+    tabs = pkg.qtables_from_quality(5)
+    head = b"PFVIDEO\0" + (211).to_bytes(4, "little") + b"".join(int(v).to_bytes(2, "little") for v in (w, h, 30, 4))
+    head += b"".join(np.asarray(tabs[k], dtype="<u2").tobytes() for k in range(4))
+    tb = int(pkg._lib.load().pfv_total_blocks(w, h))
+    table = bytes([0, 255] + [0] * 14)
+
+    def ipacket():       # tb x 128 runs of (1 zero, 1-bit value): tb x 128 bits
+        bits = rng.integers(0, 2, tb * 128, dtype=np.uint8)
+        return table + bytes([0, 1, 1]) + np.packbits(bits, bitorder="little").tobytes()
+
+    def ppacket():       # block headers: no vector, has_coeff on every second macroblock; then 128 runs per coded macroblock
+        hdr = np.zeros(tb * 2, np.uint8)
+        hdr[1::4] = 1
+        n_coded = int(hdr[1::2].sum())
+        bits = np.concatenate([hdr, rng.integers(0, 2, n_coded * 128, dtype=np.uint8)])
+        return table + bytes([2, 3, 3]) + np.packbits(bits, bitorder="little").tobytes()
+    packets = [(1, ipacket()), (2, ppacket()), (2, ppacket()), (1, ipacket()), (2, ppacket())]
+    data = head + b"".join(bytes([t]) + len(p).to_bytes(4, "little") + p for t, p in packets) + bytes(5)
+    want = _outcomes_oracle(oracle, data)
+    assert [x[0] for x in want].count("frame") == len(packets), "the oracle's decoder must accept the stream"
+    for mode in ("host", "device"):
+        dec = pkg.GopDecoder(data, ctx, max_gops=2, max_gop_frames=4, threads=2, entropy=mode)
+        got = []
+        while True:
+            fr = []
+            more = dec.advance_frame(lambda f: fr.append(f.packed().tobytes()))
+            got.append(("frame", fr[0]) if fr else ("none",))
+            if not more:
+                got.append(("eof",))
+                break
+        stats = dec.stats()
+        dec.close()
+        assert got == want, f"pfv_gop_decoder ({mode}): frames differ from the oracle's"
+        if mode == "device":
+            assert stats["packets_left_to_host_parser"] == len(packets) and stats["packets_read_on_device"] == 0, stats
+            assert stats["lists_spilled"] == len(packets), stats          # every one of them outgrew its place
+    bdec = pkg.BatchDecoder([data, data], ctx, threads=2, entropy="device")
+    k = 0
+    while True:
+        fr = bdec.advance_frames()
+        if fr is False:
+            break
+        while want[k][0] != "frame":
+            k += 1
+        assert fr[0].tobytes() == want[k][1] and fr[1].tobytes() == want[k][1], f"pfv_batch_decoder: step {k} differs from the oracle's"
+        k += 1
+    assert bdec.entropy_counts()["packets_left_to_host_parser"] == 2 * len(packets)
+    bdec.close()
+    return len(packets)

@@ -255,6 +255,11 @@ def test_emu_device_block_headers(pkg, emu_ctx, oracle):
     assert sc.check_device_block_headers(pkg, emu_ctx, oracle, 272, 144, pattern="IPP") == {"low_motion": 3, "pan": 3}
 
 
+def test_emu_one_symbol_table_lists(pkg, emu_ctx, oracle):
+    """a degenerate code table whose values outnumber what the list pool set aside for the packet's bits: host parser, second parse, spill buffer"""
+    assert sc.check_one_symbol_table_lists(pkg, emu_ctx, oracle) == 5
+
+
 def test_emu_gop_decoder_device_entropy_small_stages():
     """the same check on a build whose k_entd_emit stages 8 entries and 2 macroblock starts per workgroup instead of 4096 / 1024: everything
     behind them goes to memory directly (the paths content far denser than any real frame takes)"""

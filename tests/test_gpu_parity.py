@@ -535,6 +535,12 @@ def test_gop_decoder_device_entropy(pkg, gpu_ctx, oracle, geom):
     oracle.L.pfvo_pool_shutdown()
 
 
+def test_one_symbol_table_lists(pkg, gpu_ctx, oracle):
+    """a degenerate code table whose values outnumber what the list pool set aside for the packet's bits: host parser, second parse, spill buffer"""
+    assert sc.check_one_symbol_table_lists(pkg, gpu_ctx, oracle) == 5
+    assert sc.check_one_symbol_table_lists(pkg, gpu_ctx, oracle, 320, 240, seed=6) == 5
+
+
 def test_device_block_headers(pkg, gpu_ctx, oracle):
     """k_hdr_*: the p-frames' block headers read on the device, 1080p (12 240 macroblocks: up to 96 header workgroups) and a ragged geometry"""
     sc.check_device_block_headers(pkg, gpu_ctx, oracle, 1920, 1080, pattern="IPPP")
