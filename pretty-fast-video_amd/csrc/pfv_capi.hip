@@ -80,6 +80,8 @@ struct pfv_ctx {
     int opt_entdec_lane_bits = (int)kEdSubBits, opt_entdec_launches = 3, opt_entdec_inner = kEdInner;   // PFV_OPT_ENTDEC_*
     std::vector<struct pfv_comm *> comms;             // live communicators on this context (pfv_comm.hip): torn down with it
     std::mutex comms_m;                               // pfv_comm_init may return on a watchdog thread (comm.py) while the main thread destroys
+    pfv_ctx *owner = nullptr;                         // an object's private launch context (pfv_gop_encoder): errors are also reported on the
+    //                                                   context the caller created the object on
 };
 static void comm_teardown(struct pfv_comm *c);
 
@@ -88,6 +90,7 @@ static thread_local std::string g_tls_err;
 static int fail(pfv_ctx *ctx, int code, const std::string &msg)
 {
     if (ctx) ctx->err = msg;
+    if (ctx && ctx->owner) ctx->owner->err = msg;
     g_tls_err = msg;
     return code;
 }

@@ -735,7 +735,9 @@ struct EntEntry {
     uint32_t size;             // payload bytes, kEntErrOversize or kEntErrCapacity
     uint32_t reserved;
 };
-__global__ void k_ent_retain(const uint32_t *sizes, int count, unsigned long long *cursor, unsigned long long cap, EntEntry *entries)
+// level_host: where the arena's fill level after this launch is also left for the host, in page-locked memory (a store across PCIe instead
+// of an 8-byte hipMemcpyAsync per step on the kernel stream: the host reads it once the step's event has fired)
+__global__ void k_ent_retain(const uint32_t *sizes, int count, unsigned long long *cursor, unsigned long long cap, EntEntry *entries, volatile unsigned long long *level_host)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long cur = *cursor;
@@ -749,6 +751,7 @@ __global__ void k_ent_retain(const uint32_t *sizes, int count, unsigned long lon
         entries[k] = e;
     }
     *cursor = cur;
+    *level_host = cur;
 }
 __global__ void __launch_bounds__(kEntThreads) k_ent_gather_entries(EntFrame f, EntBufs b, const EntEntry *entries, uint8_t *arena)
 {

@@ -29,6 +29,17 @@ struct GopClock {
     }
 };
 
+// PFV_GOP_TRACE=1: a host-side log of the encoder's steps (seconds since the object was created) on stderr -- where a rocprofv3 trace would
+// distort the host's own timing
+struct GopTrace {
+    bool on = getenv("PFV_GOP_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()(const char *what, long a = 0, long b = 0) const
+    {
+        if (on) fprintf(stderr, "[pfv gop %9.3f ms] %s %ld %ld\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3, what, a, b);
+    }
+};
+
 struct GopPacket {
     uint8_t type;     // 1 i-frame, 2 p-frame, 3 drop frame (src/enc.rs:175-180)
     int slot, t;
@@ -44,7 +55,8 @@ struct GopEncBatch {
     uint8_t *arena = nullptr;          // retained payloads of the batch
     EntEntry *entries_dev = nullptr;   // [max_gop_frames][max_gops]
     unsigned long long *cursor_dev = nullptr;
-    hipEvent_t ev_uploaded = nullptr, ev_done = nullptr;
+    hipEvent_t ev_uploaded = nullptr, ev_done = nullptr, ev_dev_frames = nullptr;
+    bool dev_frames = false;           // frames were copied on the caller's stream: the batch's kernels wait for ev_dev_frames
     // the payloads come over step by step, under the kernels of the steps behind them: after step t the arena's fill level is copied to
     // cursor_steps[t] (page-locked) and ev_step[t] recorded; whoever next looks at the batch (any encode call, the collection) fetches the
     // bytes the finished steps added (gop_enc_fetch)
@@ -54,12 +66,15 @@ struct GopEncBatch {
     size_t fetched_bytes = 0;
     PinnedBuf<uint8_t> payload_host;   // the batch's payloads on the host (page-locked): the pending segments point into it
     std::vector<uint8_t> heads;        // 5 bytes per packet of the batch
-    void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; steps = 0; steps_fetched = 0; fetched_bytes = 0; }
+    void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; dev_frames = false; steps = 0; steps_fetched = 0; fetched_bytes = 0; }
     int frames() const { int n = 0; for (int l : len) n += l; return n; }
 };
 
 struct pfv_gop_encoder {
-    pfv_ctx *ctx = nullptr;
+    // ctx: the encoder's OWN launch context (a stream of its own for the batches' kernels); user: the context the caller created the encoder
+    // on -- frames that lie in device memory are copied on ITS stream (the *_dev ordering), so the copies of the batch being filled run under
+    // the kernels of the batch in flight instead of queueing behind them
+    pfv_ctx *ctx = nullptr, *user = nullptr;
     pfv_enc_session *hot = nullptr;
     int width = 0, height = 0, max_gops = 0, max_len = 0;
     size_t frame_bytes = 0, total_blocks = 0, arena_cap = 0;
@@ -84,6 +99,7 @@ struct pfv_gop_encoder {
     // seconds: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,
     // [4] packet assembly
     double stats[5] = {0, 0, 0, 0, 0};
+    GopTrace trace;
 };
 
 // ---- helpers of both objects
@@ -113,6 +129,16 @@ static void gop_put_header(std::vector<uint8_t> &o, int width, int height, int f
         for (int i = 0; i < 64; i++) put_u16(o, (unsigned)q[t][i]);
 }
 
+// the options of the caller's context as they stand now (the launches read them from the encoder's own)
+static void gop_enc_take_options(pfv_gop_encoder *e)
+{
+    pfv_ctx *k = e->ctx;
+    const pfv_ctx *u = e->user;
+    k->opt_enc_transform = u->opt_enc_transform;
+    k->opt_tile_compaction = u->opt_tile_compaction;
+    k->opt_lane_mapping = u->opt_lane_mapping;
+}
+
 // every frame step of a batch, enqueued without a host round trip
 static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
 {
@@ -121,8 +147,14 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
     const int G = (int)B.len.size();
     if (G == 0 || B.in_flight) return PFV_OK;
     GopClock clk;
+    e->trace("submit begin: batch, groups", (long)(&B - e->batch), G);
+    gop_enc_take_options(e);
     HIP_TRY(ctx, hipEventRecord(B.ev_uploaded, e->copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, B.ev_uploaded, 0));
+    if (B.dev_frames) {
+        HIP_TRY(ctx, hipEventRecord(B.ev_dev_frames, e->user->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, B.ev_dev_frames, 0));
+    }
     const size_t pad = (size_t)s->geom.pad_frame_bytes;
     if (B.first_type[0] == 2 && e->cont_valid) {   // slot 0 continues the run the previous batch left open: carry its reference frame over
         const uint8_t *src = s->prev[e->cont_buf] + (size_t)e->cont_slot * pad;
@@ -148,14 +180,13 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
             EntBufs b = s->ent;
             b.sizes += first;
             b.payload += (size_t)first * (size_t)s->ent_cap;
-            hipLaunchKernelGGL(k_ent_retain, dim3(1), dim3(64), 0, ctx->stream, b.sizes, count, B.cursor_dev, (unsigned long long)e->arena_cap, ent);
+            hipLaunchKernelGGL(k_ent_retain, dim3(1), dim3(64), 0, ctx->stream, b.sizes, count, B.cursor_dev, (unsigned long long)e->arena_cap, ent, B.cursor_steps.data() + t);
             f.n_streams = count;
             hipLaunchKernelGGL(k_ent_gather_entries, dim3(32, (unsigned)count), dim3(kEntThreads), 0, ctx->stream, f, b, ent, B.arena);
             rc = launch_check(ctx, "k_ent_retain / k_ent_gather_entries");
         });
         if (rc) return rc;
         s->cur ^= 1;
-        HIP_TRY(ctx, hipMemcpyAsync(B.cursor_steps.data() + t, B.cursor_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(B.ev_step[(size_t)t], ctx->stream));
     }
     // the last group may go on in the next batch: its reference frame is in the buffer its last step wrote
@@ -169,6 +200,7 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
     B.in_flight = true;
     e->batches++;
     e->stats[1] += clk.lap();
+    e->trace("submit end: batch, steps", (long)(&B - e->batch), steps);
     return PFV_OK;
 }
 
@@ -205,8 +237,11 @@ static int gop_enc_fetch(pfv_gop_encoder *e, GopEncBatch &B, bool wait)
             memcpy(bigger.data(), B.payload_host.data(), B.fetched_bytes);
             B.payload_host.swap(bigger);
         }
-        if (upto > B.fetched_bytes)
+        if (upto > B.fetched_bytes) {
             HIP_TRY(ctx, hipMemcpyAsync(B.payload_host.data() + B.fetched_bytes, B.arena + B.fetched_bytes, upto - B.fetched_bytes, hipMemcpyDeviceToHost, e->down_stream));
+        }
+        if (e->trace.on) (void)hipLaunchHostFunc(e->down_stream, [](void *p) { (*(const GopTrace *)p)("   ... a download arrived (stream 1)"); }, &e->trace);
+        e->trace(wait ? "download issued (waited): step, bytes" : "download issued (polled): step, bytes", B.steps_fetched, (long)(upto - std::min(upto, B.fetched_bytes)));
         B.fetched_bytes = std::max(B.fetched_bytes, upto);
         B.steps_fetched++;
     }
@@ -237,6 +272,7 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
     }
     HIP_TRY(ctx, hipEventSynchronize(B.ev_done));
     e->stats[2] += clk.lap();
+    e->trace("batch done on the device: batch", (long)(&B - e->batch));
     HIP_TRY(ctx, hipMemcpyAsync(e->entries_host.data(), B.entries_dev, n_ent * sizeof(EntEntry), hipMemcpyDeviceToHost, e->down_stream));
     HIP_TRY(ctx, hipStreamSynchronize(e->down_stream));
     int rc = PFV_OK;
@@ -252,6 +288,7 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
                                                   : "the batch's packet payloads exceed the payload budget given to pfv_gop_encoder_create");
     }
     e->stats[3] += clk.lap();
+    e->trace("payloads on the host: batch, bytes", (long)(&B - e->batch), (long)B.fetched_bytes);
     // packets in stream order as segments: 5 header bytes (src/enc.rs:301-305, :453-457), then the payload where it lies
     B.heads.resize(B.order.size() * 5);
     e->segs_in |= slot_bit;
@@ -316,10 +353,12 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
     const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;   // *_dev: a frame that is in device memory already
     if (on_device) {
-        // ordered on the CONTEXT's stream like every *_dev call of the library (behind whatever produced the frame there, ahead of whatever
-        // overwrites it there), and without a host wait: the batch's kernels are enqueued on that stream behind the copy.  (Round 4 copied on
-        // the upload stream and waited for it per frame: 300 waits were a third of the 22 ms a 300-frame 4K clip took.)
-        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, ctx->stream));
+        // ordered on the stream of the CALLER's context like every *_dev call of the library (behind whatever produced the frame there, ahead of
+        // whatever overwrites it there), and without a host wait: the batch's kernels -- on the encoder's own stream -- wait for an event
+        // recorded behind the batch's last copy.  (Round 4 copied on the upload stream and waited for it per frame: 300 waits were a third
+        // of the 22 ms a 300-frame 4K clip took; until the encoder had a stream of its own the copies queued behind the previous batch's kernels.)
+        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, e->user->stream));
+        B->dev_frames = true;
         B->order.push_back(GopPacket{(uint8_t)type, slot, t});
         e->frames_in++;
         return PFV_OK;
@@ -348,15 +387,17 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
     if (!e) return;
     pfv_ctx *ctx = e->ctx;
     (void)hipSetDevice(ctx->device);
+    if (e->user) (void)hipStreamSynchronize(e->user->stream);      // frame copies into the batch buffers
     (void)hipStreamSynchronize(ctx->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     for (GopEncBatch &B : e->batch) {
+        if (B.entries_dev) (void)hipFree(B.entries_dev);
         if (B.frames_dev) (void)hipFree(B.frames_dev);
         if (B.arena) (void)hipFree(B.arena);
-        if (B.entries_dev) (void)hipFree(B.entries_dev);
         if (B.cursor_dev) (void)hipFree(B.cursor_dev);
         if (B.ev_uploaded) (void)hipEventDestroy(B.ev_uploaded);
         if (B.ev_done) (void)hipEventDestroy(B.ev_done);
+        if (B.ev_dev_frames) (void)hipEventDestroy(B.ev_dev_frames);
         for (hipEvent_t ev : B.ev_step) (void)hipEventDestroy(ev);
     }
     if (e->down_stream) { (void)hipStreamSynchronize(e->down_stream); (void)hipStreamDestroy(e->down_stream); }
@@ -366,6 +407,7 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
     if (e->cursor_host) (void)hipHostFree(e->cursor_host);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     pfv_enc_session_destroy(e->hot);
+    pfv_ctx_destroy(ctx);
     delete e;
 }
 
@@ -380,11 +422,15 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
     if (framerate < 0 || framerate > 65535) return fail(ctx, PFV_ERR_BAD_ARG, "framerate must fit u16 (src/enc.rs:197)");
     if (max_gops <= 0 || max_gop_frames <= 0 || max_gops > 4096 || max_gop_frames > 4096)
         return fail(ctx, PFV_ERR_BAD_ARG, "pfv_gop_encoder_create: max_gops and max_gop_frames must be in 1..4096");
+    pfv_ctx *user = ctx;
+    int rc = pfv_ctx_create(user->device, &ctx);        // from here on `ctx` is the encoder's own launch context
+    if (rc) return fail(user, rc, pfv_last_error(nullptr));
+    ctx->owner = user;
     pfv_enc_session *hot = nullptr;
-    int rc = pfv_enc_session_create(ctx, width, height, quality, max_gops, &hot);
-    if (rc) return rc;
+    rc = pfv_enc_session_create(ctx, width, height, quality, max_gops, &hot);
+    if (rc) { pfv_ctx_destroy(ctx); return rc; }
     pfv_gop_encoder *e = new pfv_gop_encoder();
-    e->ctx = ctx; e->hot = hot; e->width = width; e->height = height; e->max_gops = max_gops; e->max_len = max_gop_frames;
+    e->ctx = ctx; e->user = user; e->hot = hot; e->width = width; e->height = height; e->max_gops = max_gops; e->max_len = max_gop_frames;
     e->frame_bytes = pfv_frame_bytes(width, height);
     e->total_blocks = (size_t)pfv_total_blocks(width, height);
     const size_t cap_frames = (size_t)max_gops * (size_t)max_gop_frames, nmb = (size_t)max_gops * e->total_blocks;
@@ -400,13 +446,14 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
             he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
             if (he == hipSuccess) B.ev_step.push_back(ev);
         }
-        if (he == hipSuccess && !B.cursor_steps.resize((size_t)max_gop_frames)) he = hipErrorOutOfMemory;
+        if (he == hipSuccess && (!B.cursor_steps.resize((size_t)max_gop_frames) || !B.cursor_steps.pinned)) he = hipErrorOutOfMemory;   // k_ent_retain stores to it
         if (he == hipSuccess) he = hipMalloc((void **)&B.frames_dev, cap_frames * e->frame_bytes);
         if (he == hipSuccess) he = hipMalloc((void **)&B.arena, e->arena_cap);
         if (he == hipSuccess) he = hipMalloc((void **)&B.entries_dev, cap_frames * sizeof(EntEntry));
         if (he == hipSuccess) he = hipMalloc((void **)&B.cursor_dev, sizeof(unsigned long long));
         if (he == hipSuccess) he = hipEventCreateWithFlags(&B.ev_uploaded, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&B.ev_done, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&B.ev_dev_frames, hipEventDisableTiming);
     }
     if (he == hipSuccess) he = hipMalloc((void **)&e->coef, nmb * 512);
     if (he == hipSuccess) he = hipMalloc((void **)&e->mv, nmb * 2);
@@ -419,10 +466,10 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
     }
     rc = pfv_enc_entropy_enable(hot, 0);
     if (!rc && !e->entries_host.resize(cap_frames)) rc = fail(ctx, PFV_ERR_NOMEM, "pinned staging");
-    // landing zones for the payloads of a batch: a sixth of its raw bytes to begin with (quality-5 p-frames of noisy content reach a
-    // tenth); they grow on demand
+    // landing zones for the payloads of a batch: a sixth of its raw bytes (+ 64 KiB) to begin with (quality-5 p-frames of noisy content
+    // reach a tenth); they grow on demand
     for (GopEncBatch &B : e->batch)
-        if (!rc && !B.payload_host.resize(std::min(e->arena_cap, cap_frames * e->frame_bytes / 6 + ((size_t)4 << 20)))) rc = fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
+        if (!rc && !B.payload_host.resize(std::min(e->arena_cap, cap_frames * e->frame_bytes / 6 + ((size_t)64 << 10)))) rc = fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
     if (rc) { pfv_gop_encoder_destroy(e); return rc; }
     gop_put_header(e->out, width, height, framerate, quality);               // write_header (src/enc.rs:190-219)
     *out = e;

@@ -181,6 +181,7 @@ static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (void *)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+static inline hipError_t hipLaunchHostFunc(hipStream_t, void (*fn)(void *), void *arg) { fn(arg); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (void *)1; return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -541,6 +541,18 @@ def check_gop_encoder_flush_and_errors(pkg, ctx, oracle, w=64, h=48):
     assert ctypes.string_at(data.value, n.value) == serial, "undrained GOP encoder lost or reordered bytes"
     assert L.pfv_gop_encoder_batches(hnd) >= 4
     L.pfv_gop_encoder_destroy(hnd)
+    # a batch whose payloads outgrow its landing zone (a sixth of the raw bytes + 64 KiB, pfv_gop.hip): noise at the finest quantiser (half
+    # the raw bytes): the zone grows while the steps' payloads come over, what has arrived moves along
+    rng = np.random.default_rng(77)
+    fb = w * h + 2 * (w // 2) * (h // 2)
+    noise = [rng.integers(0, 256, fb, dtype=np.uint8) for _ in range(12)]
+    npat = ("I" + "P" * 7) * (int((64 << 10) / (0.3 * fb)) // 8 + 1)
+    src = lambda t: noise[t % len(noise)]
+    serial_n, _ = encode_pattern(pkg, ctx, oracle, w, h, 10, npat, lambda buf: pkg.Encoder(buf, w, h, 30, 10, ctx), src, with_oracle=False)
+    assert len(serial_n) > len(npat) * fb // 6 + (64 << 10) + 4096, ("the case no longer outgrows the landing zone", len(serial_n), len(npat) * fb)
+    got_n, _ = encode_pattern(pkg, ctx, oracle, w, h, 10, npat,
+                              lambda buf: pkg.GopEncoder(buf, w, h, 30, 10, ctx, max_gops=len(npat) // 8, max_gop_frames=8), src, with_oracle=False)
+    assert got_n == serial_n, "GOP encoder: a batch that outgrew its landing zone wrote a different stream"
     # payload budget: 64 bytes cannot hold an i-frame
     enc = pkg.GopEncoder(io.BytesIO(), w, h, 30, 5, ctx, max_gops=2, max_gop_frames=4, payload_budget=64)
     enc.encode_iframe(frame_of(pkg, w, h, st.frame(0)))

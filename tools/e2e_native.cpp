@@ -94,6 +94,60 @@ int main(int argc, char **argv)
         CHECK(pfv_synth_frames_dev(ctx, W, H, 1, &seed, t, (uint8_t *)dev));
         CHECK(pfv_dev_download(ctx, frames + (size_t)t * fb, dev, fb));
     }
+    // ---- pfv_gop_encoder with the frames already in device memory (a renderer's output): nothing crosses PCIe on the way in.  The FIRST
+    // object of the process, before anything else has been created and destroyed: once a process has freed a multi-GB device buffer
+    // (pfv_gop_encoder_destroy does), device-to-host copies on most streams run at half the link's rate (24-29 instead of 55 GB/s) and
+    // the payloads of a whole-clip batch arrive 2.6-6 ms behind its last kernel instead of 0.5 (PFV_GOP_TRACE=1) --
+    // an application that keeps one encoder is in the first object's position, the passes further down are not.
+    uint8_t *all_dev = nullptr;
+    CHECK(pfv_dev_alloc(ctx, fb * (size_t)N, (void **)&all_dev));
+    for (int t = 0; t < N; t++) CHECK(pfv_synth_frames_dev(ctx, W, H, 1, &seed, t, all_dev + (size_t)t * fb));
+    CHECK(pfv_ctx_sync(ctx));
+    auto hbm_pass = [&](int G, double *seconds, double *stats, size_t *bytes) -> int {
+        pfv_gop_encoder *e = nullptr;
+        CHECK(pfv_gop_encoder_create(ctx, W, H, 30, Q, G, GOP, 0, &e));
+        size_t total = 0;
+        auto drain = [&]() -> int {
+            const pfv_iovec *iov = nullptr;
+            size_t cnt = 0;
+            int rc = pfv_gop_encoder_drain_iov(e, &iov, &cnt);
+            for (size_t i = 0; !rc && i < cnt; i++) total += iov[i].len;
+            return rc;
+        };
+        const double t0 = now();
+        CHECK(drain());
+        for (int t = 0; t < N; t++) {
+            const uint8_t *f = all_dev + (size_t)t * fb;
+            CHECK(t % GOP == 0 ? pfv_gop_encoder_encode_iframe_dev(e, f) : pfv_gop_encoder_encode_pframe_dev(e, f));
+            CHECK(drain());
+        }
+        CHECK(pfv_gop_encoder_finish(e));
+        CHECK(drain());
+        *seconds = now() - t0;
+        pfv_gop_encoder_stats(e, stats, 5);
+        pfv_gop_encoder_destroy(e);
+        *bytes = total;
+        return 0;
+    };
+    double t_enc_hbm_first = 0, enc_hbm_first_stats[5] = {0, 0, 0, 0, 0};
+    size_t hbm_first_total = 0;
+    {
+        {   // a warm-up object at 64x48 first (code objects, first launches): a few hundred KB, it leaves no such trace
+            pfv_gop_encoder *e = nullptr;
+            void *tiny = nullptr;
+            CHECK(pfv_dev_alloc(ctx, pfv_frame_bytes(64, 48), &tiny));
+            CHECK(pfv_gop_encoder_create(ctx, 64, 48, 30, Q, 2, GOP, 0, &e));
+            for (int t = 0; t < 2 * GOP; t++) {
+                CHECK(pfv_synth_frames_dev(ctx, 64, 48, 1, &seed, t, (uint8_t *)tiny));
+                CHECK(t % GOP == 0 ? pfv_gop_encoder_encode_iframe_dev(e, (const uint8_t *)tiny) : pfv_gop_encoder_encode_pframe_dev(e, (const uint8_t *)tiny));
+            }
+            CHECK(pfv_gop_encoder_finish(e));
+            pfv_gop_encoder_destroy(e);
+            pfv_dev_free(ctx, tiny);
+        }
+        const int rc = hbm_pass(getenv("PFV_E2E_HBM_GOPS") ? atoi(getenv("PFV_E2E_HBM_GOPS")) : (EG > DG ? EG : DG), &t_enc_hbm_first, enc_hbm_first_stats, &hbm_first_total);
+        if (rc) return rc;
+    }
     // ---- encode: a timed pass whose writer only counts the segments, then one that keeps the bytes
     std::vector<uint8_t> stream;
     double t_enc = 0, enc_stats[5] = {0, 0, 0, 0, 0};
@@ -125,54 +179,53 @@ int main(int argc, char **argv)
         pfv_gop_encoder_destroy(e);
         if (pass == 1 && total != stream.size()) return 2;
     }
-    // ---- encode once more with the frames already in device memory (a renderer's output): nothing crosses PCIe on the way in
-    double t_enc_hbm = 0, enc_hbm_stats[5] = {0, 0, 0, 0, 0};
+    // ---- the widths of the frames-in-HBM encoder (objects created after others were destroyed: see hbm_pass above)
+    double t_enc_hbm = t_enc_hbm_first, enc_hbm_stats[5];
+    for (int i = 0; i < 5; i++) enc_hbm_stats[i] = enc_hbm_first_stats[i];
+    int hbm_gops = EG > DG ? EG : DG;
+    std::string hbm_by_width;
     {
-        uint8_t *all_dev = nullptr;
-        CHECK(pfv_dev_alloc(ctx, fb * (size_t)N, (void **)&all_dev));
-        for (int t = 0; t < N; t++) CHECK(pfv_synth_frames_dev(ctx, W, H, 1, &seed, t, all_dev + (size_t)t * fb));
-        CHECK(pfv_ctx_sync(ctx));
-        pfv_gop_encoder *e = nullptr;
-        // frames that are resident need no upload to hide behind the previous batch's kernels: the widest batch is the fastest (measured: 10 GOPs
-        // per batch 0.89 G macroblocks/s, 20 -- the whole clip -- 1.06 G; the payloads come over step by step under the kernels either way)
-        CHECK(pfv_gop_encoder_create(ctx, W, H, 30, Q, EG > DG ? EG : DG, GOP, 0, &e));
-        size_t total = 0;
-        auto drain = [&]() -> int {
-            const pfv_iovec *iov = nullptr;
-            size_t cnt = 0;
-            int rc = pfv_gop_encoder_drain_iov(e, &iov, &cnt);
-            for (size_t i = 0; !rc && i < cnt; i++) total += iov[i].len;
-            return rc;
-        };
-        const double t0 = now();
-        CHECK(drain());
-        for (int t = 0; t < N; t++) {
-            const uint8_t *f = all_dev + (size_t)t * fb;
-            CHECK(t % GOP == 0 ? pfv_gop_encoder_encode_iframe_dev(e, f) : pfv_gop_encoder_encode_pframe_dev(e, f));
-            CHECK(drain());
+        // the encoder copies a device frame on the caller's stream and runs its kernels on a stream of its own: with the clip in ONE batch the
+        // copies (2.5 ms for 300 4K frames) stand in front of the kernels, with two or more they run under the kernels of the batch before;
+        // narrower launches cost kernel efficiency.  Every width is timed (two passes each, the better one counts).
+        const int whole = EG > DG ? EG : DG;
+        int widths[3] = {whole, (whole + 1) / 2, (whole + 3) / 4};
+        if (getenv("PFV_E2E_HBM_GOPS")) { widths[0] = atoi(getenv("PFV_E2E_HBM_GOPS")); widths[1] = widths[2] = 0; }
+        for (int wi = 0; wi < 3; wi++) {
+            const int G = widths[wi];
+            if (G <= 0 || (wi && G == widths[wi - 1])) continue;
+            double best = 0, best_stats[5] = {0, 0, 0, 0, 0};
+            for (int pass = 0; pass < 2; pass++) {
+                double dt = 0, st[5];
+                size_t total = 0;
+                const int rc = hbm_pass(G, &dt, st, &total);
+                if (rc) return rc;
+                if (pass == 0 || dt < best) { best = dt; for (int i = 0; i < 5; i++) best_stats[i] = st[i]; }
+                if (total != stream.size()) { fprintf(stderr, "encoder fed from device memory wrote %zu bytes, from host memory %zu\n", total, stream.size()); return 7; }
+            }
+            char b[96];
+            snprintf(b, sizeof b, "%s\"%d\": %.1f", hbm_by_width.empty() ? "" : ", ", G, (double)N * n_mb / best);
+            hbm_by_width += b;
+            if (best < t_enc_hbm) { t_enc_hbm = best; hbm_gops = G; for (int i = 0; i < 5; i++) enc_hbm_stats[i] = best_stats[i]; }
         }
-        CHECK(pfv_gop_encoder_finish(e));
-        CHECK(drain());
-        t_enc_hbm = now() - t0;
-        pfv_gop_encoder_stats(e, enc_hbm_stats, 5);
-        pfv_gop_encoder_destroy(e);
+        if (hbm_first_total != stream.size()) { fprintf(stderr, "encoder fed from device memory wrote %zu bytes, from host memory %zu\n", hbm_first_total, stream.size()); return 7; }
         pfv_dev_free(ctx, all_dev);
-        if (total != stream.size()) { fprintf(stderr, "encoder fed from device memory wrote %zu bytes, from host memory %zu\n", total, stream.size()); return 7; }
     }
+    if (getenv("PFV_E2E_STOP_AFTER_ENCODE")) { printf("{\"encode_value\": %.1f, \"encode_value_frames_in_hbm\": %.1f, \"first_object\": %.1f, \"by_width\": {%s}}\n", (double)N * n_mb / t_enc, (double)N * n_mb / t_enc_hbm, (double)N * n_mb / t_enc_hbm_first, hbm_by_width.c_str()); return 0; }   // timelines
     // ---- decode
     struct Mode { const char *name; int entropy; bool device_out; };
     const Mode modes[] = {{"payloads_read_on_host", PFV_ENTROPY_DECODE_HOST, false},
                           {"payloads_read_on_device", PFV_ENTROPY_DECODE_DEVICE, false},
                           {"payloads_read_on_device_frames_left_in_hbm", PFV_ENTROPY_DECODE_DEVICE, true}};
     std::string out = "{";
-    char buf[2048];
+    char buf[4096];
     snprintf(buf, sizeof buf,
              "\"workload\": \"%dx%d, %d frames, GOP-%d, quality %d\", \"stream_bytes\": %zu, \"encode_value\": %.1f, \"encode_value_frames_in_hbm\": %.1f, \"encode_s\": %.5f, "
              "\"encoder_host_seconds\": {\"upload_wait_s\": %.5f, \"enqueue_s\": %.5f, \"kernel_wait_s\": %.5f, \"payload_download_s\": %.5f, \"packet_assembly_s\": %.5f}, "
              "\"encode_frames_in_hbm_s\": %.5f, \"encoder_host_seconds_frames_in_hbm\": {\"upload_wait_s\": %.5f, \"enqueue_s\": %.5f, \"kernel_wait_s\": %.5f, \"payload_download_s\": %.5f, \"packet_assembly_s\": %.5f}, "
-             "\"gops_per_batch\": {\"encoder\": %d, \"encoder_frames_in_hbm\": %d, \"decoder\": %d}, \"parse_threads\": %d, \"decode\": {",
+             "\"encode_value_frames_in_hbm_first_object_of_the_process\": %.1f, \"encode_value_frames_in_hbm_later_objects_by_gops_per_batch\": {%s}, \"gops_per_batch\": {\"encoder\": %d, \"encoder_frames_in_hbm\": %d, \"decoder\": %d}, \"parse_threads\": %d, \"decode\": {",
              W, H, N, GOP, Q, stream.size(), (double)N * n_mb / t_enc, (double)N * n_mb / t_enc_hbm, t_enc, enc_stats[0], enc_stats[1], enc_stats[2], enc_stats[3], enc_stats[4],
-             t_enc_hbm, enc_hbm_stats[0], enc_hbm_stats[1], enc_hbm_stats[2], enc_hbm_stats[3], enc_hbm_stats[4], EG, EG > DG ? EG : DG, DG, threads);
+             t_enc_hbm, enc_hbm_stats[0], enc_hbm_stats[1], enc_hbm_stats[2], enc_hbm_stats[3], enc_hbm_stats[4], (double)N * n_mb / t_enc_hbm_first, hbm_by_width.c_str(), EG, hbm_gops, DG, threads);
     out += buf;
     uint64_t want_hash = 0;
     const char *only = getenv("PFV_E2E_ONLY");        // profiling runs: one decode mode by name, nothing behind it
@@ -263,7 +316,8 @@ int main(int argc, char **argv)
              "(default look-ahead of 4 threads; no_parser_threads: pfv_decoder_set_lookahead(d, 0) -- the block headers are read on the device, the caller's thread stages the next payload); the same bytes and frames\"", (double)N * n_mb / t_senc, (double)N * n_mb / t_sdec, (double)N * n_mb / t_sdec_hbm, (double)N * n_mb / t_sdec_host,
              (double)N * n_mb / t_sdec0, (double)N * n_mb / t_sdec_hbm0, sdec_counts[0], sdec_counts[1]);
     out += buf;
-    out += "}, \"frames_checked\": \"every 101st frame sampled (every 61st word) in every mode: identical\"}";
+    out += "}";
+    out += ", \"frames_checked\": \"every 101st frame sampled (every 61st word) in every mode: identical\"}";
     puts(out.c_str());
     pfv_host_free(ctx, frames);
     pfv_ctx_destroy(ctx);
