@@ -466,10 +466,10 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
     }
     rc = pfv_enc_entropy_enable(hot, 0);
     if (!rc && !e->entries_host.resize(cap_frames)) rc = fail(ctx, PFV_ERR_NOMEM, "pinned staging");
-    // landing zones for the payloads of a batch: a sixth of its raw bytes (+ 64 KiB) to begin with (quality-5 p-frames of noisy content
+    // landing zones for the payloads of a batch: a sixth of its raw bytes (+ 16 KiB) to begin with (quality-5 p-frames of noisy content
     // reach a tenth); they grow on demand
     for (GopEncBatch &B : e->batch)
-        if (!rc && !B.payload_host.resize(std::min(e->arena_cap, cap_frames * e->frame_bytes / 6 + ((size_t)64 << 10)))) rc = fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
+        if (!rc && !B.payload_host.resize(std::min(e->arena_cap, cap_frames * e->frame_bytes / 6 + ((size_t)16 << 10)))) rc = fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
     if (rc) { pfv_gop_encoder_destroy(e); return rc; }
     gop_put_header(e->out, width, height, framerate, quality);               // write_header (src/enc.rs:190-219)
     *out = e;
@@ -1508,8 +1508,14 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
         if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
         if (fits) {
             hipError_t e2 = hipSuccess;
-            for (int k = 0; k < v.n_streams && e2 == hipSuccess; k++) e2 = hipStreamCreateWithFlags(&v.streams[k], hipStreamNonBlocking);
-            if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&v.up_stream, hipStreamNonBlocking);
+            {   // EXPERIMENT: PFV_GOPD_WIN_PRIO = -1 / 1: the window streams at the least / greatest priority (a hardware-queue pool of their own)
+                int least = 0, greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                const int wp = getenv("PFV_GOPD_WIN_PRIO") ? atoi(getenv("PFV_GOPD_WIN_PRIO")) : 0, up = getenv("PFV_GOPD_UP_PRIO") ? atoi(getenv("PFV_GOPD_UP_PRIO")) : 0;
+                auto mk = [&](hipStream_t *st, int pr) { return pr == 0 ? hipStreamCreateWithFlags(st, hipStreamNonBlocking) : hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr > 0 ? greatest : least); };
+                for (int k = 0; k < v.n_streams && e2 == hipSuccess; k++) e2 = mk(&v.streams[k], wp);
+                if (e2 == hipSuccess) e2 = mk(&v.up_stream, up);
+            }
             if (e2 == hipSuccess && v.lists.create(ctx, F, tb, list_guess) != PFV_OK) e2 = hipErrorOutOfMemory;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.mv_dev, F * tb * 2);
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.has_dev, F * tb);

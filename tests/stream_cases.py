@@ -541,15 +541,15 @@ def check_gop_encoder_flush_and_errors(pkg, ctx, oracle, w=64, h=48):
     assert ctypes.string_at(data.value, n.value) == serial, "undrained GOP encoder lost or reordered bytes"
     assert L.pfv_gop_encoder_batches(hnd) >= 4
     L.pfv_gop_encoder_destroy(hnd)
-    # a batch whose payloads outgrow its landing zone (a sixth of the raw bytes + 64 KiB, pfv_gop.hip): noise at the finest quantiser (half
+    # a batch whose payloads outgrow its landing zone (a sixth of the raw bytes + 16 KiB, pfv_gop.hip): noise at the finest quantiser (half
     # the raw bytes): the zone grows while the steps' payloads come over, what has arrived moves along
     rng = np.random.default_rng(77)
     fb = w * h + 2 * (w // 2) * (h // 2)
     noise = [rng.integers(0, 256, fb, dtype=np.uint8) for _ in range(12)]
-    npat = ("I" + "P" * 7) * (int((64 << 10) / (0.3 * fb)) // 8 + 1)
+    npat = ("I" + "P" * 7) * (int((16 << 10) / (0.3 * fb)) // 8 + 1)
     src = lambda t: noise[t % len(noise)]
     serial_n, _ = encode_pattern(pkg, ctx, oracle, w, h, 10, npat, lambda buf: pkg.Encoder(buf, w, h, 30, 10, ctx), src, with_oracle=False)
-    assert len(serial_n) > len(npat) * fb // 6 + (64 << 10) + 4096, ("the case no longer outgrows the landing zone", len(serial_n), len(npat) * fb)
+    assert len(serial_n) > len(npat) * fb // 6 + (16 << 10) + 4096, ("the case no longer outgrows the landing zone", len(serial_n), len(npat) * fb)
     got_n, _ = encode_pattern(pkg, ctx, oracle, w, h, 10, npat,
                               lambda buf: pkg.GopEncoder(buf, w, h, 30, 10, ctx, max_gops=len(npat) // 8, max_gop_frames=8), src, with_oracle=False)
     assert got_n == serial_n, "GOP encoder: a batch that outgrew its landing zone wrote a different stream"
@@ -605,7 +605,7 @@ def check_gop_decoder_corrupted(pkg, ctx, oracle, data, n_trials, seed, shapes=(
     return stats
 
 
-def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quality=1, require_hit=True, shapes=((8, 15), (2, 2), (1, 15))):
+def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quality=1, require_hit=True, shapes=((8, 15), (2, 2), (1, 15)), fracs=(0.55, 0.7, 0.8, 0.9, 0.97)):
     """Found by tools/soak.py (round 4): at a fine quantiser an i-frame is denser than 1 non-zero in 4, its coefficient LIST overflows
     before the parser reaches a corrupted byte further on, and the GOP-batched decoder took the frame for good when it cut its chains --
     the p-frames behind it then decoded against the slot's stale framebuffer instead of the previous run's last frame.  P P I P with the
@@ -620,7 +620,7 @@ def check_gop_decoder_dense_iframe_failure(pkg, ctx, oracle, w=124, h=212, quali
     assert [t for t, _, _ in pk] == [2, 2, 1, 2, 0]
     _, p, n = pk[2]
     hit = 0
-    for frac in (0.55, 0.7, 0.8, 0.9, 0.97):
+    for frac in fracs:
         bad = bytearray(data)
         at = p + 5 + int(n * frac)
         bad[at:at + 4] = bytes(4)                                      # a hole of zero bits: a long run the frame has no room for
