@@ -636,10 +636,14 @@ struct GopDecDev {
     // that one window's settling tail (a few lanes in a few wavefronts, round after round) runs beside the next windows' full reads.
     // Measured, config 4 with the frames left in HBM (tools/gpu_inner_sweep.sh, three passes each): one stream 1.25-1.27 G macroblocks/s at
     // the device's greatest stream priority (1.22-1.29 without), two / three streams 1.12-1.24 / 1.16-1.25 (0.89-1.10 without priority: the
-    // decode launches then wait behind them), four streams at normal priority 1.27-1.40.
+    // decode launches then wait behind them), four streams at normal priority 1.27-1.40.  Re-measured at the end of round 5 on one box, passes
+    // interleaved (tools/e2e_native.cpp; PFV_GOPD_WINDOW_STREAMS): four 1.14-1.18 G, THREE 1.27-1.34, two 1.03-1.05; the Python probe's wait for
+    // the entropy stage 8.0-8.6 / 6.9-7.4 / 9.5-9.7 ms.  (The runtime multiplexes a process's streams over four hardware queues; with the context's
+    // stream and the upload stream four window streams make six.  The upload stream at the greatest priority -- a queue pool of its own -- also
+    // gave 1.21-1.24 with four; the two together nothing more.)
     static constexpr int kStreams = 4;
     hipStream_t streams[kStreams] = {nullptr, nullptr, nullptr, nullptr};
-    int n_streams = kStreams;
+    int n_streams = 3;
     hipStream_t up_stream = nullptr;     // ... and the uploads / clears it needs run ahead of it on a third
     std::vector<hipEvent_t> window_done; // per step: payloads read, statuses on the host
     std::vector<hipEvent_t> window_up;   // per step: payloads, headers and cleared coefficient arrays in place
@@ -1508,14 +1512,9 @@ PFV_API int pfv_gop_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len
         if (ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE) fits = true;
         if (fits) {
             hipError_t e2 = hipSuccess;
-            {   // EXPERIMENT: PFV_GOPD_WIN_PRIO = -1 / 1: the window streams at the least / greatest priority (a hardware-queue pool of their own)
-                int least = 0, greatest = 0;
-                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-                const int wp = getenv("PFV_GOPD_WIN_PRIO") ? atoi(getenv("PFV_GOPD_WIN_PRIO")) : 0, up = getenv("PFV_GOPD_UP_PRIO") ? atoi(getenv("PFV_GOPD_UP_PRIO")) : 0;
-                auto mk = [&](hipStream_t *st, int pr) { return pr == 0 ? hipStreamCreateWithFlags(st, hipStreamNonBlocking) : hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr > 0 ? greatest : least); };
-                for (int k = 0; k < v.n_streams && e2 == hipSuccess; k++) e2 = mk(&v.streams[k], wp);
-                if (e2 == hipSuccess) e2 = mk(&v.up_stream, up);
-            }
+            if (getenv("PFV_GOPD_WINDOW_STREAMS")) v.n_streams = std::max(1, std::min((int)GopDecDev::kStreams, atoi(getenv("PFV_GOPD_WINDOW_STREAMS"))));   // experiments
+            for (int k = 0; k < v.n_streams && e2 == hipSuccess; k++) e2 = hipStreamCreateWithFlags(&v.streams[k], hipStreamNonBlocking);
+            if (e2 == hipSuccess) e2 = hipStreamCreateWithFlags(&v.up_stream, hipStreamNonBlocking);
             if (e2 == hipSuccess && v.lists.create(ctx, F, tb, list_guess) != PFV_OK) e2 = hipErrorOutOfMemory;
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.mv_dev, F * tb * 2);
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&v.has_dev, F * tb);
