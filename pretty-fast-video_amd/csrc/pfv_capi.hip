@@ -2071,6 +2071,8 @@ struct DecEvent {
 // switches, shape and counters of the device entropy stage in pfv_decoder / pfv_batch_decoder (the buffers: DecWindow)
 struct DecEntd {
     bool on = false, force = false;      // force: every packet (PFV_ENTROPY_DECODE_DEVICE); otherwise payloads of kDecEntdMinBytes and more
+    bool ready = false;                  // the window stream and the window sets exist: made by the first packet / step that takes the device form
+    //                                      (a decoder of small packets never needs them), entd_windows_make
     uint32_t sub_bits = kEdSubBits;
     int launches = 3, inner = kEdInner;
     long packets_dev = 0, packets_host = 0;
@@ -2104,6 +2106,30 @@ struct DecWindow {
         if (done) (void)hipEventDestroy(done);
     }
 };
+
+// The window stream and the fixed-size part of every window set, for S packets per window: on the caller's thread, when the first packet (step)
+// takes the device form.
+template <size_t N>
+static int entd_windows_make(pfv_ctx *ctx, DecEntd &v, DecWindow (&win)[N], hipStream_t *stream, size_t S, size_t tb)
+{
+    if (v.ready) return PFV_OK;
+    hipError_t he = *stream ? hipSuccess : hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+    bool host_ok = true;
+    for (DecWindow &w : win) {
+        if (he == hipSuccess && !w.pk_dev) he = hipMalloc((void **)&w.pk_dev, S * sizeof(EdPacket));
+        if (he == hipSuccess && !w.status_dev) he = hipMalloc((void **)&w.status_dev, S * sizeof(uint32_t));
+        if (he == hipSuccess && !w.coded_dev) he = hipMalloc((void **)&w.coded_dev, S * tb * sizeof(uint32_t));
+        if (he == hipSuccess && !w.lists.ptr_dev && w.lists.create(ctx, S, tb, 0) != PFV_OK) he = hipErrorOutOfMemory;
+        if (he == hipSuccess && !w.mv_dev) he = hipMalloc((void **)&w.mv_dev, S * tb * 2);
+        if (he == hipSuccess && !w.has_dev) he = hipMalloc((void **)&w.has_dev, S * tb);
+        if (he == hipSuccess && !w.done) he = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+        host_ok = host_ok && w.status_host.resize(S);
+    }
+    if (he != hipSuccess) return hip_fail(ctx, he, "device entropy stage: window sets");
+    if (!host_ok) return fail(ctx, PFV_ERR_NOMEM, "device entropy stage: pinned status words");
+    v.ready = true;
+    return PFV_OK;
+}
 // host staging of one packet the host parser reads into list form (a decoder whose coefficients travel as lists)
 struct ListStage {
     PinnedBuf<uint32_t> ent, counts;
@@ -2697,8 +2723,10 @@ static int bd_window_enqueue(pfv_batch_decoder *b, BdSet *s, DecWindow &w)
 {
     pfv_ctx *ctx = b->ctx;
     DecEntd &v = b->entd;
-    hipStream_t st = b->win_stream;
     const size_t S = (size_t)b->n, tb = b->total_blocks;
+    int mrc = entd_windows_make(ctx, v, b->win, &b->win_stream, S, tb);
+    if (mrc) return mrc;
+    hipStream_t st = b->win_stream;
     size_t total_sub = 0, n_groups = 0, hdr_total = 0;
     unsigned max_hdr = 0;
     for (size_t k = 0; k < S; k++) {
@@ -2826,25 +2854,12 @@ PFV_API int pfv_batch_decoder_create(pfv_ctx *ctx, const uint8_t *const *streams
         DecEntd &v = b->entd;
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
-        hipError_t he = hipStreamCreateWithFlags(&b->win_stream, hipStreamNonBlocking);
-        bool host_ok = true;
-        for (DecWindow &w : b->win) {
-            if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, S * sizeof(EdPacket));
-            if (he == hipSuccess) he = hipMalloc((void **)&w.status_dev, S * sizeof(uint32_t));
-            if (he == hipSuccess) he = hipMalloc((void **)&w.coded_dev, S * tb * sizeof(uint32_t));
-            if (he == hipSuccess && w.lists.create(ctx, S, tb, 0) != PFV_OK) he = hipErrorOutOfMemory;
-            if (he == hipSuccess) he = hipMalloc((void **)&w.mv_dev, S * tb * 2);
-            if (he == hipSuccess) he = hipMalloc((void **)&w.has_dev, S * tb);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
-            host_ok = host_ok && w.status_host.resize(S);
-        }
-        host_ok = host_ok && he == hipSuccess;
+        bool host_ok = true;                // the window stream and sets: with the first step that takes the device form (bd_window_enqueue)
         for (auto &s : b->set) {
             host_ok = host_ok && s.pk.resize(S);
             s.host_parse.assign(S, 0);
         }
         v.on = host_ok;
-        if (!v.on) (void)hipGetLastError();
         if (!v.on && v.force) ok = false;
     }
     hipError_t e = ok ? hipMalloc((void **)&b->frames_dev, S * b->frame_bytes) : hipErrorOutOfMemory;
@@ -3066,25 +3081,7 @@ PFV_API int pfv_decoder_create(pfv_ctx *ctx, const uint8_t *data, size_t len, pf
         DecEntd &v = d->entd;
         v.force = ctx->opt_entropy_decode == PFV_ENTROPY_DECODE_DEVICE;
         v.sub_bits = (uint32_t)ctx->opt_entdec_lane_bits; v.launches = ctx->opt_entdec_launches; v.inner = ctx->opt_entdec_inner;
-        const size_t tbs = (size_t)d->total_blocks;
-        hipError_t he = hipStreamCreateWithFlags(&d->win_stream, hipStreamNonBlocking);
-        bool host_ok = true;
-        for (DecWindow &w : d->win) {
-            if (he == hipSuccess) he = hipMalloc((void **)&w.pk_dev, sizeof(EdPacket));
-            if (he == hipSuccess) he = hipMalloc((void **)&w.status_dev, sizeof(uint32_t));
-            if (he == hipSuccess) he = hipMalloc((void **)&w.coded_dev, tbs * sizeof(uint32_t));
-            if (he == hipSuccess && w.lists.create(ctx, 1, tbs, 0) != PFV_OK) he = hipErrorOutOfMemory;
-            if (he == hipSuccess) he = hipMalloc((void **)&w.mv_dev, tbs * 2);
-            if (he == hipSuccess) he = hipMalloc((void **)&w.has_dev, tbs);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
-            host_ok = host_ok && w.status_host.resize(1);
-        }
-        v.on = he == hipSuccess && host_ok;
-        if (!v.on) (void)hipGetLastError();
-        if (!v.on && v.force) {
-            pfv_decoder_destroy(d);
-            return fail(ctx, PFV_ERR_NOMEM, "pfv_decoder_create: device entropy stage (PFV_ENTROPY_DECODE_DEVICE)");
-        }
+        v.on = true;                     // the window stream and sets: with the first packet that takes the device form (dec_window_enqueue)
     }
     const unsigned hw = std::thread::hardware_concurrency();
     if ((rc = pfv_decoder_set_lookahead(d, hw > 1 ? (int)std::min(4u, hw - 1) : 0))) {
@@ -3309,8 +3306,10 @@ static int dec_window_enqueue(pfv_decoder *d, DecEvent *e, DecWindow &w)
 {
     pfv_ctx *ctx = d->ctx;
     DecEntd &v = d->entd;
-    hipStream_t st = d->win_stream;
     const size_t tb = (size_t)d->total_blocks;
+    int mrc = entd_windows_make(ctx, v, d->win, &d->win_stream, 1, tb);
+    if (mrc) return mrc;
+    hipStream_t st = d->win_stream;
     const EdPacket &k = *e->pk.data();
     const uint32_t ng = (k.n_sub + kEdOwn - 1) / kEdOwn;
     auto room = [&](auto **p, size_t *cap, size_t need) -> int {
