@@ -509,7 +509,9 @@ PFV_API int pfv_gop_encoder_encode_iframe(pfv_gop_encoder *e, const uint8_t *y, 
 PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 /* the same for a packed frame (Y | U | V, pfv_frame_bytes) that already lies in DEVICE memory (frames a renderer or another kernel left in
  * HBM): nothing crosses PCIe on the way in.  Ordered on the context's stream like every *_dev call: the frame is read behind the work
- * enqueued there before the call and may be overwritten by work enqueued there after it; no host wait. */
+ * enqueued there before the call and may be overwritten by work enqueued there after it; no host wait.  (The frame is COPIED on that stream
+ * into the batch being filled; the batches' kernels run on a stream the encoder owns, so the copies of one batch run under the kernels of the
+ * batch before it.  PFV_GOP_TRACE=1 in the environment: a host-side log of the encoder's submits, step downloads and arrivals on stderr.) */
 PFV_API int pfv_gop_encoder_encode_iframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
 PFV_API int pfv_gop_encoder_encode_pframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
 PFV_API int pfv_gop_encoder_encode_dropframe(pfv_gop_encoder *e);
