@@ -82,6 +82,16 @@ int main(int argc, char **argv)
     if (lane_bits) CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTDEC_LANE_BITS, lane_bits));
     if (getenv("PFV_E2E_INNER")) CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTDEC_INNER_ROUNDS, atoi(getenv("PFV_E2E_INNER"))));       // experiments: settling rounds of k_entd_sync
     if (getenv("PFV_E2E_LAUNCHES")) CHECK(pfv_ctx_set_option(ctx, PFV_OPT_ENTDEC_LAUNCHES, atoi(getenv("PFV_E2E_LAUNCHES"))));
+    // The GOP encoders of this program hold 6-22 GB of device memory each.  They are destroyed when the encode section is over, not between its
+    // timed passes: after the hipFree of a multi-GB buffer, device-to-host copies on most streams run at half the link's rate for the life of
+    // the next object (24-29 instead of 55 GB/s; bisected inside pfv_gop_encoder_destroy with a probe copy), and a pass timed
+    // behind it measures that, not the object (measured both ways on one box: 173-176 M / 1.04-1.08 G macroblocks/s this way, 132 M / 0.90-0.91 G
+    // with every object destroyed before the next is created).  An application's encoder is long-lived.  PFV_E2E_DESTROY_EAGERLY=1: the old order.
+    // (The decoders ARE destroyed one by one: keeping a dozen idle objects' streams alive makes the runtime share hardware queues between the
+    // streams of the next one -- its entropy windows then wait behind the frame downloads, 51 ms instead of 7.)
+    const bool eager = getenv("PFV_E2E_DESTROY_EAGERLY") != nullptr;
+    std::vector<pfv_gop_encoder *> old_encoders;
+    auto retire = [&](pfv_gop_encoder *e) { if (eager) pfv_gop_encoder_destroy(e); else old_encoders.push_back(e); };
     const size_t fb = pfv_frame_bytes(W, H), ny = (size_t)W * H, nc = (size_t)(W / 2) * (H / 2);
     const long n_mb = pfv_total_blocks(W, H);
     // the producer's frames, page-locked
@@ -94,11 +104,8 @@ int main(int argc, char **argv)
         CHECK(pfv_synth_frames_dev(ctx, W, H, 1, &seed, t, (uint8_t *)dev));
         CHECK(pfv_dev_download(ctx, frames + (size_t)t * fb, dev, fb));
     }
-    // ---- pfv_gop_encoder with the frames already in device memory (a renderer's output): nothing crosses PCIe on the way in.  The FIRST
-    // object of the process, before anything else has been created and destroyed: once a process has freed a multi-GB device buffer
-    // (pfv_gop_encoder_destroy does), device-to-host copies on most streams run at half the link's rate (24-29 instead of 55 GB/s) and
-    // the payloads of a whole-clip batch arrive 2.6-6 ms behind its last kernel instead of 0.5 (PFV_GOP_TRACE=1) --
-    // an application that keeps one encoder is in the first object's position, the passes further down are not.
+    // ---- pfv_gop_encoder with the frames already in device memory (a renderer's output): nothing crosses PCIe on the way in.  Timed first as
+    // the FIRST object of the process (behind a 64x48 warm-up object), then by batch width further down.
     uint8_t *all_dev = nullptr;
     CHECK(pfv_dev_alloc(ctx, fb * (size_t)N, (void **)&all_dev));
     for (int t = 0; t < N; t++) CHECK(pfv_synth_frames_dev(ctx, W, H, 1, &seed, t, all_dev + (size_t)t * fb));
@@ -125,7 +132,7 @@ int main(int argc, char **argv)
         CHECK(drain());
         *seconds = now() - t0;
         pfv_gop_encoder_stats(e, stats, 5);
-        pfv_gop_encoder_destroy(e);
+        retire(e);
         *bytes = total;
         return 0;
     };
@@ -176,7 +183,7 @@ int main(int argc, char **argv)
         CHECK(pfv_gop_encoder_finish(e));
         CHECK(drain());
         if (pass == 0) { t_enc = now() - t0; pfv_gop_encoder_stats(e, enc_stats, 5); }
-        pfv_gop_encoder_destroy(e);
+        retire(e);
         if (pass == 1 && total != stream.size()) return 2;
     }
     // ---- the widths of the frames-in-HBM encoder (objects created after others were destroyed: see hbm_pass above)
@@ -211,6 +218,8 @@ int main(int argc, char **argv)
         if (hbm_first_total != stream.size()) { fprintf(stderr, "encoder fed from device memory wrote %zu bytes, from host memory %zu\n", hbm_first_total, stream.size()); return 7; }
         pfv_dev_free(ctx, all_dev);
     }
+    for (pfv_gop_encoder *e : old_encoders) pfv_gop_encoder_destroy(e);
+    old_encoders.clear();
     if (getenv("PFV_E2E_STOP_AFTER_ENCODE")) { printf("{\"encode_value\": %.1f, \"encode_value_frames_in_hbm\": %.1f, \"first_object\": %.1f, \"by_width\": {%s}}\n", (double)N * n_mb / t_enc, (double)N * n_mb / t_enc_hbm, (double)N * n_mb / t_enc_hbm_first, hbm_by_width.c_str()); return 0; }   // timelines
     // ---- decode
     struct Mode { const char *name; int entropy; bool device_out; };
@@ -223,7 +232,7 @@ int main(int argc, char **argv)
              "\"workload\": \"%dx%d, %d frames, GOP-%d, quality %d\", \"stream_bytes\": %zu, \"encode_value\": %.1f, \"encode_value_frames_in_hbm\": %.1f, \"encode_s\": %.5f, "
              "\"encoder_host_seconds\": {\"upload_wait_s\": %.5f, \"enqueue_s\": %.5f, \"kernel_wait_s\": %.5f, \"payload_download_s\": %.5f, \"packet_assembly_s\": %.5f}, "
              "\"encode_frames_in_hbm_s\": %.5f, \"encoder_host_seconds_frames_in_hbm\": {\"upload_wait_s\": %.5f, \"enqueue_s\": %.5f, \"kernel_wait_s\": %.5f, \"payload_download_s\": %.5f, \"packet_assembly_s\": %.5f}, "
-             "\"encode_value_frames_in_hbm_first_object_of_the_process\": %.1f, \"encode_value_frames_in_hbm_later_objects_by_gops_per_batch\": {%s}, \"gops_per_batch\": {\"encoder\": %d, \"encoder_frames_in_hbm\": %d, \"decoder\": %d}, \"parse_threads\": %d, \"decode\": {",
+             "\"encode_value_frames_in_hbm_first_object_of_the_process\": %.1f, \"encode_value_frames_in_hbm_by_gops_per_batch\": {%s}, \"gops_per_batch\": {\"encoder\": %d, \"encoder_frames_in_hbm\": %d, \"decoder\": %d}, \"parse_threads\": %d, \"decode\": {",
              W, H, N, GOP, Q, stream.size(), (double)N * n_mb / t_enc, (double)N * n_mb / t_enc_hbm, t_enc, enc_stats[0], enc_stats[1], enc_stats[2], enc_stats[3], enc_stats[4],
              t_enc_hbm, enc_hbm_stats[0], enc_hbm_stats[1], enc_hbm_stats[2], enc_hbm_stats[3], enc_hbm_stats[4], (double)N * n_mb / t_enc_hbm_first, hbm_by_width.c_str(), EG, hbm_gops, DG, threads);
     out += buf;
