@@ -16,6 +16,37 @@ void __tsan_switch_to_fiber(void *fiber, unsigned flags);
 #define PFV_TSAN_FIBERS 0
 #endif
 
+// Context switch.  glibc's swapcontext / getcontext make a signal-mask system call each: a third of the CPU suite's time was spent in the
+// kernel.  On x86-64 without a sanitizer the fibers switch with a dozen instructions of their own (callee-saved registers + stack pointer);
+// sanitizer builds and other targets keep ucontext (ASan follows swapcontext; TSan is told, above).
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__) && !defined(PFV_EMU_UCONTEXT)
+#define PFV_FAST_SWITCH 1
+extern "C" void pfv_emu_switch(void **save_sp, void *to_sp);
+asm(".text\n"
+    ".hidden pfv_emu_switch\n"
+    ".globl pfv_emu_switch\n"
+    ".type pfv_emu_switch,@function\n"
+    "pfv_emu_switch:\n"
+    "    pushq %rbp\n"
+    "    pushq %rbx\n"
+    "    pushq %r12\n"
+    "    pushq %r13\n"
+    "    pushq %r14\n"
+    "    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq %rsi, %rsp\n"
+    "    popq %r15\n"
+    "    popq %r14\n"
+    "    popq %r13\n"
+    "    popq %r12\n"
+    "    popq %rbx\n"
+    "    popq %rbp\n"
+    "    ret\n"
+    ".size pfv_emu_switch,.-pfv_emu_switch\n");
+#else
+#define PFV_FAST_SWITCH 0
+#endif
+
 namespace hipemu {
 
 Graph *g_capture = nullptr;
@@ -24,7 +55,11 @@ Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 namespace {
 constexpr size_t kStack = 128 * 1024;
 struct Fiber {
+#if PFV_FAST_SWITCH
+    void *sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     void *stack = nullptr;
     bool done = false;
     Idx tid;
@@ -32,7 +67,11 @@ struct Fiber {
 };
 void *sched_tsan = nullptr;
 std::vector<Fiber> fibers;
+#if PFV_FAST_SWITCH
+void *sched_sp = nullptr;
+#else
 ucontext_t sched_ctx;
+#endif
 int cur = -1;
 const std::function<void()> *cur_body = nullptr;
 
@@ -49,7 +88,11 @@ void yield()
 #if PFV_TSAN_FIBERS
     __tsan_switch_to_fiber(sched_tsan, 0);
 #endif
+#if PFV_FAST_SWITCH
+    pfv_emu_switch(&fibers[me].sp, sched_sp);
+#else
     swapcontext(&fibers[me].ctx, &sched_ctx);
+#endif
     g_threadIdx = fibers[me].tid;
 }
 void trampoline()
@@ -59,7 +102,12 @@ void trampoline()
 #if PFV_TSAN_FIBERS
     __tsan_switch_to_fiber(sched_tsan, 0);
 #endif
+#if PFV_FAST_SWITCH
+    pfv_emu_switch(&fibers[cur].sp, sched_sp);
+    __builtin_trap();          // a finished fiber is never resumed
+#else
     swapcontext(&fibers[cur].ctx, &sched_ctx);
+#endif
 }
 int lane_id() { return (int)(g_threadIdx.x & 63); }
 Wave &my_wave() { return waves[g_threadIdx.x >> 6]; }
@@ -127,11 +175,21 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body)
                     Fiber &f = fibers[t];
                     f.done = false;
                     f.tid = Idx{(unsigned)t, 0, 0};
+#if PFV_FAST_SWITCH
+                    // the frame pfv_emu_switch pops: r15 r14 r13 r12 rbx rbp, then `ret` into trampoline with the stack as after a call
+                    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+                    void **fr = (void **)(top - 64);
+                    for (int i = 0; i < 6; i++) fr[i] = nullptr;
+                    fr[6] = (void *)&trampoline;
+                    fr[7] = nullptr;                      // the return address trampoline never uses
+                    f.sp = fr;
+#else
                     getcontext(&f.ctx);
                     f.ctx.uc_stack.ss_sp = f.stack;
                     f.ctx.uc_stack.ss_size = kStack;
                     f.ctx.uc_link = nullptr;
                     makecontext(&f.ctx, trampoline, 0);
+#endif
                 }
                 int remaining = n_threads;
                 long spins = 0;
@@ -145,7 +203,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body)
                         if (!f.tsan) f.tsan = __tsan_create_fiber(0);
                         __tsan_switch_to_fiber(f.tsan, 0);
 #endif
+#if PFV_FAST_SWITCH
+                        pfv_emu_switch(&sched_sp, f.sp);
+#else
                         swapcontext(&sched_ctx, &f.ctx);
+#endif
                         if (f.done) remaining--;
                     }
                     if (++spins > 10000000) { fprintf(stderr, "hipemu: deadlock (divergent barrier?)\n"); abort(); }
