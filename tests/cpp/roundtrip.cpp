@@ -19,6 +19,8 @@ int main(int argc, char **argv)
     const int quality = std::atoi(argv[4]), gop = std::atoi(argv[5]), drop_at = std::atoi(argv[6]);
     try {
         pfv::Context ctx(0);
+        if (const char *m = std::getenv("PFV_TEST_ENTROPY_DECODE"))      // tools/sanitize.sh: the decoders' device entropy stage on packets of any size
+            ctx.check(pfv_ctx_set_option(ctx.handle(), PFV_OPT_ENTROPY_DECODE, std::atoi(m)));
         std::ifstream in(argv[7], std::ios::binary);
         std::stringstream stream(std::ios::in | std::ios::out | std::ios::binary);
         int n_in = 0;

@@ -1,11 +1,10 @@
 #!/bin/bash
 # Sanitizer passes over the HOST half of the library (untrusted .pfv bytes parsed on worker threads; C++ where the reference has safe Rust,
 # SURVEY section 5): the CPU-emulator build of the unmodified csrc/ (tests/hipemu) under AddressSanitizer + UndefinedBehaviorSanitizer and
-# under ThreadSanitizer, running tools/sanitize_run.py (the damaged-stream, GOP-object, device-entropy and batch-object checks of the CPU
-# suite, without pytest: its process handling hangs under ThreadSanitizer's runtime).  The emulator's fibers are announced to TSan
-# (tests/hipemu/hipemu.cpp: __tsan_switch_to_fiber).  TSan runs one process per step: a process that has created and joined several hundred
-# pool threads AND switched fibers a few million times dies inside the TSan runtime (SEGV in its own shadow, no report) -- every step alone passes.
-# Logs: profiles/r05_sanitize_{asan_ubsan,tsan}.log       usage: bash tools/sanitize.sh [asan|tsan|all]   (no GPU needed; `make sanitize`)
+# under ThreadSanitizer.  ASan + UBSan run tools/sanitize_run.py (the damaged-stream, GOP-object, device-entropy and batch-object checks of the CPU
+# suite, without pytest).  TSan runs the C++ mirror's round-trip program natively (tools/sanitize_native.py: python with a preloaded libtsan
+# hangs at start-up here); the emulator's fibers are announced to TSan (tests/hipemu/hipemu.cpp: __tsan_switch_to_fiber).
+# Logs: profiles/r05_sanitize_{asan_ubsan,tsan_native}.log (r05_sanitize_tsan.log: the python-driven TSan runs of mid-round, kept)       usage: bash tools/sanitize.sh [asan|tsan|all]   (no GPU needed; `make sanitize`)
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
@@ -22,25 +21,23 @@ if [ "$WHAT" = asan ] || [ "$WHAT" = all ]; then
   echo "== exit code $rc; sanitizer reports in this log: $(count $log)" >> $log; tail -2 $log
 fi
 if [ "$WHAT" = tsan ] || [ "$WHAT" = all ]; then
-  log=profiles/r05_sanitize_tsan.log
+  # ThreadSanitizer, natively: the emulator library and the C++ mirror's round-trip program (tests/cpp/roundtrip.cpp) built with -fsanitize=thread,
+  # run without python (gcc 11's libtsan preloaded into python hangs at start-up in this container: 5 of 5 processes at the end of round 5).
+  # Twice: payloads read by the host parsers (look-ahead threads, parse pool), then by the device entropy stage (PFV_ENTROPY_DECODE_DEVICE = 2).
+  log=profiles/r05_sanitize_tsan_native.log
   flags="-fsanitize=thread -fno-omit-frame-pointer"
-  echo "== tsan: g++ $flags (tests/conftest.py build_emulator, PFV_EMU_DEFS); tools/sanitize_run.py, one process per step -- $(date -u +%FT%TZ), $(gcc --version | head -1)" > $log
-  for s in "${STEPS[@]}"; do
-    # gcc 11's libtsan preloaded into python hangs at start-up every other process here (no CPU, no output): a step that has printed nothing
-    # after 150 s is stopped (its own PID) and started again, up to 6 times; one that is running gets 900 s
-    done_step=0
-    for attempt in 1 2 3 4 5 6; do
-      tmp=$(mktemp)
-      PFV_SAN_ONLY="$s" PFV_EMU_DEFS="$flags" LD_PRELOAD="$GCC_LIBDIR/libtsan.so" TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 report_signal_unsafe=0" timeout 900 python tools/sanitize_run.py > $tmp 2>&1 &
-      pid=$!
-      for i in $(seq 1 30); do sleep 5; [ -s $tmp ] && break; kill -0 $pid 2>/dev/null || break; done
-      if [ ! -s $tmp ] && kill -0 $pid 2>/dev/null; then kill $pid; wait $pid 2>/dev/null; echo "== step '$s': attempt $attempt hung at start-up (no output after 150 s), stopped" >> $log; rm -f $tmp; continue; fi
-      if wait $pid; then done_step=1; fi
-      cat $tmp >> $log; rm -f $tmp
-      break
+  echo "== tsan, native: g++ $flags -- emulator library + tests/cpp/roundtrip.cpp (tools/sanitize_native.py) -- $(date -u +%FT%TZ), $(gcc --version | head -1)" > $log
+  tmp=$(mktemp -d)
+  exe=$(PFV_EMU_DEFS="$flags" python tools/sanitize_native.py $tmp 2>> $log | tail -1)
+  if [ -x "$exe" ]; then
+    for mode in "" 2; do
+      echo "== run: PFV_TEST_ENTROPY_DECODE='$mode'" >> $log
+      ( cd $tmp && PFV_TEST_ENTROPY_DECODE=$mode TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1" timeout 1500 $exe 64 48 30 5 4 -1 in.yuv out.pfv out.yuv ) >> $log 2>&1 || { rc=1; echo "== run failed" >> $log; }
     done
-    [ $done_step = 1 ] || { rc=1; echo "== step '$s' did not finish" >> $log; }
-  done
+  else
+    rc=1; echo "== build failed" >> $log
+  fi
+  rm -rf $tmp
   echo "== exit code $rc; sanitizer reports in this log: $(count $log)" >> $log; tail -2 $log
 fi
 exit $rc
