@@ -277,3 +277,21 @@ def test_emu_gop_decoder_corrupted_streams(pkg, emu_ctx, oracle):
 
 def test_emu_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle):
     assert sc.check_gop_decoder_dense_iframe_failure(pkg, emu_ctx, oracle, shapes=((8, 15), (2, 2), (1, 15))) >= 1
+
+
+def test_emu_soak_iterations(pkg, emu_ctx, oracle, lane_mapping):
+    """a few passes of tools/soak.py's randomised iteration (every checker, random geometry / quality / packet pattern / lane mapping /
+    option settings) at sizes the emulator finishes in seconds; fixed seeds.  The GPU box runs the same function at full sizes for minutes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak
+    L = pkg._lib
+    stats = {"plane_cases": 0, "sessions": 0, "entropy_payloads": 0, "corrupted_trials": 0, "stream_roundtrips": 0, "batch": 0}
+    try:
+        for it, seed in enumerate((11, 12, 13, 14)):
+            soak.iteration(pkg, emu_ctx, oracle, seed, it, stats, small=True)
+    finally:
+        emu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_AUTO)
+        emu_ctx.set_option(L.PFV_OPT_TILE_COMPACTION, 1)
+        emu_ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_AUTO)
+    assert stats["sessions"] == 4 and stats["gop_batched"] == 4 and stats["corrupted_trials"] == 48
