@@ -174,10 +174,11 @@ def test_forward_dct_is_exact(oracle):
 def test_config1_plumbing_161_frames_1080p(oracle, pkg):
     """BASELINE config #1 (the reference's own CPU-runnable case; its test_frames/ fixtures are Git-LFS stubs, so the
     161 frames are synthetic 1080p): encode_iframe every 15th frame, encode_pframe otherwise, q=5, on the
-    CPU oracle -> .pfv bytes -> decode; every decoded frame equals the encoder's closed-loop reconstruction."""
+    CPU oracle -> .pfv bytes -> decode; every decoded frame equals the encoder's closed-loop reconstruction.  As BASELINE.json words it:
+    num_threads = 1 (src/enc.rs:54) and 161 DISTINCT frames."""
     from oracle_bind import OracleEncoder, OracleStreamDecoder, OracleStreamEncoder
     W, H, Q, N = 1920, 1080, 5, 161
-    th = min(8, os.cpu_count() or 1)
+    th = 1
     st = pkg.SyntheticStream(W, H)
     senc = OracleStreamEncoder(oracle, W, H, 30, Q, threads=th)
     henc = OracleEncoder(oracle, W, H, Q, threads=th)          # same hot path; exposes prev_frame
@@ -186,7 +187,7 @@ def test_config1_plumbing_161_frames_1080p(oracle, pkg):
     ny, nc = W * H, (W // 2) * (H // 2)
     pwy, phy = 1920, 1088
     for t in range(N):
-        f = st.frame(t % 30)                                    # 30 distinct frames, replayed (generation is the slow part)
+        f = st.frame(t)                                         # every frame its own (the texture's translation has period 23 x 17 frames)
         if t % 15 == 0:
             senc.encode_iframe(f); henc.encode_iframe(f)
         else:

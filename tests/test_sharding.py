@@ -329,7 +329,12 @@ def test_bench_config5_single_rank_fields():
     for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cgroup_cpu_quota", "affinity_cpus", "value_1thread", "value_best",
               "threads_best"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["cores"] == cb["threads_best"] and "threads" not in cb and cb["value_1thread"] > 0
-    # the pool search never reports a best below what one thread does (the best is re-measured; a noisy pass is repeated)
-    assert cb["value_best"] >= 0.75 * cb["value_1thread"]
+    # `cores` is a core count -- the CPUs' worth of time the container owns -- not a pool size; the pool that won is threads_best, one of
+    # {1, usable, 2 x usable}; the value is the median of three passes of the winner
+    assert cb["kind"] == "port" and cb["cores"] == cb["usable_cpus"] and "threads" not in cb and cb["value_1thread"] > 0
+    quota = cb["cgroup_cpu_quota"]
+    assert quota in (None, "max") or cb["cores"] <= max(1, round(float(quota)))
+    assert cb["threads_best"] in (1, cb["usable_cpus"], 2 * cb["usable_cpus"], cb["affinity_cpus"])
+    assert len(cb["passes_of_the_winner"]) == 3 and cb["passes_of_the_winner"][0] <= cb["value"] <= cb["passes_of_the_winner"][2] + 1
+    assert cb["value_best"] >= 0.6 * cb["value_1thread"]
     assert set(res["sections_s"]) >= {"setup", "timed", "cpu_baseline"} and res["step_roofline"]["algorithmic_bytes_per_macroblock"] > 2000
