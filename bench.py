@@ -1325,6 +1325,8 @@ def main():
     else:
         table = shard.assign_streams(n_streams_total=S * world, world=world, base_seed=pkg.synth.SEED)
     ctx = pkg.Context(local_rank)
+    if os.environ.get("PFV_BENCH_PENC_FORM"):        # A/B runs: the p-frame encoder's form (PFV_OPT_TILE_COMPACTION: 0 strips, 1 tile compaction, 2 split kernels)
+        ctx.set_option(pkg._lib.PFV_OPT_TILE_COMPACTION, int(os.environ["PFV_BENCH_PENC_FORM"]))
     # ncclCommInitRank of 8 ranks on one node takes seconds; past 90 s every rank falls back to the socket backend together (comm.py)
     comm = commlib.Comm(ctx, rdzv, use_rccl=not share, init_timeout=float(os.environ.get("PFV_RCCL_INIT_TIMEOUT", "90"))) if use_comm else None
     if use_comm:

@@ -128,7 +128,7 @@ PFV_API int pfv_ctx_set_option(pfv_ctx *ctx, int option, int value)
         ctx->opt_enc_transform = value;
         return PFV_OK;
     case PFV_OPT_TILE_COMPACTION:
-        if (value != 0 && value != 1) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_TILE_COMPACTION: 0 or 1");
+        if (value < 0 || value > 2) return fail(ctx, PFV_ERR_BAD_ARG, "PFV_OPT_TILE_COMPACTION: 0, 1 or 2");
         ctx->opt_tile_compaction = value;
         return PFV_OK;
     case PFV_OPT_LANE_MAPPING:
@@ -527,10 +527,27 @@ static void launch_enc_iframe(pfv_ctx *ctx, bool flt, bool small, const FrameGeo
         else hipLaunchKernelGGL((k_enc_iframe<false, 8>), dim3(strip_blocks(g)), dim3(kThreads), 0, ctx->stream, g, src, coef, recon, qt, kQuantMagic);
     }
 }
-static void launch_enc_pframe(pfv_ctx *ctx, bool flt, bool small, bool compaction, const FrameGeom &g, const uint8_t *src, const uint8_t *ref, int8_t *mv,
+static void launch_enc_pframe(pfv_ctx *ctx, bool flt, bool small, int compaction, const FrameGeom &g, const uint8_t *src, const uint8_t *ref, int8_t *mv,
                               uint8_t *has, int16_t *coef, uint8_t *recon, const QTab *qt, float min_err)
 {
-    launch_enc_pframe_kernels(ctx->stream, flt, small, compaction ? kPencCompactMax : 0, g, penc_blocks(ctx, g), src, ref, mv, has, coef, recon, qt, min_err);
+    const bool split = compaction == 2 && !small;      // PFV_OPT_TILE_COMPACTION = 2: k_pf_search + k_pf_transform
+    launch_enc_pframe_kernels(ctx->stream, flt, small, split ? kPencSplit : (compaction ? kPencCompactMax : 0), g, penc_blocks(ctx, g), src, ref, mv, has, coef, recon, qt, min_err);
+    if (split) {
+        const unsigned tf = (unsigned)((long)g.n_streams * tf_groups_per_frame(g));
+        static const int variant = getenv("PFV_EXP_PTRANSFORM") ? atoi(getenv("PFV_EXP_PTRANSFORM")) : 0;      // EXPERIMENT (round 6): occupancy the transform kernel is compiled for
+#define PFV_TF_LAUNCH(F, W) hipLaunchKernelGGL((k_pf_transform<F, W>), dim3(tf), dim3(64), 0, ctx->stream, g, src, ref, (const int8_t *)mv, (const uint8_t *)has, coef, recon, qt, kQuantMagic)
+        if (flt) {
+            switch (variant) {
+            case 1: PFV_TF_LAUNCH(true, 6); break;
+            case 2: PFV_TF_LAUNCH(true, 7); break;
+            case 3: PFV_TF_LAUNCH(true, 8); break;
+            default: PFV_TF_LAUNCH(true, 5); break;
+            }
+        } else {
+            PFV_TF_LAUNCH(false, 5);
+        }
+#undef PFV_TF_LAUNCH
+    }
 }
 // where a decode launch finds its coefficients: the dense [slot][macroblock][256] array, or coefficient lists (pfv_device.h: CoefLists)
 struct DecCoefs {
@@ -639,7 +656,7 @@ PFV_API int pfv_encode_plane_delta(pfv_ctx *ctx, const uint8_t *px, int w, int h
     HIP_TRY(ctx, hipMemcpyAsync(d_src, px, (size_t)w * h, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_ref, ref, pad_bytes, hipMemcpyHostToDevice, ctx->stream));
     float min_err = px_err * px_err * 256.0f;   // src/common.rs:209
-    launch_enc_pframe(ctx, ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT, use_small_grid(ctx->opt_lane_mapping, g), ctx->opt_tile_compaction != 0, g,
+    launch_enc_pframe(ctx, ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT, use_small_grid(ctx->opt_lane_mapping, g), ctx->opt_tile_compaction, g,
                       (const uint8_t *)d_src, (const uint8_t *)d_ref, (int8_t *)d_mv, (uint8_t *)d_has, (int16_t *)d_coef, nullptr, ctx->qtab_dev, min_err);
     if ((rc = launch_check(ctx, "k_enc_pframe"))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(coef_out, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -971,7 +988,7 @@ struct pfv_enc_session {
     QTab *qtab_dev = nullptr;       // intra_l, intra_c, inter_l, inter_c
     float px_err = 0.0f;
     bool flt = false;                        // the closed loop may run in f32 (enc_float_exact holds for all four tables)
-    bool tile_compaction = true;             // PFV_OPT_TILE_COMPACTION at creation
+    int tile_compaction = 1;                 // PFV_OPT_TILE_COMPACTION at creation
     int lane_mapping = PFV_LANES_AUTO;       // PFV_OPT_LANE_MAPPING at creation
     uint8_t *prev[2] = {nullptr, nullptr};   // ping-pong prev_frame, padded, n_streams wide
     int cur = 0;                             // prev[cur] is the current prev_frame
@@ -1045,7 +1062,7 @@ PFV_API int pfv_enc_session_create(pfv_ctx *ctx, int width, int height, int qual
         int rc = make_qtab(ctx, q[i], &tabs[i]);
         if (rc) { delete s; return rc; }
     }
-    s->tile_compaction = ctx->opt_tile_compaction != 0;
+    s->tile_compaction = ctx->opt_tile_compaction;
     s->lane_mapping = ctx->opt_lane_mapping;
     s->flt = ctx->opt_enc_transform != PFV_ENC_TRANSFORM_INT && enc_float_exact(q[0], 128.0 * 256.0) && enc_float_exact(q[1], 128.0 * 256.0) &&
              enc_float_exact(q[2], 127.0 * 256.0) && enc_float_exact(q[3], 127.0 * 256.0);

@@ -386,6 +386,18 @@ __device__ __forceinline__ uint4 load_src16(const uint8_t *plane, const PlaneGeo
     return val;
 }
 
+// 16 bytes at an arbitrary byte address of a padded plane (get_block, src/common.rs:327-339)
+__device__ __forceinline__ uint4 load_unaligned16(const uint8_t *p)
+{
+    // 16 bytes at an arbitrary address from aligned dwords; the 5th dword is only touched when
+    // the address is misaligned, in which case it holds wanted bytes
+    int sh = (int)((uintptr_t)p & 3);
+    const unsigned *d = reinterpret_cast<const unsigned *>(p - sh);
+    unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = sh ? d[4] : 0u;
+    return make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                      __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+}
+
 // Decoder::advance_frame's crop of the padded framebuffer into the unpadded retframe
 // (src/dec.rs:195-197, 209-211), fused into the decode kernels: the lane's 16 reconstructed pixels
 // of row y, columns x..x+15, also go to the tightly packed output plane if they lie inside it.
@@ -906,6 +918,10 @@ __device__ __forceinline__ unsigned sq4(unsigned b0, unsigned b1, unsigned b2, u
 // wavefront-private LDS region (8 ds_write_b32 + 2 ds_read_b128 per lane: LDS-pipe work) so that lane c ends up with
 // the 8 row-pair partials of candidate c and adds them with plain VALU adds -- instead of all-reducing all 8 values over
 // the 8 lanes with 24 DPP adds and building 8 keys in every lane.
+constexpr int kPencSplit = -1;        // launch_enc_pframe_kernels: compact_max value that selects the split form (k_pf_search + k_pf_transform)
+#ifndef PFV_PSEARCH_WAVES
+#define PFV_PSEARCH_WAVES 6      // wavefronts per SIMD k_pf_search is compiled for (26.3 KiB of LDS per workgroup: six workgroups per CU)
+#endif
 constexpr int kPencCompactMax = 16;   // k_enc_pframe: a tile's coded macroblocks are moved together when there are at most this many (see there)
 constexpr int kRedPitch = 72;   // dwords per macroblock: 64 used; 72 = 8 (mod 32) spreads the 4 macroblocks of a 32-lane group over the banks
 constexpr int kRedDwords = kStripMB * kRedPitch;
@@ -946,7 +962,10 @@ __device__ __forceinline__ unsigned mb_min(unsigned v)
 // Per candidate the lane accumulates  sum b^2 - 2 sum ab  over its two rows.  In the aligned levels (S = 8, 4) the three
 // horizontal candidates of one row read overlapping dwords of the same span, so their sums of squares share the dwords
 // they have in common (16 instead of 24 v_dot4 per row pair at S = 8, 12 instead of 24 at S = 4).
-template <int S, bool FIRST, bool BOUNDS>
+// DPPRED: the 8 partials reach the lane that owns the candidate by a three-step reduce-scatter in registers (pairings i ^ 7, i ^ 2, i ^ 1:
+// each step a lane keeps the half of its values whose owners lie on its side and adds the partner's partials of those; 14 selects + 7 DPP
+// adds) instead of the LDS transpose -- no reduction region, which is what lets k_pf_search hold more than six workgroups per CU.
+template <int S, bool FIRST, bool BOUNDS, bool DPPRED = false>
 __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int wcol0, const uint4 &top, const uint4 &bot,
                                              int a2, int mbx, int mby, int pw, int ph, SearchState &st, const SearchLane &sl)
 {
@@ -1070,6 +1089,19 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
 #pragma unroll
         for (int c = 0; c < 3; c++) part[my + 1][c] = __mul24((int)ab[c], sl.neg2) + (int)bb[c];   // sum ab < 2^22
     }
+    int err;
+    if (DPPRED) {
+        // v[c]: this lane's partial of candidate c (visiting order); lane i ends up with the total of candidate i
+        const int v[8] = {part[0][0], part[0][1], part[0][2], part[1][0], part[1][2], part[2][0], part[2][1], part[2][2]};
+        const int i = sl.ord - 1;
+        const bool b2 = (i & 4) != 0, b1 = (i & 2) != 0, b0 = (i & 1) != 0;
+        int k4[4], k2[2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) k4[k] = (b2 ? v[4 + k] : v[k]) + dpp<kRowHalfMirror>(b2 ? v[k] : v[4 + k]);
+#pragma unroll
+        for (int k = 0; k < 2; k++) k2[k] = (b1 ? k4[2 + k] : k4[k]) + dpp<kQuadXor2>(b1 ? k4[k] : k4[2 + k]);
+        err = a2 + (b0 ? k2[1] : k2[0]) + dpp<kQuadXor1>(b0 ? k2[0] : k2[1]);
+    } else {
     // transposed reduction: lane c of the macroblock collects the 8 row-pair partials of candidate c
     int ord = 0;
 #pragma unroll
@@ -1084,7 +1116,8 @@ __device__ __forceinline__ void search_level(const uint8_t *win, int wrow0, int 
     wave_lds_sync();
     const int4 x = sl.rd[0], y = sl.rd[1];
     wave_lds_sync();
-    const int err = a2 + ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+    err = a2 + ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+    }
     // this lane's candidate against the plane, then the sequential accept rule of the reference: strict `<`, first
     // visited wins (:189), centre first -- the lexicographic minimum of (error, visiting order)
     bool valid = true;
@@ -1160,6 +1193,7 @@ struct SearchOut {
 
 // Phase 1 of a tile for one wavefront: motion search, skip decision, fetch of the chosen patch rows.
 // Reads the window; issues no global memory operation.
+template <bool DPPRED = false>
 __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &tp, const uint8_t *win, int *red, const uint4 (&rows)[2], int lane,
                                             float min_err, int neg2, SearchOut &so)
 {
@@ -1189,19 +1223,19 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
     // strips at least 15 px inside the plane on every side (84 % of a 1080p luma plane) skip the bounds tests
     const bool interior = sp.x0 >= 16 && sp.x0 + kStripMB * 16 + 16 <= p.pw && sp.y0 >= 16 && sp.y0 + 32 <= p.ph;   // wave-uniform
     if (interior) {
-        search_level<8, true, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<8, true, false, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(3);
-        search_level<4, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<4, false, false, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(4);
-        search_level<2, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<2, false, false, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(5);
-        search_level<1, false, false>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<1, false, false, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
         KMARK(6);
     } else {
-        search_level<8, true, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
-        search_level<4, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
-        search_level<2, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
-        search_level<1, false, true>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<8, true, true, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<4, false, true, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<2, false, true, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
+        search_level<1, false, true, DPPRED>(win, wrow0, wcol0, rows[0], rows[1], a2, mbx, mby, p.pw, p.ph, st, sl);
     }
 
     // skip decision (src/common.rs:209, :221): best_err <= px_err^2 * 256, compared in f32
@@ -1225,7 +1259,17 @@ __device__ __forceinline__ void penc_search(const FrameGeom &g, const TilePos &t
 // -> decode_subblock -> apply_residuals (src/common.rs:108-123, 300-311, 313-325, 98-104).  Returns the lane's reconstructed
 // 16-pixel row.  A slot whose source row equals its prediction row (skipped or empty slot) yields zero coefficients and the
 // prediction itself.
-template <bool FLT, class Store>
+// REUNPACK (k_pf_transform): the prediction row stays PACKED (4 registers) across the transforms and is converted to floats a second time
+// for the reconstruction, instead of 16 float registers living through both transforms -- 16 conversions per half for 12 registers.
+__device__ __forceinline__ void opaque_row(uint4 &r)   // the compiler must not know this is the row it has already unpacked
+{
+#ifndef PFV_HIPEMU
+    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+#else
+    (void)r;
+#endif
+}
+template <bool FLT, bool REUNPACK = false, class Store>
 __device__ __forceinline__ uint4 penc_half(const uint4 &srow, const uint4 &prow, int *xw, int m, int i, const LaneQ &lq, float qmagic, bool want_recon,
                                            Store &&store)
 {
@@ -1241,6 +1285,11 @@ __device__ __forceinline__ uint4 penc_half(const uint4 &srow, const uint4 &prow,
         wave_lds_sync();
         if (want_recon) {
             inverse_half_f<false>(x, xw, m, i, lq);
+            if (REUNPACK) {
+                uint4 again = prow;
+                opaque_row(again);
+                unpack_row_f(again, pp);
+            }
 #pragma unroll
             for (int k = 0; k < 8; k++) {   // apply_residuals (:98-104): prev + 2 * min(t, 127), saturated by the pack
                 const f2 t = f2{__builtin_fminf(x[k][0], 127.0f), __builtin_fminf(x[k][1], 127.0f)};
@@ -1465,6 +1514,160 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
         penc_transform<FLT>(g, cur, so, rows, xw, lane, coef, recon, qtab_lds, qmagic);
     }
     KMARK(11);
+}
+
+// ================================================================== P-frame encode, SPLIT form (round 6): search kernel + transform kernel
+// The same operator as k_enc_pframe (encode_plane_delta + the closed loop's decode_plane_delta, src/common.rs:388-421, 448-475) as two
+// launches, so that each phase runs at the occupancy ITS registers allow and the transform runs on coded macroblocks only:
+//   k_pf_search     one workgroup per 128 x 64 tile as before: window DMA, 4-step search (src/common.rs:154-204), skip decision (:209, :221)
+//                   -> motion vectors and flags; a SKIPPED macroblock is finished here (zero coefficients at the fixed 512-byte stride, the
+//                   prediction as its reconstruction, :281-283: its patch is in the LDS window anyway); a coded one is left to the second
+//                   kernel.  No transform registers, no quantiser table, no window-release barrier.
+//   k_pf_transform  one wavefront per GROUP of kTfStrips consecutive strips of one plane of one stream (64 macroblocks): reads the group's
+//                   flags, numbers its coded macroblocks 0 .. n-1 (ballot + mbcnt, table in LDS) and transforms them 8 per pass: source rows,
+//                   patch rows by motion vector from the previous reconstruction (get_block, :327-339, as k_dec_pframe fetches them),
+//                   residual -> forward DCT -> quantise -> store -> closed-loop inverse -> reconstruction (penc_half).  ceil(n / 8) passes
+//                   instead of one pass per strip that holds a coded macroblock: no work on skipped slots beyond the last pass's tail.
+// Extra traffic against the fused kernel: a coded macroblock's 256 source bytes and its 256-byte patch are read a second time.
+template <int WAVES, bool DPPRED>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_pf_search(FrameGeom g, const uint8_t *__restrict__ src,
+                                                          const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
+                                                          uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
+                                                          uint8_t *__restrict__ recon, float min_err, int neg2)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t win_lds[16 + kWinAlloc];
+    __shared__ __attribute__((aligned(16))) int red_lds[DPPRED ? 1 : kStripsPerWG][DPPRED ? 4 : kRedDwords];
+    uint8_t *win = win_lds + 16;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m = lane >> 3, i = lane & 7;
+    const int vt = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const TilePos cur = locate_tile(g, vt, wave);
+    const PlaneGeom &p = g.p[cur.sp.plane];
+    issue_window(p, ref + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off, cur, win, wave, lane);
+    uint4 rows[2];
+    rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
+    if (cur.wave_valid) {
+        const uint8_t *plane = src + (long)cur.sp.stream * g.src_frame_bytes + p.src_off;
+        rows[0] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i);
+        rows[1] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i + 8);
+    }
+    __syncthreads();   // window complete (vmcnt drained at the barrier); the only barrier of the kernel
+    if (!cur.wave_valid) return;
+    SearchOut so;
+    penc_search<DPPRED>(g, cur, win, red_lds[DPPRED ? 0 : wave], rows, lane, min_err, neg2, so);
+    if (m < cur.sp.n_mb) {
+        const long mbi = (long)cur.sp.stream * g.mbs_per_frame + cur.sp.mb_first + m;
+        if (i == 0) {   // block headers (DeltaEncodedMacroBlock.motion_x / _y, subblocks.is_some(); src/common.rs:14-19)
+            mv_out[mbi * 2 + 0] = (int8_t)so.cx;
+            mv_out[mbi * 2 + 1] = (int8_t)so.cy;
+            has_out[mbi] = so.coded ? 1 : 0;
+        }
+        if (!so.coded)
+            penc_store_skipped(coef + mbi * 256, recon ? recon + (long)cur.sp.stream * g.pad_frame_bytes + p.pad_off + (long)(cur.sp.y0 + i) * p.pw + cur.sp.x0 + m * 16 : nullptr,
+                               p.pw, i, so.patch);
+    }
+}
+
+constexpr int kTfStrips = 8;                       // strips per wavefront of k_pf_transform: 64 macroblocks = one flag per lane
+// groups of one plane of one frame
+__host__ __device__ __forceinline__ int tf_groups_of_plane(const PlaneGeom &p) { return (p.strips_x * p.bh + kTfStrips - 1) / kTfStrips; }
+__host__ __device__ __forceinline__ int tf_groups_per_frame(const FrameGeom &g)
+{
+    int n = 0;
+    for (int k = 0; k < g.n_planes; k++) n += tf_groups_of_plane(g.p[k]);
+    return n;
+}
+
+template <bool FLT, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_pf_transform(FrameGeom g, const uint8_t *__restrict__ src, const uint8_t *__restrict__ ref,
+                                                     const int8_t *__restrict__ mv, const uint8_t *__restrict__ has, int16_t *__restrict__ coef,
+                                                     uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs, float qmagic)
+{
+    __shared__ __attribute__((aligned(16))) int xw[kXchgDwords];
+    __shared__ __attribute__((aligned(16))) int qtab_lds[kQTabDwords];
+    __shared__ __attribute__((aligned(16))) int strip_tab[kTfStrips][4];   // per strip of the group: x0, y0, first macroblock (frame-relative)
+    __shared__ int slot_tab[64];                                            // per coded macroblock, in group order: place (0..63) | cx << 8 | cy << 16
+    __shared__ int pass_mbi[kStripMB];                                      // the pass's 8 macroblocks (frame-relative index, -1: empty slot)
+
+    const int lane = threadIdx.x & 63, m = lane >> 3, i = lane & 7;
+    // group -> stream, plane, first strip (all wave-uniform)
+    const int gpf = tf_groups_per_frame(g);
+    const int gq = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int stream = gq / gpf;
+    int gr = gq - stream * gpf, plane = 0;
+    for (; plane + 1 < g.n_planes && gr >= tf_groups_of_plane(g.p[plane]); plane++) gr -= tf_groups_of_plane(g.p[plane]);
+    const PlaneGeom &p = g.p[plane];
+    const int strips_p = p.strips_x * p.bh;
+    const int s_first = gr * kTfStrips;
+
+    // lane j <-> macroblock (j & 7) of strip s_first + (j >> 3)
+    bool coded = false;
+    int cxy = 0;
+    {
+        const int s = s_first + m;
+        const int by = s / p.strips_x, sx = s - by * p.strips_x;
+        const int n_mb = min(kStripMB, p.bw - sx * kStripMB), mb_first = p.mb0 + by * p.bw + sx * kStripMB;
+        if (i == 0) reinterpret_cast<int4 *>(strip_tab[m])[0] = make_int4(sx * (kStripMB * 16), by * 16, mb_first, 0);
+        if (s < strips_p && i < n_mb) {
+            const long mbi = (long)stream * g.mbs_per_frame + mb_first + i;
+            if (has[mbi]) {
+                coded = true;
+                cxy = ((int)mv[mbi * 2 + 0] & 0xff) << 8 | ((int)mv[mbi * 2 + 1] & 0xff) << 16;
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(coded);
+    const int n_coded = __builtin_popcountll(bal);
+    if (n_coded == 0) return;
+    if (coded) slot_tab[__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = lane | cxy;
+    fill_qtable<true, FLT>(qtab_lds, qtabs + p.qsel, lane);
+    wave_lds_sync();
+
+    const LaneQ lq{qtab_lds, i};
+    const uint8_t *splane = src + (long)stream * g.src_frame_bytes + p.src_off;
+    const uint8_t *rplane = ref + (long)stream * g.pad_frame_bytes + p.pad_off;
+    uint8_t *oplane = recon ? recon + (long)stream * g.pad_frame_bytes + p.pad_off : nullptr;
+    int16_t *coef_frame = coef + (long)stream * g.mbs_per_frame * 256;
+    for (int k0 = 0; k0 < n_coded; k0 += kStripMB) {
+        const bool has_slot = k0 + m < n_coded;
+        if (i == 0) {
+            int mbf = -1;
+            if (has_slot) {
+                const int e = slot_tab[k0 + m];
+                mbf = strip_tab[(e >> 3) & 7][2] + (e & 7);
+            }
+            pass_mbi[m] = mbf;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            // the rows are fetched half by half: 8 registers of pixels alive instead of 16
+            uint4 srow = make_uint4(0, 0, 0, 0), prow = srow;
+            if (has_slot) {
+                const int e = slot_tab[k0 + m];
+                const int4 st = reinterpret_cast<const int4 *>(strip_tab[(e >> 3) & 7])[0];
+                const int mbx = st.x + (e & 7) * 16, y = st.y + i + 8 * h;
+                const int cx = (int)(int8_t)(e >> 8), cy = (int)(int8_t)(e >> 16);
+                srow = load_src16(splane, p, mbx, y);
+                prow = load_unaligned16(rplane + (long)(y + cy) * p.pw + (mbx + cx));
+            }
+            const uint4 o = penc_half<FLT, true>(srow, prow, xw, m, i, lq, qmagic, recon != nullptr, [&]() {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {   // the stage's 128 16-byte chunks, 16 per slot, to the slots' macroblocks
+                    const int ch = j * 64 + lane, mbf = pass_mbi[ch >> 4];
+                    if (mbf >= 0)
+                        st_stream(&reinterpret_cast<uint4 *>(coef_frame + (long)mbf * 256)[h * 16 + (ch & 15)], reinterpret_cast<const uint4 *>(xw)[stage_chunk(ch)]);
+                }
+            });
+            if (oplane && has_slot) {
+                // the macroblock's place is looked up again after the pipeline: nothing of it stays alive across the transforms
+                const int e = slot_tab[k0 + m];
+                const int4 st = reinterpret_cast<const int4 *>(strip_tab[(e >> 3) & 7])[0];
+                *reinterpret_cast<uint4 *>(oplane + (long)(st.y + i + 8 * h) * p.pw + st.x + (e & 7) * 16) = o;
+            }
+        }
+        wave_lds_sync();   // pass_mbi is rewritten by the next pass
+    }
 }
 
 // ================================================================== P-frame encode, small-grid lane mapping (16 lanes per macroblock)
@@ -1770,17 +1973,6 @@ __global__ __launch_bounds__(kThreads) void k_dec_iframe(FrameGeom g, const int1
 // reference reads every patch from the old plane before it writes anything (:498-521).
 // err_flag[stream] is set when a motion vector leaves the plane (:258-259 debug_assert); the
 // vector is then treated as (0,0) so that no out-of-bounds access happens.
-__device__ __forceinline__ uint4 load_unaligned16(const uint8_t *p)
-{
-    // 16 bytes at an arbitrary address from aligned dwords; the 5th dword is only touched when
-    // the address is misaligned, in which case it holds wanted bytes
-    int sh = (int)((uintptr_t)p & 3);
-    const unsigned *d = reinterpret_cast<const unsigned *>(p - sh);
-    unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = sh ? d[4] : 0u;
-    return make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                      __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
-}
-
 template <int LPM = 8, bool LISTS = false>
 __global__ __launch_bounds__(kThreads) void k_dec_pframe(FrameGeom g, const int8_t *__restrict__ mv,
                                                           const uint8_t *__restrict__ has, const int16_t *__restrict__ coef, CoefLists cl,

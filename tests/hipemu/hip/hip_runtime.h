@@ -160,6 +160,19 @@ static inline unsigned hipemu_cvt_pk_u8_f32(float v, unsigned idx, unsigned old)
     return (old & ~(0xffu << (8 * (idx & 3)))) | (b << (8 * (idx & 3)));
 }
 #define __builtin_amdgcn_cvt_pk_u8_f32 hipemu_cvt_pk_u8_f32
+// v_mbcnt_lo / _hi: the number of set mask bits BELOW the lane (lo: lanes 0..31 of the mask, hi: lanes 32..63), added to `v`
+static inline unsigned hipemu_mbcnt_lo(unsigned mask, unsigned v)
+{
+    const unsigned lane = threadIdx.x & 63;
+    return v + (unsigned)__builtin_popcount(mask & (lane >= 32 ? 0xffffffffu : ((1u << lane) - 1u)));
+}
+static inline unsigned hipemu_mbcnt_hi(unsigned mask, unsigned v)
+{
+    const unsigned lane = threadIdx.x & 63;
+    return v + (lane > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (lane - 32)) - 1u)) : 0u);
+}
+#define __builtin_amdgcn_mbcnt_lo hipemu_mbcnt_lo
+#define __builtin_amdgcn_mbcnt_hi hipemu_mbcnt_hi
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_readlane(v, l) hipemu::wave_exchange((v), (l))   // every lane of the wavefront executes it (the source lane is uniform)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)

@@ -17,15 +17,23 @@ import stream_cases as sc
 _BOTH_MAPPINGS = ("plane_ops", "golden", "trap", "session", "sparse_coded", "bad_motion", "gop_graph", "colour", "blit", "lists_decode")
 
 
-@pytest.fixture(autouse=True, params=["auto", "lanes8"])
+# "lanes8split": the batch mapping with the p-frame encoder in its split form (k_pf_search + k_pf_transform, PFV_OPT_TILE_COMPACTION = 2), on the
+# tests that encode p-frames
+_SPLIT = ("plane_ops", "golden", "trap", "session", "sparse_coded", "gop_graph")
+
+
+@pytest.fixture(autouse=True, params=["auto", "lanes8", "lanes8split"])
 def lane_mapping(request, pkg, emu_ctx):
     L = pkg._lib
-    if request.param == "lanes8":
-        if not any(k in request.node.name for k in _BOTH_MAPPINGS):
-            pytest.skip("stream-level test: automatic lane mapping only")
+    if request.param != "auto":
+        if not any(k in request.node.name for k in (_BOTH_MAPPINGS if request.param == "lanes8" else _SPLIT)):
+            pytest.skip("stream-level test: automatic lane mapping only" if request.param == "lanes8" else "no p-frame encode in this test")
         emu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_PER_MB_8)
+        if request.param == "lanes8split":
+            emu_ctx.set_option(L.PFV_OPT_TILE_COMPACTION, 2)
     yield request.param
     emu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_AUTO)
+    emu_ctx.set_option(L.PFV_OPT_TILE_COMPACTION, 1)
 
 
 @pytest.mark.parametrize("w,h", [(64, 48), (50, 38), (144, 16), (400, 80)])   # 400x80 has interior strips (bounds-check-free search path)

@@ -13,15 +13,25 @@ import stream_cases as sc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lanes8", "lanes16"])
+# tests that encode p-frames: they run a third time with the p-frame encoder in its split form (k_pf_search + k_pf_transform)
+_PFRAME_TESTS = ("golden", "gop_graph", "trap", "pframe", "session", "benched_shape", "gop_batched", "config5", "sparse", "fuzz", "search")
+
+
+@pytest.fixture(autouse=True, params=["lanes8", "lanes16", "lanes8split"])
 def lane_mapping(request, pkg, gpu_ctx):
     """every test of this file runs under BOTH lane mappings of the codec kernels (pfv_kernels.hip, "Lane mappings": 8 lanes per
     macroblock = the batch mapping, 16 = the small-grid mapping the library picks for launches of fewer than 4 096 strips), forced
-    through pfv_ctx_set_option; sessions pick the option up when they are created"""
+    through pfv_ctx_set_option; sessions pick the option up when they are created.  lanes8split: the batch mapping with the p-frame
+    encoder as two kernels (PFV_OPT_TILE_COMPACTION = 2), on the tests that encode p-frames."""
     L = pkg._lib
-    gpu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_PER_MB_8 if request.param == "lanes8" else L.PFV_LANES_PER_MB_16)
+    if request.param == "lanes8split":
+        if not any(k in request.node.name for k in _PFRAME_TESTS):
+            pytest.skip("no p-frame encode in this test")
+        gpu_ctx.set_option(L.PFV_OPT_TILE_COMPACTION, 2)
+    gpu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_PER_MB_16 if request.param == "lanes16" else L.PFV_LANES_PER_MB_8)
     yield request.param
     gpu_ctx.set_option(L.PFV_OPT_LANE_MAPPING, L.PFV_LANES_AUTO)
+    gpu_ctx.set_option(L.PFV_OPT_TILE_COMPACTION, 1)
 
 
 def test_native_library_is_the_one_loaded(pkg, gpu_ctx):
