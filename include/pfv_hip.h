@@ -106,7 +106,10 @@ PFV_API const char *pfv_version(void);
  *       PFV_ENC_TRANSFORM_INT             always the i32 kernels
  *   PFV_OPT_TILE_COMPACTION  1 (default): the p-frame encoder transforms only CODED macroblocks where that saves work -- a
  *       skipped macroblock is not transformed by the reference either (src/common.rs:221-222) -- by moving the coded macroblocks of
- *       a 128 x 64 tile together before the transform phase; 0: every wavefront transforms its own strip (measurements)
+ *       a 128 x 64 tile together before the transform phase; 0: every wavefront transforms its own strip (measurements);
+ *       2: the p-frame encoder as TWO kernels (measurements: 17 % slower, profiles/r06_enc_pframe_split.md) -- k_pf_search (search, skip
+ *       decision, skipped macroblocks finished) and k_pf_transform (coded macroblocks only, numbered per 64 macroblocks); launches of
+ *       the 8-lanes-per-macroblock mapping only, the small-grid mapping ignores it
  *   PFV_OPT_LANE_MAPPING  how the four codec kernels spread a macroblock over lanes:
  *       PFV_LANES_AUTO (default)   by grid size: 8 lanes per macroblock (a wavefront = a strip of 8 macroblocks) for launches that
  *                                  fill the device, 16 (a wavefront = 4 macroblocks, half as long) for launches of fewer than

@@ -534,19 +534,8 @@ static void launch_enc_pframe(pfv_ctx *ctx, bool flt, bool small, int compaction
     launch_enc_pframe_kernels(ctx->stream, flt, small, split ? kPencSplit : (compaction ? kPencCompactMax : 0), g, penc_blocks(ctx, g), src, ref, mv, has, coef, recon, qt, min_err);
     if (split) {
         const unsigned tf = (unsigned)((long)g.n_streams * tf_groups_per_frame(g));
-        static const int variant = getenv("PFV_EXP_PTRANSFORM") ? atoi(getenv("PFV_EXP_PTRANSFORM")) : 0;      // EXPERIMENT (round 6): occupancy the transform kernel is compiled for
-#define PFV_TF_LAUNCH(F, W) hipLaunchKernelGGL((k_pf_transform<F, W>), dim3(tf), dim3(64), 0, ctx->stream, g, src, ref, (const int8_t *)mv, (const uint8_t *)has, coef, recon, qt, kQuantMagic)
-        if (flt) {
-            switch (variant) {
-            case 1: PFV_TF_LAUNCH(true, 6); break;
-            case 2: PFV_TF_LAUNCH(true, 7); break;
-            case 3: PFV_TF_LAUNCH(true, 8); break;
-            default: PFV_TF_LAUNCH(true, 5); break;
-            }
-        } else {
-            PFV_TF_LAUNCH(false, 5);
-        }
-#undef PFV_TF_LAUNCH
+        if (flt) hipLaunchKernelGGL(k_pf_transform<true>, dim3(tf), dim3(64), 0, ctx->stream, g, src, ref, (const int8_t *)mv, (const uint8_t *)has, coef, recon, qt, kQuantMagic);
+        else hipLaunchKernelGGL(k_pf_transform<false>, dim3(tf), dim3(64), 0, ctx->stream, g, src, ref, (const int8_t *)mv, (const uint8_t *)has, coef, recon, qt, kQuantMagic);
     }
 }
 // where a decode launch finds its coefficients: the dense [slot][macroblock][256] array, or coefficient lists (pfv_device.h: CoefLists)

@@ -919,9 +919,8 @@ __device__ __forceinline__ unsigned sq4(unsigned b0, unsigned b1, unsigned b2, u
 // the 8 row-pair partials of candidate c and adds them with plain VALU adds -- instead of all-reducing all 8 values over
 // the 8 lanes with 24 DPP adds and building 8 keys in every lane.
 constexpr int kPencSplit = -1;        // launch_enc_pframe_kernels: compact_max value that selects the split form (k_pf_search + k_pf_transform)
-#ifndef PFV_PSEARCH_WAVES
-#define PFV_PSEARCH_WAVES 6      // wavefronts per SIMD k_pf_search is compiled for (26.3 KiB of LDS per workgroup: six workgroups per CU)
-#endif
+constexpr int kPsWaves = 7;           // wavefronts per SIMD k_pf_search is compiled for: 69 VGPRs, 17 KiB of LDS per workgroup (register reduce-scatter: no reduction regions)
+constexpr int kTfWaves = 7;           // and k_pf_transform: 72 VGPRs, 5.4 KiB of LDS per wavefront
 constexpr int kPencCompactMax = 16;   // k_enc_pframe: a tile's coded macroblocks are moved together when there are at most this many (see there)
 constexpr int kRedPitch = 72;   // dwords per macroblock: 64 used; 72 = 8 (mod 32) spreads the 4 macroblocks of a 32-lane group over the banks
 constexpr int kRedDwords = kStripMB * kRedPitch;
@@ -1529,8 +1528,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
 //                   residual -> forward DCT -> quantise -> store -> closed-loop inverse -> reconstruction (penc_half).  ceil(n / 8) passes
 //                   instead of one pass per strip that holds a coded macroblock: no work on skipped slots beyond the last pass's tail.
 // Extra traffic against the fused kernel: a coded macroblock's 256 source bytes and its 256-byte patch are read a second time.
-template <int WAVES, bool DPPRED>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_pf_search(FrameGeom g, const uint8_t *__restrict__ src,
+template <bool DPPRED>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kPsWaves, kPsWaves))) void k_pf_search(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ recon, float min_err, int neg2)
@@ -1579,8 +1578,8 @@ __host__ __device__ __forceinline__ int tf_groups_per_frame(const FrameGeom &g)
     return n;
 }
 
-template <bool FLT, int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_pf_transform(FrameGeom g, const uint8_t *__restrict__ src, const uint8_t *__restrict__ ref,
+template <bool FLT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kTfWaves, kTfWaves))) void k_pf_transform(FrameGeom g, const uint8_t *__restrict__ src, const uint8_t *__restrict__ ref,
                                                      const int8_t *__restrict__ mv, const uint8_t *__restrict__ has, int16_t *__restrict__ coef,
                                                      uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs, float qmagic)
 {

@@ -11,7 +11,6 @@
 #define PFV_PENC_TU
 #include "pfv_kernels.hip"
 #endif
-#include <stdlib.h>
 
 namespace pfv {
 
@@ -23,14 +22,7 @@ void launch_enc_pframe_kernels(hipStream_t stream, bool flt, bool small, int com
         else hipLaunchKernelGGL(k_enc_pframe16<false>, dim3(blocks), dim3(kThreads16), 0, stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic);
     } else if (compact_max == kPencSplit) {   // search kernel + transform kernel (PFV_OPT_TILE_COMPACTION = 2)
         // the search kernel only: the transform kernel is launched by the caller, from the main translation unit (default scheduling strategy)
-        static const int variant = getenv("PFV_EXP_PSEARCH") ? atoi(getenv("PFV_EXP_PSEARCH")) : 0;      // EXPERIMENT (round 6): which build of the search kernel
-        switch (variant) {
-        case 1: hipLaunchKernelGGL((k_pf_search<6, true>), dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, min_err, -2); break;
-        case 2: hipLaunchKernelGGL((k_pf_search<7, true>), dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, min_err, -2); break;
-        case 3: hipLaunchKernelGGL((k_pf_search<8, true>), dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, min_err, -2); break;
-        case 4: hipLaunchKernelGGL((k_pf_search<5, false>), dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, min_err, -2); break;
-        default: hipLaunchKernelGGL((k_pf_search<6, false>), dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, min_err, -2); break;
-        }
+        hipLaunchKernelGGL(k_pf_search<true>, dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, min_err, -2);
     } else {
         if (flt) hipLaunchKernelGGL(k_enc_pframe<true>, dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic, compact_max);
         else hipLaunchKernelGGL(k_enc_pframe<false>, dim3(blocks), dim3(kThreads), 0, stream, g, src, ref, mv, has, coef, recon, qt, min_err, -2, kQuantMagic, compact_max);

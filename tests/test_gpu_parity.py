@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 # tests that encode p-frames: they run a third time with the p-frame encoder in its split form (k_pf_search + k_pf_transform)
-_PFRAME_TESTS = ("golden", "gop_graph", "trap", "pframe", "session", "benched_shape", "gop_batched", "config5", "sparse", "fuzz", "search")
+_PFRAME_TESTS = ("golden", "gop_graph", "trap", "pframe", "session", "benched_shape", "gop_batched", "config5", "sparse_coded", "fuzz", "extreme_aspect", "misaligned")
 
 
 @pytest.fixture(autouse=True, params=["lanes8", "lanes16", "lanes8split"])

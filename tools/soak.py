@@ -22,7 +22,7 @@ def iteration(pkg, ctx, oracle, s, it, stats, small=False):
     L = pkg._lib
     lanes = [L.PFV_LANES_AUTO, L.PFV_LANES_PER_MB_8, L.PFV_LANES_PER_MB_16][int(r.integers(0, 3))]
     ctx.set_option(L.PFV_OPT_LANE_MAPPING, lanes)
-    ctx.set_option(L.PFV_OPT_TILE_COMPACTION, int(r.integers(0, 4) != 0))
+    ctx.set_option(L.PFV_OPT_TILE_COMPACTION, int((0, 1, 1, 2)[int(r.integers(0, 4))]))      # strips / tile compaction (default) / split kernels
     ctx.set_option(L.PFV_OPT_ENC_TRANSFORM, L.PFV_ENC_TRANSFORM_INT if int(r.integers(0, 6)) == 0 else L.PFV_ENC_TRANSFORM_AUTO)
     kind = ["pan", "low_motion", "static"][int(r.integers(0, 3))]
     stats["lanes8"] = stats.get("lanes8", 0) + (lanes == L.PFV_LANES_PER_MB_8)
