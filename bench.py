@@ -1328,7 +1328,35 @@ def main():
     if os.environ.get("PFV_BENCH_PENC_FORM"):        # A/B runs: the p-frame encoder's form (PFV_OPT_TILE_COMPACTION: 0 strips, 1 tile compaction, 2 split kernels)
         ctx.set_option(pkg._lib.PFV_OPT_TILE_COMPACTION, int(os.environ["PFV_BENCH_PENC_FORM"]))
     # ncclCommInitRank of 8 ranks on one node takes seconds; past 90 s every rank falls back to the socket backend together (comm.py)
-    comm = commlib.Comm(ctx, rdzv, use_rccl=not share, init_timeout=float(os.environ.get("PFV_RCCL_INIT_TIMEOUT", "90"))) if use_comm else None
+    comm_ctx = ctx
+    if EMU and os.environ.get("PFV_BENCH_FAKE_RCCL_FAILURE") == "1":
+        # test-only (tests/test_sharding.py::test_rccl_fallback_is_loud): pretend every rank has its own GPU and ncclCommInitRank fails on rank 1
+        import ctypes
+
+        class _FailingRccl:
+            def pfv_comm_unique_id(self, p):
+                ctypes.memset(p, 7, 128)
+                return 0
+
+            def pfv_comm_init(self, c, r, w, uid, out):
+                ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = ctypes.c_void_p(0)
+                return -2 if r == 1 else 0
+
+            def pfv_last_error(self, c):
+                return b"simulated ncclCommInitRank failure"
+
+            def pfv_comm_destroy(self, h):
+                return 0
+
+        class _Shim:
+            handle, _lib, keep_alive = ctx.handle, _FailingRccl(), False
+        share, comm_ctx = False, _Shim()
+    comm = commlib.Comm(comm_ctx, rdzv, use_rccl=not share, init_timeout=float(os.environ.get("PFV_RCCL_INIT_TIMEOUT", "90"))) if use_comm else None
+    rccl_fallback = bool(use_comm and world > 1 and not share and comm.backend != "rccl")
+    if rccl_fallback:
+        # one GPU per rank and RCCL asked for, but the communicator did not come up on every rank: the job carries on over the rendezvous
+        # sockets (same results; the collectives are a table broadcast, barriers and one reduction) -- and says so LOUDLY
+        print(f"bench.py[rank {rank}]: RCCL FALLBACK -- control plane on TCP sockets instead of RCCL/xGMI: {comm.rccl_error}", file=sys.stderr, flush=True)
     if use_comm:
         table = comm.broadcast_array(np.asarray(table, dtype=np.int64) if rank == 0 else np.zeros_like(np.asarray(table, dtype=np.int64)))
     mine = shard.streams_of_rank(table, rank)
@@ -1445,6 +1473,12 @@ def main():
             "dtype": "i32 (encoder transforms evaluated in exact f32; decoders i32)",
             "data": f"synthetic, generated on the device ({S} distinct integer-hash texture streams per GPU, seed per stream; quality {Q})",
             "rccl_ranks": world if comm is not None and comm.backend == "rccl" else 0,
+            "rccl_fallback": rccl_fallback,       # true: every rank had its own GPU, RCCL was asked for and did NOT come up (control_plane.rccl_error says why)
+            "launch": {"mode": ("torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else ("self-launch" if os.environ.get("PFV_RDZV_NONCE") else "env")) if world > 1 else "single process",
+                       "world": world, "visible_gpus": None if EMU else int(pkg._lib.load().pfv_device_count()),
+                       "same_code_path_for_every_n": "one main() for N = 1 and for a rank of N > 1 (torch-free process; StreamSet.step in the timed loop); at N > 1 the "
+                                                     "table broadcast, the barriers and the counter reduction go through comm.py, at N = 1 they are no-ops; the "
+                                                     "extra / cpu_baseline / live-PMC legs run on rank 0 at N = 1 only, after the timed region"},
             "control_plane": {"backend": comm.backend if comm is not None else None, "shared_gpu": bool(share and world > 1), "emulated": EMU,
                               "rccl_error": comm.rccl_error if comm is not None else None, "ranks": per_rank,
                               "collectives": "assignment-table broadcast + barriers + counter all-reduce only (no data-path collective); "

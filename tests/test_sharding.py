@@ -338,3 +338,36 @@ def test_bench_config5_single_rank_fields():
     assert len(cb["passes_of_the_winner"]) == 3 and cb["passes_of_the_winner"][0] <= cb["value"] <= cb["passes_of_the_winner"][2] + 1
     assert cb["value_best"] >= 0.6 * cb["value_1thread"]
     assert set(res["sections_s"]) >= {"setup", "timed", "cpu_baseline"} and res["step_roofline"]["algorithmic_bytes_per_macroblock"] > 2000
+
+
+@pytest.mark.parametrize("mode", ["self", "env", "torchrun"])
+def test_preflight_eight_ranks(mode):
+    """First-contact readiness of the 8-GPU run (tools/preflight_multi.py): `bench.py --gpus 8` in the three ways it can be started -- its own
+    launcher; the launcher environment set by hand (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / TORCHELASTIC_RUN_ID) with MASTER_PORT and the
+    first port of the rendezvous walk OCCUPIED; and the driver's command line (python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...) -- 8 ranks on the CPU emulator: one JSON line from rank 0, whole-job
+    count, every rank's own row, `rccl_fallback` false (a shared device is TCP by design), `launch.mode` as started."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import preflight_multi as pm
+    res = pm.MODES[mode](8)
+    assert res["n_gpus"] == 8 and res["control_plane"]["backend"] == "tcp" and res["rccl_ranks"] == 0
+    assert res["launch"]["mode"] == ("self-launch" if mode == "self" else "torchrun")
+    if mode == "env":
+        assert res["_port_walk_forced"] in (True, False)
+
+
+def test_rccl_fallback_is_loud(tmp_path):
+    """one GPU per rank, RCCL asked for, ncclCommInitRank failing on a rank: the job finishes over the sockets, says `rccl_fallback`: true at
+    the TOP level of the line and prints the reason on stderr (bench.py; PFV_BENCH_FAKE_RCCL_FAILURE is a test hook of the emulator run)"""
+    import json
+    import subprocess
+    env = dict(os.environ, PFV_BENCH_EMU="1", PFV_BENCH_FAKE_RCCL_FAILURE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--streams", "1", "--width", "64", "--height", "48",
+                        "--frames", "2", "--no-entropy"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["rccl_fallback"] is True and res["rccl_ranks"] == 0 and res["control_plane"]["backend"] == "tcp"
+    assert "simulated" in res["control_plane"]["rccl_error"]
+    assert "RCCL FALLBACK" in r.stderr and "simulated" in r.stderr
