@@ -489,8 +489,11 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
  *   max_gops        runs ("groups") per batch = slots per launch; a group starts at every i-frame
  *   max_gop_frames  frames of a group inside one batch; a longer run continues in the next batch (its reference frame is
  *                   carried over on the device), and so does a stream that starts with p-frames
- *   payload_budget  device bytes for the packet payloads of one batch (0: twice the batch's raw frame bytes, at least 16 MiB);
- *                   PFV_ERR_NOMEM from the call that completes a batch whose payloads do not fit
+ *   payload_budget  device bytes for the packet payloads of one batch.  0: the format's worst case for the batch
+ *                   (pfv_payload_worst_case per frame, 3.75 x the raw bytes; untouched beyond what real payloads need) -- like
+ *                   Encoder::encode_pframe (src/enc.rs:125-173) the object then cannot fail for size; twice the raw bytes if that
+ *                   much device memory cannot be had.  An explicit budget is kept as given: PFV_ERR_NOMEM from the call that
+ *                   completes a batch whose payloads do not fit it
  * Encoder: the planes may be reused when an encode call returns; frames are uploaded on a copy stream while the kernels of the
  * previous batch run.  A packet reaches pfv_gop_encoder_drain when its batch is complete (max_gops groups seen, flush, finish);
  * the byte stream is the one pfv_encoder writes.  After an error the stream is incomplete and every call returns PFV_ERR_STATE.

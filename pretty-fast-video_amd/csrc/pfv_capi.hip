@@ -25,6 +25,7 @@ void launch_enc_pframe_kernels(hipStream_t stream, bool flt, bool small, int com
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -81,8 +82,20 @@ struct pfv_ctx {
     std::vector<struct pfv_comm *> comms;             // live communicators on this context (pfv_comm.hip): torn down with it
     std::mutex comms_m;                               // pfv_comm_init may return on a watchdog thread (comm.py) while the main thread destroys
     pfv_ctx *owner = nullptr;                         // an object's private launch context (pfv_gop_encoder): errors are also reported on the
-    //                                                   context the caller created the object on
+    //                                                   context the caller created the object on; nullptr again once that context is destroyed
+    std::vector<pfv_ctx *> children;                  // the private contexts that name this one as their owner: detached by pfv_ctx_destroy
+    int priority = 0;                                 // pfv_ctx_create_prio's argument (a private context inherits it)
 };
+// a private launch context of an object created on `user`: same device, same stream priority, errors mirrored to `user`
+static int ctx_create_child(pfv_ctx *user, pfv_ctx **out)
+{
+    int rc = pfv_ctx_create_prio(user->device, user->priority, out);
+    if (rc) return rc;
+    (*out)->owner = user;
+    std::lock_guard<std::mutex> lk(user->comms_m);
+    user->children.push_back(*out);
+    return PFV_OK;
+}
 static void comm_teardown(struct pfv_comm *c);
 
 static thread_local std::string g_tls_err;
@@ -193,6 +206,7 @@ PFV_API int pfv_ctx_create_prio(int device, int priority, pfv_ctx **out)
     HIP_TRY(nullptr, hipSetDevice(device));
     pfv_ctx *ctx = new pfv_ctx();
     ctx->device = device;
+    ctx->priority = priority;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
@@ -226,6 +240,17 @@ PFV_API void pfv_ctx_destroy(pfv_ctx *ctx)
         std::vector<pfv_comm *> live;
         { std::lock_guard<std::mutex> lk(ctx->comms_m); live.swap(ctx->comms); }
         for (pfv_comm *c : live) comm_teardown(c);
+    }
+    {   // objects with a private context that were created on this one and are still alive (pfv_gop_encoder): they lose their link -- no error
+        // mirroring, no *_dev intake on this context's stream any more -- instead of keeping a dangling pointer
+        std::lock_guard<std::mutex> lk(ctx->comms_m);
+        for (pfv_ctx *c : ctx->children) c->owner = nullptr;
+        ctx->children.clear();
+    }
+    if (ctx->owner) {   // a private context going away first: the usual order
+        std::lock_guard<std::mutex> lk(ctx->owner->comms_m);
+        auto &v = ctx->owner->children;
+        v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
     }
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
@@ -2076,7 +2101,8 @@ struct DecEvent {
 
 // switches, shape and counters of the device entropy stage in pfv_decoder / pfv_batch_decoder (the buffers: DecWindow)
 struct DecEntd {
-    bool on = false, force = false;      // force: every packet (PFV_ENTROPY_DECODE_DEVICE); otherwise payloads of kDecEntdMinBytes and more
+    std::atomic<bool> on{false};         // read by the parser threads; cleared by the caller's thread when the window sets cannot be made (AUTO: the host parser takes over)
+    bool force = false;                  // force: every packet (PFV_ENTROPY_DECODE_DEVICE); otherwise payloads of kDecEntdMinBytes and more
     bool ready = false;                  // the window stream and the window sets exist: made by the first packet / step that takes the device form
     //                                      (a decoder of small packets never needs them), entd_windows_make
     uint32_t sub_bits = kEdSubBits;
@@ -3466,12 +3492,26 @@ PFV_API int pfv_decoder_advance_frame(pfv_decoder *d, pfv_video_cb onvideo, void
         rc = e->rc;
         if (rc) rc = fail(d->ctx, rc, rc == PFV_ERR_NOMEM ? "pinned staging for a parsed packet" : "malformed packet payload");
         if (!rc && e->host_parse && !e->dev_form) d->entd.packets_host++;   // a packet of device size the host parser had to read (degenerate table, 64 MiB and more)
-        if (!rc && e->dev_form)
+        if (!rc && e->dev_form) {
             rc = dec_consume_entd(d, e);
-        else if (!rc && e->dense)
+            if (rc && !d->entd.ready && !d->entd.force) {
+                // PFV_ENTROPY_DECODE_AUTO and the window stream / sets could not be made (they are created with the first packet that takes the
+                // device form): the device stage is switched off for this decoder and the host parser reads this packet -- and the ones the
+                // parser threads have already prepared in device form, each when its turn comes.  An error only under PFV_ENTROPY_DECODE_DEVICE.
+                (void)hipGetLastError();
+                d->entd.on = false;
+                dec_parse(d, e);
+                rc = e->rc;
+                if (rc) rc = fail(d->ctx, rc, rc == PFV_ERR_NOMEM ? "pinned staging for a parsed packet" : "malformed packet payload");
+                else d->entd.packets_host++;
+            }
+        }
+        if (rc || e->dev_form)
+            ;
+        else if (e->dense)
             rc = e->type == 1 ? pfv_dec_iframe(d->hot, e->coef.data(), e->qidx)
                               : pfv_dec_pframe(d->hot, e->mv.data(), e->has.data(), e->coef.data(), e->qidx);
-        else if (!rc)
+        else
             rc = e->type == 1 ? pfv_dec_iframe_sparse(d->hot, e->idx.data(), e->val.data(), e->n_sparse, e->qidx)
                               : pfv_dec_pframe_sparse(d->hot, e->mv.data(), e->has.data(), e->idx.data(), e->val.data(),
                                                       e->n_sparse, e->qidx);

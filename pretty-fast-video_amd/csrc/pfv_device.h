@@ -3,6 +3,13 @@
 #pragma once
 #include <stdint.h>
 
+// wavefronts per SIMD a kernel is compiled for (register budget); nothing on the CPU emulator build of the sources
+#ifdef PFV_HIPEMU
+#define PFV_WAVES_PER_EU(n)
+#else
+#define PFV_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+
 namespace pfv {
 
 constexpr int kStripMB = 8;     // macroblocks per wavefront: a 128 x 16 pixel strip, 8 lanes per macroblock

@@ -395,7 +395,11 @@ __global__ void __launch_bounds__(kEdFixThreads) k_entd_fix(EdBufs b, uint32_t n
     }
     const uint32_t *src = (const uint32_t *)(b.bytes + pk.byte_off);
     const uint32_t have = (pk.total_bits + 31u) / 32u + 3u;
-    for (; i < pk.n_sub; i++, at++) {
+    // the repair stops at the end of the seam's OWN group of lanes: running on into the next group's lanes would have two threads of
+    // different workgroups rewrite one lane's (used, end, cnt) triple at the same time; a wrong phase that lives longer than a group leaves the
+    // next seam unsettled, k_entd_verify sees it and the packet goes to the host parser
+    const uint32_t stop = min(pk.n_sub, (grp.y + 1u) * kEdOwn);
+    for (; i < stop; i++, at++) {
         if (b.used[at] == start) break;
         const uint32_t limit = ed_limit(pk, i), w0 = start >> 5;
 #pragma unroll

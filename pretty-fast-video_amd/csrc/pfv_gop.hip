@@ -74,7 +74,7 @@ struct pfv_gop_encoder {
     // ctx: the encoder's OWN launch context (a stream of its own for the batches' kernels); user: the context the caller created the encoder
     // on -- frames that lie in device memory are copied on ITS stream (the *_dev ordering), so the copies of the batch being filled run under
     // the kernels of the batch in flight instead of queueing behind them
-    pfv_ctx *ctx = nullptr, *user = nullptr;
+    pfv_ctx *ctx = nullptr;      // ctx->owner = the caller's context, or nullptr once that has been destroyed
     pfv_enc_session *hot = nullptr;
     int width = 0, height = 0, max_gops = 0, max_len = 0;
     size_t frame_bytes = 0, total_blocks = 0, arena_cap = 0;
@@ -133,7 +133,8 @@ static void gop_put_header(std::vector<uint8_t> &o, int width, int height, int f
 static void gop_enc_take_options(pfv_gop_encoder *e)
 {
     pfv_ctx *k = e->ctx;
-    const pfv_ctx *u = e->user;
+    const pfv_ctx *u = e->ctx->owner;
+    if (!u) return;          // the caller's context is gone: the options stay as they were last taken
     k->opt_enc_transform = u->opt_enc_transform;
     k->opt_tile_compaction = u->opt_tile_compaction;
     k->opt_lane_mapping = u->opt_lane_mapping;
@@ -152,7 +153,8 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
     HIP_TRY(ctx, hipEventRecord(B.ev_uploaded, e->copy_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, B.ev_uploaded, 0));
     if (B.dev_frames) {
-        HIP_TRY(ctx, hipEventRecord(B.ev_dev_frames, e->user->stream));
+        if (!ctx->owner) return fail(ctx, PFV_ERR_STATE, "the context the encoder was created on has been destroyed: its device-frame copies have no stream");
+        HIP_TRY(ctx, hipEventRecord(B.ev_dev_frames, ctx->owner->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, B.ev_dev_frames, 0));
     }
     const size_t pad = (size_t)s->geom.pad_frame_bytes;
@@ -357,7 +359,8 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
         // whatever overwrites it there), and without a host wait: the batch's kernels -- on the encoder's own stream -- wait for an event
         // recorded behind the batch's last copy.  (Round 4 copied on the upload stream and waited for it per frame: 300 waits were a third
         // of the 22 ms a 300-frame 4K clip took; until the encoder had a stream of its own the copies queued behind the previous batch's kernels.)
-        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, e->user->stream));
+        if (!ctx->owner) return fail(ctx, PFV_ERR_STATE, "the context the encoder was created on has been destroyed (pfv_gop_encoder_encode_*_dev copies on its stream)");
+        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, ctx->owner->stream));
         B->dev_frames = true;
         B->order.push_back(GopPacket{(uint8_t)type, slot, t});
         e->frames_in++;
@@ -387,7 +390,7 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
     if (!e) return;
     pfv_ctx *ctx = e->ctx;
     (void)hipSetDevice(ctx->device);
-    if (e->user) (void)hipStreamSynchronize(e->user->stream);      // frame copies into the batch buffers
+    if (ctx->owner) (void)hipStreamSynchronize(ctx->owner->stream);      // frame copies into the batch buffers
     (void)hipStreamSynchronize(ctx->stream);
     if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     for (GopEncBatch &B : e->batch) {
@@ -413,7 +416,11 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
 
 // Encoder::new (src/enc.rs:37-73) + the batch shape.  max_gops: groups per batch = slots per launch; max_gop_frames: frames a group may
 // have inside one batch (a longer run continues in the next batch); payload_budget: bytes of device memory for the packet payloads of
-// ONE batch (0: twice the batch's raw frame bytes, at least 16 MiB) -- a batch whose payloads exceed it fails with PFV_ERR_NOMEM.
+// ONE batch.  0 (default): the FORMAT'S WORST CASE for the batch (pfv_payload_worst_case per frame: two 15-bit codes + 15 value bits per
+// coefficient, 3.75 x the raw bytes) -- no input can outgrow it, so like Encoder::encode_pframe (src/enc.rs:125-173) the object cannot
+// fail for size; real content stays below 1.6 x raw (binary noise at quality 0: 1.52 x) and the unused part of the arena is never touched.
+// Only if that allocation fails does the default fall back to twice the raw bytes.  An explicit budget is kept as given: a batch whose
+// payloads exceed it fails with PFV_ERR_NOMEM and the stream stays incomplete (the caller asked for the bound).
 PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int max_gops, int max_gop_frames,
                                    size_t payload_budget, pfv_gop_encoder **out)
 {
@@ -423,21 +430,27 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
     if (max_gops <= 0 || max_gop_frames <= 0 || max_gops > 4096 || max_gop_frames > 4096)
         return fail(ctx, PFV_ERR_BAD_ARG, "pfv_gop_encoder_create: max_gops and max_gop_frames must be in 1..4096");
     pfv_ctx *user = ctx;
-    int rc = pfv_ctx_create(user->device, &ctx);        // from here on `ctx` is the encoder's own launch context
+    int rc = ctx_create_child(user, &ctx);              // from here on `ctx` is the encoder's own launch context (the caller's device and stream priority)
     if (rc) return fail(user, rc, pfv_last_error(nullptr));
-    ctx->owner = user;
     pfv_enc_session *hot = nullptr;
     rc = pfv_enc_session_create(ctx, width, height, quality, max_gops, &hot);
     if (rc) { pfv_ctx_destroy(ctx); return rc; }
     pfv_gop_encoder *e = new pfv_gop_encoder();
-    e->ctx = ctx; e->user = user; e->hot = hot; e->width = width; e->height = height; e->max_gops = max_gops; e->max_len = max_gop_frames;
+    e->ctx = ctx; e->hot = hot; e->width = width; e->height = height; e->max_gops = max_gops; e->max_len = max_gop_frames;
     e->frame_bytes = pfv_frame_bytes(width, height);
     e->total_blocks = (size_t)pfv_total_blocks(width, height);
     const size_t cap_frames = (size_t)max_gops * (size_t)max_gop_frames, nmb = (size_t)max_gops * e->total_blocks;
-    // default: twice the batch's raw frame bytes -- 16 bits per sample; noise at the finest quantiser costs 10-12 (run code + size code + value
-    // bits), so only pathological tables get near it (the frame-by-frame object sizes for the format's worst case, 31 bits per coefficient)
-    e->arena_cap = payload_budget ? payload_budget : std::max<size_t>(2 * cap_frames * e->frame_bytes, (size_t)16 << 20);
+    const size_t worst = cap_frames * ((pfv_payload_worst_case(width, height) + 15) & ~(size_t)15);
+    const size_t modest = std::max<size_t>(2 * cap_frames * e->frame_bytes, (size_t)16 << 20);      // the fallback when the worst case cannot be had
+    e->arena_cap = payload_budget ? payload_budget : worst;
     e->arena_cap = (e->arena_cap + 15) & ~(size_t)15;
+    if (!payload_budget) {   // both arenas at the worst case, or both at the modest size
+        void *a = nullptr, *b = nullptr;
+        const bool ok = hipMalloc(&a, e->arena_cap) == hipSuccess && hipMalloc(&b, e->arena_cap) == hipSuccess;
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        if (!ok) { (void)hipGetLastError(); e->arena_cap = (std::min(modest, worst) + 15) & ~(size_t)15; }
+    }
     hipError_t he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->down_stream, hipStreamNonBlocking);
     for (GopEncBatch &B : e->batch) {

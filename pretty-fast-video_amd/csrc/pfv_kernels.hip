@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void penc_transform_compact(const FrameGeom &g, const
 // LDS per workgroup: 17 KiB window (+ 16 bytes in front of it: the 1-pixel level reads one dword to the left of the
 // leftmost candidate of the first window row) + 9 KiB reduction regions + 1 KiB quantiser tables.
 template <bool FLT>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PENC_WAVES, PFV_PENC_WAVES))) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(kThreads) PFV_WAVES_PER_EU(PFV_PENC_WAVES) void k_enc_pframe(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs,
@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PFV_PE
 //                   instead of one pass per strip that holds a coded macroblock: no work on skipped slots beyond the last pass's tail.
 // Extra traffic against the fused kernel: a coded macroblock's 256 source bytes and its 256-byte patch are read a second time.
 template <bool DPPRED>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kPsWaves, kPsWaves))) void k_pf_search(FrameGeom g, const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(kThreads) PFV_WAVES_PER_EU(kPsWaves) void k_pf_search(FrameGeom g, const uint8_t *__restrict__ src,
                                                           const uint8_t *__restrict__ ref, int8_t *__restrict__ mv_out,
                                                           uint8_t *__restrict__ has_out, int16_t *__restrict__ coef,
                                                           uint8_t *__restrict__ recon, float min_err, int neg2)
@@ -1579,7 +1579,7 @@ __host__ __device__ __forceinline__ int tf_groups_per_frame(const FrameGeom &g)
 }
 
 template <bool FLT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kTfWaves, kTfWaves))) void k_pf_transform(FrameGeom g, const uint8_t *__restrict__ src, const uint8_t *__restrict__ ref,
+__global__ __launch_bounds__(64) PFV_WAVES_PER_EU(kTfWaves) void k_pf_transform(FrameGeom g, const uint8_t *__restrict__ src, const uint8_t *__restrict__ ref,
                                                      const int8_t *__restrict__ mv, const uint8_t *__restrict__ has, int16_t *__restrict__ coef,
                                                      uint8_t *__restrict__ recon, const QTab *__restrict__ qtabs, float qmagic)
 {

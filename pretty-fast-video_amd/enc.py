@@ -227,12 +227,17 @@ class GopEncoder(Encoder):
         self._flush()
 
     def encode_iframe_dev(self, frame_dev: int):
-        """a packed frame (Y | U | V) that already lies in device memory, complete: pfv_gop_encoder_encode_iframe_dev"""
+        """a packed frame (Y | U | V) in DEVICE memory: pfv_gop_encoder_encode_iframe_dev.  STREAM-ORDERED on the context this encoder was created
+        on, like every *_dev call: the frame is copied into the batch asynchronously on that context's stream and the call returns WITHOUT a host
+        wait.  Whatever produces the frame, and whatever overwrites it afterwards, must be enqueued on the same context's stream (or ordered
+        against it: Context.wait_event) -- a hipMemcpy from the host or a kernel on another stream right after the call races with the copy.
+        The encoder must be closed before its context is."""
         assert not self.finished
         self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_iframe_dev(self.handle, ctypes.c_void_p(int(frame_dev))))
         self._flush()
 
     def encode_pframe_dev(self, frame_dev: int):
+        """see encode_iframe_dev: stream-ordered on the encoder's context, no host wait"""
         assert not self.finished
         self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_pframe_dev(self.handle, ctypes.c_void_p(int(frame_dev))))
         self._flush()

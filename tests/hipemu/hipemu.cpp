@@ -3,6 +3,15 @@
 
 #include <stdio.h>
 
+// clang announces its sanitizers through __has_feature, gcc through macros: one spelling below
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer) && !defined(__SANITIZE_THREAD__)
+#define __SANITIZE_THREAD__ 1
+#endif
+#if __has_feature(address_sanitizer) && !defined(__SANITIZE_ADDRESS__)
+#define __SANITIZE_ADDRESS__ 1
+#endif
+#endif
 // ThreadSanitizer does not follow swapcontext by itself: tell it which fiber runs (tools/sanitize.sh builds this file with -fsanitize=thread)
 #if defined(__SANITIZE_THREAD__)
 extern "C" {

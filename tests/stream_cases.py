@@ -553,7 +553,17 @@ def check_gop_encoder_flush_and_errors(pkg, ctx, oracle, w=64, h=48):
     got_n, _ = encode_pattern(pkg, ctx, oracle, w, h, 10, npat,
                               lambda buf: pkg.GopEncoder(buf, w, h, 30, 10, ctx, max_gops=len(npat) // 8, max_gop_frames=8), src, with_oracle=False)
     assert got_n == serial_n, "GOP encoder: a batch that outgrew its landing zone wrote a different stream"
-    # payload budget: 64 bytes cannot hold an i-frame
+    # no budget given: the arena holds the format's worst case, so the densest content there is -- binary noise at quality 0, 1.5 x the raw
+    # bytes, three times the old default's margin per frame step when the batch is one group of 8 -- goes through like it does through
+    # Encoder::encode_pframe (src/enc.rs:125-173), byte for byte
+    dense = [(rng.integers(0, 2, fb, dtype=np.uint8) * 255) for _ in range(8)]
+    dsrc = lambda t: dense[t % len(dense)]
+    dpat = "IPPPPPPP" * 2
+    serial_d, _ = encode_pattern(pkg, ctx, oracle, w, h, 0, dpat, lambda buf: pkg.Encoder(buf, w, h, 30, 0, ctx), dsrc, with_oracle=False)
+    assert len(serial_d) > 1.3 * len(dpat) * fb, ("binary noise at quality 0 should cost more than its raw bytes", len(serial_d), len(dpat) * fb)
+    got_d, _ = encode_pattern(pkg, ctx, oracle, w, h, 0, dpat, lambda buf: pkg.GopEncoder(buf, w, h, 30, 0, ctx, max_gops=2, max_gop_frames=8), dsrc, with_oracle=False)
+    assert got_d == serial_d, "GOP encoder: dense content wrote a different stream"
+    # an explicit payload budget is kept as given: 64 bytes cannot hold an i-frame
     enc = pkg.GopEncoder(io.BytesIO(), w, h, 30, 5, ctx, max_gops=2, max_gop_frames=4, payload_budget=64)
     enc.encode_iframe(frame_of(pkg, w, h, st.frame(0)))
     with pytest.raises(pkg.PfvError) as e:
