@@ -22,7 +22,7 @@ def build_emulator() -> str:
     emu = os.path.join(ROOT, "tests", "hipemu")
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if os.path.isfile(os.path.join(csrc, f))] + [os.path.join(emu, "hipemu.cpp"),
                                                                 os.path.join(emu, "hip", "hip_runtime.h"),
-                                                                os.path.join(ROOT, "include", "pfv_hip.h")]
+                                                                *[os.path.join(ROOT, "include", h) for h in ("pfv_hip.h", "pfv_hip_core.h", "pfv_hip_ext.h")]]
     defs = os.environ.get("PFV_EMU_DEFS", "").split()      # developer switch: e.g. -DPFV_PENC_PERSISTENT
     lib = EMU_LIB if not defs else EMU_LIB.replace(".so", "_" + "".join(c for c in "".join(defs) if c.isalnum()) + ".so")
     if os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):

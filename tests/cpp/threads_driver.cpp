@@ -8,7 +8,8 @@
 //   pfv_batch_encoder / pfv_batch_decoder   their pools (upload / collection thread; parsers)
 // Check beside the sanitizer's: for every stream, ALL configurations of an object deliver the same frames (a hash per frame), the same
 // number of them and the same final error code -- "per-call results are those of the sequential loop" (src/dec.rs:169-224).
-// usage: threads_driver [n_damaged]     (no input files: the clip is generated here)
+// usage: threads_driver [n_damaged [only_stream]]     (no input files: the clip is generated here; only_stream: run that stream alone --
+// under ThreadSanitizer one process per stream keeps the run inside the runtime's per-process limits on fibers and trace memory)
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
@@ -31,7 +32,7 @@ static uint32_t rnd(uint32_t &s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; retu
 
 int main(int argc, char **argv)
 {
-    const int n_damaged = argc > 1 ? std::atoi(argv[1]) : 6;
+    const int n_damaged = argc > 1 ? std::atoi(argv[1]) : 6, only_stream = argc > 2 ? std::atoi(argv[2]) : -1;
     const size_t w = 96, h = 64;
     const int n_frames = 12, gop = 4, fps = 30, quality = 5;
     try {
@@ -98,6 +99,7 @@ int main(int argc, char **argv)
         auto hash_frame = [](const pfv::VideoFrame &fr) { return fnv(fr.plane_v.pixels, fnv(fr.plane_u.pixels, fnv(fr.plane_y.pixels, 1469598103934665603ull))); };
         int configs = 0;
         for (size_t si = 0; si < streams.size(); si++) {
+            if (only_stream >= 0 && (int)si != only_stream) continue;
             std::vector<Outcome> outs;
             for (int mode : {PFV_ENTROPY_DECODE_HOST, PFV_ENTROPY_DECODE_DEVICE}) {
                 ctx.check(pfv_ctx_set_option(ctx.handle(), PFV_OPT_ENTROPY_DECODE, mode));

@@ -8,9 +8,32 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "pfv_hip.h")).read()
+HEADERS = ("pfv_hip_core.h", "pfv_hip_ext.h")       # pfv_hip.h includes both and declares nothing itself
+
+
+def declared_symbols(headers=HEADERS):
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in headers)
     return sorted(set(re.findall(r"PFV_API\s+[\w\s\*]+?\b(pfv_\w+)\s*\(", text)))
+
+
+def test_header_tiers():
+    """pfv_hip_core.h = the drop-in boundary (what INTEGRATION.md binds): the six plane operators, q-tables, sessions, the frame-at-a-time
+    stream objects, context, geometry -- host pointers only, nothing else; pfv_hip.h declares nothing of its own; both tiers are valid C99"""
+    import subprocess
+    core = declared_symbols(("pfv_hip_core.h",))
+    assert {"pfv_encode_plane", "pfv_encode_plane_delta", "pfv_decode_plane_into", "pfv_decode_plane_delta", "pfv_decode_plane_delta_into",
+            "pfv_qtables_from_quality", "pfv_enc_session_create", "pfv_enc_iframe", "pfv_enc_pframe", "pfv_dec_session_create", "pfv_dec_iframe",
+            "pfv_dec_pframe", "pfv_dec_get_frame", "pfv_encoder_create", "pfv_encoder_encode_pframe", "pfv_decoder_create",
+            "pfv_decoder_advance_frame", "pfv_ctx_create"} <= set(core)
+    assert not [n for n in core if n.endswith("_dev") or n.startswith(("pfv_gop_", "pfv_batch_", "pfv_comm_", "pfv_graph_", "pfv_event_", "pfv_synth_"))], core
+    assert len(core) <= 48
+    assert not set(core) & set(declared_symbols(("pfv_hip_ext.h",)))
+    assert not declared_symbols(("pfv_hip.h",))
+    for h in ("pfv_hip_core.h", "pfv_hip.h"):
+        subprocess.run(["gcc", "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", os.path.join(ROOT, "include", h)], check=True)
+    # every symbol INTEGRATION.md binds from Rust is a core symbol
+    bound = set(re.findall(r"\bfn (pfv_\w+)\(", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert bound and bound <= set(core), bound - set(core)
 
 
 def test_header_symbols_are_all_bound_and_exported(graft, pkg):
