@@ -68,3 +68,29 @@ def test_cpp_mirror_on_gpu(graft, pkg, oracle, tmp_path):
     _build(graft.build_hip(), exe)
     _run(pkg, oracle, exe, tmp_path, 320, 240, 6, n_frames=7, gop=3, drop_at=4)
     _run(pkg, oracle, exe, tmp_path, 1920, 1080, 5, n_frames=3, gop=15, drop_at=-1)
+
+
+def _build_driver(lib_path, exe):
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "threads_driver.cpp"), "-o", exe, lib_path, "-Wl,-rpath," + os.path.dirname(lib_path)], check=True)
+
+
+def test_threads_driver_on_emulator(tmp_path):
+    """tests/cpp/threads_driver.cpp (the program tools/sanitize.sh runs under ThreadSanitizer), plain: every threaded object -- pfv_decoder with
+    0 / 1 / 3 look-ahead threads, pfv_gop_decoder's parse pool and device windows, pfv_gop_encoder, the batch objects -- on the intact stream and on
+    damaged ones, host and device entropy: all configurations deliver the same frames and the same final error"""
+    import conftest
+    exe = str(tmp_path / "threads_driver_emu")
+    _build_driver(conftest.build_emulator(), exe)
+    r = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "threads_driver OK: 4 streams" in r.stdout and "stream 0 (intact): 12 frames, final error 0" in r.stdout
+
+
+@pytest.mark.gpu
+def test_threads_driver_on_gpu(graft, tmp_path):
+    exe = str(tmp_path / "threads_driver")
+    _build_driver(graft.build_hip(), exe)
+    r = subprocess.run([exe, "8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "threads_driver OK: 9 streams" in r.stdout

@@ -20,6 +20,9 @@ lib = conftest.build_emulator()
 exe = os.path.join(out, "roundtrip_san")
 subprocess.run(["g++", "-std=c++17", "-O1", "-g", *flags, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "roundtrip.cpp"), "-o", exe, lib,
                 "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+drv = os.path.join(out, "threads_driver_san")     # every threaded object, intact + damaged streams (one process per stream: tools/sanitize.sh)
+subprocess.run(["g++", "-std=c++17", "-O1", "-g", *flags, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "threads_driver.cpp"), "-o", drv, lib,
+                "-Wl,-rpath," + os.path.dirname(lib)], check=True)
 pkg = g.load_package()
 w, h, n = 64, 48, 12
 st = pkg.SyntheticStream(w, h)
