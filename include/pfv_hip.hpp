@@ -249,7 +249,11 @@ class GopEncoder {
         ctx_.check(pfv_gop_encoder_encode_pframe(h_, f.plane_y.pixels.data(), f.plane_u.pixels.data(), f.plane_v.pixels.data()));
         drain();
     }
-    // a packed frame (Y | U | V) that already lies in device memory, complete when the call is made: nothing crosses PCIe on the way in
+    // device frames are read where they lie instead of being copied into the batch; the caller keeps each one valid and unchanged until its
+    // packet has reached the writer (or flush() / finish() returned)
+    void set_frames_by_reference(bool on) { ctx_.check(pfv_gop_encoder_set_frames_by_reference(h_, on ? 1 : 0)); }
+    // a packed frame (Y | U | V) that already lies in device memory: nothing crosses PCIe on the way in.  Stream-ordered on the context's
+    // stream like every *_dev call: no host wait, the frame may only be overwritten by work enqueued on that stream afterwards
     void encode_iframe_device(const uint8_t *frame_dev)
     {
         ctx_.check(pfv_gop_encoder_encode_iframe_dev(h_, frame_dev));

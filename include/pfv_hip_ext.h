@@ -319,11 +319,10 @@ PFV_API void pfv_batch_decoder_destroy(pfv_batch_decoder *b);
  *   max_gops        runs ("groups") per batch = slots per launch; a group starts at every i-frame
  *   max_gop_frames  frames of a group inside one batch; a longer run continues in the next batch (its reference frame is
  *                   carried over on the device), and so does a stream that starts with p-frames
- *   payload_budget  device bytes for the packet payloads of one batch.  0: the format's worst case for the batch
- *                   (pfv_payload_worst_case per frame, 3.75 x the raw bytes; untouched beyond what real payloads need) -- like
- *                   Encoder::encode_pframe (src/enc.rs:125-173) the object then cannot fail for size; twice the raw bytes if that
- *                   much device memory cannot be had.  An explicit budget is kept as given: PFV_ERR_NOMEM from the call that
- *                   completes a batch whose payloads do not fit it
+ *   payload_budget  device bytes for the packet payloads of one batch.  0: twice the batch's raw frame bytes (real content stays below
+ *                   1.6 x); a batch that outgrows that all the same is encoded again frame by frame and the arena grows -- like
+ *                   Encoder::encode_pframe (src/enc.rs:125-173) the object cannot fail for size.  An explicit budget is kept as given:
+ *                   PFV_ERR_NOMEM from the call that completes a batch whose payloads do not fit it
  * Encoder: the planes may be reused when an encode call returns; frames are uploaded on a copy stream while the kernels of the
  * previous batch run.  A packet reaches pfv_gop_encoder_drain when its batch is complete (max_gops groups seen, flush, finish);
  * the byte stream is the one pfv_encoder writes.  After an error the stream is incomplete and every call returns PFV_ERR_STATE.
@@ -350,6 +349,12 @@ PFV_API int pfv_gop_encoder_encode_pframe(pfv_gop_encoder *e, const uint8_t *y, 
  * batch before it.  PFV_GOP_TRACE=1 in the environment: a host-side log of the encoder's submits, step downloads and arrivals on stderr.) */
 PFV_API int pfv_gop_encoder_encode_iframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
 PFV_API int pfv_gop_encoder_encode_pframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev);
+/* on != 0: frames handed to the two calls above are taken BY REFERENCE -- the batch's kernels read them where they lie, no copy (16-byte
+ * aligned frames; a misaligned one is copied as before).  The caller then promises that such a frame stays valid and unchanged until its batch
+ * has been collected: until the packet of that frame has been handed out by pfv_gop_encoder_drain / _drain_iov, or pfv_gop_encoder_flush /
+ * _finish has returned.  Same bytes.  (The frame-at-a-time contract of Encoder::encode_pframe, src/enc.rs:125 -- the frame is borrowed for
+ * the call only -- is what forces the copy by default; a renderer that keeps a ring of frames does not need it.) */
+PFV_API int pfv_gop_encoder_set_frames_by_reference(pfv_gop_encoder *e, int on);
 PFV_API int pfv_gop_encoder_encode_dropframe(pfv_gop_encoder *e);
 PFV_API int pfv_gop_encoder_flush(pfv_gop_encoder *e);
 PFV_API int pfv_gop_encoder_finish(pfv_gop_encoder *e);
@@ -362,7 +367,8 @@ PFV_API int pfv_gop_encoder_drain_iov(pfv_gop_encoder *e, const pfv_iovec **iov,
 PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e);
 /* where the object's host time went, in seconds since creation (returns the number of entries written, <= n).
  * encoder: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,
- *          [4] packet assembly
+ *          [4] packet assembly; counts: [5] device frames read by reference (pfv_gop_encoder_set_frames_by_reference), [6] batches that
+ *          outgrew their payload arena and were encoded again
  * decoder: [0] header scan, [1] waiting for the packet parsers, [2] waiting for the device before a staging set is reused,
  *          [3] enqueueing, [4] waiting for a batch's last frames, [5] waiting for the device's entropy stage (PFV_OPT_ENTROPY_DECODE);
  *          counts: [6] packets whose payload the device read, [7] packets of such batches that were left to the host parser, of which

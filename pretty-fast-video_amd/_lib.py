@@ -166,6 +166,7 @@ SIGNATURES = [
     ("pfv_gop_encoder_create", c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_size_t, POINTER(_P)]),
     ("pfv_gop_encoder_encode_iframe", c_int, [_P, _P, _P, _P]),
     ("pfv_gop_encoder_encode_pframe", c_int, [_P, _P, _P, _P]),
+    ("pfv_gop_encoder_set_frames_by_reference", c_int, [_P, c_int]),
     ("pfv_gop_encoder_encode_iframe_dev", c_int, [_P, _P]),
     ("pfv_gop_encoder_encode_pframe_dev", c_int, [_P, _P]),
     ("pfv_gop_encoder_encode_dropframe", c_int, [_P]),

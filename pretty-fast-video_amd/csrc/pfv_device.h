@@ -56,7 +56,16 @@ struct FrameGeom {
     int n_streams;
     long src_frame_bytes;   // stride between streams, unpadded frames
     long pad_frame_bytes;   // stride between streams, padded frames
+    // Encoders only, nullptr otherwise: the launch's source frames by POINTER instead of base + stream * src_frame_bytes -- slot s reads the
+    // packed frame at src_slots[s] (a table in device memory).  pfv_gop_encoder's frames that already lie in device memory, taken by
+    // reference (pfv_gop_encoder_set_frames_by_reference) instead of copied into the batch.
+    const uint8_t *const *src_slots;
 };
+// the source frame of `stream` (wave-uniform: the table entry is one scalar load)
+__host__ __device__ inline const uint8_t *frame_src(const FrameGeom &g, const uint8_t *src, int stream)
+{
+    return g.src_slots ? g.src_slots[stream] : src + (long)stream * g.src_frame_bytes;
+}
 
 // Coefficient lists (round 5): a frame's non-zero coefficients instead of its dense [macroblock][256] array -- what the decode kernels
 // take from the decoders' entropy stage (k_entd_emit) and from the host parser (ListSink), so that nothing is cleared, written sparsely and

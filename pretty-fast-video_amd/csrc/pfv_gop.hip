@@ -52,7 +52,15 @@ struct GopEncBatch {
     bool in_flight = false;            // kernels enqueued, payloads not yet collected
     int steps = 0;                     // frame steps enqueued (longest group)
     uint8_t *frames_dev = nullptr;     // [max_gop_frames][max_gops][frame_bytes]
+    // where each frame of the batch lies: its place in frames_dev, or -- device frames taken BY REFERENCE -- the caller's own buffer
+    PinnedBuf<const uint8_t *> slots_host;      // [max_gop_frames][max_gops]
+    const uint8_t **slots_dev = nullptr;
+    bool by_ref = false;               // some frame of the batch is read where the caller left it
     uint8_t *arena = nullptr;          // retained payloads of the batch
+    size_t arena_cap = 0;              // its size: grows (this batch's arena alone) after a batch outgrew it
+    uint8_t *cont_save = nullptr;      // the reference frame slot 0 continued from, saved at submit (one padded frame; allocated with the first such batch):
+    bool cont_saved = false;           //   what a batch that outgrew its arena is encoded again from (gop_enc_redo)
+    std::vector<uint8_t> redo;         // the packets' payloads of such a batch, made again frame by frame; the pending segments point into it
     EntEntry *entries_dev = nullptr;   // [max_gop_frames][max_gops]
     unsigned long long *cursor_dev = nullptr;
     hipEvent_t ev_uploaded = nullptr, ev_done = nullptr, ev_dev_frames = nullptr;
@@ -66,7 +74,7 @@ struct GopEncBatch {
     size_t fetched_bytes = 0;
     PinnedBuf<uint8_t> payload_host;   // the batch's payloads on the host (page-locked): the pending segments point into it
     std::vector<uint8_t> heads;        // 5 bytes per packet of the batch
-    void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; dev_frames = false; steps = 0; steps_fetched = 0; fetched_bytes = 0; }
+    void clear() { len.clear(); first_type.clear(); order.clear(); in_flight = false; dev_frames = false; by_ref = false; steps = 0; steps_fetched = 0; fetched_bytes = 0; }
     int frames() const { int n = 0; for (int l : len) n += l; return n; }
 };
 
@@ -77,7 +85,11 @@ struct pfv_gop_encoder {
     pfv_ctx *ctx = nullptr;      // ctx->owner = the caller's context, or nullptr once that has been destroyed
     pfv_enc_session *hot = nullptr;
     int width = 0, height = 0, max_gops = 0, max_len = 0;
-    size_t frame_bytes = 0, total_blocks = 0, arena_cap = 0;
+    size_t frame_bytes = 0, total_blocks = 0, arena_cap = 0;       // arena_cap: what a batch's arena starts with
+    bool explicit_budget = false;          // the caller gave pfv_gop_encoder_create a payload budget: outgrowing it is an error, not a reason to grow
+    int quality = 0;
+    long batches_redone = 0;
+    std::vector<uint32_t> redo_sizes;      // payload bytes of the packets of the batch made again, in stream order (drop frames left out)
     GopEncBatch batch[2];
     int cur = 0;                           // batch being filled
     hipStream_t copy_stream = nullptr;     // plane uploads
@@ -95,7 +107,8 @@ struct pfv_gop_encoder {
     std::vector<pfv_iovec> segs, segs_drained;
     unsigned segs_in = 0;                  // bit b: pending segments point into batch[b]'s landing zone / header bytes
     bool finished = false, failed = false;
-    long frames_in = 0, batches = 0;
+    bool frames_by_ref = false;            // pfv_gop_encoder_set_frames_by_reference
+    long frames_in = 0, batches = 0, frames_by_reference = 0;
     // seconds: [0] waiting for plane uploads, [1] enqueueing batches, [2] waiting for a batch's kernels, [3] payloads device -> host,
     // [4] packet assembly
     double stats[5] = {0, 0, 0, 0, 0};
@@ -158,12 +171,20 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, B.ev_dev_frames, 0));
     }
     const size_t pad = (size_t)s->geom.pad_frame_bytes;
+    B.cont_saved = false;
     if (B.first_type[0] == 2 && e->cont_valid) {   // slot 0 continues the run the previous batch left open: carry its reference frame over
         const uint8_t *src = s->prev[e->cont_buf] + (size_t)e->cont_slot * pad;
         uint8_t *dst = s->prev[s->cur];
         if (src != dst) HIP_TRY(ctx, hipMemcpyAsync(dst, src, pad, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!e->explicit_budget) {                 // and keep a copy: what the batch is encoded again from should it outgrow its arena
+            if (!B.cont_save) HIP_TRY(ctx, hipMalloc((void **)&B.cont_save, pad));
+            HIP_TRY(ctx, hipMemcpyAsync(B.cont_save, src, pad, hipMemcpyDeviceToDevice, ctx->stream));
+            B.cont_saved = true;
+        }
     }
     HIP_TRY(ctx, hipMemsetAsync(B.cursor_dev, 0, sizeof(unsigned long long), ctx->stream));
+    if (B.by_ref)    // the batch's table of frame pointers (page-locked -> device, ahead of the kernels on their stream)
+        HIP_TRY(ctx, hipMemcpyAsync(B.slots_dev, B.slots_host.data(), (size_t)e->max_len * (size_t)e->max_gops * sizeof(const uint8_t *), hipMemcpyHostToDevice, ctx->stream));
     int steps = 0;
     for (int l : B.len) steps = std::max(steps, l);
     const int cur0 = s->cur;
@@ -175,14 +196,14 @@ static int gop_enc_submit(pfv_gop_encoder *e, GopEncBatch &B)
         const uint8_t *frames_t = B.frames_dev + (size_t)t * (size_t)e->max_gops * e->frame_bytes;
         int rc = PFV_OK;
         gop_runs(key, [&](int first, int count, int type) {
-            if (!rc) rc = enc_launch(s, type == 2, first, count, frames_t, e->mv, e->has, e->coef);
+            if (!rc) rc = enc_launch(s, type == 2, first, count, frames_t, e->mv, e->has, e->coef, B.by_ref ? B.slots_dev + (size_t)t * (size_t)e->max_gops : nullptr);
             if (!rc) rc = ent_pack_win(s, type == 2, first, count, e->mv, e->has, e->coef);
             if (rc) return;
             EntEntry *ent = B.entries_dev + (size_t)t * (size_t)e->max_gops + (size_t)first;
             EntBufs b = s->ent;
             b.sizes += first;
             b.payload += (size_t)first * (size_t)s->ent_cap;
-            hipLaunchKernelGGL(k_ent_retain, dim3(1), dim3(64), 0, ctx->stream, b.sizes, count, B.cursor_dev, (unsigned long long)e->arena_cap, ent, B.cursor_steps.data() + t);
+            hipLaunchKernelGGL(k_ent_retain, dim3(1), dim3(64), 0, ctx->stream, b.sizes, count, B.cursor_dev, (unsigned long long)B.arena_cap, ent, B.cursor_steps.data() + t);
             f.n_streams = count;
             hipLaunchKernelGGL(k_ent_gather_entries, dim3(32, (unsigned)count), dim3(kEntThreads), 0, ctx->stream, f, b, ent, B.arena);
             rc = launch_check(ctx, "k_ent_retain / k_ent_gather_entries");
@@ -230,12 +251,12 @@ static int gop_enc_fetch(pfv_gop_encoder *e, GopEncBatch &B, bool wait)
         hipEvent_t ev = B.ev_step[(size_t)B.steps_fetched];
         if (wait) HIP_TRY(ctx, hipEventSynchronize(ev));
         else if (hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); break; }
-        const size_t upto = std::min((size_t)B.cursor_steps.data()[B.steps_fetched], e->arena_cap);
+        const size_t upto = std::min((size_t)B.cursor_steps.data()[B.steps_fetched], B.arena_cap);
         if (upto > B.payload_host.size()) {
             // the landing zone is too small (page-locking is slow: it grows in big steps): what has arrived moves to the new one
             HIP_TRY(ctx, hipStreamSynchronize(e->down_stream));
             PinnedBuf<uint8_t> bigger;
-            if (!bigger.resize(std::min(e->arena_cap, upto + upto / 2 + ((size_t)4 << 20)))) return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
+            if (!bigger.resize(std::min(B.arena_cap, upto + upto / 2 + ((size_t)4 << 20)))) return fail(ctx, PFV_ERR_NOMEM, "pinned payload staging");
             memcpy(bigger.data(), B.payload_host.data(), B.fetched_bytes);
             B.payload_host.swap(bigger);
         }
@@ -246,6 +267,60 @@ static int gop_enc_fetch(pfv_gop_encoder *e, GopEncBatch &B, bool wait)
         e->trace(wait ? "download issued (waited): step, bytes" : "download issued (polled): step, bytes", B.steps_fetched, (long)(upto - std::min(upto, B.fetched_bytes)));
         B.fetched_bytes = std::max(B.fetched_bytes, upto);
         B.steps_fetched++;
+    }
+    return PFV_OK;
+}
+
+// A batch whose payloads outgrew its arena (default budget): every packet of it is made again, one frame at a time, on a one-stream session of
+// its own -- the frames still lie where the batch read them (its frame array, or the caller's buffers under the by-reference contract), a
+// group starts with an i-frame or, slot 0, from the reference frame saved at submit.  Same arithmetic, same bytes; serial and slow, which is
+// fine for what is at most a once-per-content event: the batch's arena then grows so that the batches behind it fit.
+static int gop_enc_redo(pfv_gop_encoder *e, GopEncBatch &B)
+{
+    pfv_ctx *ctx = e->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the batch behind this one may be running: it shares coef / mv / has with the pass below
+    HIP_TRY(ctx, hipStreamSynchronize(e->down_stream));
+    pfv_enc_session *r = nullptr;
+    int rc = pfv_enc_session_create(ctx, e->width, e->height, e->quality, 1, &r);
+    if (!rc) rc = pfv_enc_entropy_enable(r, 0);
+    B.redo.clear();
+    e->redo_sizes.clear();
+    const size_t pad = (size_t)e->hot->geom.pad_frame_bytes;
+    int last_slot = -1;
+    for (size_t i = 0; !rc && i < B.order.size(); i++) {
+        const GopPacket &p = B.order[i];
+        if (p.type == 3) continue;
+        if (p.slot != last_slot && p.type == 2) {             // a group that starts with a p-frame: slot 0 continuing the run before the batch
+            if (B.cont_saved) rc = hipMemcpyAsync((void *)pfv_enc_prev_frame_dev(r, 0), B.cont_save, pad, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? PFV_OK : hip_fail(ctx, hipGetLastError(), "gop_enc_redo");
+            // (no saved frame: the stream itself starts with p-frames, and a new session's prev_frame is the state they start from, src/frame.rs:38-43)
+        }
+        last_slot = p.slot;
+        const uint8_t *f = B.slots_host.data()[(size_t)p.t * (size_t)e->max_gops + (size_t)p.slot];
+        if (!rc) rc = p.type == 1 ? pfv_enc_iframe_dev(r, f, e->coef) : pfv_enc_pframe_dev(r, f, e->mv, e->has, e->coef);
+        if (!rc) rc = p.type == 1 ? pfv_enc_pack_iframe_dev(r, e->coef) : pfv_enc_pack_pframe_dev(r, e->mv, e->has, e->coef);
+        uint32_t size = 0;
+        if (!rc) rc = pfv_enc_payload_sizes(r, &size);          // synchronises; PFV_ERR_FORMAT for a coefficient of more than 15 size bits
+        if (rc) break;
+        const size_t at = B.redo.size();
+        B.redo.resize(at + size);
+        if (size) rc = pfv_enc_payload_fetch(r, 0, B.redo.data() + at, size);
+        e->redo_sizes.push_back(size);
+    }
+    pfv_enc_session_destroy(r);
+    if (rc) return rc;
+    e->batches_redone++;
+    // this batch's arena for the batches to come: one and a half times what the batch needed (every payload on a 16-byte boundary)
+    const size_t need = B.redo.size() + 16 * e->redo_sizes.size();
+    const size_t want = ((need + need / 2) + 15) & ~(size_t)15;
+    if (want > B.arena_cap) {
+        uint8_t *bigger = nullptr;
+        if (hipMalloc((void **)&bigger, want) == hipSuccess) {
+            (void)hipFree(B.arena);
+            B.arena = bigger;
+            B.arena_cap = want;
+        } else {
+            (void)hipGetLastError();                            // it stays as it is; the next batch that outgrows it is made again like this one
+        }
     }
     return PFV_OK;
 }
@@ -283,6 +358,29 @@ static int gop_enc_collect(pfv_gop_encoder *e, GopEncBatch &B)
         const uint32_t sz = e->entries_host.data()[(size_t)p.t * (size_t)e->max_gops + (size_t)p.slot].size;
         if (sz == kEntErrOversize) rc = PFV_ERR_FORMAT;
         else if (sz == kEntErrCapacity && rc == PFV_OK) rc = PFV_ERR_NOMEM;
+    }
+    if (rc == PFV_ERR_NOMEM && !e->explicit_budget) {
+        // the batch outgrew its arena and nobody asked for a bound: Encoder::encode_pframe cannot fail for size (src/enc.rs:125-173), so the
+        // batch's packets are made again, frame by frame, and this arena grows for the batches to come
+        rc = gop_enc_redo(e, B);
+        if (rc) { e->failed = true; return rc; }
+        e->stats[3] += clk.lap();
+        B.heads.resize(B.order.size() * 5);
+        e->segs_in |= slot_bit;
+        size_t hi = 0, k = 0, off = 0;
+        for (const GopPacket &p : B.order) {      // packets in stream order: 5 header bytes, then the payload where gop_enc_redo left it
+            uint8_t *h = &B.heads[hi];
+            hi += 5;
+            if (p.type == 3) { h[0] = 1; h[1] = h[2] = h[3] = h[4] = 0; e->segs.push_back(pfv_iovec{h, 5}); continue; }
+            const uint32_t size = e->redo_sizes[k++];
+            h[0] = p.type; h[1] = (uint8_t)size; h[2] = (uint8_t)(size >> 8); h[3] = (uint8_t)(size >> 16); h[4] = (uint8_t)(size >> 24);
+            e->segs.push_back(pfv_iovec{h, 5});
+            if (size) e->segs.push_back(pfv_iovec{B.redo.data() + off, (size_t)size});
+            off += size;
+        }
+        e->stats[4] += clk.lap();
+        B.clear();
+        return PFV_OK;
     }
     if (rc) {
         e->failed = true;
@@ -352,6 +450,7 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
     const int slot = (int)B->len.size() - 1, t = B->len.back()++;
     // the three planes go straight to their place in the step's frame array (VideoFrame, src/frame.rs:3-9: no packing on the host)
     uint8_t *dst = B->frames_dev + ((size_t)t * (size_t)e->max_gops + (size_t)slot) * e->frame_bytes;
+    B->slots_host.data()[(size_t)t * (size_t)e->max_gops + (size_t)slot] = dst;
     const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;   // *_dev: a frame that is in device memory already
     if (on_device) {
@@ -360,7 +459,15 @@ static int gop_enc_frame_inner(pfv_gop_encoder *e, int type, const uint8_t *y, c
         // recorded behind the batch's last copy.  (Round 4 copied on the upload stream and waited for it per frame: 300 waits were a third
         // of the 22 ms a 300-frame 4K clip took; until the encoder had a stream of its own the copies queued behind the previous batch's kernels.)
         if (!ctx->owner) return fail(ctx, PFV_ERR_STATE, "the context the encoder was created on has been destroyed (pfv_gop_encoder_encode_*_dev copies on its stream)");
-        HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, ctx->owner->stream));
+        if (e->frames_by_ref && ((uintptr_t)y & 15) == 0) {
+            // by reference: no copy at all -- the step's kernels read the frame where it lies (FrameGeom::src_slots).  The caller keeps it
+            // valid and unchanged until the batch has been collected (pfv_hip_ext.h: pfv_gop_encoder_set_frames_by_reference)
+            B->slots_host.data()[(size_t)t * (size_t)e->max_gops + (size_t)slot] = y;
+            B->by_ref = true;
+            e->frames_by_reference++;
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(dst, y, ny + 2 * nc, kind, ctx->owner->stream));
+        }
         B->dev_frames = true;
         B->order.push_back(GopPacket{(uint8_t)type, slot, t});
         e->frames_in++;
@@ -396,7 +503,9 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
     for (GopEncBatch &B : e->batch) {
         if (B.entries_dev) (void)hipFree(B.entries_dev);
         if (B.frames_dev) (void)hipFree(B.frames_dev);
+        if (B.slots_dev) (void)hipFree(B.slots_dev);
         if (B.arena) (void)hipFree(B.arena);
+        if (B.cont_save) (void)hipFree(B.cont_save);
         if (B.cursor_dev) (void)hipFree(B.cursor_dev);
         if (B.ev_uploaded) (void)hipEventDestroy(B.ev_uploaded);
         if (B.ev_done) (void)hipEventDestroy(B.ev_done);
@@ -416,11 +525,10 @@ PFV_API void pfv_gop_encoder_destroy(pfv_gop_encoder *e)
 
 // Encoder::new (src/enc.rs:37-73) + the batch shape.  max_gops: groups per batch = slots per launch; max_gop_frames: frames a group may
 // have inside one batch (a longer run continues in the next batch); payload_budget: bytes of device memory for the packet payloads of
-// ONE batch.  0 (default): the FORMAT'S WORST CASE for the batch (pfv_payload_worst_case per frame: two 15-bit codes + 15 value bits per
-// coefficient, 3.75 x the raw bytes) -- no input can outgrow it, so like Encoder::encode_pframe (src/enc.rs:125-173) the object cannot
-// fail for size; real content stays below 1.6 x raw (binary noise at quality 0: 1.52 x) and the unused part of the arena is never touched.
-// Only if that allocation fails does the default fall back to twice the raw bytes.  An explicit budget is kept as given: a batch whose
-// payloads exceed it fails with PFV_ERR_NOMEM and the stream stays incomplete (the caller asked for the bound).
+// ONE batch.  0 (default): twice the batch's raw frame bytes (at least 16 MiB) -- real content stays below 1.6 x raw (binary noise at
+// quality 0: 1.52 x); a batch that outgrows its arena all the same is encoded again frame by frame (gop_enc_redo) and the arena grows, so like
+// Encoder::encode_pframe (src/enc.rs:125-173) the object cannot fail for size.  An explicit budget is kept as given: a batch whose payloads
+// exceed it fails with PFV_ERR_NOMEM and the stream stays incomplete (the caller asked for the bound).
 PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int framerate, int quality, int max_gops, int max_gop_frames,
                                    size_t payload_budget, pfv_gop_encoder **out)
 {
@@ -440,17 +548,14 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
     e->frame_bytes = pfv_frame_bytes(width, height);
     e->total_blocks = (size_t)pfv_total_blocks(width, height);
     const size_t cap_frames = (size_t)max_gops * (size_t)max_gop_frames, nmb = (size_t)max_gops * e->total_blocks;
-    const size_t worst = cap_frames * ((pfv_payload_worst_case(width, height) + 15) & ~(size_t)15);
-    const size_t modest = std::max<size_t>(2 * cap_frames * e->frame_bytes, (size_t)16 << 20);      // the fallback when the worst case cannot be had
-    e->arena_cap = payload_budget ? payload_budget : worst;
+    // default: twice the batch's raw frame bytes -- real content stays below 1.6 x (binary noise at quality 0: 1.52 x); a batch that outgrows
+    // its arena all the same is encoded again frame by frame and the arena grows (gop_enc_redo): the object cannot fail for size.  An explicit
+    // budget is kept as given.  PFV_TEST_GOP_ARENA_BYTES (tests only): a default small enough for ordinary content to outgrow.
+    e->explicit_budget = payload_budget != 0;
+    e->quality = quality;
+    e->arena_cap = payload_budget ? payload_budget : std::max<size_t>(2 * cap_frames * e->frame_bytes, (size_t)16 << 20);
+    if (!payload_budget && getenv("PFV_TEST_GOP_ARENA_BYTES")) e->arena_cap = std::max<size_t>(64, strtoull(getenv("PFV_TEST_GOP_ARENA_BYTES"), nullptr, 10));
     e->arena_cap = (e->arena_cap + 15) & ~(size_t)15;
-    if (!payload_budget) {   // both arenas at the worst case, or both at the modest size
-        void *a = nullptr, *b = nullptr;
-        const bool ok = hipMalloc(&a, e->arena_cap) == hipSuccess && hipMalloc(&b, e->arena_cap) == hipSuccess;
-        if (a) (void)hipFree(a);
-        if (b) (void)hipFree(b);
-        if (!ok) { (void)hipGetLastError(); e->arena_cap = (std::min(modest, worst) + 15) & ~(size_t)15; }
-    }
     hipError_t he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->down_stream, hipStreamNonBlocking);
     for (GopEncBatch &B : e->batch) {
@@ -461,7 +566,9 @@ PFV_API int pfv_gop_encoder_create(pfv_ctx *ctx, int width, int height, int fram
         }
         if (he == hipSuccess && (!B.cursor_steps.resize((size_t)max_gop_frames) || !B.cursor_steps.pinned)) he = hipErrorOutOfMemory;   // k_ent_retain stores to it
         if (he == hipSuccess) he = hipMalloc((void **)&B.frames_dev, cap_frames * e->frame_bytes);
-        if (he == hipSuccess) he = hipMalloc((void **)&B.arena, e->arena_cap);
+        if (he == hipSuccess) he = hipMalloc((void **)&B.slots_dev, cap_frames * sizeof(const uint8_t *));
+        if (he == hipSuccess && (!B.slots_host.resize(cap_frames) || !B.slots_host.pinned)) he = hipErrorOutOfMemory;
+        if (he == hipSuccess) { he = hipMalloc((void **)&B.arena, e->arena_cap); B.arena_cap = e->arena_cap; }
         if (he == hipSuccess) he = hipMalloc((void **)&B.entries_dev, cap_frames * sizeof(EntEntry));
         if (he == hipSuccess) he = hipMalloc((void **)&B.cursor_dev, sizeof(unsigned long long));
         if (he == hipSuccess) he = hipEventCreateWithFlags(&B.ev_uploaded, hipEventDisableTiming);
@@ -501,6 +608,15 @@ static int gop_enc_frame_dev(pfv_gop_encoder *e, int type, const uint8_t *frame_
     if (!e || !frame_dev) return fail(e ? e->ctx : nullptr, PFV_ERR_BAD_ARG, "pfv_gop_encoder_encode_*_dev: bad argument");
     const size_t ny = (size_t)e->width * e->height, nc = (size_t)(e->width / 2) * (e->height / 2);
     return gop_enc_frame(e, type, frame_dev, frame_dev + ny, frame_dev + ny + nc, true);
+}
+// Frames handed to the *_dev calls are read WHERE THEY LIE instead of being copied into the batch (16-byte aligned frames; others are copied as
+// before).  The caller promises that such a frame stays valid and unchanged until its batch has been collected: until the packet of that frame
+// has been handed out (pfv_gop_encoder_drain*), or pfv_gop_encoder_flush / _finish has returned.  Same bytes.
+PFV_API int pfv_gop_encoder_set_frames_by_reference(pfv_gop_encoder *e, int on)
+{
+    if (!e) return fail(nullptr, PFV_ERR_BAD_ARG, "null encoder");
+    e->frames_by_ref = on != 0;
+    return PFV_OK;
 }
 PFV_API int pfv_gop_encoder_encode_iframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev) { return gop_enc_frame_dev(e, 1, frame_dev); }
 PFV_API int pfv_gop_encoder_encode_pframe_dev(pfv_gop_encoder *e, const uint8_t *frame_dev) { return gop_enc_frame_dev(e, 2, frame_dev); }
@@ -579,8 +695,8 @@ PFV_API long pfv_gop_encoder_batches(const pfv_gop_encoder *e) { return e ? e->b
 PFV_API int pfv_gop_encoder_stats(const pfv_gop_encoder *e, double *out, int n)
 {
     if (!e || !out) return 0;
-    const int k = std::min(n, 5);
-    for (int i = 0; i < k; i++) out[i] = e->stats[i];
+    const int k = std::min(n, 7);
+    for (int i = 0; i < k; i++) out[i] = i < 5 ? e->stats[i] : (i == 5 ? (double)e->frames_by_reference : (double)e->batches_redone);
     return k;
 }
 

@@ -828,7 +828,7 @@ __global__ __launch_bounds__(kThreads) void k_enc_iframe(FrameGeom g, const uint
     int *xw = xchg[wave];
 
     fill_qtable<true, FLT>(qtab_lds[wave], qtabs + p.qsel, lane);
-    const uint8_t *plane = src + (long)sp.stream * g.src_frame_bytes + p.src_off;
+    const uint8_t *plane = frame_src(g, src, sp.stream) + p.src_off;
     uint4 rows[kPasses];
 #pragma unroll
     for (int pass = 0; pass < kPasses; pass++) rows[pass] = load_src16(plane, p, sp.x0 + m * 16, sp.y0 + i + 8 * (LPM == 8 ? pass : (slot & 1)));
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(kThreads) PFV_WAVES_PER_EU(PFV_PENC_WAVES) void k_e
     uint4 rows[2];
     rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) {
-        const uint8_t *plane = src + (long)cur.sp.stream * g.src_frame_bytes + p.src_off;
+        const uint8_t *plane = frame_src(g, src, cur.sp.stream) + p.src_off;
         rows[0] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i);
         rows[1] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i + 8);
     }
@@ -1547,7 +1547,7 @@ __global__ __launch_bounds__(kThreads) PFV_WAVES_PER_EU(kPsWaves) void k_pf_sear
     uint4 rows[2];
     rows[0] = rows[1] = make_uint4(0, 0, 0, 0);
     if (cur.wave_valid) {
-        const uint8_t *plane = src + (long)cur.sp.stream * g.src_frame_bytes + p.src_off;
+        const uint8_t *plane = frame_src(g, src, cur.sp.stream) + p.src_off;
         rows[0] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i);
         rows[1] = load_src16(plane, p, cur.sp.x0 + m * 16, cur.sp.y0 + i + 8);
     }
@@ -1624,7 +1624,7 @@ __global__ __launch_bounds__(64) PFV_WAVES_PER_EU(kTfWaves) void k_pf_transform(
     wave_lds_sync();
 
     const LaneQ lq{qtab_lds, i};
-    const uint8_t *splane = src + (long)stream * g.src_frame_bytes + p.src_off;
+    const uint8_t *splane = frame_src(g, src, stream) + p.src_off;
     const uint8_t *rplane = ref + (long)stream * g.pad_frame_bytes + p.pad_off;
     uint8_t *oplane = recon ? recon + (long)stream * g.pad_frame_bytes + p.pad_off : nullptr;
     int16_t *coef_frame = coef + (long)stream * g.mbs_per_frame * 256;
@@ -1844,7 +1844,7 @@ __global__ __launch_bounds__(kThreads16) void k_enc_pframe16(FrameGeom g, const 
     const bool wave_valid = cur.wave_valid && half_strip * 4 < cur.sp.n_mb;
     const bool mb_valid = wave_valid && m < cur.sp.n_mb;
     uint4 row = make_uint4(0, 0, 0, 0);
-    if (wave_valid) row = load_src16(src + (long)cur.sp.stream * g.src_frame_bytes + p.src_off, p, cur.sp.x0 + m * 16, cur.sp.y0 + r);
+    if (wave_valid) row = load_src16(frame_src(g, src, cur.sp.stream) + p.src_off, p, cur.sp.x0 + m * 16, cur.sp.y0 + r);
     __syncthreads();   // window complete
     int cx = 0, cy = 0;
     bool coded = false;

@@ -219,14 +219,17 @@ static FrameGeom enc_win_geom(const pfv_enc_session *s, int count, const uint8_t
     }
     return with_base_alignment(g, frames_win);
 }
+// slots_dev (pfv_gop_encoder with frames taken by reference): a device table of one frame pointer per slot, every pointer 16-byte aligned;
+// slot k of the session reads the packed frame at slots_dev[k] instead of frames_dev + k * stride
 static int enc_launch(pfv_enc_session *s, bool pframe, int first, int count, const uint8_t *frames_dev, int8_t *mv_dev, uint8_t *has_dev,
-                      int16_t *coef_dev)
+                      int16_t *coef_dev, const uint8_t *const *slots_dev = nullptr)
 {
     pfv_ctx *ctx = s->ctx;
     const size_t stride = s->in_stride ? s->in_stride : (size_t)s->geom.src_frame_bytes;
     const uint8_t *src = frames_dev + (size_t)first * stride;
     const size_t mb0 = (size_t)first * (size_t)s->geom.mbs_per_frame, pad0 = (size_t)first * (size_t)s->geom.pad_frame_bytes;
-    const FrameGeom g = enc_win_geom(s, count, src);
+    FrameGeom g = enc_win_geom(s, count, src);
+    if (slots_dev) g.src_slots = slots_dev + first;
     const int nxt = s->cur ^ 1;
     if (pframe) {
         const float min_err = s->px_err * s->px_err * 256.0f;   // src/common.rs:209

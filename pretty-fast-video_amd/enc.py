@@ -226,6 +226,11 @@ class GopEncoder(Encoder):
         self.ctx.check(self.ctx._lib.pfv_gop_encoder_encode_pframe(self.handle, *self._planes(frame)))
         self._flush()
 
+    def set_frames_by_reference(self, on: bool = True):
+        """device frames (encode_*_dev) are read where they lie instead of being copied into the batch: the caller keeps each frame valid and
+        unchanged until its packet has reached the writer (or flush() / finish() returned).  pfv_gop_encoder_set_frames_by_reference."""
+        self.ctx.check(self.ctx._lib.pfv_gop_encoder_set_frames_by_reference(self.handle, 1 if on else 0))
+
     def encode_iframe_dev(self, frame_dev: int):
         """a packed frame (Y | U | V) in DEVICE memory: pfv_gop_encoder_encode_iframe_dev.  STREAM-ORDERED on the context this encoder was created
         on, like every *_dev call: the frame is copied into the batch asynchronously on that context's stream and the call returns WITHOUT a host
@@ -263,9 +268,10 @@ class GopEncoder(Encoder):
 
     def stats(self) -> dict:
         """host seconds so far, by what the object was waiting for (pfv_gop_encoder_stats)"""
-        a = (ctypes.c_double * 5)()
-        n = self.ctx._lib.pfv_gop_encoder_stats(self.handle, a, 5)
-        return dict(zip(("upload_wait_s", "enqueue_s", "kernel_wait_s", "payload_download_s", "packet_assembly_s"), list(a)[:n]))
+        a = (ctypes.c_double * 7)()
+        n = self.ctx._lib.pfv_gop_encoder_stats(self.handle, a, 7)
+        return dict(zip(("upload_wait_s", "enqueue_s", "kernel_wait_s", "payload_download_s", "packet_assembly_s", "frames_by_reference", "batches_redone"),
+                        list(a)[:n]))
 
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:

@@ -3,6 +3,7 @@ Encoder/Decoder (device hot path + host entropy/container) against the CPU oracl
 from __future__ import annotations
 
 import io
+import os
 
 import numpy as np
 
@@ -400,8 +401,9 @@ def _outcomes(make_decoder, pkg, n_calls=96, stop_at_error=True):
     return out
 
 
-def encode_pattern(pkg, ctx, oracle, w, h, quality, pattern, make_encoder, frame_src=None, threads=1, with_oracle=True):
-    """pattern: a string of 'I' / 'P' / 'D' (drop frame), one per packet.  Returns (product bytes, oracle bytes or None)."""
+def encode_pattern(pkg, ctx, oracle, w, h, quality, pattern, make_encoder, frame_src=None, threads=1, with_oracle=True, keep_open=False):
+    """pattern: a string of 'I' / 'P' / 'D' (drop frame), one per packet.  Returns (product bytes, oracle bytes or None).  keep_open: the
+    encoder is finished but not closed (the caller wants its statistics)"""
     if frame_src is None:
         frame_src = pkg.SyntheticStream(w, h).frame
     buf = io.BytesIO()
@@ -423,7 +425,8 @@ def encode_pattern(pkg, ctx, oracle, w, h, quality, pattern, make_encoder, frame
             if oenc: oenc.encode_pframe(f)
     enc.finish()
     if oenc: oenc.finish()
-    enc.close()
+    if not keep_open:
+        enc.close()
     return buf.getvalue(), (oenc.bytes() if oenc else None)
 
 
@@ -464,6 +467,36 @@ def check_gop_objects(pkg, ctx, oracle, w, h, quality, pattern, shapes, frame_sr
         denc.close()
         ctx.free(dev)
         assert dbuf.getvalue() == serial, "GOP-batched encoder fed from device memory wrote a different .pfv stream"
+        # ... and BY REFERENCE (pfv_gop_encoder_set_frames_by_reference): every frame of the clip stays resident where the caller put it, the
+        # batches' kernels read it there; one misaligned frame in between falls back to the copy.  For every batch shape.
+        n_coded = sum(1 for c in pattern if c != "D")
+        stride = (fbytes + 15) // 16 * 16 + 16                                        # every frame at a 16-byte aligned address of its own
+        clip = ctx.alloc(n_coded * stride + 64)
+        for shape_no, (max_gops, max_len) in enumerate(list(shapes) + [shapes[0]]):
+            tiny_arena = shape_no == len(shapes)            # once more with an arena every batch outgrows: made again FROM the caller's frames
+            rbuf = io.BytesIO()
+            if tiny_arena:
+                os.environ["PFV_TEST_GOP_ARENA_BYTES"] = "2048"
+            try:
+                renc = pkg.GopEncoder(rbuf, w, h, 30, quality, ctx, max_gops=max_gops, max_gop_frames=max_len)
+            finally:
+                os.environ.pop("PFV_TEST_GOP_ARENA_BYTES", None)
+            renc.set_frames_by_reference(True)
+            t = 0
+            for c in pattern:
+                if c == "D":
+                    renc.encode_dropframe()
+                    continue
+                at = clip + t * stride + (8 if t == 2 else 0)                         # frame 2 at an address that is not 16-byte aligned: copied
+                ctx.upload(at, np.ascontiguousarray(src(t)))
+                (renc.encode_iframe_dev if c == "I" else renc.encode_pframe_dev)(at)
+                t += 1
+            renc.finish()
+            assert renc.stats()["frames_by_reference"] == n_coded - (1 if n_coded > 2 else 0), renc.stats()      # all but the misaligned one
+            assert not tiny_arena or renc.stats()["batches_redone"] >= 1
+            renc.close()
+            assert rbuf.getvalue() == serial, f"GOP-batched encoder reading device frames by reference (max_gops {max_gops}, max_gop_frames {max_len}) wrote a different stream"
+        ctx.free(clip)
     # frames left in device memory (pfv_gop_decoder_set_output_device): the same bytes, fetched from the addresses the callback gets
     max_gops, max_len = shapes[-1]
     fb = w * h + 2 * (w // 2) * (h // 2)
@@ -553,16 +586,30 @@ def check_gop_encoder_flush_and_errors(pkg, ctx, oracle, w=64, h=48):
     got_n, _ = encode_pattern(pkg, ctx, oracle, w, h, 10, npat,
                               lambda buf: pkg.GopEncoder(buf, w, h, 30, 10, ctx, max_gops=len(npat) // 8, max_gop_frames=8), src, with_oracle=False)
     assert got_n == serial_n, "GOP encoder: a batch that outgrew its landing zone wrote a different stream"
-    # no budget given: the arena holds the format's worst case, so the densest content there is -- binary noise at quality 0, 1.5 x the raw
-    # bytes, three times the old default's margin per frame step when the batch is one group of 8 -- goes through like it does through
-    # Encoder::encode_pframe (src/enc.rs:125-173), byte for byte
+    # no budget given: a batch that outgrows its arena is encoded again frame by frame and the arena grows -- like Encoder::encode_pframe
+    # (src/enc.rs:125-173) the object cannot fail for size.  Real content never outgrows the default (binary noise at quality 0, the densest
+    # there is: 1.5 x the raw bytes against the default's 2 x), so PFV_TEST_GOP_ARENA_BYTES (tests only) shrinks the default: batches of
+    # every kind go through the redo -- a run cut in the middle (slot 0 continues from the saved reference frame), drop frames, leading
+    # p-frames, device frames by reference -- and write the serial encoder's bytes.
     dense = [(rng.integers(0, 2, fb, dtype=np.uint8) * 255) for _ in range(8)]
     dsrc = lambda t: dense[t % len(dense)]
-    dpat = "IPPPPPPP" * 2
-    serial_d, _ = encode_pattern(pkg, ctx, oracle, w, h, 0, dpat, lambda buf: pkg.Encoder(buf, w, h, 30, 0, ctx), dsrc, with_oracle=False)
-    assert len(serial_d) > 1.3 * len(dpat) * fb, ("binary noise at quality 0 should cost more than its raw bytes", len(serial_d), len(dpat) * fb)
-    got_d, _ = encode_pattern(pkg, ctx, oracle, w, h, 0, dpat, lambda buf: pkg.GopEncoder(buf, w, h, 30, 0, ctx, max_gops=2, max_gop_frames=8), dsrc, with_oracle=False)
-    assert got_d == serial_d, "GOP encoder: dense content wrote a different stream"
+    for dpat, q, shape in (("IPPPPPPP" * 2, 0, (2, 8)), ("PPIPPDPPPPIPP", 5, (2, 3)), ("IPPPPPPPPPPP", 3, (1, 4))):
+        serial_d, _ = encode_pattern(pkg, ctx, oracle, w, h, q, dpat, lambda buf: pkg.Encoder(buf, w, h, 30, q, ctx), dsrc, with_oracle=False)
+        os.environ["PFV_TEST_GOP_ARENA_BYTES"] = "4096"
+        try:
+            holder = []
+
+            def make(buf):
+                holder.append(pkg.GopEncoder(buf, w, h, 30, q, ctx, max_gops=shape[0], max_gop_frames=shape[1]))
+                return holder[-1]
+            got_d, _ = encode_pattern(pkg, ctx, oracle, w, h, q, dpat, make, dsrc, with_oracle=False, keep_open=True)
+        finally:
+            del os.environ["PFV_TEST_GOP_ARENA_BYTES"]
+        st_d = holder[-1].stats()
+        holder[-1].close()
+        assert got_d == serial_d, f"GOP encoder: batches made again after outgrowing their arena wrote a different stream ({dpat}, quality {q}, batch {shape})"
+        assert st_d["batches_redone"] >= 1, st_d
+    assert len(serial_d) > 0
     # an explicit payload budget is kept as given: 64 bytes cannot hold an i-frame
     enc = pkg.GopEncoder(io.BytesIO(), w, h, 30, 5, ctx, max_gops=2, max_gop_frames=4, payload_budget=64)
     enc.encode_iframe(frame_of(pkg, w, h, st.frame(0)))
