@@ -562,10 +562,24 @@ PFV_API int pfv_batch_decoder_advance(pfv_batch_decoder *b, const uint8_t **fram
     pfv_dec_session *hot = b->hot;
     const size_t total = tb * S * 256;
     int rc = PFV_OK;
+    if (s->dev_form && b->win[slot].owner != (DecEvent *)s && (rc = bd_window_enqueue(b, s, b->win[slot]))) {   // not enqueued ahead (first step, or its headers were late)
+        if (b->entd.ready || b->entd.force) return rc;
+        // PFV_ENTROPY_DECODE_AUTO and the window stream / sets could not be made (they are created with the first step that takes the device
+        // form): the stage is switched off for this decoder, this step is parsed by the host code here and now, the ones behind it on the pool
+        (void)hipGetLastError();
+        b->entd.on = false;
+        s->dev_form = false;
+        for (size_t k = 0; k < S; k++) {
+            bd_parse_one(b, s, (int)k);
+            if (s->rc[k] == kSinkFull) dense = true;
+            else if (s->rc[k]) { b->eof = true; return fail(ctx, s->rc[k], "malformed packet payload"); }
+        }
+        b->entd.packets_host += (long)S;
+        rc = PFV_OK;
+    }
     if (s->dev_form) {   // the step's payloads through the device's entropy stage, the host parser for what it will not take
         DecEntd &v = b->entd;
         DecWindow &w = b->win[slot];
-        if (w.owner != (DecEvent *)s && (rc = bd_window_enqueue(b, s, w))) return rc;     // not enqueued ahead (first step, or its headers were late)
         HIP_TRY(ctx, hipEventSynchronize(w.done));
         w.owner = nullptr;
         for (size_t k = 0; k < S; k++) {
