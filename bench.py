@@ -1270,6 +1270,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RCCL between processes needs dmabuf IPC on this driver stack (hipIpcGetMemHandle fails otherwise); the launcher normally exports it, a
+    # rank started some other way sets it before the HIP runtime is loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import __graft_entry__ as graft
     # No torch anywhere: its wheel bundles a second HIP / HSA runtime, and with both runtimes in one process every launch of a
