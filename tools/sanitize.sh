@@ -16,7 +16,7 @@ rc=0
 if [ "$WHAT" = asan ] || [ "$WHAT" = all ]; then
   log=profiles/r06_sanitize_asan_ubsan.log
   flags="-fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
-  echo "== asan_ubsan: g++ $flags (tests/conftest.py build_emulator, PFV_EMU_DEFS); tools/sanitize_run.py -- $(date -u +%FT%TZ), $(gcc --version | head -1)" > $log
+  echo "== asan_ubsan: g++ $flags (tests/conftest.py build_emulator, PFV_EMU_DEFS); tools/sanitize_run.py -- source_hash $(python -c "import __graft_entry__ as g; print(g.source_hash())") -- $(date -u +%FT%TZ), $(gcc --version | head -1)" > $log
   PFV_EMU_DEFS="$flags" LD_PRELOAD="$GCC_LIBDIR/libasan.so" ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 timeout 3000 python tools/sanitize_run.py >> $log 2>&1 || rc=1
   echo "== exit code $rc; sanitizer reports in this log: $(count $log)" >> $log; tail -2 $log
 fi
