@@ -119,6 +119,29 @@ int main(int argc, char **argv)
             if (!gd2.advance_delta_device(1.0 / fps, cmp_dev)) { std::fprintf(stderr, "GopDecoder::advance_delta_device ended the stream early\n"); return 1; }
             while (gd2.advance_frame_device(cmp_dev)) {}
             if (!same || n_dev != n_out) { std::fprintf(stderr, "GopDecoder frames left in device memory differ (%d of %d)\n", n_dev, n_out); return 1; }
+            // the encoder fed from DEVICE memory by reference (pfv_gop_encoder_set_frames_by_reference): the clip stays where it is, same bytes
+            {
+                const size_t fbytes = ny + 2 * nc, stride = (fbytes + 15) / 16 * 16;
+                void *clip = nullptr;
+                ctx.check(pfv_dev_alloc(ctx.handle(), stride * (size_t)n_in, &clip));
+                std::ifstream in4(argv[7], std::ios::binary);
+                std::vector<char> frame(fbytes);
+                std::stringstream rs(std::ios::in | std::ios::out | std::ios::binary);
+                {
+                    pfv::GopEncoder ge(rs, w, h, fps, quality, ctx, 2, 2);
+                    ge.set_frames_by_reference(true);
+                    for (int t = 0; t < n_in; t++) {
+                        in4.read(frame.data(), (std::streamsize)fbytes);
+                        uint8_t *at = static_cast<uint8_t *>(clip) + stride * (size_t)t;
+                        ctx.check(pfv_dev_upload(ctx.handle(), at, frame.data(), fbytes));
+                        if (t == drop_at) ge.encode_dropframe();
+                        else if (t % gop == 0) ge.encode_iframe_device(at);
+                        else ge.encode_pframe_device(at);
+                    }
+                }   // ~GopEncoder: the last batch is collected here, the clip is still alive
+                pfv_dev_free(ctx.handle(), clip);
+                if (rs.str() != bytes) { std::fprintf(stderr, "GopEncoder reading device frames by reference wrote different bytes\n"); return 1; }
+            }
             std::printf("gop: %d frames identical to the frame-by-frame objects\n", n_gop);
         }
         // the batch classes on the same clip: both streams carry the clip itself, so each writer must receive `bytes`
