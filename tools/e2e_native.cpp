@@ -221,11 +221,11 @@ int main(int argc, char **argv)
         if (hbm_first_total != stream.size()) { fprintf(stderr, "encoder fed from device memory wrote %zu bytes, from host memory %zu\n", hbm_first_total, stream.size()); return 7; }
         // the same widths with the frames taken BY REFERENCE (the clip stays where it is: no device-to-device copy at all)
         hbm_by_ref = true;
-        for (int wi = 0; wi < 3; wi++) {
+        for (int wi = 0; wi < 2; wi++) {      // the whole clip per batch (two passes) and half of it (one): every object of this section stays alive until its end (above)
             const int G = widths[wi];
             if (G <= 0 || (wi && G == widths[wi - 1])) continue;
             double best = 0;
-            for (int pass = 0; pass < 2; pass++) {
+            for (int pass = 0; pass < (wi == 0 ? 2 : 1); pass++) {
                 double dt = 0, st[5];
                 size_t total = 0;
                 const int rc = hbm_pass(G, &dt, st, &total);
