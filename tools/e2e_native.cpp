@@ -133,12 +133,12 @@ int main(int argc, char **argv)
         CHECK(pfv_gop_encoder_finish(e));
         CHECK(drain());
         *seconds = now() - t0;
-        pfv_gop_encoder_stats(e, stats, 5);
+        pfv_gop_encoder_stats(e, stats, 7);
         retire(e);
         *bytes = total;
         return 0;
     };
-    double t_enc_hbm_first = 0, enc_hbm_first_stats[5] = {0, 0, 0, 0, 0};
+    double t_enc_hbm_first = 0, enc_hbm_first_stats[7] = {0, 0, 0, 0, 0, 0, 0};
     size_t hbm_first_total = 0;
     {
         {   // a warm-up object at 64x48 first (code objects, first launches): a few hundred KB, it leaves no such trace
@@ -193,7 +193,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < 5; i++) enc_hbm_stats[i] = enc_hbm_first_stats[i];
     int hbm_gops = EG > DG ? EG : DG;
     std::string hbm_by_width, hbm_ref_by_width;
-    double t_enc_hbm_ref = 0;
+    double t_enc_hbm_ref = 0, ref_stats[7] = {0, 0, 0, 0, 0, 0, 0};
     {
         // the encoder copies a device frame on the caller's stream and runs its kernels on a stream of its own: with the clip in ONE batch the
         // copies (2.5 ms for 300 4K frames) stand in front of the kernels, with two or more they run under the kernels of the batch before;
@@ -204,9 +204,9 @@ int main(int argc, char **argv)
         for (int wi = 0; wi < 3; wi++) {
             const int G = widths[wi];
             if (G <= 0 || (wi && G == widths[wi - 1])) continue;
-            double best = 0, best_stats[5] = {0, 0, 0, 0, 0};
+            double best = 0, best_stats[7] = {0, 0, 0, 0, 0, 0, 0};
             for (int pass = 0; pass < 2; pass++) {
-                double dt = 0, st[5];
+                double dt = 0, st[7];
                 size_t total = 0;
                 const int rc = hbm_pass(G, &dt, st, &total);
                 if (rc) return rc;
@@ -226,11 +226,13 @@ int main(int argc, char **argv)
             if (G <= 0 || (wi && G == widths[wi - 1])) continue;
             double best = 0;
             for (int pass = 0; pass < (wi == 0 ? 2 : 1); pass++) {
-                double dt = 0, st[5];
+                double dt = 0, st[7];
                 size_t total = 0;
                 const int rc = hbm_pass(G, &dt, st, &total);
                 if (rc) return rc;
                 if (pass == 0 || dt < best) best = dt;
+                if (t_enc_hbm_ref == 0 || dt < t_enc_hbm_ref) for (int i = 0; i < 7; i++) ref_stats[i] = st[i];
+                if (t_enc_hbm_ref == 0 || dt < t_enc_hbm_ref) t_enc_hbm_ref = dt;
                 if (total != stream.size()) { fprintf(stderr, "encoder reading device frames by reference wrote %zu bytes, from host memory %zu\n", total, stream.size()); return 7; }
             }
             char b[96];
@@ -243,7 +245,7 @@ int main(int argc, char **argv)
     }
     for (pfv_gop_encoder *e : old_encoders) pfv_gop_encoder_destroy(e);
     old_encoders.clear();
-    if (getenv("PFV_E2E_STOP_AFTER_ENCODE")) { printf("{\"encode_value\": %.1f, \"encode_value_frames_in_hbm\": %.1f, \"first_object\": %.1f, \"by_width\": {%s}}\n", (double)N * n_mb / t_enc, (double)N * n_mb / t_enc_hbm, (double)N * n_mb / t_enc_hbm_first, hbm_by_width.c_str()); return 0; }   // timelines
+    if (getenv("PFV_E2E_STOP_AFTER_ENCODE")) { printf("{\"encode_value\": %.1f, \"encode_value_frames_in_hbm\": %.1f, \"first_object\": %.1f, \"by_width\": {%s}, \"quality\": %d, \"stream_bytes\": %zu, \"by_reference\": %.1f, \"by_reference_s\": %.5f, \"by_reference_by_width\": {%s}, \"by_reference_host_seconds\": {\"enqueue_s\": %.5f, \"kernel_wait_s\": %.5f, \"payload_download_s\": %.5f, \"packet_assembly_s\": %.5f, \"frames_by_reference\": %.0f, \"batches_redone\": %.0f}}\n", (double)N * n_mb / t_enc, (double)N * n_mb / t_enc_hbm, (double)N * n_mb / t_enc_hbm_first, hbm_by_width.c_str(), Q, stream.size(), (double)N * n_mb / t_enc_hbm_ref, t_enc_hbm_ref, hbm_ref_by_width.c_str(), ref_stats[1], ref_stats[2], ref_stats[3], ref_stats[4], ref_stats[5], ref_stats[6]); return 0; }   // timelines, quality sweeps
     // ---- decode
     struct Mode { const char *name; int entropy; bool device_out; };
     const Mode modes[] = {{"payloads_read_on_host", PFV_ENTROPY_DECODE_HOST, false},
