@@ -94,3 +94,29 @@ def test_threads_driver_on_gpu(graft, tmp_path):
     r = subprocess.run([exe, "8"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "threads_driver OK: 9 streams" in r.stdout
+
+
+def test_e2e_native_tool_on_emulator(tmp_path):
+    """tools/e2e_native.cpp (bench.py's extra.config4.end_to_end.native_host, tools/gpu_byref_quality.sh) at a toy size: the GOP encoder fed from
+    host memory, from device memory by copy and BY REFERENCE writes the same bytes (the program checks it and exits non-zero otherwise), both of
+    its output forms parse, and the by-reference pass took every frame in place"""
+    import json
+    import conftest
+    lib = conftest.build_emulator()
+    exe = str(tmp_path / "e2e_emu")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "e2e_native.cpp"), "-o", exe, lib,
+                    "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+    args = [exe, "64", "48", "12", "3", "5", "2", "4", "2"]
+    r = subprocess.run(args, env=dict(os.environ, PFV_E2E_STOP_AFTER_ENCODE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["stream_bytes"] > 600 and d["by_reference"] > 0 and d["by_reference_host_seconds"]["frames_by_reference"] == 12
+    assert d["by_reference_host_seconds"]["batches_redone"] == 0
+    line = tmp_path / "line.jsonl"
+    line.write_text(r.stdout)
+    t = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "byref_table.py"), str(line)], capture_output=True, text=True, timeout=60)
+    assert t.returncode == 0 and len(t.stdout.splitlines()) == 2, t.stderr
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)                  # the full program: decode modes behind the encoders
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["encode_value_frames_in_hbm_by_reference"] > 0 and "identical" in d["frames_checked"]
