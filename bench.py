@@ -1006,6 +1006,17 @@ def native_end_to_end(W, H, n_frames, Q, gops, parse_threads):
         out = json.loads(r.stdout)
         out["note"] = ("tools/e2e_native.cpp: page-locked producer frames -> pfv_gop_encoder -> .pfv bytes -> pfv_gop_decoder -> the consumer's callback per frame "
                        "(best of 3 per decoder mode; sampled frames identical in all modes)")
+        # config 4's clip is ONE batch of the encoder (its first and its last): the same call sequence on three times the stream, where the
+        # start of the object and the last download of a batch are off the critical path (profiles/r06_byref_floor.md, section 4)
+        try:
+            r = subprocess.run([exe, str(W), str(H), str(3 * n_frames), str(GOP), str(Q), str(gops), str(2 * gops), str(parse_threads)], check=True,
+                               capture_output=True, text=True, timeout=300, env=dict(os.environ, PFV_E2E_STOP_AFTER_ENCODE="1"))
+            d = json.loads(r.stdout)
+            out["three_times_the_stream"] = {"frames": 3 * n_frames, "stream_bytes": d["stream_bytes"], "encode_value_frames_in_hbm": d["encode_value_frames_in_hbm"],
+                                             "encode_value_frames_in_hbm_by_reference": d["by_reference"], "encode_frames_in_hbm_by_reference_s": d["by_reference_s"],
+                                             "note": "the encoder objects alone (no decode), same batch width: batches behind the first run at the kernels' rate"}
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+            out["three_times_the_stream"] = {"error": f"{type(e).__name__}: {getattr(e, 'stderr', '') or e}"[:300]}
         return out
     except (OSError, subprocess.SubprocessError, ValueError) as e:
         return {"error": f"{type(e).__name__}: {getattr(e, 'stderr', '') or e}"[:400]}
